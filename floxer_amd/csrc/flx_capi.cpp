@@ -1,0 +1,174 @@
+// C ABI: host arithmetic, PEX trees, index lifetime, device context, kernel accounting.
+#include <cstdlib>
+#include <cstring>
+#include <memory>
+
+#include "flx_context.hpp"
+
+namespace flx {
+const char* last_error_cstr();
+}
+using namespace flx;
+
+extern "C" {
+
+const char* flx_last_error(void) { return last_error_cstr(); }
+const char* flx_version(void) { return "floxer_amd 0.1.0 (gfx950)"; }
+
+uint64_t flx_ceil_div(uint64_t a, uint64_t b) { return ceil_div(a, b); }
+uint64_t flx_floating_point_error_aware_ceil(double value) { return fp_aware_ceil(value); }
+int32_t flx_saturate_value_to_int32_max(uint64_t value) { return saturate_i32(value); }
+void flx_chars_to_rank_sequence(const char* chars, uint64_t n, uint8_t* out) { for (uint64_t i = 0; i < n; ++i) out[i] = char_to_rank(chars[i]); }
+void flx_reverse_complement_rank(const uint8_t* ranks, uint64_t n, uint8_t* out) { reverse_complement(ranks, n, out); }
+
+int flx_pex_tree_build(uint64_t query_length, uint64_t query_num_errors, uint64_t leaf_max_num_errors, int bottom_up,
+                       flx_pex_node* nodes, uint64_t capacity, uint64_t* n_inner, uint64_t* n_leaves) {
+    if (!n_inner || !n_leaves) { set_error("flx_pex_tree_build: null argument"); return FLX_ERR_INVALID; }
+    if (query_length == 0 || query_length > SCH_POS_MASK || query_num_errors >= query_length) { set_error("flx_pex_tree_build: invalid length / errors"); return FLX_ERR_INVALID; }
+    PexTree const t = build_pex_tree(query_length, query_num_errors, leaf_max_num_errors, bottom_up != 0);
+    *n_inner = t.inner.size();
+    *n_leaves = t.leaves.size();
+    if (t.inner.size() + t.leaves.size() > capacity || !nodes) { set_error("node buffer too small"); return FLX_ERR_CAPACITY; }
+    if (!t.inner.empty()) memcpy(nodes, t.inner.data(), t.inner.size() * sizeof(flx_pex_node));
+    memcpy(nodes + t.inner.size(), t.leaves.data(), t.leaves.size() * sizeof(flx_pex_node));
+    return FLX_OK;
+}
+
+// ---------------------------------------------------------------- index
+int flx_index_build(const uint8_t* concat, const uint64_t* lens, uint32_t n_refs, flx_index** out) {
+    if (!concat || !lens || !out || n_refs == 0) { set_error("flx_index_build: null argument or no reference"); return FLX_ERR_INVALID; }
+    HostIndex* h = build_host_index(concat, lens, n_refs);
+    if (!h) return FLX_ERR_INVALID;
+    *out = new flx_index{h};
+    return FLX_OK;
+}
+int flx_index_save(const flx_index* index, const char* path) {
+    if (!index || !path) { set_error("flx_index_save: null argument"); return FLX_ERR_INVALID; }
+    return save_host_index(*index->host, path);
+}
+int flx_index_load(const char* path, flx_index** out) {
+    if (!path || !out) { set_error("flx_index_load: null argument"); return FLX_ERR_INVALID; }
+    HostIndex* h = load_host_index(path);
+    if (!h) return FLX_ERR_IO;
+    *out = new flx_index{h};
+    return FLX_OK;
+}
+void flx_index_free(flx_index* index) {
+    if (!index) return;
+    delete index->host;
+    delete index;
+}
+uint64_t flx_index_text_length(const flx_index* index) { return index ? index->host->n : 0; }
+uint32_t flx_index_num_references(const flx_index* index) { return index ? (uint32_t)index->host->seq_len.size() : 0; }
+uint64_t flx_index_device_bytes(const flx_index* index) {
+    if (!index) return 0;
+    HostIndex const& h = *index->host;
+    return (h.occ[0].size() + h.occ[1].size()) * sizeof(OccBlock) + h.sa.size() * 4 + h.text.size() + 2 * TEXT_PAD;
+}
+int flx_index_copy_sa(const flx_index* index, uint64_t* out) {
+    if (!index || !out) { set_error("null argument"); return FLX_ERR_INVALID; }
+    for (size_t i = 0; i < index->host->sa.size(); ++i) out[i] = index->host->sa[i];
+    return FLX_OK;
+}
+int flx_index_copy_bwt(const flx_index* index, int reversed, uint8_t* out) {
+    if (!index || !out) { set_error("null argument"); return FLX_ERR_INVALID; }
+    auto const& b = index->host->bwt[reversed ? 1 : 0];
+    memcpy(out, b.data(), b.size());
+    return FLX_OK;
+}
+
+// ---------------------------------------------------------------- context
+int flx_ctx_create(int hip_device, const flx_index* index, flx_ctx** out) {
+    if (!index || !out) { set_error("flx_ctx_create: null argument"); return FLX_ERR_INVALID; }
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count == 0) {
+        set_error(std::string("no HIP device available (") + hipGetErrorString(e) + "); floxer_amd has no CPU fallback");
+        return FLX_ERR_NO_DEVICE;
+    }
+    if (hip_device < 0 || hip_device >= count) { set_error("flx_ctx_create: device ordinal out of range"); return FLX_ERR_INVALID; }
+    FLX_HIP(hipSetDevice(hip_device));
+    auto ctx = std::make_unique<flx_ctx>();
+    ctx->device = hip_device;
+    ctx->hidx = index->host;
+    FLX_HIP(hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking));
+    ctx->stream = ctx->own_stream;
+    HostIndex const& H = *index->host;
+    int rc;
+    auto up = [&](DeviceBuffer& b, const void* src, size_t bytes) -> int {
+        if ((rc = b.ensure(bytes))) return rc;
+        FLX_HIP(hipMemcpyAsync(b.ptr, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+        return FLX_OK;
+    };
+    if ((rc = up(ctx->occ0, H.occ[0].data(), H.occ[0].size() * sizeof(OccBlock)))) return rc;
+    if ((rc = up(ctx->occ1, H.occ[1].data(), H.occ[1].size() * sizeof(OccBlock)))) return rc;
+    if ((rc = up(ctx->sa, H.sa.data(), H.sa.size() * 4))) return rc;
+    if ((rc = ctx->text.ensure(H.n + 2 * TEXT_PAD + 16))) return rc;
+    FLX_HIP(hipMemsetAsync(ctx->text.ptr, 0, ctx->text.cap, ctx->stream));
+    FLX_HIP(hipMemcpyAsync((char*)ctx->text.ptr + TEXT_PAD, H.text.data(), H.n, hipMemcpyHostToDevice, ctx->stream));
+    FLX_HIP(hipStreamSynchronize(ctx->stream));
+    ctx->didx.occ[0] = ctx->occ0.as<OccBlock>();
+    ctx->didx.occ[1] = ctx->occ1.as<OccBlock>();
+    ctx->didx.sa = ctx->sa.as<u32>();
+    ctx->didx.text = ctx->text.as<u8>() + TEXT_PAD;
+    for (int c = 0; c < 7; ++c) ctx->didx.C[c] = (u32)H.C[c];
+    ctx->didx.n = (u32)H.n;
+    // trace arena budget: FLX_TRACE_ARENA_MB, default 40% of the free HBM (288 GB parts: ~100 GB), at least 256 MB
+    size_t free_b = 0, total_b = 0;
+    FLX_HIP(hipMemGetInfo(&free_b, &total_b));
+    size_t budget = free_b / 10 * 4;
+    if (const char* env = getenv("FLX_TRACE_ARENA_MB")) { size_t const mb = strtoull(env, nullptr, 10); if (mb) budget = mb << 20; }
+    ctx->trace_budget_bytes = std::max<size_t>(budget, (size_t)256 << 20);
+    *out = ctx.release();
+    return FLX_OK;
+}
+
+void flx_ctx_destroy(flx_ctx* ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    for (auto& p : ctx->pending) { (void)hipEventDestroy(p.start); (void)hipEventDestroy(p.stop); }
+    for (auto e : ctx->event_pool) (void)hipEventDestroy(e);
+    for (DeviceBuffer* b : {&ctx->occ0, &ctx->occ1, &ctx->sa, &ctx->text, &ctx->text_rev, &ctx->seq, &ctx->seq_rev, &ctx->peq, &ctx->peq_rev,
+                            &ctx->scheme, &ctx->seeds, &ctx->stack, &ctx->hits, &ctx->counters, &ctx->rows, &ctx->rows_out, &ctx->jobs,
+                            &ctx->job_out, &ctx->trace, &ctx->tjobs, &ctx->tjob_out, &ctx->cigar, &ctx->user_text, &ctx->user_text_rev})
+        b->release();
+    if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
+    delete ctx;
+}
+
+int flx_ctx_set_stream(flx_ctx* ctx, void* hip_stream) {
+    if (!ctx) { set_error("null context"); return FLX_ERR_INVALID; }
+    int rc = ctx->sync();
+    if (rc) return rc;
+    ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+    return FLX_OK;
+}
+
+int flx_ctx_enable_kernel_timing(flx_ctx* ctx, int enable) {
+    if (!ctx) { set_error("null context"); return FLX_ERR_INVALID; }
+    int rc = ctx->sync();
+    if (rc) return rc;
+    ctx->timing = enable != 0;
+    return FLX_OK;
+}
+int flx_ctx_reset_kernel_stats(flx_ctx* ctx) {
+    if (!ctx) { set_error("null context"); return FLX_ERR_INVALID; }
+    int rc = ctx->sync();
+    if (rc) return rc;
+    ctx->stats.clear();
+    ctx->stat_order.clear();
+    return FLX_OK;
+}
+int flx_ctx_get_kernel_stats(flx_ctx* ctx, flx_kernel_stat* out, uint32_t* n) {
+    if (!ctx || !n) { set_error("null argument"); return FLX_ERR_INVALID; }
+    int rc = ctx->sync();
+    if (rc) return rc;
+    uint32_t const cap = *n;
+    *n = (uint32_t)ctx->stat_order.size();
+    if (ctx->stat_order.size() > cap || (!out && cap)) { set_error("stat buffer too small"); return FLX_ERR_CAPACITY; }
+    for (size_t i = 0; i < ctx->stat_order.size(); ++i) out[i] = ctx->stats[ctx->stat_order[i]];
+    return FLX_OK;
+}
+
+}  // extern "C"

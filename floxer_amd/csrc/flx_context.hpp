@@ -1,0 +1,87 @@
+// Device context: HBM-resident index, grow-only workspaces, stream, per-kernel accounting.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <map>
+#include <string>
+#include <vector>
+
+#include "flx_internal.hpp"
+
+namespace flx {
+
+#define FLX_HIP(expr)                                                                                   \
+    do {                                                                                                \
+        hipError_t const e__ = (expr);                                                                  \
+        if (e__ != hipSuccess) {                                                                        \
+            set_error(std::string(#expr) + ": " + hipGetErrorString(e__));                              \
+            return FLX_ERR_NO_DEVICE;                                                                   \
+        }                                                                                               \
+    } while (0)
+
+struct DeviceBuffer {
+    void* ptr = nullptr;
+    size_t cap = 0;
+    int ensure(size_t bytes);      // grow-only; contents are NOT preserved
+    void release();
+    template <class T> T* as() const { return reinterpret_cast<T*>(ptr); }
+};
+
+struct PendingTiming { std::string name; hipEvent_t start, stop; u64 bytes, units; };
+
+}  // namespace flx
+
+struct flx_index { flx::HostIndex* host = nullptr; };
+
+struct flx_ctx {
+    int device = 0;
+    hipStream_t own_stream = nullptr, stream = nullptr;
+    const flx::HostIndex* hidx = nullptr;
+    flx::DevIndex didx{};
+    flx::DeviceBuffer occ0, occ1, sa, text, text_rev;
+    bool text_rev_ready = false;
+    // workspaces
+    flx::DeviceBuffer seq, seq_rev, peq, peq_rev, scheme, seeds, stack, hits, counters, rows, rows_out;
+    flx::DeviceBuffer jobs, job_out, trace, tjobs, tjob_out, cigar, user_text, user_text_rev;
+    size_t trace_budget_bytes = 0;
+    // accounting
+    bool timing = false;
+    std::vector<flx::PendingTiming> pending;
+    std::vector<hipEvent_t> event_pool;
+    std::map<std::string, flx_kernel_stat> stats;
+    std::vector<std::string> stat_order;
+
+    int sync();                      // stream synchronize + fold pending timings
+    void account(const char* name, flx::u64 bytes, flx::u64 units, hipEvent_t start, hipEvent_t stop);
+    hipEvent_t get_event();
+};
+
+namespace flx {
+
+// brackets a launch with events when timing is enabled
+template <class F>
+int timed_launch(flx_ctx* ctx, const char* name, u64 bytes, u64 units, F&& launch) {
+    if (!ctx->timing) {
+        int const rc = launch();
+        if (rc != 0) { set_error(std::string(name) + ": launch failed: " + hipGetErrorString((hipError_t)rc)); return FLX_ERR_NO_DEVICE; }
+        return FLX_OK;
+    }
+    hipEvent_t const a = ctx->get_event(), b = ctx->get_event();
+    FLX_HIP(hipEventRecord(a, ctx->stream));
+    int const rc = launch();
+    FLX_HIP(hipEventRecord(b, ctx->stream));
+    if (rc != 0) { set_error(std::string(name) + ": launch failed: " + hipGetErrorString((hipError_t)rc)); return FLX_ERR_NO_DEVICE; }
+    ctx->pending.push_back(PendingTiming{name, a, b, bytes, units});
+    return FLX_OK;
+}
+
+// ---- pipeline pieces (flx_pipeline.cpp)
+struct HostAnchor { u32 seed_index, leaf, ref_id, errors; u64 pos; };
+struct SeedStats { u32 useful, raw, excluded_soft, fully_excluded; };
+
+int search_seeds_device(flx_ctx* ctx, const u8* d_seq_pool_or_null, const u8* h_seq_pool, u64 pool_len, const flx_seed* seeds,
+                        u64 n_seeds, const flx_search_config& cfg, std::vector<HostAnchor>& anchors, std::vector<SeedStats>& stats,
+                        std::vector<DevHit>* raw_hits, u64 raw_max_hits);
+
+}  // namespace flx

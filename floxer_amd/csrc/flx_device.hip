@@ -1,0 +1,508 @@
+// HIP kernels of the seed-and-verify path for gfx950 (MI355X, wave64). No MFMA: the path is integer rank lookups
+// (random 128-byte lines) and bit-parallel edit-distance DP walked as skewed anti-diagonals across the lanes of a wave.
+//
+//   K0 peq_build      query bytes -> per-64-row equality bit masks (6 symbols), wave ballots
+//   K1 fm_search      search_ng21::search_n per seed (search.cpp:173-188): DFS over the expanded optimum search scheme
+//   K2 fm_locate      index.locate(row) (search.cpp:253, 284) as an SA gather
+//   K3/K4 ed_align    seqan3 edit-distance semi-global DP (alignment.cpp:89-125, 160): score + end column, optional trace
+//   K5 ed_traceback   trace walk + CIGAR (alignment.cpp:166-180)
+#include <hip/hip_runtime.h>
+
+#include "flx_internal.hpp"
+
+namespace flx {
+
+// ================================================================================================ helpers
+__device__ __forceinline__ u32 lane_id() { return threadIdx.x & 63u; }
+
+// value of the previous lane (lane-1); lane 0 receives 0. wave_shr:1 DPP is a single VALU move on gfx9-family ISAs.
+__device__ __forceinline__ u32 from_prev_lane(u32 v) {
+    return (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+}
+
+__device__ __forceinline__ u32 wave_max_u32(u32 v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        u32 const o = (u32)__shfl_xor((int)v, off);
+        v = v > o ? v : o;
+    }
+    return (u32)__builtin_amdgcn_readfirstlane((int)v);
+}
+
+// ================================================================================================ K0: Peq planes
+// peq[(word * 6) + sym] bit r = (seq[64*word + r] == sym). One wave per 64 query bytes: six ballots.
+__global__ void __launch_bounds__(256) peq_build_kernel(const u8* __restrict__ seq, u64 len, u64* __restrict__ peq, u64 n_words) {
+    u64 const wave = ((u64)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (wave >= n_words) return;
+    u64 const pos = wave * 64 + lane_id();
+    u32 const sym = pos < len ? seq[pos] : 7u;
+#pragma unroll
+    for (u32 s = 0; s < 6; ++s) {
+        u64 const m = __ballot(sym == s);
+        if (lane_id() == s) peq[wave * 6 + s] = m;
+    }
+}
+
+int DeviceApi::build_peq(void* stream, const u8* d_seq, u64 len, u64* d_peq) {
+    u64 const n_words = len / 64 + 2;    // +1 partial word, +1 so that the funnel shift may read word+1
+    u64 const threads = n_words * 64;
+    hipLaunchKernelGGL(peq_build_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, (hipStream_t)stream, d_seq, len,
+                       d_peq, n_words);
+    return (int)hipGetLastError();
+}
+
+// ================================================================================================ K1: FM search
+// rank of all six symbols at BWT position i: one 128-byte block (header counts + 3 bit-planes over 256 positions)
+__device__ __forceinline__ void rank_all(const OccBlock* __restrict__ tab, u32 i, u32 out[6]) {
+    const OccBlock* __restrict__ b = tab + (i >> 8);
+    u32 const off = i & 255u;
+    uint4 const h0 = *reinterpret_cast<const uint4*>(&b->cnt[0]);
+    uint2 const h1 = *reinterpret_cast<const uint2*>(&b->cnt[4]);
+    u32 c0 = h0.x, c1 = h0.y, c2 = h0.z, c3 = h0.w, c4 = h1.x, c5 = h1.y;
+#pragma unroll
+    for (u32 w = 0; w < 4; ++w) {
+        // positions of this word that lie below `off`
+        u32 const lo = w * 64;
+        u64 mask;
+        if (off >= lo + 64) mask = ~0ull;
+        else if (off > lo) mask = (1ull << (off - lo)) - 1ull;
+        else mask = 0ull;
+        u64 const p0 = b->planes[w][0], p1 = b->planes[w][1], p2 = b->planes[w][2];
+        u64 const n2 = ~p2 & mask, q2 = p2 & mask;
+        u64 const a00 = ~p1 & ~p0, a01 = ~p1 & p0, a10 = p1 & ~p0, a11 = p1 & p0;
+        c0 += (u32)__popcll(n2 & a00);
+        c1 += (u32)__popcll(n2 & a01);
+        c2 += (u32)__popcll(n2 & a10);
+        c3 += (u32)__popcll(n2 & a11);
+        c4 += (u32)__popcll(q2 & a00);
+        c5 += (u32)__popcll(q2 & a01);
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3; out[4] = c4; out[5] = c5;
+}
+
+// frame state word: x:20 | e:3 | linfo:2 | rinfo:2 | next_sym:3 | right:1
+enum : u32 { INFO_M = 0, INFO_I = 1, INFO_D = 2, INFO_S = 3 };
+__device__ __forceinline__ u32 st_pack(u32 x, u32 e, u32 li, u32 ri, u32 sym, u32 right) {
+    return x | (e << 20) | (li << 23) | (ri << 25) | (sym << 27) | (right << 30);
+}
+#define ST_X(s) ((s) & 0xFFFFFu)
+#define ST_E(s) (((s) >> 20) & 7u)
+#define ST_LI(s) (((s) >> 23) & 3u)
+#define ST_RI(s) (((s) >> 25) & 3u)
+#define ST_SYM(s) (((s) >> 27) & 7u)
+#define ST_RIGHT(s) (((s) >> 30) & 1u)
+
+// counters: [0] hits written/reserved, [1] stack overflow flag, [2] cursor extensions (rank pairs), [3] hit overflow
+__global__ void __launch_bounds__(64) fm_search_kernel(DevIndex idx, const u8* __restrict__ seq, const u32* __restrict__ scheme,
+                                                       const DevSeed* __restrict__ seeds, u32 n_seeds, u32 max_hits,
+                                                       DevFrame* __restrict__ stack, DevHit* __restrict__ hits, u32 hit_cap,
+                                                       u32* __restrict__ counters) {
+    u32 const sid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (sid >= n_seeds) return;
+    DevSeed const seed = seeds[sid];
+    const u8* __restrict__ q = seq + seed.seq_off;
+    DevFrame* __restrict__ stk = stack + seed.stack_off;
+    u32 const len = seed.length;
+    u32 n_ext = 0;
+    u32 ct = 0;                     // hits collected for this seed (search_n's counter)
+    bool aborted = false;
+
+    for (u32 srch = 0; srch < seed.num_searches && !aborted; ++srch) {
+        const u32* __restrict__ ex = scheme + seed.scheme_off + (u64)srch * len;
+        u32 const last_entry = ex[len - 1];
+        u32 const l_last = (last_entry >> 20) & 7u, u_last = (last_entry >> 23) & 7u;
+        // node under inspection
+        u32 nlb = 0, nlbr = 0, nlen = idx.n, nx = 0, ne = 0, nli = INFO_M, nri = INFO_M;
+        // top frame (registers)
+        DevFrame F;
+        F.mask = 0;
+        F.lb = F.lb_rev = F.len = F.state = 0;
+#pragma unroll
+        for (int c = 0; c < 5; ++c) F.child_abs[c] = 0;
+#pragma unroll
+        for (int c = 0; c < 6; ++c) F.child_len[c] = 0;
+        u32 depth = 0;              // frames stored in memory below F
+        bool have_frame = false;    // F holds a real frame
+        bool need_child = false;
+
+        while (true) {
+            if (need_child) {
+                if (!have_frame || F.mask == 0) {
+                    if (depth == 0) break;                  // search exhausted
+                    F = stk[--depth];
+                    have_frame = true;
+                    continue;
+                }
+                u32 const ci = (u32)__ffs((int)F.mask) - 1u;
+                F.mask &= F.mask - 1u;
+                u32 const st = F.state;
+                u32 const right = ST_RIGHT(st);
+                u32 const px = ST_X(st), pe = ST_E(st);
+                u32 info, sym;
+                if (ci == 0) { sym = ST_SYM(st); nx = px + 1; ne = pe; info = INFO_M; }
+                else if (ci == 11) { sym = 0; nx = px + 1; ne = pe + 1; info = INFO_I; }
+                else {
+                    sym = (ci + 1) >> 1;
+                    bool const del = ci & 1u;
+                    nx = del ? px : px + 1;
+                    ne = pe + 1;
+                    info = del ? INFO_D : INFO_S;
+                }
+                if (ci == 11) { nlb = F.lb; nlbr = F.lb_rev; nlen = F.len; }
+                else {
+                    u32 pre = 0, clen = 0, cabs = 0;
+#pragma unroll
+                    for (u32 c = 0; c < 6; ++c) {
+                        if (c < sym) pre += F.child_len[c];
+                        if (c == sym) { clen = F.child_len[c]; cabs = c > 0 ? F.child_abs[c > 0 ? c - 1 : 0] : 0; }
+                    }
+                    nlen = clen;
+                    if (right) { nlbr = cabs; nlb = F.lb + pre; }
+                    else { nlb = cabs; nlbr = F.lb_rev + pre; }
+                }
+                nli = right ? ST_LI(st) : info;
+                nri = right ? info : ST_RI(st);
+                need_child = false;
+            }
+
+            // ---- inspect node (nlb, nlbr, nlen, nx, ne, nli, nri); nlen > 0 by construction
+            if (nx == len) {
+                bool const ok_l = nli == INFO_M || nli == INFO_I, ok_r = nri == INFO_M || nri == INFO_I;
+                if (ok_l && ok_r && l_last <= ne && ne <= u_last) {
+                    u32 rep = nlen;
+                    if (ct + rep > max_hits) rep = max_hits - ct;        // search_n truncates the last cursor
+                    ct += rep;
+                    u32 const slot = atomicAdd(&counters[0], 1u);
+                    if (slot < hit_cap) hits[slot] = DevHit{sid, nlb, rep, ne};
+                    else atomicOr(&counters[3], 1u);
+                    if (ct == max_hits) { aborted = true; break; }
+                }
+                need_child = true;
+                continue;
+            }
+            u32 const entry = ex[nx];
+            u32 const lower = (entry >> 20) & 7u, upper = (entry >> 23) & 7u, right = (entry >> 26) & 1u;
+            if (ne > upper) { need_child = true; continue; }
+            bool const mismatch_allowed = lower <= ne + 1 && ne + 1 <= upper;
+            bool const match_allowed = lower <= ne && ne <= upper;
+            if (!mismatch_allowed && !match_allowed) { need_child = true; continue; }
+
+            u32 const next_sym = q[entry & SCH_POS_MASK];
+            u32 a[6], b[6];
+            const OccBlock* __restrict__ tab = idx.occ[right];
+            u32 const lo = right ? nlbr : nlb;
+            rank_all(tab, lo, a);
+            rank_all(tab, lo + nlen, b);
+            ++n_ext;
+
+            if (mismatch_allowed) {
+                // this node branches: it becomes the top frame, the previous top goes to memory
+                if (have_frame) {
+                    if (depth >= seed.stack_frames) { atomicOr(&counters[1], 1u); aborted = true; break; }
+                    stk[depth++] = F;
+                }
+                have_frame = true;
+                u32 const tinfo = right ? nri : nli;
+                bool const deletion = tinfo == INFO_M || tinfo == INFO_D;
+                bool const insertion = tinfo == INFO_M || tinfo == INFO_I;
+                F.lb = nlb; F.lb_rev = nlbr; F.len = nlen;
+                F.state = st_pack(nx, ne, nli, nri, next_sym, right);
+                u32 mask = 0;
+#pragma unroll
+                for (u32 c = 0; c < 6; ++c) {
+                    u32 const cl = b[c] - a[c];
+                    F.child_len[c] = cl;
+                    if (c > 0) {
+                        F.child_abs[c - 1] = idx.C[c] + a[c];
+                        if (cl > 0) {
+                            if (deletion) mask |= 1u << (2 * c - 1);
+                            if (c != next_sym) mask |= 1u << (2 * c);
+                            else if (match_allowed) mask |= 1u;
+                        }
+                    }
+                }
+                if (insertion) mask |= 1u << 11;
+                F.mask = mask;
+                need_child = true;
+            } else {
+                // only an exact extension is possible: continue in place (no frame)
+                u32 pre = 0, clen = 0, cabs = 0;
+#pragma unroll
+                for (u32 c = 0; c < 6; ++c) {
+                    u32 const cl = b[c] - a[c];
+                    if (c < next_sym) pre += cl;
+                    if (c == next_sym) { clen = cl; cabs = idx.C[c] + a[c]; }
+                }
+                if (clen == 0) { need_child = true; continue; }
+                if (right) { nlbr = cabs; nlb = nlb + pre; nri = INFO_M; }
+                else { nlb = cabs; nlbr = nlbr + pre; nli = INFO_M; }
+                nlen = clen;
+                nx = nx + 1;
+            }
+        }
+    }
+    atomicAdd(&counters[2], n_ext);
+}
+
+int DeviceApi::search(void* stream, const DevIndex& idx, const u8* d_seq, const u32* d_scheme, const DevSeed* d_seeds, u32 n_seeds,
+                      u32 max_hits_per_seed, DevFrame* d_stack, DevHit* d_hits, u32 hit_cap, u32* d_counters) {
+    if (n_seeds == 0) return 0;
+    hipLaunchKernelGGL(fm_search_kernel, dim3((n_seeds + 63) / 64), dim3(64), 0, (hipStream_t)stream, idx, d_seq, d_scheme, d_seeds,
+                       n_seeds, max_hits_per_seed, d_stack, d_hits, hit_cap, d_counters);
+    return (int)hipGetLastError();
+}
+
+// ================================================================================================ K2: locate
+__global__ void __launch_bounds__(256) fm_locate_kernel(const u32* __restrict__ sa, u32 n_text, const u32* __restrict__ rows, u32 n,
+                                                        u32* __restrict__ out) {
+    u32 const i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    u32 const r = rows[i];
+    out[i] = r < n_text ? sa[r] : 0xFFFFFFFFu;
+}
+
+int DeviceApi::locate(void* stream, const DevIndex& idx, const u32* d_rows, u32 n, u32* d_out) {
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(fm_locate_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, idx.sa, idx.n, d_rows, n, d_out);
+    return (int)hipGetLastError();
+}
+
+// ================================================================================================ K3/K4: edit-distance DP
+// Myers/Hyyro bit-vector columns, semi-global (free reference ends). One job occupies G = lanes_per_job consecutive lanes,
+// lane g owns W consecutive 64-row words of the column. Lanes run skewed: at step t lane g computes reference column
+// t - g, so the carries of column c travel lane g -> g+1 between step t and t+1 (wave_shr DPP) and every lane is busy
+// after the G-step fill. With TRACE the horizontal-positive and vertical-positive delta words of every (column, word) are
+// stored in step-major ("skewed") order so that each step's stores of a job are one contiguous, fully coalesced run.
+template <int W, bool TRACE>
+__global__ void __launch_bounds__(64) ed_align_kernel(const u8* __restrict__ text, const u64* __restrict__ peq,
+                                                      const DevAlignJob* __restrict__ jobs, u32 n_jobs, u32 log2_g,
+                                                      u64* __restrict__ trace, DevAlignOut* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) u64 lds_eq[];     // [6 symbols][64 lanes][W words]
+    u32 const lane = lane_id();
+    u32 const G = 1u << log2_g;
+    u32 const lg = lane & (G - 1u);
+    u32 const jobs_per_wave = 64u >> log2_g;
+    u32 const job_id = blockIdx.x * jobs_per_wave + (lane >> log2_g);
+    bool const valid = job_id < n_jobs;
+    DevAlignJob job;
+    if (valid) job = jobs[job_id];
+    else { job.ref_off = 0; job.q_off = 0; job.trace_off = 0; job.n = 0; job.m = 1; job.k = 0; job.out_index = 0; }
+
+    u32 const nw = (job.m + 63u) >> 6;                  // words in a column
+    u32 const L = (nw + W - 1u) / W;                    // lanes that own words
+    bool const owner = valid && lg < L;
+
+    // ---- equality masks of this lane's words: funnel-shift of the pool-wide Peq planes to the job's row origin
+    {
+        u64 const a = job.q_off >> 6;
+        u32 const sh = (u32)(job.q_off & 63u);
+#pragma unroll
+        for (int w = 0; w < W; ++w) {
+            u32 const gw = lg * W + w;
+#pragma unroll
+            for (u32 s = 0; s < 6; ++s) {
+                u64 v = 0;
+                if (owner && gw < nw) {
+                    u64 const lo = peq[(a + gw) * 6 + s];
+                    u64 const hi = peq[(a + gw + 1) * 6 + s];
+                    v = sh ? (lo >> sh) | (hi << (64 - sh)) : lo;
+                    u32 const rows_left = job.m - gw * 64u;             // rows of this word that belong to the query
+                    if (rows_left < 64u) v &= (1ull << rows_left) - 1ull;
+                }
+                lds_eq[(s * 64u + lane) * W + w] = v;
+            }
+        }
+    }
+    __syncthreads();
+
+    u64 vp[W], vn[W];
+#pragma unroll
+    for (int w = 0; w < W; ++w) { vp[w] = ~0ull; vn[w] = 0ull; }
+
+    bool const last_lane = owner && lg == L - 1u;
+    u32 const w_last = (nw - 1u) - (L - 1u) * W;        // local index of the word that holds row m-1
+    u64 const last_bit = 1ull << ((job.m - 1u) & 63u);
+    u32 score = job.m, best = job.m, best_col = 0;
+
+    u32 const my_steps = owner ? job.n + L - 1u : 0u;
+    u32 const t_max = wave_max_u32(my_steps);
+
+    // per-lane reference stream: this lane needs p[t] at step t (column t - lg)
+    const u8* __restrict__ p = text + job.ref_off - lg;
+    auto load8 = [&](u32 t) -> u64 {
+        // unaligned 8-byte read assembled from two aligned ones (never faults: text has TEXT_PAD bytes on both sides)
+        const u8* const addr = p + t;
+        uintptr_t const ai = (uintptr_t)addr;
+        const u64* const base = reinterpret_cast<const u64*>(ai & ~(uintptr_t)7);
+        u32 const shb = (u32)(ai & 7u) * 8u;
+        u64 const lo = base[0], hi = base[1];
+        return shb ? (lo >> shb) | (hi << (64u - shb)) : lo;
+    };
+    u32 const my_last = owner ? job.n + lg : 0u;         // steps [lg, n+lg) are this lane's columns
+    u64 queue = 0, next_queue = 0;
+    if (owner) { queue = load8(0); if (8 < my_last) next_queue = load8(8); }
+
+    u32 cout = 0;
+    u64 const trace_lane_base = job.trace_off + (u64)lg * W;
+    u64 const trace_step_stride = (u64)L * W;
+
+    for (u32 t = 0; t < t_max; ++t) {
+        if ((t & 7u) == 0u && t > 0u) {
+            queue = next_queue;
+            if (owner && t + 8u < my_last) next_queue = load8(t + 8u);
+        }
+        u32 const sym = (u32)(queue & 7ull);
+        queue >>= 8;
+        u32 cin = from_prev_lane(cout);
+        if (lg == 0u) cin = 0u;
+        bool const active = owner && t >= lg && t < my_last;
+        if (active) {
+            u64 c_d0 = cin & 1u, c_hp = (cin >> 1) & 1u, c_hn = (cin >> 2) & 1u;
+            const u64* __restrict__ eqp = &lds_eq[(sym * 64u + lane) * W];
+#pragma unroll
+            for (int w = 0; w < W; ++w) {
+                u64 const eq = eqp[w];
+                u64 const pv = vp[w], mv = vn[w];
+                u64 const x = eq | mv;
+                u64 const t1 = pv + (x & pv);
+                u64 const tt = t1 + c_d0;
+                u64 const carry = (u64)(t1 < pv) | (u64)(tt < t1);
+                u64 const d0 = (tt ^ pv) | x;
+                u64 const hn = pv & d0;
+                u64 const hp = mv | ~(pv | d0);
+                u64 const xh = (hp << 1) | c_hp;
+                u64 const nvn = xh & d0;
+                u64 const nvp = (hn << 1) | ~(xh | d0) | c_hn;
+                c_d0 = carry;
+                c_hp = hp >> 63;
+                c_hn = hn >> 63;
+                vn[w] = nvn;
+                vp[w] = nvp;
+                if (TRACE) {
+                    ulonglong2 v;
+                    v.x = hp;
+                    v.y = nvp;
+                    *reinterpret_cast<ulonglong2*>(trace + 2ull * (trace_lane_base + (u64)t * trace_step_stride + (u64)w)) = v;
+                }
+                if (last_lane && (u32)w == w_last) {
+                    score += (hp & last_bit) ? 1u : 0u;
+                    score -= (hn & last_bit) ? 1u : 0u;
+                }
+            }
+            cout = (u32)c_d0 | ((u32)c_hp << 1) | ((u32)c_hn << 2);
+            if (last_lane && score <= best) { best = score; best_col = t - lg + 1u; }
+        }
+    }
+    if (last_lane) {
+        DevAlignOut o;
+        o.score = best <= job.k ? best : 0xFFFFFFFFu;
+        o.end_col = best_col;
+        out[job.out_index] = o;
+    }
+}
+
+AlignShape choose_align_shape(u32 m) {
+    static const u32 ws[] = {1, 2, 3, 4, 6, 8, 13, 25};
+    u32 const nw = (m + 63) / 64;
+    AlignShape best{0, 0};
+    u64 best_cost = ~0ull;
+    for (u32 w : ws)
+        for (u32 g = 1; g <= 64; g *= 2) {
+            if ((u64)w * g < nw) continue;
+            // cost ~ wave slots consumed: words per lane times lanes reserved; prefer fewer words per lane on ties
+            u64 const cost = (u64)w * g * 1000 + w;
+            if (cost < best_cost) { best_cost = cost; best = AlignShape{w, g}; }
+        }
+    return best;
+}
+u32 align_supported_max_query() { return 25u * 64u * 64u; }
+
+template <int W>
+static int launch_align(hipStream_t s, const u8* d_text, const u64* d_peq, const DevAlignJob* d_jobs, u32 n_jobs, u32 log2_g, bool trace,
+                        u64* d_trace, DevAlignOut* d_out) {
+    u32 const jobs_per_wave = 64u >> log2_g;
+    u32 const blocks = (n_jobs + jobs_per_wave - 1) / jobs_per_wave;
+    size_t const lds = (size_t)6 * 64 * W * sizeof(u64);
+    if (trace) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&ed_align_kernel<W, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL((ed_align_kernel<W, true>), dim3(blocks), dim3(64), lds, s, d_text, d_peq, d_jobs, n_jobs, log2_g, d_trace, d_out);
+    } else {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&ed_align_kernel<W, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL((ed_align_kernel<W, false>), dim3(blocks), dim3(64), lds, s, d_text, d_peq, d_jobs, n_jobs, log2_g, d_trace, d_out);
+    }
+    return (int)hipGetLastError();
+}
+
+int DeviceApi::align(void* stream, const u8* d_text, const u64* d_peq, const DevAlignJob* d_jobs, u32 n_jobs, AlignShape shape, bool trace,
+                     u64* d_trace, DevAlignOut* d_out) {
+    if (n_jobs == 0) return 0;
+    u32 log2_g = 0;
+    while ((1u << log2_g) < shape.lanes_per_job) ++log2_g;
+    hipStream_t s = (hipStream_t)stream;
+    switch (shape.words_per_lane) {
+        case 1: return launch_align<1>(s, d_text, d_peq, d_jobs, n_jobs, log2_g, trace, d_trace, d_out);
+        case 2: return launch_align<2>(s, d_text, d_peq, d_jobs, n_jobs, log2_g, trace, d_trace, d_out);
+        case 3: return launch_align<3>(s, d_text, d_peq, d_jobs, n_jobs, log2_g, trace, d_trace, d_out);
+        case 4: return launch_align<4>(s, d_text, d_peq, d_jobs, n_jobs, log2_g, trace, d_trace, d_out);
+        case 6: return launch_align<6>(s, d_text, d_peq, d_jobs, n_jobs, log2_g, trace, d_trace, d_out);
+        case 8: return launch_align<8>(s, d_text, d_peq, d_jobs, n_jobs, log2_g, trace, d_trace, d_out);
+        case 13: return launch_align<13>(s, d_text, d_peq, d_jobs, n_jobs, log2_g, trace, d_trace, d_out);
+        case 25: return launch_align<25>(s, d_text, d_peq, d_jobs, n_jobs, log2_g, trace, d_trace, d_out);
+        default: return (int)hipErrorInvalidValue;
+    }
+}
+
+// ================================================================================================ K5: traceback + CIGAR
+// One lane walks one job's path from (m, end_col) to row 0 with seqan3's preference up (I) > left (D) > diagonal (=/X).
+// The CIGAR is written backwards into the job's slab so that it ends up in forward order without a reversal pass.
+__global__ void __launch_bounds__(64) ed_traceback_kernel(const u8* __restrict__ text, const u8* __restrict__ query,
+                                                          const u64* __restrict__ trace, const DevTraceJob* __restrict__ jobs, u32 n_jobs,
+                                                          u32* __restrict__ cigar, DevTraceOut* __restrict__ out) {
+    u32 const id = blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= n_jobs) return;
+    DevTraceJob const job = jobs[id];
+    const u8* __restrict__ r = text + job.ref_off;
+    const u8* __restrict__ q = query + job.q_off;
+    u32* __restrict__ slab = cigar + job.cigar_off;
+    u32 wpos = job.cigar_cap;
+    u32 i = job.m, j = job.end_col;
+    u32 cur_op = 0xFFu, cur_len = 0;
+    u32 const W = job.words_per_lane, L = job.lanes;
+    bool overflow = false;
+    while (i > 0) {
+        u32 op;
+        if (j == 0) { op = 1u; --i; }
+        else {
+            u32 const gw = (i - 1u) >> 6, bit = (i - 1u) & 63u;
+            u32 const lgx = gw / W, w = gw - lgx * W;
+            u64 const slot = job.trace_off + ((u64)(j - 1u + lgx) * L + lgx) * W + w;
+            ulonglong2 const v = *reinterpret_cast<const ulonglong2*>(trace + 2ull * slot);
+            if ((v.y >> bit) & 1ull) { op = 1u; --i; }                  // up: query symbol unmatched (I)
+            else if ((v.x >> bit) & 1ull) { op = 2u; --j; }             // left: reference symbol skipped (D)
+            else { op = q[i - 1u] == r[j - 1u] ? 7u : 8u; --i; --j; }   // diagonal
+        }
+        if (op == cur_op) ++cur_len;
+        else {
+            if (cur_len) { if (wpos == 0) { overflow = true; break; } slab[--wpos] = (cur_len << 4) | cur_op; }
+            cur_op = op;
+            cur_len = 1;
+        }
+    }
+    if (!overflow && cur_len) { if (wpos == 0) overflow = true; else slab[--wpos] = (cur_len << 4) | cur_op; }
+    DevTraceOut o;
+    o.begin = j;
+    o.cigar_start = wpos;
+    o.cigar_len = overflow ? 0xFFFFFFFFu : job.cigar_cap - wpos;
+    o.pad = 0;
+    out[job.out_index] = o;
+}
+
+int DeviceApi::traceback(void* stream, const u8* d_text, const u8* d_query, const u64* d_trace, const DevTraceJob* d_jobs, u32 n_jobs,
+                         u32* d_cigar, DevTraceOut* d_out) {
+    if (n_jobs == 0) return 0;
+    hipLaunchKernelGGL(ed_traceback_kernel, dim3((n_jobs + 63) / 64), dim3(64), 0, (hipStream_t)stream, d_text, d_query, d_trace, d_jobs,
+                       n_jobs, d_cigar, d_out);
+    return (int)hipGetLastError();
+}
+
+}  // namespace flx

@@ -1,0 +1,140 @@
+// floxer_amd internal declarations shared by the host sources and the HIP translation unit.
+#pragma once
+
+#include <cstddef>
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "../../include/floxer_amd.h"
+
+namespace flx {
+
+using u8 = uint8_t;
+using u16 = uint16_t;
+using u32 = uint32_t;
+using u64 = uint64_t;
+using i64 = int64_t;
+
+void set_error(const std::string& msg);
+
+// ------------------------------------------------------------------------------------------------ HBM data layout
+// Occurrence table block: 256 BWT positions in one 128-byte line (one L2 line / one HBM request on gfx950).
+//   cnt[c]        = number of symbol c in bwt[0, 256*b)           (absolute; text < 2^32 symbols)
+//   planes[w][p]  = bit p of the symbols bwt[256*b + 64*w + 0..63]  (3 bit-planes, symbols 0..5; tail filled with 7)
+struct alignas(128) OccBlock {
+    u32 cnt[6];
+    u32 pad[2];
+    u64 planes[4][3];
+};
+static_assert(sizeof(OccBlock) == 128, "occ block must be one 128-byte line");
+
+constexpr u32 TEXT_PAD = 128;     // bytes of padding in front of and behind the device copy of a reference text
+
+struct HostIndex {
+    u64 n = 0;                            // padded text length
+    std::vector<u8> text;                 // concatenated references, each followed by 4-(len%4) zero sentinels
+    std::vector<u64> seq_start, seq_len;
+    std::vector<u32> sa;                  // full suffix array (u32: n < 2^32)
+    std::vector<OccBlock> occ[2];         // 0: BWT of text (extendLeft), 1: BWT of reversed text (extendRight)
+    u64 C[7] = {0, 0, 0, 0, 0, 0, 0};
+    std::vector<u8> bwt[2];               // kept for tests (flx_index_copy_bwt); not uploaded
+};
+
+// Device-side view handed to kernels (plain pointers into HBM)
+struct DevIndex {
+    const OccBlock* occ[2];
+    const u32* sa;
+    const u8* text;        // points at text[0]; TEXT_PAD readable bytes on both sides
+    u32 C[7];
+    u32 n;
+};
+
+// ------------------------------------------------------------------------------------------------ K1: FM search
+// Expanded search-scheme entry for one query character in search order (search_schemes::expand):
+//   bits 0..19 query position, 20..22 lower bound, 23..25 upper bound, 26 extension direction (1 = right)
+constexpr u32 SCH_POS_MASK = 0xFFFFF;
+inline u32 sch_pack(u32 pos, u32 l, u32 u, bool right) { return pos | (l << 20) | (u << 23) | ((right ? 1u : 0u) << 26); }
+
+struct DevSeed {
+    u64 seq_off;        // into the device sequence pool
+    u64 stack_off;      // first frame of this seed's DFS stack
+    u32 length;
+    u32 scheme_off;     // first entry of this (length, errors) expanded scheme; searches are consecutive, `length` entries each
+    u32 num_searches;
+    u32 stack_frames;   // frames reserved
+};
+
+struct DevFrame {       // 64 bytes: one branching node of the DFS
+    u32 lb, lb_rev, len;        // cursor of the node
+    u32 state;                  // x:20 | e:3 | linfo:2 | rinfo:2 | next_sym:3 | right:1
+    u32 child_abs[5];           // for symbols 1..5: absolute lb on the side that was extended (C[c] + occ)
+    u32 child_len[6];           // for symbols 0..5
+    u32 mask;                   // remaining children (bit ci)
+};
+static_assert(sizeof(DevFrame) == 64, "frame is one 64-byte line");
+
+struct DevHit { u32 seed, lb, len, errors; };
+
+// ------------------------------------------------------------------------------------------------ K3/K4: alignment
+struct DevAlignJob {
+    u64 ref_off;        // into the device text the launch uses
+    u64 q_off;          // into the device query pool (also addresses the Peq planes)
+    u64 trace_off;      // first 16-byte slot of this job's trace arena (TRACE launches)
+    u32 n, m, k;
+    u32 out_index;      // where the result goes
+};
+struct DevAlignOut { u32 score; u32 end_col; };    // score 0xFFFFFFFF: no alignment within k
+
+struct DevTraceJob {
+    u64 ref_off, q_off, trace_off, cigar_off;      // cigar_off: first word of this job's CIGAR slab
+    u32 n, m, lanes, words_per_lane;
+    u32 end_col, cigar_cap, out_index, pad;
+};
+struct DevTraceOut { u32 begin; u32 cigar_start; u32 cigar_len; u32 pad; };   // cigar_start relative to the slab
+
+// launch geometry for one alignment job shape
+struct AlignShape { u32 words_per_lane; u32 lanes_per_job; };
+AlignShape choose_align_shape(u32 m);
+u32 align_supported_max_query();
+
+// ------------------------------------------------------------------------------------------------ device launchers (flx_device.hip)
+struct KernelTimer;   // opaque, owned by the context
+
+struct DeviceApi {
+    // all return 0 or a hipError_t (non-zero)
+    static int build_peq(void* stream, const u8* d_seq, u64 len, u64* d_peq);
+    static int search(void* stream, const DevIndex& idx, const u8* d_seq, const u32* d_scheme, const DevSeed* d_seeds,
+                      u32 n_seeds, u32 max_hits_per_seed, DevFrame* d_stack, DevHit* d_hits, u32 hit_cap, u32* d_counters);
+    static int locate(void* stream, const DevIndex& idx, const u32* d_rows, u32 n, u32* d_out);
+    static int align(void* stream, const u8* d_text, const u64* d_peq, const DevAlignJob* d_jobs, u32 n_jobs, AlignShape shape,
+                     bool trace, u64* d_trace, DevAlignOut* d_out);
+    static int traceback(void* stream, const u8* d_text, const u8* d_query, const u64* d_trace, const DevTraceJob* d_jobs,
+                         u32 n_jobs, u32* d_cigar, DevTraceOut* d_out);
+};
+
+// ------------------------------------------------------------------------------------------------ host logic
+u64 ceil_div(u64 a, u64 b);
+u64 fp_aware_ceil(double v);
+int32_t saturate_i32(u64 v);
+u8 char_to_rank(char c);
+char rank_to_char(u8 r);
+void reverse_complement(const u8* in, u64 n, u8* out);
+
+struct PexTree {
+    std::vector<flx_pex_node> inner, leaves;
+    const flx_pex_node& root() const { return inner.empty() ? leaves[0] : inner[0]; }
+};
+PexTree build_pex_tree(u64 len, u64 k, u64 s, bool bottom_up);
+
+struct SearchDef { std::vector<u32> pi, l, u; };
+const std::vector<SearchDef>& optimum_scheme(u32 k);
+// expanded + packed (sch_pack) entries for all searches of optimum(0,k) at this length, `len` entries per search; empty if
+// the scheme cannot be expanded (len < number of parts)
+std::vector<u32> expanded_scheme(u32 k, u32 len);
+
+HostIndex* build_host_index(const u8* concat, const u64* lens, u32 n_refs);
+int save_host_index(const HostIndex& idx, const char* path);
+HostIndex* load_host_index(const char* path);
+
+}  // namespace flx

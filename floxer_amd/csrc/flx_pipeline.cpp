@@ -1,0 +1,907 @@
+// Host orchestration of the device path: seeding (K1/K2 + anchor selection, search.cpp:143-324), alignment batches
+// (K0/K3/K4/K5, alignment.cpp:83-181) and the level-synchronous PEX verification driver (verification.cpp:8-245) with
+// --threads 1 record order (parallelization.cpp:14-43, 230-276; output.cpp:49-108).
+#include <algorithm>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <numeric>
+#include <queue>
+#include <set>
+
+#include "flx_context.hpp"
+
+namespace flx {
+
+// ================================================================================================ buffers / context
+int DeviceBuffer::ensure(size_t bytes) {
+    if (bytes <= cap && ptr) return FLX_OK;
+    release();
+    size_t const want = std::max<size_t>(bytes + bytes / 4, 4096);
+    void* p = nullptr;
+    hipError_t e = hipMalloc(&p, want);
+    size_t got = want;
+    if (e != hipSuccess) { (void)hipGetLastError(); got = bytes; e = hipMalloc(&p, bytes); }   // retry without slack
+    if (e != hipSuccess) { set_error(std::string("hipMalloc of ") + std::to_string(bytes) + " bytes failed: " + hipGetErrorString(e)); return FLX_ERR_NO_DEVICE; }
+    ptr = p;
+    cap = got;
+    return FLX_OK;
+}
+void DeviceBuffer::release() {
+    if (ptr) (void)hipFree(ptr);
+    ptr = nullptr;
+    cap = 0;
+}
+
+}  // namespace flx
+
+using namespace flx;
+
+hipEvent_t flx_ctx::get_event() {
+    if (!event_pool.empty()) { hipEvent_t e = event_pool.back(); event_pool.pop_back(); return e; }
+    hipEvent_t e = nullptr;
+    (void)hipEventCreate(&e);
+    return e;
+}
+void flx_ctx::account(const char* name, u64 bytes, u64 units, hipEvent_t start, hipEvent_t stop) {
+    float ms = 0.f;
+    (void)hipEventElapsedTime(&ms, start, stop);
+    auto it = stats.find(name);
+    if (it == stats.end()) {
+        flx_kernel_stat s{};
+        strncpy(s.name, name, sizeof(s.name) - 1);
+        it = stats.emplace(name, s).first;
+        stat_order.push_back(name);
+    }
+    it->second.launches += 1;
+    it->second.device_ms += ms;
+    it->second.algorithmic_bytes += bytes;
+    it->second.work_units += units;
+}
+int flx_ctx::sync() {
+    FLX_HIP(hipStreamSynchronize(stream));
+    for (auto& p : pending) {
+        account(p.name.c_str(), p.bytes, p.units, p.start, p.stop);
+        event_pool.push_back(p.start);
+        event_pool.push_back(p.stop);
+    }
+    pending.clear();
+    return FLX_OK;
+}
+
+namespace flx {
+
+static int h2d(flx_ctx* ctx, DeviceBuffer& buf, const void* src, size_t bytes, size_t extra_zero_tail = 0) {
+    int rc = buf.ensure(bytes + extra_zero_tail + 16);
+    if (rc) return rc;
+    if (bytes) FLX_HIP(hipMemcpyAsync(buf.ptr, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+    if (extra_zero_tail) FLX_HIP(hipMemsetAsync((char*)buf.ptr + bytes, 0, extra_zero_tail, ctx->stream));
+    return FLX_OK;
+}
+static int d2h(flx_ctx* ctx, void* dst, const void* src, size_t bytes) {
+    if (bytes) FLX_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    return FLX_OK;
+}
+// upload a byte sequence with TEXT_PAD zero bytes in front and behind; returns pointer to element 0
+static int upload_padded(flx_ctx* ctx, DeviceBuffer& buf, const u8* src, u64 len, const u8** d_first) {
+    int rc = buf.ensure(len + 2 * TEXT_PAD + 16);
+    if (rc) return rc;
+    FLX_HIP(hipMemsetAsync(buf.ptr, 0, TEXT_PAD, ctx->stream));
+    if (len) FLX_HIP(hipMemcpyAsync((char*)buf.ptr + TEXT_PAD, src, len, hipMemcpyHostToDevice, ctx->stream));
+    FLX_HIP(hipMemsetAsync((char*)buf.ptr + TEXT_PAD + len, 0, TEXT_PAD + 16, ctx->stream));
+    *d_first = (const u8*)buf.ptr + TEXT_PAD;
+    return FLX_OK;
+}
+
+// ================================================================================================ seeding
+namespace {
+
+struct Group { u32 lb, len, errors; };
+
+bool anchor_better(u64 pos_a, u64 err_a, u64 pos_b, u64 err_b) {                         // search.cpp:38-44
+    u64 const d = pos_a < pos_b ? pos_b - pos_a : pos_a - pos_b;
+    return err_a <= err_b && d <= err_b - err_a;
+}
+
+constexpr u64 ERASED = ~0ull;
+struct RefAnchor { u64 pos; u64 errors; };
+
+// search.cpp:352-389 for one (seed, reference) bucket
+void erase_useless(std::vector<RefAnchor>& v) {
+    if (v.empty()) return;
+    std::sort(v.begin(), v.end(), [](RefAnchor const& a, RefAnchor const& b) { return a.pos < b.pos; });
+    for (size_t cur = 0; cur + 1 < v.size();) {
+        size_t other = cur + 1;
+        while (other < v.size() && anchor_better(v[cur].pos, v[cur].errors, v[other].pos, v[other].errors)) {
+            v[other].errors = ERASED;
+            ++other;
+        }
+        if (other < v.size() && anchor_better(v[other].pos, v[other].errors, v[cur].pos, v[cur].errors)) v[cur].errors = ERASED;
+        cur = other;
+    }
+    v.erase(std::remove_if(v.begin(), v.end(), [](RefAnchor const& a) { return a.errors == ERASED; }), v.end());
+}
+
+}  // namespace
+
+int search_seeds_device(flx_ctx* ctx, const u8* d_seq_pool_or_null, const u8* h_seq_pool, u64 pool_len, const flx_seed* seeds,
+                        u64 n_seeds, const flx_search_config& cfg, std::vector<HostAnchor>& anchors, std::vector<SeedStats>& stats,
+                        std::vector<DevHit>* raw_hits, u64 raw_max_hits) {
+    anchors.clear();
+    stats.assign(n_seeds, SeedStats{0, 0, 0, 0});
+    if (n_seeds == 0) return FLX_OK;
+    if (n_seeds >= (1ull << 31)) { set_error("too many seeds in one call"); return FLX_ERR_INVALID; }
+    HostIndex const& H = *ctx->hidx;
+
+    // ---- expanded schemes (search_scheme_cache, search.cpp:328-350) and DFS stack reservations
+    std::map<std::pair<u32, u32>, std::pair<u32, u32>> scheme_of;      // (len, k) -> (offset, searches)
+    std::vector<u32> scheme_table;
+    std::vector<DevSeed> dseeds(n_seeds);
+    u64 frames = 0;
+    for (u64 i = 0; i < n_seeds; ++i) {
+        flx_seed const& s = seeds[i];
+        if (s.num_errors > 3) { set_error("seed errors must be in [0,3] (floxer_cli.cpp:299)"); return FLX_ERR_INVALID; }
+        if (s.length == 0 || s.length > SCH_POS_MASK || s.seq_offset + s.length > pool_len) { set_error("seed outside the sequence pool"); return FLX_ERR_INVALID; }
+        auto key = std::make_pair(s.length, s.num_errors);
+        auto it = scheme_of.find(key);
+        if (it == scheme_of.end()) {
+            std::vector<u32> e = expanded_scheme(s.num_errors, s.length);
+            u32 const nsearch = e.empty() ? 0 : (u32)(e.size() / s.length);
+            it = scheme_of.emplace(key, std::make_pair((u32)scheme_table.size(), nsearch)).first;
+            scheme_table.insert(scheme_table.end(), e.begin(), e.end());
+        }
+        DevSeed& d = dseeds[i];
+        d.seq_off = s.seq_offset;
+        d.length = s.length;
+        d.scheme_off = it->second.first;
+        d.num_searches = it->second.second;
+        d.stack_frames = s.length + s.num_errors + 2;
+        d.stack_off = frames;
+        frames += d.stack_frames;
+    }
+    if (scheme_table.empty()) scheme_table.push_back(0);
+
+    int rc;
+    const u8* d_seq = d_seq_pool_or_null;
+    if (!d_seq) {
+        if ((rc = h2d(ctx, ctx->seq, h_seq_pool, pool_len, 64))) return rc;
+        d_seq = ctx->seq.as<u8>();
+    }
+    if ((rc = h2d(ctx, ctx->scheme, scheme_table.data(), scheme_table.size() * 4))) return rc;
+    if ((rc = h2d(ctx, ctx->seeds, dseeds.data(), dseeds.size() * sizeof(DevSeed)))) return rc;
+    if ((rc = ctx->stack.ensure(frames * sizeof(DevFrame)))) return rc;
+    if ((rc = ctx->counters.ensure(64))) return rc;
+
+    u32 const max_hits = raw_hits ? (u32)std::min<u64>(raw_max_hits, 0xFFFFFFF0u)
+                                  : (cfg.anchor_choice_strategy == FLX_CHOICE_FIRST_REPORTED
+                                         ? (u32)cfg.max_num_anchors_soft
+                                         : (u32)std::max(cfg.max_num_anchors_hard, cfg.max_num_anchors_hard + 1));
+    u64 hit_cap = std::max<u64>(n_seeds * 6, 4096);
+    u32 counters[4];
+    for (int attempt = 0;; ++attempt) {
+        if ((rc = ctx->hits.ensure(hit_cap * sizeof(DevHit)))) return rc;
+        FLX_HIP(hipMemsetAsync(ctx->counters.ptr, 0, 64, ctx->stream));
+        rc = timed_launch(ctx, "fm_search", 0, n_seeds, [&] {
+            return DeviceApi::search(ctx->stream, ctx->didx, d_seq, ctx->scheme.as<u32>(), ctx->seeds.as<DevSeed>(), (u32)n_seeds,
+                                     max_hits, ctx->stack.as<DevFrame>(), ctx->hits.as<DevHit>(), (u32)std::min<u64>(hit_cap, 0xFFFFFFFFu),
+                                     ctx->counters.as<u32>());
+        });
+        if (rc) return rc;
+        if ((rc = d2h(ctx, counters, ctx->counters.ptr, 16))) return rc;
+        if ((rc = ctx->sync())) return rc;
+        if (counters[1]) { set_error("fm_search: DFS stack reservation exceeded"); return FLX_ERR_INTERNAL; }
+        if (counters[0] <= hit_cap) break;
+        if (attempt >= 2) { set_error("fm_search: hit buffer could not be sized"); return FLX_ERR_INTERNAL; }
+        hit_cap = (u64)counters[0] + 1024;      // exact size is known now; run again
+    }
+    // fold the extension count into the kernel's accounting: 2 rank positions of one 128-byte block each
+    if (ctx->timing) {
+        auto it = ctx->stats.find("fm_search");
+        if (it != ctx->stats.end()) { it->second.algorithmic_bytes += (u64)counters[2] * 2 * sizeof(OccBlock); it->second.work_units += counters[2]; }
+    }
+    u32 const n_hits = counters[0];
+    std::vector<DevHit> hits(n_hits);
+    if ((rc = d2h(ctx, hits.data(), ctx->hits.ptr, (size_t)n_hits * sizeof(DevHit)))) return rc;
+    if ((rc = ctx->sync())) return rc;
+
+    // group by seed, keeping each seed's emission order (a lane's slots are reserved in increasing order)
+    std::vector<u32> first(n_seeds + 1, 0);
+    for (auto const& h : hits) first[h.seed + 1]++;
+    for (u64 i = 0; i < n_seeds; ++i) first[i + 1] += first[i];
+    std::vector<DevHit> by_seed(n_hits);
+    {
+        std::vector<u32> cursor(first.begin(), first.end() - 1);
+        for (auto const& h : hits) by_seed[cursor[h.seed]++] = h;
+    }
+    if (raw_hits) { *raw_hits = std::move(by_seed); return FLX_OK; }
+
+    // ---- hard cap, group order, anchor choice (search.cpp:190-302)
+    struct RowReq { u32 seed, errors, row; };
+    std::vector<RowReq> reqs;
+    std::vector<u64> total_raw(n_seeds, 0);
+    std::vector<u8> excluded(n_seeds, 0);
+    std::vector<Group> groups;
+    for (u64 si = 0; si < n_seeds; ++si) {
+        groups.clear();
+        u64 total = 0;
+        for (u32 h = first[si]; h < first[si + 1]; ++h) { groups.push_back(Group{by_seed[h].lb, by_seed[h].len, by_seed[h].errors}); total += by_seed[h].len; }
+        total_raw[si] = total;
+        if (total > cfg.max_num_anchors_hard && cfg.anchor_choice_strategy != FLX_CHOICE_FIRST_REPORTED) { excluded[si] = 1; continue; }
+        switch (cfg.anchor_group_order) {
+            case FLX_ORDER_COUNT_FIRST:
+                std::sort(groups.begin(), groups.end(), [](Group const& a, Group const& b) {
+                    if (a.len != b.len) return a.len < b.len;
+                    return a.errors < b.errors;
+                });
+                break;
+            case FLX_ORDER_ERRORS_FIRST:     // literally as written in search.cpp:215-222
+                std::sort(groups.begin(), groups.end(), [](Group const& a, Group const& b) {
+                    if (a.errors != b.errors) return a.len < b.len;
+                    return a.errors < b.errors;
+                });
+                break;
+            default: break;
+        }
+        u64 kept = 0;
+        if (cfg.anchor_choice_strategy == FLX_CHOICE_ROUND_ROBIN) {
+            std::set<size_t> remaining;
+            for (size_t g = 0; g < groups.size(); ++g) remaining.insert(g);
+            auto it = remaining.begin();
+            u64 round = 0;
+            while (kept != cfg.max_num_anchors_soft && !remaining.empty()) {
+                Group const& g = groups[*it];
+                reqs.push_back(RowReq{(u32)si, g.errors, (u32)(g.lb + round)});
+                ++kept;
+                auto prev = it;
+                ++it;
+                if (g.len == round + 1) remaining.erase(prev);
+                if (it == remaining.end()) { it = remaining.begin(); ++round; }
+            }
+        } else {
+            size_t gi = 0;
+            while (kept != cfg.max_num_anchors_soft && gi < groups.size()) {
+                Group const& g = groups[gi];
+                for (u32 r = 0; r < g.len; ++r) {
+                    reqs.push_back(RowReq{(u32)si, g.errors, g.lb + r});
+                    if (++kept == cfg.max_num_anchors_soft) break;
+                }
+                ++gi;
+            }
+        }
+    }
+
+    // ---- locate (search.cpp:253, 284) as one SA gather
+    std::vector<u32> rows(reqs.size()), textpos(reqs.size());
+    for (size_t i = 0; i < reqs.size(); ++i) rows[i] = reqs[i].row;
+    if (!reqs.empty()) {
+        if ((rc = h2d(ctx, ctx->rows, rows.data(), rows.size() * 4))) return rc;
+        if ((rc = ctx->rows_out.ensure(rows.size() * 4))) return rc;
+        rc = timed_launch(ctx, "fm_locate", rows.size() * 8, rows.size(), [&] {
+            return DeviceApi::locate(ctx->stream, ctx->didx, ctx->rows.as<u32>(), (u32)rows.size(), ctx->rows_out.as<u32>());
+        });
+        if (rc) return rc;
+        if ((rc = d2h(ctx, textpos.data(), ctx->rows_out.ptr, rows.size() * 4))) return rc;
+        if ((rc = ctx->sync())) return rc;
+    }
+
+    // ---- per seed: bucket per reference, erase useless anchors, flatten (search.cpp:78-100, 304-318)
+    size_t const nref = H.seq_len.size();
+    std::vector<std::vector<RefAnchor>> by_ref(nref);
+    size_t ri = 0;
+    for (u64 si = 0; si < n_seeds; ++si) {
+        if (excluded[si]) { stats[si] = SeedStats{0, 0, 0, 1}; continue; }
+        for (auto& v : by_ref) v.clear();
+        u32 raw = 0;
+        while (ri < reqs.size() && reqs[ri].seed == si) {
+            u64 const p = textpos[ri];
+            if (p >= H.n) { set_error("fm_locate returned a position outside the text"); return FLX_ERR_INTERNAL; }
+            size_t const s = std::upper_bound(H.seq_start.begin(), H.seq_start.end(), p) - H.seq_start.begin() - 1;
+            by_ref[s].push_back(RefAnchor{p - H.seq_start[s], reqs[ri].errors});
+            ++raw;
+            ++ri;
+        }
+        u32 useful = raw;
+        if (cfg.erase_useless_anchors) {
+            useful = 0;
+            for (auto& v : by_ref) { erase_useless(v); useful += (u32)v.size(); }
+        }
+        stats[si] = SeedStats{useful, raw, (u32)(total_raw[si] - raw), 0};
+        for (size_t r = 0; r < nref; ++r)
+            for (auto const& a : by_ref[r]) anchors.push_back(HostAnchor{(u32)si, seeds[si].pex_leaf_index, (u32)r, (u32)a.errors, a.pos});
+    }
+    return FLX_OK;
+}
+
+// ================================================================================================ alignment batches
+namespace {
+
+struct AlignRequest { u64 ref_off, q_off; u32 n, m, k; };
+
+u64 trace_slots(u32 n, u32 m, AlignShape sh) {
+    u32 const nw = (m + 63) / 64;
+    u64 const L = (nw + sh.words_per_lane - 1) / sh.words_per_lane;
+    return ((u64)n + L - 1) * L * sh.words_per_lane;
+}
+
+struct ShapeKey {
+    u32 w, g;
+    bool operator<(ShapeKey const& o) const { return w != o.w ? w < o.w : g < o.g; }
+};
+
+// score + end column for every request (no trace)
+int run_score_jobs(flx_ctx* ctx, const u8* d_text, const u64* d_peq, std::vector<AlignRequest> const& reqs,
+                   std::vector<DevAlignOut>& outs, const char* kernel_name) {
+    outs.assign(reqs.size(), DevAlignOut{0xFFFFFFFFu, 0});
+    if (reqs.empty()) return FLX_OK;
+    std::map<ShapeKey, std::vector<u32>> by_shape;
+    for (u32 i = 0; i < reqs.size(); ++i) {
+        AlignShape const sh = choose_align_shape(reqs[i].m);
+        if (sh.words_per_lane == 0) { set_error("query longer than the supported maximum"); return FLX_ERR_UNSUPPORTED; }
+        by_shape[ShapeKey{sh.words_per_lane, sh.lanes_per_job}].push_back(i);
+    }
+    std::vector<DevAlignJob> jobs;
+    jobs.reserve(reqs.size());
+    struct Launch { ShapeKey key; u32 first, count; u64 word_steps, bytes; };
+    std::vector<Launch> launches;
+    for (auto& kv : by_shape) {
+        auto& ids = kv.second;
+        // longest windows first so that the waves of one launch finish together
+        std::stable_sort(ids.begin(), ids.end(), [&](u32 a, u32 b) { return reqs[a].n > reqs[b].n; });
+        Launch l{kv.first, (u32)jobs.size(), (u32)ids.size(), 0, 0};
+        for (u32 id : ids) {
+            AlignRequest const& r = reqs[id];
+            jobs.push_back(DevAlignJob{r.ref_off, r.q_off, 0, r.n, r.m, r.k, id});
+            l.word_steps += (u64)r.n * ((r.m + 63) / 64);
+            l.bytes += (u64)r.n + r.m;
+        }
+        launches.push_back(l);
+    }
+    int rc;
+    if ((rc = h2d(ctx, ctx->jobs, jobs.data(), jobs.size() * sizeof(DevAlignJob)))) return rc;
+    if ((rc = ctx->job_out.ensure(reqs.size() * sizeof(DevAlignOut)))) return rc;
+    for (auto const& l : launches) {
+        rc = timed_launch(ctx, kernel_name, l.bytes, l.word_steps, [&] {
+            return DeviceApi::align(ctx->stream, d_text, d_peq, ctx->jobs.as<DevAlignJob>() + l.first, l.count,
+                                    AlignShape{l.key.w, l.key.g}, false, nullptr, ctx->job_out.as<DevAlignOut>());
+        });
+        if (rc) return rc;
+    }
+    if ((rc = d2h(ctx, outs.data(), ctx->job_out.ptr, reqs.size() * sizeof(DevAlignOut)))) return rc;
+    return ctx->sync();
+}
+
+struct TraceResult { bool exists = false; u32 nm = 0; u32 begin = 0; u64 cigar_off = 0; u32 cigar_len = 0; };
+
+// score, begin position and CIGAR for every request (alignment.cpp:147-180); CIGAR words appended to cigar_pool
+int run_trace_jobs(flx_ctx* ctx, const u8* d_text, const u8* d_query, const u64* d_peq, std::vector<AlignRequest> const& reqs,
+                   std::vector<TraceResult>& results, std::vector<u32>& cigar_pool) {
+    results.assign(reqs.size(), TraceResult{});
+    if (reqs.empty()) return FLX_OK;
+    std::vector<AlignShape> shapes(reqs.size());
+    std::vector<u64> slots(reqs.size());
+    u64 const budget_slots = std::max<u64>(ctx->trace_budget_bytes / 16, 1);
+    for (size_t i = 0; i < reqs.size(); ++i) {
+        shapes[i] = choose_align_shape(reqs[i].m);
+        if (shapes[i].words_per_lane == 0) { set_error("query longer than the supported maximum"); return FLX_ERR_UNSUPPORTED; }
+        slots[i] = trace_slots(reqs[i].n, reqs[i].m, shapes[i]);
+        if (slots[i] > budget_slots) { set_error("one alignment needs more trace memory than the configured budget (FLX_TRACE_ARENA_MB)"); return FLX_ERR_CAPACITY; }
+    }
+    int rc;
+    size_t next = 0;
+    while (next < reqs.size()) {
+        // ---- chunk of jobs whose trace planes fit the arena
+        size_t begin = next;
+        u64 used = 0;
+        while (next < reqs.size() && used + slots[next] <= budget_slots) { used += slots[next]; ++next; }
+        size_t const count = next - begin;
+        if ((rc = ctx->trace.ensure(used * 16 + 64))) return rc;
+
+        std::map<ShapeKey, std::vector<u32>> by_shape;
+        for (size_t i = begin; i < next; ++i) by_shape[ShapeKey{shapes[i].words_per_lane, shapes[i].lanes_per_job}].push_back((u32)i);
+        std::vector<DevAlignJob> jobs;
+        std::vector<u64> trace_off(count);
+        struct Launch { ShapeKey key; u32 first, count; u64 word_steps, bytes; };
+        std::vector<Launch> launches;
+        u64 off = 0;
+        for (auto& kv : by_shape) {
+            auto& ids = kv.second;
+            std::stable_sort(ids.begin(), ids.end(), [&](u32 a, u32 b) { return reqs[a].n > reqs[b].n; });
+            Launch l{kv.first, (u32)jobs.size(), (u32)ids.size(), 0, 0};
+            for (u32 id : ids) {
+                AlignRequest const& r = reqs[id];
+                trace_off[id - begin] = off;
+                jobs.push_back(DevAlignJob{r.ref_off, r.q_off, off, r.n, r.m, r.k, (u32)(id - begin)});
+                off += slots[id];
+                u64 const ws = (u64)r.n * ((r.m + 63) / 64);
+                l.word_steps += ws;
+                l.bytes += (u64)r.n + r.m + ws * 16;        // reference + query symbols read, 2 trace words written per word-step
+            }
+            launches.push_back(l);
+        }
+        if ((rc = h2d(ctx, ctx->jobs, jobs.data(), jobs.size() * sizeof(DevAlignJob)))) return rc;
+        if ((rc = ctx->job_out.ensure(count * sizeof(DevAlignOut)))) return rc;
+        for (auto const& l : launches) {
+            rc = timed_launch(ctx, "ed_align_trace", l.bytes, l.word_steps, [&] {
+                return DeviceApi::align(ctx->stream, d_text, d_peq, ctx->jobs.as<DevAlignJob>() + l.first, l.count,
+                                        AlignShape{l.key.w, l.key.g}, true, ctx->trace.as<u64>(), ctx->job_out.as<DevAlignOut>());
+            });
+            if (rc) return rc;
+        }
+        std::vector<DevAlignOut> outs(count);
+        if ((rc = d2h(ctx, outs.data(), ctx->job_out.ptr, count * sizeof(DevAlignOut)))) return rc;
+        if ((rc = ctx->sync())) return rc;
+
+        // ---- traceback for the jobs that have an alignment within k
+        std::vector<DevTraceJob> tjobs;
+        std::vector<u32> tjob_req;
+        u64 cigar_words = 0, path_steps = 0;
+        for (size_t c = 0; c < count; ++c) {
+            if (outs[c].score == 0xFFFFFFFFu) continue;
+            size_t const id = begin + c;
+            AlignRequest const& r = reqs[id];
+            AlignShape const sh = shapes[id];
+            u32 const nw = (r.m + 63) / 64;
+            u32 const L = (nw + sh.words_per_lane - 1) / sh.words_per_lane;
+            u32 const cap = 2 * outs[c].score + 2;      // runs <= 2*NM + 1
+            tjobs.push_back(DevTraceJob{r.ref_off, r.q_off, trace_off[c], cigar_words, r.n, r.m, L, sh.words_per_lane, outs[c].end_col,
+                                        cap, (u32)tjob_req.size(), 0});
+            tjob_req.push_back((u32)id);
+            cigar_words += cap;
+            path_steps += (u64)r.m + outs[c].score;
+        }
+        if (!tjobs.empty()) {
+            if ((rc = h2d(ctx, ctx->tjobs, tjobs.data(), tjobs.size() * sizeof(DevTraceJob)))) return rc;
+            if ((rc = ctx->tjob_out.ensure(tjobs.size() * sizeof(DevTraceOut)))) return rc;
+            if ((rc = ctx->cigar.ensure(cigar_words * 4 + 16))) return rc;
+            rc = timed_launch(ctx, "ed_traceback", path_steps * 18, path_steps, [&] {
+                return DeviceApi::traceback(ctx->stream, d_text, d_query, ctx->trace.as<u64>(), ctx->tjobs.as<DevTraceJob>(),
+                                            (u32)tjobs.size(), ctx->cigar.as<u32>(), ctx->tjob_out.as<DevTraceOut>());
+            });
+            if (rc) return rc;
+            std::vector<DevTraceOut> touts(tjobs.size());
+            std::vector<u32> cig(cigar_words);
+            if ((rc = d2h(ctx, touts.data(), ctx->tjob_out.ptr, touts.size() * sizeof(DevTraceOut)))) return rc;
+            if ((rc = d2h(ctx, cig.data(), ctx->cigar.ptr, cigar_words * 4))) return rc;
+            if ((rc = ctx->sync())) return rc;
+            for (size_t j = 0; j < tjobs.size(); ++j) {
+                if (touts[j].cigar_len == 0xFFFFFFFFu) { set_error("ed_traceback: CIGAR slab overflow"); return FLX_ERR_INTERNAL; }
+                TraceResult& res = results[tjob_req[j]];
+                res.exists = true;
+                res.nm = outs[tjob_req[j] - begin].score;
+                res.begin = touts[j].begin;
+                res.cigar_off = cigar_pool.size();
+                res.cigar_len = touts[j].cigar_len;
+                const u32* src = cig.data() + tjobs[j].cigar_off + touts[j].cigar_start;
+                cigar_pool.insert(cigar_pool.end(), src, src + touts[j].cigar_len);
+            }
+        }
+    }
+    return FLX_OK;
+}
+
+int build_peq(flx_ctx* ctx, const u8* d_seq, u64 len, DeviceBuffer& peq) {
+    u64 const n_words = len / 64 + 2;
+    int rc = peq.ensure(n_words * 6 * 8 + 64);
+    if (rc) return rc;
+    return timed_launch(ctx, "peq_build", len + n_words * 48, n_words, [&] { return DeviceApi::build_peq(ctx->stream, d_seq, len, peq.as<u64>()); });
+}
+
+int ensure_reversed_text(flx_ctx* ctx) {
+    if (ctx->text_rev_ready) return FLX_OK;
+    HostIndex const& H = *ctx->hidx;
+    std::vector<u8> rev(H.text.rbegin(), H.text.rend());
+    const u8* first = nullptr;
+    int rc = upload_padded(ctx, ctx->text_rev, rev.data(), rev.size(), &first);
+    if (rc) return rc;
+    if ((rc = ctx->sync())) return rc;
+    ctx->text_rev_ready = true;
+    return FLX_OK;
+}
+
+}  // namespace
+
+}  // namespace flx
+
+// ================================================================================================ C ABI: seams 1 and 2
+extern "C" int flx_search_seeds(flx_ctx* ctx, const uint8_t* seq_pool, uint64_t seq_pool_len, const flx_seed* seeds, uint64_t n_seeds,
+                                const flx_search_config* cfg, flx_anchor* out_anchors, uint64_t* n_anchors, flx_seed_stats* out_stats) {
+    if (!ctx || !cfg || !n_anchors || (n_seeds && (!seeds || !seq_pool))) { set_error("flx_search_seeds: null argument"); return FLX_ERR_INVALID; }
+    if (cfg->max_num_anchors_hard < cfg->max_num_anchors_soft) { set_error("max-anchors-hard must not be smaller than max-anchors-soft (floxer_cli.cpp:194)"); return FLX_ERR_INVALID; }
+    FLX_HIP(hipSetDevice(ctx->device));
+    std::vector<HostAnchor> anchors;
+    std::vector<SeedStats> stats;
+    int rc = search_seeds_device(ctx, nullptr, seq_pool, seq_pool_len, seeds, n_seeds, *cfg, anchors, stats, nullptr, 0);
+    if (rc) return rc;
+    uint64_t const cap = *n_anchors;
+    *n_anchors = anchors.size();
+    if (out_stats) for (uint64_t i = 0; i < n_seeds; ++i) out_stats[i] = flx_seed_stats{stats[i].useful, stats[i].raw, stats[i].excluded_soft, stats[i].fully_excluded};
+    if (anchors.size() > cap) { set_error("anchor buffer too small"); return FLX_ERR_CAPACITY; }
+    for (size_t i = 0; i < anchors.size(); ++i)
+        out_anchors[i] = flx_anchor{anchors[i].seed_index, anchors[i].leaf, anchors[i].ref_id, anchors[i].errors, anchors[i].pos};
+    return FLX_OK;
+}
+
+extern "C" int flx_search_groups(flx_ctx* ctx, const uint8_t* seq_pool, uint64_t seq_pool_len, const flx_seed* seeds, uint64_t n_seeds,
+                                 uint64_t max_hits_per_seed, flx_hit_group* out, uint64_t* n_out) {
+    if (!ctx || !n_out || (n_seeds && (!seeds || !seq_pool))) { set_error("flx_search_groups: null argument"); return FLX_ERR_INVALID; }
+    FLX_HIP(hipSetDevice(ctx->device));
+    std::vector<HostAnchor> anchors;
+    std::vector<SeedStats> stats;
+    std::vector<DevHit> hits;
+    flx_search_config cfg{};
+    int rc = search_seeds_device(ctx, nullptr, seq_pool, seq_pool_len, seeds, n_seeds, cfg, anchors, stats, &hits, max_hits_per_seed);
+    if (rc) return rc;
+    uint64_t const cap = *n_out;
+    *n_out = hits.size();
+    if (hits.size() > cap) { set_error("hit buffer too small"); return FLX_ERR_CAPACITY; }
+    for (size_t i = 0; i < hits.size(); ++i) out[i] = flx_hit_group{hits[i].seed, hits[i].lb, hits[i].len, hits[i].errors};
+    return FLX_OK;
+}
+
+extern "C" int flx_align_batch(flx_ctx* ctx, const uint8_t* ref_pool, uint64_t ref_pool_len, const uint8_t* query_pool,
+                               uint64_t query_pool_len, const flx_align_job* jobs, uint64_t n_jobs, flx_align_result* out,
+                               uint32_t* cigar_pool, uint64_t* cigar_pool_words) {
+    if (!ctx || (n_jobs && (!jobs || !out || !query_pool))) { set_error("flx_align_batch: null argument"); return FLX_ERR_INVALID; }
+    FLX_HIP(hipSetDevice(ctx->device));
+    if (n_jobs >= (1ull << 31)) { set_error("too many jobs in one call"); return FLX_ERR_INVALID; }
+    u64 const text_len = ref_pool ? ref_pool_len : ctx->hidx->n;
+    bool any_rev = false, any_trace = false;
+    for (uint64_t i = 0; i < n_jobs; ++i) {
+        flx_align_job const& j = jobs[i];
+        if (j.query_length == 0 || j.query_offset + j.query_length > query_pool_len || j.ref_offset + j.ref_length > text_len || j.mode > 2) {
+            set_error("flx_align_batch: job outside its pools"); return FLX_ERR_INVALID;
+        }
+        if (j.query_length > align_supported_max_query()) { set_error("query longer than the supported maximum"); return FLX_ERR_UNSUPPORTED; }
+        any_rev |= j.mode == FLX_MODE_WITHOUT_CIGAR;
+        any_trace |= j.mode == FLX_MODE_WITH_CIGAR;
+    }
+    int rc;
+    const u8* d_text = ctx->didx.text;
+    const u8* d_text_rev = nullptr;
+    std::vector<u8> tmp;
+    if (ref_pool) {
+        if ((rc = upload_padded(ctx, ctx->user_text, ref_pool, ref_pool_len, &d_text))) return rc;
+        if (any_rev) {
+            tmp.assign(ref_pool, ref_pool + ref_pool_len);
+            std::reverse(tmp.begin(), tmp.end());
+            if ((rc = upload_padded(ctx, ctx->user_text_rev, tmp.data(), tmp.size(), &d_text_rev))) return rc;
+            if ((rc = ctx->sync())) return rc;
+        }
+    } else if (any_rev) {
+        if ((rc = ensure_reversed_text(ctx))) return rc;
+        d_text_rev = ctx->text_rev.as<u8>() + TEXT_PAD;
+    }
+    if ((rc = h2d(ctx, ctx->seq, query_pool, query_pool_len, 64))) return rc;
+    if ((rc = build_peq(ctx, ctx->seq.as<u8>(), query_pool_len, ctx->peq))) return rc;
+    std::vector<u8> qrev;
+    if (any_rev) {
+        qrev.assign(query_pool, query_pool + query_pool_len);
+        std::reverse(qrev.begin(), qrev.end());
+        if ((rc = h2d(ctx, ctx->seq_rev, qrev.data(), qrev.size(), 64))) return rc;
+        if ((rc = build_peq(ctx, ctx->seq_rev.as<u8>(), query_pool_len, ctx->peq_rev))) return rc;
+    }
+    std::vector<AlignRequest> score_reqs, rev_reqs, trace_reqs;
+    std::vector<u32> score_ids, rev_ids, trace_ids;
+    for (uint64_t i = 0; i < n_jobs; ++i) {
+        flx_align_job const& j = jobs[i];
+        if (j.mode == FLX_MODE_EXISTS) { score_reqs.push_back({j.ref_offset, j.query_offset, j.ref_length, j.query_length, j.num_allowed_errors}); score_ids.push_back((u32)i); }
+        else if (j.mode == FLX_MODE_WITHOUT_CIGAR) {
+            rev_reqs.push_back({text_len - j.ref_offset - j.ref_length, query_pool_len - j.query_offset - j.query_length, j.ref_length, j.query_length, j.num_allowed_errors});
+            rev_ids.push_back((u32)i);
+        } else { trace_reqs.push_back({j.ref_offset, j.query_offset, j.ref_length, j.query_length, j.num_allowed_errors}); trace_ids.push_back((u32)i); }
+    }
+    for (uint64_t i = 0; i < n_jobs; ++i) out[i] = flx_align_result{0, 0, 0, 0, 0, 0};
+    std::vector<DevAlignOut> outs;
+    if ((rc = run_score_jobs(ctx, d_text, ctx->peq.as<u64>(), score_reqs, outs, "ed_align_exists"))) return rc;
+    for (size_t i = 0; i < outs.size(); ++i)
+        if (outs[i].score != 0xFFFFFFFFu) { out[score_ids[i]].exists = 1; out[score_ids[i]].num_errors = outs[i].score; }
+    if ((rc = run_score_jobs(ctx, d_text_rev, ctx->peq_rev.as<u64>(), rev_reqs, outs, "ed_align_exists"))) return rc;
+    for (size_t i = 0; i < outs.size(); ++i)
+        if (outs[i].score != 0xFFFFFFFFu) {
+            flx_align_result& r = out[rev_ids[i]];
+            r.exists = 1; r.num_errors = outs[i].score; r.begin = rev_reqs[i].n - outs[i].end_col;      // alignment.cpp:135
+        }
+    std::vector<TraceResult> tres;
+    std::vector<u32> cig;
+    if ((rc = run_trace_jobs(ctx, d_text, ctx->seq.as<u8>(), ctx->peq.as<u64>(), trace_reqs, tres, cig))) return rc;
+    uint64_t const cap = cigar_pool_words ? *cigar_pool_words : 0;
+    if (cigar_pool_words) *cigar_pool_words = cig.size();
+    if (any_trace && (!cigar_pool || cig.size() > cap)) { set_error("cigar pool too small"); return FLX_ERR_CAPACITY; }
+    if (!cig.empty()) memcpy(cigar_pool, cig.data(), cig.size() * 4);
+    for (size_t i = 0; i < tres.size(); ++i)
+        if (tres[i].exists) {
+            flx_align_result& r = out[trace_ids[i]];
+            r.exists = 1; r.num_errors = tres[i].nm; r.begin = tres[i].begin; r.cigar_offset = tres[i].cigar_off; r.cigar_length = tres[i].cigar_len;
+        }
+    return FLX_OK;
+}
+
+// ================================================================================================ seam 3: whole path
+namespace {
+
+struct half_open { u64 start, end; };
+half_open trim_both(half_open a, u64 amount) {                                                  // intervals.cpp:48-58
+    u64 const new_end = std::max(a.start + 1, amount > a.end ? 0 : a.end - amount);
+    u64 const new_start = std::min(new_end - 1, a.start + amount);
+    return {new_start, new_end};
+}
+struct VerifiedIntervals {                                                                     // intervals.cpp:84-127
+    std::vector<half_open> ivs;
+    bool contains(half_open t) const {
+        for (auto const& e : ivs) if (e.start <= t.start && e.end >= t.end) return true;      // equal or contains
+        return false;
+    }
+    void insert(half_open t) { if (!contains(t)) ivs.push_back(t); }
+};
+
+struct Span { u64 offset, length, extra; };
+Span compute_span(u64 anchor_pos, flx_pex_node const& node, u64 leaf_from, u64 reflen, double ratio) {   // verification.cpp:157-184
+    u64 const base = (u64)(node.to - node.from + 1) + 2ull * node.num_errors + 1;
+    u64 const extra = fp_aware_ceil(base * ratio);
+    i64 const start_signed = (i64)anchor_pos - (i64)(leaf_from - node.from) - (i64)node.num_errors - (i64)extra;
+    u64 const start = start_signed >= 0 ? (u64)start_signed : 0;
+    u64 const length = std::min(base + 2 * extra, reflen - start);
+    return {start, length, extra};
+}
+
+struct pr_task { int priority; int id; bool operator<(pr_task const& o) const { return priority < o.priority; } };
+// order in which one worker runs the verification packages of a read (BS::thread_pool's priority queue), parallelization.cpp:131-148
+std::vector<int> package_order(int n) {
+    std::priority_queue<pr_task> q;
+    for (int i = 0; i < n; ++i) q.push(pr_task{16383, i});
+    q.push(pr_task{-16384, -1});
+    std::vector<int> order;
+    while (!q.empty()) { pr_task t = q.top(); q.pop(); if (t.id < 0) break; order.push_back(t.id); }
+    return order;
+}
+
+struct ReadState {
+    u64 read_index;
+    u32 len, k;
+    u64 pool_off[2];            // forward, reverse complement
+    PexTree tree;
+    std::vector<u32> anchor_ids[2];
+};
+
+struct AnchorState {
+    u32 read;                   // index into kept reads
+    u8 orientation;
+    u32 leaf, ref_id;
+    u64 pos;
+    u32 node;                   // inner node under test
+    bool alive = true, at_root = false, wants_root = false;
+};
+
+}  // namespace
+
+struct flx_run {
+    std::vector<flx_record> records;
+    std::vector<u32> cigars;
+    std::vector<u8> skipped;
+};
+
+extern "C" void flx_params_default(flx_params* p) {
+    memset(p, 0, sizeof(*p));
+    p->query_error_probability = -1.0;
+    p->pex_seed_num_errors = 2;
+    p->search.max_num_anchors_hard = 500;
+    p->search.max_num_anchors_soft = 50;
+    p->search.anchor_group_order = FLX_ORDER_COUNT_FIRST;
+    p->search.anchor_choice_strategy = FLX_CHOICE_ROUND_ROBIN;
+    p->search.erase_useless_anchors = 1;
+    p->seed_sampling_step_size = 1;
+    p->extra_verification_ratio = 0.05;
+    p->num_anchors_per_verification_task = 3000;
+}
+
+extern "C" int flx_align_reads(flx_ctx* ctx, const flx_params* P, const uint8_t* read_pool, const uint64_t* read_offsets,
+                               uint64_t n_reads, flx_run** out) {
+    if (!ctx || !P || !out || (n_reads && (!read_pool || !read_offsets))) { set_error("flx_align_reads: null argument"); return FLX_ERR_INVALID; }
+    FLX_HIP(hipSetDevice(ctx->device));
+    if (P->query_error_probability < 0 && P->query_num_errors < P->pex_seed_num_errors) { set_error("query errors must be >= seed errors (floxer_cli.cpp:180)"); return FLX_ERR_INVALID; }
+    if (P->pex_seed_num_errors > 3 || P->seed_sampling_step_size == 0 || P->num_anchors_per_verification_task == 0) { set_error("invalid parameters"); return FLX_ERR_INVALID; }
+    if (P->search.max_num_anchors_hard < P->search.max_num_anchors_soft) { set_error("max-anchors-hard must not be smaller than max-anchors-soft"); return FLX_ERR_INVALID; }
+    HostIndex const& H = *ctx->hidx;
+    auto run = std::make_unique<flx_run>();
+    run->skipped.assign(n_reads, 0);
+
+    // ---- reads -> PEX trees, sequence pool (forward + reverse complement), seeds (parallelization.cpp:77-98)
+    std::vector<ReadState> reads;
+    std::vector<u8> pool;
+    std::vector<flx_seed> seeds;
+    struct SeedOwner { u32 read; u8 orientation; };
+    std::vector<SeedOwner> seed_owner;
+    for (u64 i = 0; i < n_reads; ++i) {
+        u64 const len = read_offsets[i + 1] - read_offsets[i];
+        if (len == 0 || len > 100000) { run->skipped[i] = 1; continue; }                       // input.cpp:95-110
+        u64 const k = P->query_error_probability >= 0 ? fp_aware_ceil(len * P->query_error_probability) : P->query_num_errors;
+        if (len <= k || k < P->pex_seed_num_errors) { run->skipped[i] = 1; continue; }         // input.cpp:115-129
+        if (len > align_supported_max_query()) { set_error("read longer than the supported maximum"); return FLX_ERR_UNSUPPORTED; }
+        ReadState rs;
+        rs.read_index = i;
+        rs.len = (u32)len;
+        rs.k = (u32)k;
+        rs.tree = build_pex_tree(len, k, P->pex_seed_num_errors, P->bottom_up_pex_tree_building != 0);
+        const u8* src = read_pool + read_offsets[i];
+        rs.pool_off[0] = pool.size();
+        pool.insert(pool.end(), src, src + len);
+        rs.pool_off[1] = pool.size();
+        pool.resize(pool.size() + len);
+        reverse_complement(src, len, pool.data() + rs.pool_off[1]);
+        for (int o = 0; o < 2; ++o)
+            for (u64 l = 0; l < rs.tree.leaves.size(); l += P->seed_sampling_step_size) {      // pex.cpp:258-277
+                flx_pex_node const& leaf = rs.tree.leaves[l];
+                seeds.push_back(flx_seed{rs.pool_off[o] + leaf.from, leaf.to - leaf.from + 1, leaf.num_errors, (u32)l, 0});
+                seed_owner.push_back(SeedOwner{(u32)reads.size(), (u8)o});
+            }
+        reads.push_back(std::move(rs));
+    }
+    for (u8 c : pool) if (c > 5) { set_error("read rank > 5"); return FLX_ERR_INVALID; }
+
+    int rc;
+    if ((rc = h2d(ctx, ctx->seq, pool.data(), pool.size(), 64))) return rc;
+    const u8* d_pool = ctx->seq.as<u8>();
+
+    // ---- seeding
+    std::vector<HostAnchor> anchors;
+    std::vector<SeedStats> sstats;
+    if ((rc = search_seeds_device(ctx, d_pool, pool.data(), pool.size(), seeds.data(), seeds.size(), P->search, anchors, sstats, nullptr, 0))) return rc;
+
+    std::vector<AnchorState> A(anchors.size());
+    for (size_t a = 0; a < anchors.size(); ++a) {
+        SeedOwner const so = seed_owner[anchors[a].seed_index];
+        A[a].read = so.read;
+        A[a].orientation = so.orientation;
+        A[a].leaf = anchors[a].leaf;
+        A[a].ref_id = anchors[a].ref_id;
+        A[a].pos = anchors[a].pos;
+        reads[so.read].anchor_ids[so.orientation].push_back((u32)a);
+    }
+
+    // ---- verification order of each read: packages (forward then reverse complement, <= N anchors each) in the order one
+    //      worker would run them (parallelization.cpp:14-43, 230)
+    std::vector<std::vector<u32>> exec_order(reads.size());
+    for (size_t r = 0; r < reads.size(); ++r) {
+        std::vector<std::pair<u32, u32>> pkgs;          // (first, count) into a concatenated list
+        std::vector<u32> concat;
+        for (int o = 0; o < 2; ++o) {
+            auto const& ids = reads[r].anchor_ids[o];
+            for (size_t i = 0; i < ids.size(); i += P->num_anchors_per_verification_task) {
+                u32 const cnt = (u32)std::min<size_t>(P->num_anchors_per_verification_task, ids.size() - i);
+                pkgs.emplace_back((u32)concat.size(), cnt);
+                concat.insert(concat.end(), ids.begin() + i, ids.begin() + i + cnt);
+            }
+        }
+        for (int pid : package_order((int)pkgs.size()))
+            for (u32 j = 0; j < pkgs[pid].second; ++j) exec_order[r].push_back(concat[pkgs[pid].first + j]);
+    }
+
+    // ---- Peq planes of the whole pool
+    if ((rc = build_peq(ctx, d_pool, pool.size(), ctx->peq))) return rc;
+    const u8* d_text = ctx->didx.text;
+
+    auto window_request = [&](AnchorState const& a, flx_pex_node const& node, double ratio, Span* span_out) {
+        ReadState const& rs = reads[a.read];
+        flx_pex_node const& leaf = rs.tree.leaves[a.leaf];
+        Span const sp = compute_span(a.pos, node, leaf.from, H.seq_len[a.ref_id], ratio);
+        if (span_out) *span_out = sp;
+        return AlignRequest{H.seq_start[a.ref_id] + sp.offset, rs.pool_off[a.orientation] + node.from, (u32)sp.length,
+                            node.to - node.from + 1, node.num_errors};
+    };
+
+    // ---- hierarchical verification, level-synchronous (verification.cpp:44-117): inner nodes only test existence and do
+    //      not depend on the interval cache, so all anchors climb together; an anchor stops at its first failing node.
+    for (auto& a : A) {
+        ReadState const& rs = reads[a.read];
+        flx_pex_node const& leaf = rs.tree.leaves[a.leaf];
+        if (P->direct_full_verification || leaf.parent_id == FLX_NULL_ID) { a.at_root = true; continue; }   // verification.cpp:23-42, 52-72
+        a.node = leaf.parent_id;
+        if (rs.tree.inner[a.node].parent_id == FLX_NULL_ID) a.at_root = true;
+    }
+    while (true) {
+        std::vector<AlignRequest> reqs;
+        std::vector<u32> req_anchor;
+        for (u32 ai = 0; ai < A.size(); ++ai) {
+            AnchorState& a = A[ai];
+            if (!a.alive || a.at_root) continue;
+            reqs.push_back(window_request(a, reads[a.read].tree.inner[a.node], 0.0, nullptr));
+            req_anchor.push_back(ai);
+        }
+        if (reqs.empty()) break;
+        std::vector<DevAlignOut> outs;
+        if ((rc = run_score_jobs(ctx, d_text, ctx->peq.as<u64>(), reqs, outs, "ed_align_exists"))) return rc;
+        for (size_t i = 0; i < outs.size(); ++i) {
+            AnchorState& a = A[req_anchor[i]];
+            if (outs[i].score == 0xFFFFFFFFu) { a.alive = false; continue; }
+            a.node = reads[a.read].tree.inner[a.node].parent_id;
+            if (reads[a.read].tree.inner[a.node].parent_id == FLX_NULL_ID) a.at_root = true;
+        }
+    }
+
+    // ---- interval pass in verification order (verification.cpp:45, 106-109, 119-136): decides which anchors align the root
+    std::vector<AlignRequest> root_reqs;
+    std::vector<u32> root_anchor;
+    std::vector<Span> root_spans;
+    for (size_t r = 0; r < reads.size(); ++r) {
+        std::vector<VerifiedIntervals> cache[2];
+        if (P->use_interval_optimization) { cache[0].resize(H.seq_len.size()); cache[1].resize(H.seq_len.size()); }
+        for (u32 ai : exec_order[r]) {
+            AnchorState& a = A[ai];
+            ReadState const& rs = reads[a.read];
+            Span sp;
+            AlignRequest const req = window_request(a, rs.tree.root(), P->extra_verification_ratio, &sp);
+            if (P->use_interval_optimization) {
+                auto& ivs = cache[a.orientation][a.ref_id];
+                if (ivs.contains(trim_both({sp.offset, sp.offset + sp.length}, sp.extra))) continue;   // root_was_already_verified
+                if (!(a.alive && a.at_root)) continue;
+                ivs.insert({sp.offset, sp.offset + sp.length});
+            } else if (!(a.alive && a.at_root)) continue;
+            a.wants_root = true;
+            root_reqs.push_back(req);
+            root_anchor.push_back(ai);
+            root_spans.push_back(sp);
+        }
+    }
+
+    // ---- root alignments (alignment.cpp:115-180)
+    struct RootAlignment { bool exists = false; u64 start = 0; u32 nm = 0; u64 cigar_off = 0; u32 cigar_len = 0; };
+    std::vector<RootAlignment> root_res(root_reqs.size());
+    std::vector<u32> cig;
+    if (P->without_cigar) {
+        if ((rc = ensure_reversed_text(ctx))) return rc;
+        std::vector<u8> qrev(pool.rbegin(), pool.rend());
+        if ((rc = h2d(ctx, ctx->seq_rev, qrev.data(), qrev.size(), 64))) return rc;
+        if ((rc = build_peq(ctx, ctx->seq_rev.as<u8>(), qrev.size(), ctx->peq_rev))) return rc;
+        std::vector<AlignRequest> rev(root_reqs.size());
+        for (size_t i = 0; i < rev.size(); ++i)
+            rev[i] = AlignRequest{H.n - root_reqs[i].ref_off - root_reqs[i].n, pool.size() - root_reqs[i].q_off - root_reqs[i].m,
+                                  root_reqs[i].n, root_reqs[i].m, root_reqs[i].k};
+        std::vector<DevAlignOut> outs;
+        if ((rc = run_score_jobs(ctx, ctx->text_rev.as<u8>() + TEXT_PAD, ctx->peq_rev.as<u64>(), rev, outs, "ed_align_exists"))) return rc;
+        for (size_t i = 0; i < outs.size(); ++i)
+            if (outs[i].score != 0xFFFFFFFFu) { root_res[i].exists = true; root_res[i].nm = outs[i].score; root_res[i].start = root_spans[i].offset + (root_reqs[i].n - outs[i].end_col); }
+    } else {
+        std::vector<TraceResult> tres;
+        if ((rc = run_trace_jobs(ctx, d_text, d_pool, ctx->peq.as<u64>(), root_reqs, tres, cig))) return rc;
+        for (size_t i = 0; i < tres.size(); ++i)
+            if (tres[i].exists) root_res[i] = RootAlignment{true, root_spans[i].offset + tres[i].begin, tres[i].nm, tres[i].cigar_off, tres[i].cigar_len};
+    }
+
+    // ---- records (alignment.cpp:37-79, output.cpp:49-108): per reference in id order, alignments in verification order
+    std::vector<std::vector<u32>> roots_of_read(reads.size());
+    for (u32 i = 0; i < root_anchor.size(); ++i) roots_of_read[A[root_anchor[i]].read].push_back(i);   // already in verification order
+    for (size_t r = 0; r < reads.size(); ++r) {
+        bool have_best = false;
+        u32 best = 0;
+        for (u32 i : roots_of_read[r]) if (root_res[i].exists && (!have_best || root_res[i].nm < best)) { best = root_res[i].nm; have_best = true; }
+        bool primary_written = false;
+        for (u32 ref = 0; ref < H.seq_len.size(); ++ref)
+            for (u32 i : roots_of_read[r]) {
+                AnchorState const& a = A[root_anchor[i]];
+                if (a.ref_id != ref || !root_res[i].exists) continue;
+                u32 flag = a.orientation ? 16u : 0u;
+                bool const primary = !primary_written && root_res[i].nm == best;
+                if (primary) primary_written = true;
+                else flag |= 256u;
+                flx_record rec{reads[r].read_index, flag, (int32_t)ref, saturate_i32(root_res[i].start), root_res[i].nm, run->cigars.size(),
+                               root_res[i].cigar_len, 0};
+                run->cigars.insert(run->cigars.end(), cig.begin() + root_res[i].cigar_off, cig.begin() + root_res[i].cigar_off + root_res[i].cigar_len);
+                run->records.push_back(rec);
+            }
+        if (!primary_written) run->records.push_back(flx_record{reads[r].read_index, 4u, -1, 0, 0, 0, 0, 0});
+    }
+    *out = run.release();
+    return FLX_OK;
+}
+
+extern "C" uint64_t flx_run_num_records(const flx_run* run) { return run ? run->records.size() : 0; }
+extern "C" uint64_t flx_run_num_cigar_words(const flx_run* run) { return run ? run->cigars.size() : 0; }
+extern "C" int flx_run_copy(const flx_run* run, flx_record* records, uint32_t* cigar_words, uint8_t* skipped) {
+    if (!run) { set_error("null run"); return FLX_ERR_INVALID; }
+    if (records && !run->records.empty()) memcpy(records, run->records.data(), run->records.size() * sizeof(flx_record));
+    if (cigar_words && !run->cigars.empty()) memcpy(cigar_words, run->cigars.data(), run->cigars.size() * 4);
+    if (skipped && !run->skipped.empty()) memcpy(skipped, run->skipped.data(), run->skipped.size());
+    return FLX_OK;
+}
+extern "C" void flx_run_free(flx_run* run) { delete run; }

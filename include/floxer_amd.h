@@ -1,0 +1,217 @@
+/*
+ * floxer_amd — C ABI of the MI355X-native seed-and-verify path (libfloxer_amd.so).
+ *
+ * floxer has no plugin/FFI interface; its hot path sits behind four C++ seams. Each entry point
+ * below replaces one of those seams and cites it. Conventions: caller owns every buffer; plain pointers + sizes; no
+ * exceptions cross the boundary — every function returns FLX_OK (0) or a negative flx_status and flx_last_error()
+ * describes the failure (the reference throws C++ exceptions that its task wrappers turn into a stop flag,
+ * parallelization.cpp:149-157). A flx_ctx owns one HIP device, one stream and its HBM-resident index; calls on
+ * different contexts are independent, calls on one context must not overlap.
+ *
+ * Sequences are rank sequences as the reference stores them (input.cpp:165-176): $=0 A=1 C=2 G=3 T=4 N/other=5.
+ * CIGARs are BAM words (len<<4|op) with ops I=1 D=2 '='=7 X=8 (extended CIGAR, alignment.cpp:178).
+ */
+#ifndef FLOXER_AMD_H
+#define FLOXER_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum flx_status {
+    FLX_OK = 0,
+    FLX_ERR_INVALID = -1,      /* bad argument / shape */
+    FLX_ERR_NO_DEVICE = -2,    /* no HIP device / HIP runtime failure: the product never falls back to a CPU path */
+    FLX_ERR_CAPACITY = -3,     /* caller buffer too small; required size is reported through the size out-parameter */
+    FLX_ERR_UNSUPPORTED = -4,
+    FLX_ERR_INTERNAL = -5,
+    FLX_ERR_IO = -6
+} flx_status;
+
+const char* flx_last_error(void);
+const char* flx_version(void);
+
+/* ------------------------------------------------------------------------------------------------ host-side arithmetic
+ * math.hpp:10-27, input.cpp:26-34 — must be bit-identical incl. the double arithmetic, so it is host code. */
+uint64_t flx_ceil_div(uint64_t a, uint64_t b);
+uint64_t flx_floating_point_error_aware_ceil(double value);
+int32_t flx_saturate_value_to_int32_max(uint64_t value);
+/* input.cpp:161-176 + ivs::reverse_complement_rank (input.cpp:132) */
+void flx_chars_to_rank_sequence(const char* chars, uint64_t n, uint8_t* out_ranks);
+void flx_reverse_complement_rank(const uint8_t* ranks, uint64_t n, uint8_t* out_ranks);
+
+/* ------------------------------------------------------------------------------------------------ PEX tree
+ * replaces pex::pex_tree::pex_tree (pex.hpp:57-126, pex.cpp:84-256). Nodes: inner nodes first (root = inner[0], or
+ * leaves[0] when the tree is a single node), then leaves. parent_id indexes the inner nodes; FLX_NULL_ID for the root. */
+#define FLX_NULL_ID 0xFFFFFFFFu
+typedef struct flx_pex_node {
+    uint32_t parent_id;
+    uint32_t from;        /* inclusive */
+    uint32_t to;          /* inclusive */
+    uint32_t num_errors;
+} flx_pex_node;
+int flx_pex_tree_build(uint64_t query_length, uint64_t query_num_errors, uint64_t leaf_max_num_errors, int bottom_up,
+                       flx_pex_node* nodes, uint64_t capacity, uint64_t* n_inner, uint64_t* n_leaves);
+
+/* ------------------------------------------------------------------------------------------------ index lifetime
+ * replaces fmindex(refs, sampling_rate=4, threads) / load_index / save_index (floxer.cpp:62-107, input.cpp:150-157,
+ * output.cpp:25-40). Built on the host; own versioned file format (not cereal-compatible). */
+typedef struct flx_index flx_index;
+int flx_index_build(const uint8_t* ref_ranks_concat, const uint64_t* ref_lens, uint32_t n_refs, flx_index** out);
+int flx_index_save(const flx_index* index, const char* path);
+int flx_index_load(const char* path, flx_index** out);
+void flx_index_free(flx_index* index);
+uint64_t flx_index_text_length(const flx_index* index);     /* concatenated text incl. sentinel padding */
+uint32_t flx_index_num_references(const flx_index* index);
+uint64_t flx_index_device_bytes(const flx_index* index);    /* HBM footprint once uploaded */
+/* test hooks: suffix array / BWT as built (text_length entries) */
+int flx_index_copy_sa(const flx_index* index, uint64_t* out);
+int flx_index_copy_bwt(const flx_index* index, int reversed, uint8_t* out);
+
+/* ------------------------------------------------------------------------------------------------ device context */
+typedef struct flx_ctx flx_ctx;
+int flx_ctx_create(int hip_device, const flx_index* index, flx_ctx** out);   /* uploads index + reference text to HBM */
+void flx_ctx_destroy(flx_ctx* ctx);
+/* use a caller-owned HIP stream (hipStream_t passed as void*) for all launches; NULL restores the context's own stream */
+int flx_ctx_set_stream(flx_ctx* ctx, void* hip_stream);
+
+/* ------------------------------------------------------------------------------------------------ seam 1: seeding
+ * replaces search_result searcher::search_seeds(std::vector<seed> const&) const (search.hpp:104-112, search.cpp:143-324) */
+typedef struct flx_seed {            /* search::seed, search.hpp:17-22 */
+    uint64_t seq_offset;             /* into the sequence pool */
+    uint32_t length;
+    uint32_t num_errors;             /* 0..3 */
+    uint32_t pex_leaf_index;
+    uint32_t reserved;
+} flx_seed;
+
+enum { FLX_ORDER_ERRORS_FIRST = 0, FLX_ORDER_COUNT_FIRST = 1, FLX_ORDER_NONE = 2 };             /* search.hpp:44-46 */
+enum { FLX_CHOICE_ROUND_ROBIN = 0, FLX_CHOICE_FULL_GROUPS = 1, FLX_CHOICE_FIRST_REPORTED = 2 };  /* search.hpp:50-52 */
+
+typedef struct flx_search_config {   /* search::search_config, search.hpp:56-62; defaults floxer_cli.hpp:52-56 */
+    uint64_t max_num_anchors_hard;
+    uint64_t max_num_anchors_soft;
+    int32_t anchor_group_order;
+    int32_t anchor_choice_strategy;
+    int32_t erase_useless_anchors;
+    int32_t reserved;
+} flx_search_config;
+
+typedef struct flx_anchor {          /* search::anchor_t, search.hpp:27-38 */
+    uint32_t seed_index;             /* index into the seeds array of the call */
+    uint32_t pex_leaf_index;
+    uint32_t reference_id;
+    uint32_t num_errors;
+    uint64_t reference_position;
+} flx_anchor;
+
+typedef struct flx_seed_stats {      /* search_result::anchors_of_seed, search.hpp:80-87 */
+    uint32_t num_kept_useful_anchors;
+    uint32_t num_kept_raw_anchors;
+    uint32_t num_excluded_raw_anchors_by_soft_cap;
+    uint32_t fully_excluded;
+} flx_seed_stats;
+
+/* anchors are written in search_result::anchor_iterator order (seed, reference, position; search.cpp:78-100).
+ * n_anchors: in = capacity, out = number produced (FLX_ERR_CAPACITY if larger than capacity). */
+int flx_search_seeds(flx_ctx* ctx, const uint8_t* seq_pool, uint64_t seq_pool_len, const flx_seed* seeds, uint64_t n_seeds,
+                     const flx_search_config* cfg, flx_anchor* out_anchors, uint64_t* n_anchors, flx_seed_stats* out_stats);
+
+/* raw search_ng21::search_n emission for the seeds (test hook for kernel K1): rows {seed_index, lb, len, errors} */
+typedef struct flx_hit_group { uint32_t seed_index, lb, len, num_errors; } flx_hit_group;
+int flx_search_groups(flx_ctx* ctx, const uint8_t* seq_pool, uint64_t seq_pool_len, const flx_seed* seeds, uint64_t n_seeds,
+                      uint64_t max_hits_per_seed, flx_hit_group* out, uint64_t* n_out);
+
+/* ------------------------------------------------------------------------------------------------ seam 2: alignment
+ * replaces alignment_result align(span<const u8> reference, span<const u8> query, alignment_config const&)
+ * (alignment.hpp:57-77, alignment.cpp:83-181), batched. */
+enum { FLX_MODE_EXISTS = 0, FLX_MODE_WITHOUT_CIGAR = 1, FLX_MODE_WITH_CIGAR = 2 };                /* alignment.hpp:53-55 */
+typedef struct flx_align_job {
+    uint64_t ref_offset;     /* into ref_pool, or into the context's reference text when ref_pool == NULL */
+    uint64_t query_offset;   /* into query_pool */
+    uint32_t ref_length;
+    uint32_t query_length;
+    uint32_t num_allowed_errors;
+    uint32_t mode;
+} flx_align_job;
+typedef struct flx_align_result {
+    uint32_t exists;         /* alignment_outcome::alignment_exists */
+    uint32_t num_errors;
+    uint64_t begin;          /* start in the given reference window (caller adds reference_span_offset) */
+    uint64_t cigar_offset;   /* into cigar_pool (words) */
+    uint32_t cigar_length;
+    uint32_t reserved;
+} flx_align_result;
+int flx_align_batch(flx_ctx* ctx, const uint8_t* ref_pool, uint64_t ref_pool_len, const uint8_t* query_pool,
+                    uint64_t query_pool_len, const flx_align_job* jobs, uint64_t n_jobs, flx_align_result* out,
+                    uint32_t* cigar_pool, uint64_t* cigar_pool_words /* in: capacity, out: used */);
+
+/* ------------------------------------------------------------------------------------------------ seam 3: whole path
+ * replaces parallelization::spawn_search_task + spawn_verification_task + query_verifier::verify +
+ * alignment_output::write_alignments_for_query (parallelization.cpp:45-293, verification.hpp:22-48, output.cpp:49-108)
+ * for a batch of reads, with --threads 1 record order. */
+typedef struct flx_params {          /* cli::command_line_input, floxer_cli.hpp:41-70 */
+    double query_error_probability;  /* < 0: use query_num_errors */
+    uint64_t query_num_errors;
+    uint64_t pex_seed_num_errors;    /* default 2 */
+    flx_search_config search;
+    uint64_t seed_sampling_step_size;/* default 1 */
+    int32_t bottom_up_pex_tree_building;
+    int32_t use_interval_optimization;
+    double extra_verification_ratio; /* default 0.05 */
+    int32_t direct_full_verification;
+    int32_t without_cigar;
+    uint64_t num_anchors_per_verification_task;   /* default 3000 */
+} flx_params;
+void flx_params_default(flx_params* p);
+
+typedef struct flx_record {          /* one SAM/BAM record, output.cpp:49-108 */
+    uint64_t read_index;
+    uint32_t flag;                   /* 0 / 16 / 256 / 272 / 4 */
+    int32_t reference_id;            /* -1 when unmapped */
+    int32_t position;                /* 0-based, saturated to int32 (output.cpp:85) */
+    uint32_t num_errors;             /* NM */
+    uint64_t cigar_offset;
+    uint32_t cigar_length;
+    uint32_t reserved;
+} flx_record;
+
+typedef struct flx_run flx_run;      /* result of one batch */
+/* Reads are given as one rank pool; read i = pool[offsets[i], offsets[i+1]). The read filters of input.cpp:95-129 apply
+ * (filtered reads produce no record and are flagged in the skipped array). */
+int flx_align_reads(flx_ctx* ctx, const flx_params* params, const uint8_t* read_pool, const uint64_t* read_offsets,
+                    uint64_t n_reads, flx_run** out);
+uint64_t flx_run_num_records(const flx_run* run);
+uint64_t flx_run_num_cigar_words(const flx_run* run);
+int flx_run_copy(const flx_run* run, flx_record* records, uint32_t* cigar_words, uint8_t* skipped);
+void flx_run_free(flx_run* run);
+
+/* ------------------------------------------------------------------------------------------------ measurement
+ * Per-kernel accounting (bench.py): when enabled every launch is bracketed with HIP events on the launch stream. */
+typedef struct flx_kernel_stat {
+    char name[32];
+    uint64_t launches;
+    double device_ms;            /* sum of hipEventElapsedTime over the launches */
+    uint64_t algorithmic_bytes;  /* bytes the algorithm must move, summed over launches */
+    uint64_t work_units;         /* word-steps / rank queries / locates, per kernel */
+} flx_kernel_stat;
+int flx_ctx_enable_kernel_timing(flx_ctx* ctx, int enable);
+int flx_ctx_reset_kernel_stats(flx_ctx* ctx);
+int flx_ctx_get_kernel_stats(flx_ctx* ctx, flx_kernel_stat* out, uint32_t* n /* in: capacity, out: count */);
+
+/* ------------------------------------------------------------------------------------------------ file boundary
+ * FASTA/FASTQ in (input.cpp:36-148), SAM/BAM out (output.cpp:49-108, 197-212) — used by the floxer-compatible CLI. */
+typedef struct flx_sam_writer flx_sam_writer;
+int flx_sam_open(const char* path /* .sam or .bam */, const char* const* ref_ids, const uint64_t* ref_lens, uint32_t n_refs,
+                 flx_sam_writer** out);
+int flx_sam_write(flx_sam_writer* w, const char* const* read_ids, const uint8_t* read_pool, const uint64_t* read_offsets,
+                  const char* const* quals, const flx_record* records, uint64_t n_records, const uint32_t* cigar_words);
+int flx_sam_close(flx_sam_writer* w);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FLOXER_AMD_H */

@@ -1,0 +1,279 @@
+"""Parity of the HIP path (through the C ABI) against the CPU oracle on the same seeded inputs, plus the reference's pins
+run through the GPU path. Bit-exact: integer / byte / index work only. Needs an MI355X (-m gpu)."""
+import os
+
+import numpy as np
+import pytest
+
+import floxer_amd as F
+from floxer_amd import simulate as S
+import oracle_lib as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def small_genome():
+    rng = np.random.default_rng(11)
+    refs = [rng.integers(1, 5, size=n).astype(np.uint8) for n in (60000, 20000, 777)]
+    refs[0][1000:1400] = 1                          # homopolymer: many hits, exercises the hard cap
+    refs[1][500:3500] = refs[0][20000:23000]        # 3 kb repeat across references
+    refs[2][100:110] = 5                            # a run of N
+    idx = F.fmindex(refs)
+    ctx = F.context(idx)
+    yield refs, idx, ctx, O.Index(refs)
+    ctx.close()
+
+
+# ---------------------------------------------------------------- K1: search_n emission
+def _make_seeds(rng, refs, n, kmax=3, lens=(8, 60)):
+    pool, seeds = [], []
+    for i in range(n):
+        r = refs[int(rng.integers(0, len(refs)))]
+        L = int(rng.integers(lens[0], lens[1]))
+        st = int(rng.integers(0, len(r) - L))
+        s = r[st:st + L].copy()
+        k = int(rng.integers(0, kmax + 1))
+        for _ in range(int(rng.integers(0, k + 2))):
+            p = int(rng.integers(0, len(s)))
+            kind = rng.integers(0, 3)
+            if kind == 0:
+                s[p] = rng.integers(1, 5)
+            elif kind == 1 and len(s) > 6:
+                s = np.delete(s, p)
+            else:
+                s = np.insert(s, p, rng.integers(1, 5))
+        if i % 17 == 0:
+            s = rng.integers(1, 5, size=len(s)).astype(np.uint8)     # unrelated seed
+        if i % 29 == 0:
+            s[:] = 1                                                   # poly-A seed (hits the 400-A run)
+        seeds.append((sum(len(x) for x in pool), len(s), k, i))
+        pool.append(s.astype(np.uint8))
+    return np.concatenate(pool), seeds
+
+
+def test_search_groups_match_oracle(small_genome):
+    refs, idx, ctx, oidx = small_genome
+    rng = np.random.default_rng(21)
+    pool, seeds = _make_seeds(rng, refs, 400)
+    sr = F.searcher(ctx)
+    for cap in (501, 50, 10 ** 6):
+        got = sr.search_groups(pool, seeds, max_hits=cap)
+        for i, (off, ln, k, _) in enumerate(seeds):
+            exp, _ctr = oidx.search_groups(pool[off:off + ln], k, n=cap)
+            mine = got[got[:, 0] == i][:, 1:]
+            assert mine.tolist() == exp.tolist(), (cap, i, ln, k)
+
+
+def test_search_short_and_degenerate_seeds(small_genome):
+    refs, idx, ctx, oidx = small_genome
+    sr = F.searcher(ctx)
+    pool = np.concatenate([refs[0][:40], np.array([5, 5, 5, 5, 5, 5], np.uint8), refs[2][95:115]])
+    seeds = [(0, 1, 0, 0), (0, 2, 1, 1), (0, 3, 2, 2), (0, 4, 3, 3), (0, 5, 3, 4), (40, 6, 1, 5), (46, 20, 2, 6), (3, 4, 2, 7)]
+    got = sr.search_groups(pool, seeds, max_hits=501)
+    for i, (off, ln, k, _) in enumerate(seeds):
+        exp, _ = oidx.search_groups(pool[off:off + ln], k, n=501)
+        assert got[got[:, 0] == i][:, 1:].tolist() == exp.tolist(), i
+
+
+# ---------------------------------------------------------------- seam 1: search_seeds
+@pytest.mark.parametrize("order,choice,erase", [("count_first", "round_robin", True), ("errors_first", "full_groups", True),
+                                                 ("none", "first_reported", False), ("count_first", "full_groups", False)])
+def test_search_seeds_match_oracle(small_genome, order, choice, erase):
+    refs, idx, ctx, oidx = small_genome
+    rng = np.random.default_rng(22)
+    pool, seeds = _make_seeds(rng, refs, 300, kmax=2, lens=(12, 50))
+    cfg = F.search_config(60, 7, order, choice, erase)
+    anchors, stats = F.searcher(ctx, cfg).search_seeds(pool, seeds)
+    exp_a, exp_s = oidx.search_seeds(pool, [(o, l, k, leaf) for o, l, k, leaf in seeds], hard=60, soft=7, order=F.ORDER[order],
+                                     choice=F.CHOICE[choice], erase=erase)
+    assert stats.tolist() == exp_s.tolist()
+    assert anchors.tolist() == exp_a.tolist()
+
+
+def test_search_seeds_reference_setup(pins):
+    s = pins["search_seeds_setup"]
+    idx = F.fmindex(s["references"])
+    ctx = F.context(idx)
+    cfg = F.search_config(10, 10, "count_first", "round_robin", True)
+    anchors, stats = F.searcher(ctx, cfg).search_seeds(s["query"], [tuple(x) for x in s["seeds"]])
+    assert stats[:, 3].sum() == 0                      # search_test.cpp:74
+    oa, os_ = O.Index(s["references"]).search_seeds(s["query"], s["seeds"], hard=10, soft=10)
+    assert anchors.tolist() == oa.tolist() and stats.tolist() == os_.tolist()
+    ctx.close()
+
+
+# ---------------------------------------------------------------- seam 2: align
+def _rand_align_case(rng, m, err, slack):
+    q = rng.integers(1, 5, size=m).astype(np.uint8)
+    core = []
+    for c in q:
+        r = rng.random()
+        if r < err / 3:
+            continue
+        if r < 2 * err / 3:
+            core.append(rng.integers(1, 5))
+        core.append(rng.integers(1, 5) if r < err else c)
+    left = int(rng.integers(0, slack + 1))
+    ref = np.concatenate([rng.integers(1, 5, size=left), np.array(core, dtype=np.uint8), rng.integers(1, 5, size=slack - left)]).astype(np.uint8)
+    return ref, q
+
+
+def test_align_pins_on_gpu(pins, small_genome):
+    _, _, ctx, _ = small_genome
+    a = pins["alignment"]
+    assert F.align(ctx, a["reference"], a["query"], a["k"]) == (a["nm"], a["start"], a["cigar"])
+    assert F.align(ctx, a["reference"], a["query"], 0, F.MODE_EXISTS) is None
+    assert F.align(ctx, a["reference"], a["query"], a["k"], F.MODE_WITHOUT_CIGAR)[:2] == (a["nm"], a["start"])
+    ref = O.chars_to_ranks("A" * 17 + "C" * 19 + "G" * 18 + "T" * 17)
+    rc = lambda s: O.revcomp(O.chars_to_ranks(s))
+    assert F.align(ctx, ref, O.chars_to_ranks("GGGGAAGGGGGG"), 2) == (2, 44, "4=2I6=")
+    assert F.align(ctx, ref, rc("GGGGAAGGGGGG"), 2) == (2, 26, "6=2I4=")
+    assert F.align(ctx, ref, O.chars_to_ranks("TTTTTTTTTTGG"), 2) == (2, 61, "10=2I")
+    assert F.align(ctx, ref, rc("TTTTTTTTTTGG"), 2) == (2, 7, "2I10=")
+    t = pins["try_align_node"]
+    w = np.array(t["reference"], np.uint8)[t["span"][0]: t["span"][0] + t["span"][1]]
+    q = np.array(t["query"], np.uint8)[t["node"][0]: t["node"][1] + 1]
+    r = F.align(ctx, w, q, t["node"][2])
+    assert r[0] == t["nm"] and t["span"][0] + r[1] == t["start"]
+
+
+def test_align_batch_random_all_shapes(small_genome):
+    """every (words per lane, lanes per job) shape of the kernel, all three modes, ragged sizes in one batch"""
+    _, _, ctx, _ = small_genome
+    rng = np.random.default_rng(31)
+    sizes = [1, 2, 7, 63, 64, 65, 127, 128, 129, 200, 256, 257, 300, 511, 513, 700, 1000, 1025, 1500, 2047, 2049, 3000, 4097,
+             5000, 6200, 8200, 12500, 16500, 26000]
+    refs, queries, jobs = [], [], []
+    ro = qo = 0
+    for m in sizes:
+        for rep in range(2):
+            err = 0.08 if rep == 0 else 0.3
+            ref, q = _rand_align_case(rng, m, err, int(rng.integers(0, m // 4 + 10)))
+            if m in (64, 200) and rep == 1:      # low complexity -> many ties
+                ref = (ref % 2 + 1).astype(np.uint8)
+                q = (q % 2 + 1).astype(np.uint8)
+            k = int(m * (0.15 if rep == 0 else 0.25)) + int(rng.integers(0, 3))
+            for mode in (0, 1, 2):
+                jobs.append((ro, len(ref), qo, len(q), k, mode))
+            refs.append(ref)
+            queries.append(q)
+            ro += len(ref)
+            qo += len(q)
+    rpool, qpool = np.concatenate(refs), np.concatenate(queries)
+    got = F.align_batch(ctx, qpool, jobs, reference_pool=rpool)
+    for (ro_, rl, qo_, ql, k, mode), g in zip(jobs, got):
+        exp = O.align(rpool[ro_:ro_ + rl], qpool[qo_:qo_ + ql], k, mode=mode, algo=1)
+        if mode == 0 and exp is not None:
+            exp = (exp[0], 0, "")
+        if mode == 1 and exp is not None:
+            exp = (exp[0], exp[1], "")
+        assert g == exp, (ql, rl, k, mode)
+
+
+def test_align_against_context_text(small_genome):
+    refs, idx, ctx, _ = small_genome
+    rng = np.random.default_rng(32)
+    q = refs[0][30000:30500].copy()
+    q[100] = q[100] % 4 + 1
+    q = np.delete(q, 300)
+    jobs = [(29950, 620, 0, len(q), 10, 2), (0, 600, 0, len(q), 10, 0)]
+    got = F.align_batch(ctx, q, jobs)
+    exp = O.align(refs[0][29950:29950 + 620], q, 10, mode=2)
+    assert got[0] == exp and got[1] is None
+
+
+# ---------------------------------------------------------------- seam 3: whole path
+def _records_equal(got, exp):
+    assert got.skipped.tolist() == exp.skipped.tolist()
+    assert got.records() == exp.records()
+
+
+@pytest.mark.parametrize("kw", [dict(), dict(interval_optimization=True), dict(without_cigar=True),
+                                dict(direct_full_verification=True, interval_optimization=True), dict(bottom_up_pex_tree=True),
+                                dict(seed_errors=1, anchor_choice_strategy="full_groups"), dict(seed_sampling_step_size=2, num_anchors_per_task=3)])
+def test_whole_path_matches_oracle(kw):
+    genome = S.make_genome(200000, 2, seed=5)
+    reads, names, truth = S.make_reads(genome, 24, 1200, 0.06, seed=6)
+    reads += [np.zeros(0, np.uint8), np.array([1, 2, 3], np.uint8), np.random.default_rng(1).integers(1, 5, size=900).astype(np.uint8)]
+    idx = F.fmindex(genome)
+    ctx = F.context(idx)
+    oidx = O.Index(genome)
+    p = F.params(error_probability=0.06, **kw)
+    got = F.aligner(ctx, p).align_reads(reads)
+    okw = dict(error_probability=0.06, seed_errors=kw.get("seed_errors", 2), choice=kw.get("anchor_choice_strategy", "round_robin"),
+               seed_step=kw.get("seed_sampling_step_size", 1), bottom_up=kw.get("bottom_up_pex_tree", False),
+               interval_opt=kw.get("interval_optimization", False), direct_full=kw.get("direct_full_verification", False),
+               anchors_per_task=kw.get("num_anchors_per_task", 3000), without_cigar=kw.get("without_cigar", False))
+    exp = oidx.run(reads, O.params(**okw), threads=4)
+    _records_equal(got, exp)
+    mapped = sum(1 for r in got.records() if not r[1] & 4 and not r[1] & 256)
+    assert mapped >= 20
+    ctx.close()
+
+
+@pytest.mark.parametrize("seed_errors", [0, 1])
+def test_whole_program_pins_on_gpu(pins, seed_errors):
+    """floxer_whole_program_via_cli_test.cpp:47-93 through the HIP path"""
+    from test_oracle_pins import _read_fasta, _read_fastq
+    g = os.path.join(os.path.dirname(__file__), "golden")
+    refs = _read_fasta(os.path.join(g, "reference.fasta"))
+    reads = _read_fastq(os.path.join(g, "queries.fastq"))
+    idx = F.fmindex([F.chars_to_rank_sequence(s) for _, s in refs])
+    ctx = F.context(idx)
+    p = F.params(query_errors=2, seed_errors=seed_errors, extra_verification_ratio=2.0, interval_optimization=True)
+    res = F.aligner(ctx, p).align_reads([F.chars_to_rank_sequence(s) for _, s, _ in reads])
+    wp = pins["whole_program"]
+    ids = [r[0] for r in reads]
+    recs = res.records()
+    assert {ids[r[0]] for r in recs} == set(wp["ids"])
+    for ridx, flag, ref_id, pos, nm, cig in recs:
+        name = ids[ridx]
+        if name in wp["unmapped"]:
+            assert flag == 4
+            continue
+        for ename, erev, pmin, pmax, enm, ecig in wp["expect"]:
+            if ename == name and erev == bool(flag & 16):
+                assert pmin <= pos <= pmax and nm == enm and cig == ecig
+    seen = {(ids[r[0]], bool(r[1] & 16)) for r in recs if not r[1] & 4}
+    for ename, erev, *_ in wp["expect"]:
+        assert (ename, erev) in seen
+    exp = O.Index([O.chars_to_ranks(s) for _, s in refs]).run([O.chars_to_ranks(s) for _, s, _ in reads],
+                                                               O.params(query_errors=2, seed_errors=seed_errors, extra_ratio=2.0, interval_opt=True))
+    assert recs == exp.records()
+    ctx.close()
+
+
+def test_full_size_reads_properties():
+    """BASELINE config-1 read shape (5 kb @ 8 %): size-independent properties + equality with the oracle on a sample."""
+    import re
+    genome = S.make_genome(1000000, 1, seed=9)
+    reads, names, truth = S.make_reads(genome, 48, 5000, 0.08, seed=10)
+    idx = F.fmindex(genome)
+    ctx = F.context(idx)
+    p = F.params(error_probability=0.08)
+    res = F.aligner(ctx, p).align_reads(reads)
+    recs = res.records()
+    g = genome[0]
+    for ridx, flag, ref_id, pos, nm, cig in recs:
+        if flag & 4:
+            continue
+        q = reads[ridx] if not flag & 16 else F.reverse_complement_rank(reads[ridx])
+        i, j, cost = 0, pos, 0
+        for ln, op in re.findall(r"(\d+)([=XID])", cig):
+            ln = int(ln)
+            if op == "=":
+                assert (q[i:i + ln] == g[j:j + ln]).all(); i += ln; j += ln
+            elif op == "X":
+                assert (q[i:i + ln] != g[j:j + ln]).all(); i += ln; j += ln; cost += ln
+            elif op == "I":
+                i += ln; cost += ln
+            else:
+                j += ln; cost += ln
+        assert i == len(q) and cost == nm and nm <= F.floating_point_error_aware_ceil(len(q) * 0.08)
+    for i, (c, start, rev) in enumerate(truth):
+        prim = [r for r in recs if r[0] == i and not r[1] & 256]
+        assert len(prim) == 1 and not prim[0][1] & 4 and abs(prim[0][3] - start) <= 400 and bool(prim[0][1] & 16) == rev
+    exp = O.Index(genome).run(reads[:12], O.params(error_probability=0.08), threads=8)
+    assert [r for r in recs if r[0] < 12] == exp.records()
+    ctx.close()
