@@ -173,11 +173,13 @@ class Index:
     def search_groups(self, seq, k, n=501):
         seq = as_u8(seq)
         cap = 4096
-        out = np.zeros((cap, 3), dtype=np.uint64)
-        ctr = np.zeros(2, dtype=np.uint64)
-        r = lib().orc_search_groups(self.h, _p(seq, u8p), len(seq), k, n, _p(out, u64p), cap, _p(ctr, u64p))
-        assert r >= 0
-        return out[:r].copy(), ctr
+        while True:
+            out = np.zeros((cap, 3), dtype=np.uint64)
+            ctr = np.zeros(2, dtype=np.uint64)
+            r = lib().orc_search_groups(self.h, _p(seq, u8p), len(seq), k, n, _p(out, u64p), cap, _p(ctr, u64p))
+            if r >= 0:
+                return out[:r].copy(), ctr
+            cap = -r
 
     def search_seeds(self, pool, seeds, hard=500, soft=50, order=1, choice=0, erase=True):
         """seeds: rows {offset, len, errors, leaf_index}. Returns (anchors rows {seed,leaf,ref,pos,err}, stats rows)."""
