@@ -1,0 +1,182 @@
+#!/usr/bin/env python3
+"""bench.py — reads/s of the seed-and-verify hot path on MI355X.
+
+One "step" = one pass of the whole path (PEX seeding -> FM search -> hierarchical verification -> root alignment with
+CIGAR -> records) over one batch of synthetic long reads that is already resident in HBM. Reads shard across ranks with
+no data-path collective (FM index replicated per GPU); the only exchange is the gather of alignment records to rank 0
+(RCCL) at the end of every step. Prints ONE JSON line on rank 0.
+
+  python bench.py --gpus 1 --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0      # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--reads-per-step", type=int, default=int(os.environ.get("FLX_BENCH_READS", 1024)), help="per GPU")
+    ap.add_argument("--genome", type=int, default=4_600_000, help="synthetic reference length (E. coli K-12 size)")
+    ap.add_argument("--read-length", type=int, default=5000)
+    ap.add_argument("--error-rate", type=float, default=0.08)
+    ap.add_argument("--interval-optimization", action="store_true")
+    ap.add_argument("--cpu-sample", type=int, default=int(os.environ.get("FLX_BENCH_CPU_SAMPLE", 256)))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    return ap.parse_args()
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", 0))
+    local_rank = int(os.environ.get("LOCAL_RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+
+    import torch
+    import torch.distributed as dist
+    import floxer_amd as F
+    from floxer_amd import simulate as S
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the product has no CPU path")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    # ---- workload: BASELINE.json configs[1] shape (4.6 Mb reference, 5 kb reads @ 8 %), synthetic (no network for E. coli)
+    genome = S.make_genome(args.genome, 1, seed=S.DEFAULT_SEED)
+    n_batches = args.steps + args.warmup
+    B = args.reads_per_step
+    batches = []
+    for b in range(n_batches):
+        # every rank and every step gets its own reads (weak scaling: per-GPU work is fixed)
+        reads, _, _ = S.make_reads(genome, B, args.read_length, args.error_rate, seed=S.DEFAULT_SEED + 1 + rank * 1000 + b)
+        batches.append(reads)
+
+    t0 = time.time()
+    index = F.fmindex(genome)                       # built on the host, not timed (floxer's stopwatch excludes it too, floxer.cpp:154)
+    index_s = time.time() - t0
+    ctx = F.context(index, device=local_rank)
+    p = F.params(error_probability=args.error_rate, interval_optimization=args.interval_optimization)
+    al = F.aligner(ctx, p)
+    resident = [F.resident_reads(ctx, r) for r in batches]       # inputs resident in HBM before the timed region
+
+    def gather_records(res):
+        """the path's one exchange step: variable-length gather of alignment records to rank 0 over RCCL"""
+        if world == 1:
+            return len(res.rows)
+        dev = torch.device("cuda", local_rank)
+        rows = torch.from_numpy(res.rows.astype(np.int64)).to(dev)
+        cig = torch.from_numpy(res.cigars.astype(np.int64)).to(dev)
+        counts = torch.tensor([rows.shape[0], cig.shape[0]], device=dev, dtype=torch.int64)
+        all_counts = [torch.zeros_like(counts) for _ in range(world)]
+        dist.all_gather(all_counts, counts)
+        max_r = int(max(c[0].item() for c in all_counts))
+        max_c = int(max(c[1].item() for c in all_counts))
+        pad_r = torch.zeros((max_r, 7), device=dev, dtype=torch.int64)
+        pad_r[: rows.shape[0]] = rows
+        pad_c = torch.zeros((max(max_c, 1),), device=dev, dtype=torch.int64)
+        pad_c[: cig.shape[0]] = cig
+        if rank == 0:
+            gr = [torch.zeros_like(pad_r) for _ in range(world)]
+            gc = [torch.zeros_like(pad_c) for _ in range(world)]
+            dist.gather(pad_r, gr, dst=0)
+            dist.gather(pad_c, gc, dst=0)
+            return sum(int(c[0].item()) for c in all_counts)
+        dist.gather(pad_r, None, dst=0)
+        dist.gather(pad_c, None, dst=0)
+        return 0
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for w in range(args.warmup):
+        gather_records(al.align_reads(resident[w]))
+    ctx.enable_kernel_timing(True)
+    ctx.reset_kernel_stats()
+
+    barrier()
+    t_start = time.perf_counter()
+    n_records = 0
+    for s in range(args.steps):
+        res = al.align_reads(resident[args.warmup + s])
+        n_records += gather_records(res)
+    barrier()
+    elapsed = time.perf_counter() - t_start
+    if world > 1:
+        t = torch.tensor([elapsed], device=torch.device("cuda", local_rank), dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    stats = ctx.kernel_stats()
+    ctx.enable_kernel_timing(False)
+
+    if rank == 0:
+        total_reads = B * args.steps * world
+        mean_len = float(np.mean([len(r) for r in batches[args.warmup]]))
+        value = total_reads / elapsed
+        # ---- roofline of the dominant kernel (largest summed device time in the timed region, HIP events on the launch stream)
+        dom = max(stats.items(), key=lambda kv: kv[1]["device_ms"]) if stats else None
+        roofline = None
+        kernels = {}
+        for name, st in stats.items():
+            ms = st["device_ms"]
+            kernels[name] = {"launches": st["launches"], "device_ms": round(ms, 3),
+                             "algorithmic_GB": round(st["algorithmic_bytes"] / 1e9, 4), "work_units": st["work_units"],
+                             "GBps": round(st["algorithmic_bytes"] / 1e6 / ms, 2) if ms > 0 else None}
+        if dom:
+            name, st = dom
+            achieved = st["algorithmic_bytes"] / 1e9 / (st["device_ms"] / 1e3)
+            roofline = {"kernel": name, "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                        "avg_launch_ms": round(st["device_ms"] / st["launches"], 4),
+                        "algorithmic_bytes_per_launch": int(st["algorithmic_bytes"] / st["launches"]), "launches": st["launches"]}
+
+        cpu = None
+        if not args.no_cpu_baseline:
+            sys.path.insert(0, os.path.join(ROOT, "tests"))
+            import oracle_lib as O                      # the checker, timed as the reported CPU baseline only
+            cores = os.cpu_count() or 1
+            sample = batches[args.warmup][: args.cpu_sample]
+            oidx = O.Index(genome)
+            ores = oidx.run(sample, O.params(error_probability=args.error_rate, interval_opt=args.interval_optimization), threads=cores)
+            cpu = {"value": round(len(sample) / ores.seconds, 3), "unit": "reads/s", "cores": cores, "kind": "port",
+                   "sample": f"first {len(sample)} reads of the first timed batch, oracle (CPU restatement of floxer's path), "
+                             f"{cores} threads, index build excluded"}
+        line = {
+            "metric": "aligned reads/sec, simulated long reads vs synthetic reference (seed-and-verify path, CIGAR)",
+            "value": round(value, 2), "unit": "reads/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u64", "data": "synthetic",
+            "config": {"workload": f"{args.genome / 1e6:.1f} Mb uniform random reference + {B} reads/GPU/step of {args.read_length} bp "
+                                   f"@ {args.error_rate:.0%} error (BASELINE.json configs[1] shape; E. coli itself is not available offline)",
+                       "reads_per_step_per_gpu": B, "mean_read_length": round(mean_len, 1), "cli_flags": "defaults (-s 2 -M 500 -m 50 "
+                       "-g count_first -y round_robin -v 0.05)" + (" -I" if args.interval_optimization else ""),
+                       "parallelism": f"read-sharded x{world}, index replicated"},
+            "gbases_per_s": round(value * mean_len / 1e9, 5), "records": n_records, "index_build_s": round(index_s, 2),
+            "roofline": roofline, "cpu_baseline": cpu, "kernels": kernels,
+        }
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -273,38 +273,67 @@ class RunResult:
         return [(int(r[0]), int(r[1]), int(r[2]), int(r[3]), int(r[4]), cigar_string(self.cigars[r[5]: r[5] + r[6]])) for r in self.rows]
 
 
+def _pool_and_offsets(reads):
+    if isinstance(reads, tuple):
+        pool, offs = as_u8(reads[0]), np.ascontiguousarray(reads[1], dtype=np.uint64)
+        n = len(offs) - 1
+    else:
+        rs = [as_u8(r) for r in reads]
+        n = len(rs)
+        offs = np.zeros(n + 1, dtype=np.uint64)
+        if n:
+            offs[1:] = np.cumsum([len(r) for r in rs])
+        pool = np.concatenate(rs) if n else np.zeros(0, np.uint8)
+    if len(pool) == 0:
+        pool = np.zeros(1, np.uint8)
+    return pool, offs, n
+
+
+class resident_reads:
+    """A batch of reads uploaded to HBM once (forward + reverse complement); align it any number of times."""
+
+    def __init__(self, ctx, reads):
+        pool, offs, n = _pool_and_offsets(reads)
+        self.ctx, self.n = ctx, n
+        self.h = C.c_void_p()
+        check(lib().flx_reads_upload(ctx.h, ptr(pool, u8p), ptr(offs, u64p), n, C.byref(self.h)))
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().flx_reads_free(self.h)
+            self.h = None
+
+    __del__ = close
+
+
+def _collect_run(run, n):
+    try:
+        nr = lib().flx_run_num_records(run)
+        nc = lib().flx_run_num_cigar_words(run)
+        recs = (capi.Record * max(1, nr))()
+        cig = np.zeros(max(1, nc), dtype=np.uint32)
+        skipped = np.zeros(max(1, n), dtype=np.uint8)
+        check(lib().flx_run_copy(run, recs, ptr(cig, u32p), ptr(skipped, u8p)))
+        raw = np.frombuffer(recs, dtype=np.dtype([("read", "<u8"), ("flag", "<u4"), ("ref", "<i4"), ("pos", "<i4"), ("nm", "<u4"),
+                                                  ("coff", "<u8"), ("clen", "<u4"), ("res", "<u4")]), count=nr)
+        rows = np.stack([raw["read"].astype(np.int64), raw["flag"].astype(np.int64), raw["ref"].astype(np.int64),
+                         raw["pos"].astype(np.int64), raw["nm"].astype(np.int64), raw["coff"].astype(np.int64),
+                         raw["clen"].astype(np.int64)], axis=1) if nr else np.zeros((0, 7), dtype=np.int64)
+    finally:
+        lib().flx_run_free(run)
+    return RunResult(rows, cig[:nc], skipped[:n])
+
+
 class aligner:
     def __init__(self, ctx, p):
         self.ctx, self.params = ctx, p
 
     def align_reads(self, reads):
-        """reads: list of rank arrays, or (pool, offsets). Returns RunResult with records in --threads 1 order."""
-        if isinstance(reads, tuple):
-            pool, offs = as_u8(reads[0]), np.ascontiguousarray(reads[1], dtype=np.uint64)
-            n = len(offs) - 1
-        else:
-            rs = [as_u8(r) for r in reads]
-            n = len(rs)
-            offs = np.zeros(n + 1, dtype=np.uint64)
-            if n:
-                offs[1:] = np.cumsum([len(r) for r in rs])
-            pool = np.concatenate(rs) if n else np.zeros(0, np.uint8)
-        if len(pool) == 0:
-            pool = np.zeros(1, np.uint8)
+        """reads: list of rank arrays, (pool, offsets), or resident_reads. Returns RunResult with records in --threads 1 order."""
         run = C.c_void_p()
+        if isinstance(reads, resident_reads):
+            check(lib().flx_align_reads_resident(self.ctx.h, C.byref(self.params), reads.h, C.byref(run)))
+            return _collect_run(run, reads.n)
+        pool, offs, n = _pool_and_offsets(reads)
         check(lib().flx_align_reads(self.ctx.h, C.byref(self.params), ptr(pool, u8p), ptr(offs, u64p), n, C.byref(run)))
-        try:
-            nr = lib().flx_run_num_records(run)
-            nc = lib().flx_run_num_cigar_words(run)
-            recs = (capi.Record * max(1, nr))()
-            cig = np.zeros(max(1, nc), dtype=np.uint32)
-            skipped = np.zeros(max(1, n), dtype=np.uint8)
-            check(lib().flx_run_copy(run, recs, ptr(cig, u32p), ptr(skipped, u8p)))
-            raw = np.frombuffer(recs, dtype=np.dtype([("read", "<u8"), ("flag", "<u4"), ("ref", "<i4"), ("pos", "<i4"), ("nm", "<u4"),
-                                                      ("coff", "<u8"), ("clen", "<u4"), ("res", "<u4")]), count=nr)
-            rows = np.stack([raw["read"].astype(np.int64), raw["flag"].astype(np.int64), raw["ref"].astype(np.int64),
-                             raw["pos"].astype(np.int64), raw["nm"].astype(np.int64), raw["coff"].astype(np.int64),
-                             raw["clen"].astype(np.int64)], axis=1) if nr else np.zeros((0, 7), dtype=np.int64)
-        finally:
-            lib().flx_run_free(run)
-        return RunResult(rows, cig[:nc], skipped[:n])
+        return _collect_run(run, n)

@@ -80,7 +80,8 @@ EXPORTED = [
     "flx_chars_to_rank_sequence", "flx_reverse_complement_rank", "flx_pex_tree_build", "flx_index_build", "flx_index_save",
     "flx_index_load", "flx_index_free", "flx_index_text_length", "flx_index_num_references", "flx_index_device_bytes",
     "flx_index_copy_sa", "flx_index_copy_bwt", "flx_ctx_create", "flx_ctx_destroy", "flx_ctx_set_stream", "flx_search_seeds",
-    "flx_search_groups", "flx_align_batch", "flx_params_default", "flx_align_reads", "flx_run_num_records",
+    "flx_search_groups", "flx_align_batch", "flx_params_default", "flx_align_reads", "flx_reads_upload", "flx_reads_free",
+    "flx_align_reads_resident", "flx_run_num_records",
     "flx_run_num_cigar_words", "flx_run_copy", "flx_run_free", "flx_ctx_enable_kernel_timing", "flx_ctx_reset_kernel_stats",
     "flx_ctx_get_kernel_stats", "flx_sam_open", "flx_sam_write", "flx_sam_close",
 ]
@@ -129,6 +130,9 @@ def lib():
                                   C.POINTER(AlignResult), u32p, u64p]
     L.flx_params_default.argtypes = [C.POINTER(Params)]
     L.flx_align_reads.argtypes = [C.c_void_p, C.POINTER(Params), u8p, u64p, C.c_uint64, C.POINTER(C.c_void_p)]
+    L.flx_reads_upload.argtypes = [C.c_void_p, u8p, u64p, C.c_uint64, C.POINTER(C.c_void_p)]
+    L.flx_reads_free.argtypes = [C.c_void_p]
+    L.flx_align_reads_resident.argtypes = [C.c_void_p, C.POINTER(Params), C.c_void_p, C.POINTER(C.c_void_p)]
     L.flx_run_num_records.restype = C.c_uint64
     L.flx_run_num_records.argtypes = [C.c_void_p]
     L.flx_run_num_cigar_words.restype = C.c_uint64

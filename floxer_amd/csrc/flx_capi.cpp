@@ -91,34 +91,44 @@ int flx_ctx_create(int hip_device, const flx_index* index, flx_ctx** out) {
     auto ctx = std::make_unique<flx_ctx>();
     ctx->device = hip_device;
     ctx->hidx = index->host;
-    FLX_HIP(hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking));
-    ctx->stream = ctx->own_stream;
+    size_t n_lanes = 4;
+    if (const char* env = getenv("FLX_LANES")) { size_t const v = strtoull(env, nullptr, 10); if (v >= 1 && v <= 16) n_lanes = v; }
+    for (size_t l = 0; l < n_lanes; ++l) {
+        auto lane = std::make_unique<Lane>();
+        lane->ctx = ctx.get();
+        lane->id = (int)l;
+        FLX_HIP(hipStreamCreateWithFlags(&lane->own_stream, hipStreamNonBlocking));
+        lane->stream = lane->own_stream;
+        ctx->lanes.push_back(std::move(lane));
+    }
+    hipStream_t const s0 = ctx->lanes[0]->stream;
     HostIndex const& H = *index->host;
     int rc;
     auto up = [&](DeviceBuffer& b, const void* src, size_t bytes) -> int {
         if ((rc = b.ensure(bytes))) return rc;
-        FLX_HIP(hipMemcpyAsync(b.ptr, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+        FLX_HIP(hipMemcpyAsync(b.ptr, src, bytes, hipMemcpyHostToDevice, s0));
         return FLX_OK;
     };
     if ((rc = up(ctx->occ0, H.occ[0].data(), H.occ[0].size() * sizeof(OccBlock)))) return rc;
     if ((rc = up(ctx->occ1, H.occ[1].data(), H.occ[1].size() * sizeof(OccBlock)))) return rc;
     if ((rc = up(ctx->sa, H.sa.data(), H.sa.size() * 4))) return rc;
     if ((rc = ctx->text.ensure(H.n + 2 * TEXT_PAD + 16))) return rc;
-    FLX_HIP(hipMemsetAsync(ctx->text.ptr, 0, ctx->text.cap, ctx->stream));
-    FLX_HIP(hipMemcpyAsync((char*)ctx->text.ptr + TEXT_PAD, H.text.data(), H.n, hipMemcpyHostToDevice, ctx->stream));
-    FLX_HIP(hipStreamSynchronize(ctx->stream));
+    FLX_HIP(hipMemsetAsync(ctx->text.ptr, 0, ctx->text.cap, s0));
+    FLX_HIP(hipMemcpyAsync((char*)ctx->text.ptr + TEXT_PAD, H.text.data(), H.n, hipMemcpyHostToDevice, s0));
+    FLX_HIP(hipStreamSynchronize(s0));
     ctx->didx.occ[0] = ctx->occ0.as<OccBlock>();
     ctx->didx.occ[1] = ctx->occ1.as<OccBlock>();
     ctx->didx.sa = ctx->sa.as<u32>();
     ctx->didx.text = ctx->text.as<u8>() + TEXT_PAD;
     for (int c = 0; c < 7; ++c) ctx->didx.C[c] = (u32)H.C[c];
     ctx->didx.n = (u32)H.n;
-    // trace arena budget: FLX_TRACE_ARENA_MB, default 40% of the free HBM (288 GB parts: ~100 GB), at least 256 MB
+    // trace arena budget: FLX_TRACE_ARENA_MB (whole context), default 40% of the free HBM, at least 256 MB; split over the lanes
     size_t free_b = 0, total_b = 0;
     FLX_HIP(hipMemGetInfo(&free_b, &total_b));
     size_t budget = free_b / 10 * 4;
     if (const char* env = getenv("FLX_TRACE_ARENA_MB")) { size_t const mb = strtoull(env, nullptr, 10); if (mb) budget = mb << 20; }
-    ctx->trace_budget_bytes = std::max<size_t>(budget, (size_t)256 << 20);
+    budget = std::max<size_t>(budget, (size_t)256 << 20);
+    for (auto& lane : ctx->lanes) lane->trace_budget_bytes = std::max<size_t>(budget / n_lanes, (size_t)128 << 20);
     *out = ctx.release();
     return FLX_OK;
 }
@@ -126,44 +136,42 @@ int flx_ctx_create(int hip_device, const flx_index* index, flx_ctx** out) {
 void flx_ctx_destroy(flx_ctx* ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
-    (void)hipStreamSynchronize(ctx->stream);
-    for (auto& p : ctx->pending) { (void)hipEventDestroy(p.start); (void)hipEventDestroy(p.stop); }
-    for (auto e : ctx->event_pool) (void)hipEventDestroy(e);
-    for (DeviceBuffer* b : {&ctx->occ0, &ctx->occ1, &ctx->sa, &ctx->text, &ctx->text_rev, &ctx->seq, &ctx->seq_rev, &ctx->peq, &ctx->peq_rev,
-                            &ctx->scheme, &ctx->seeds, &ctx->stack, &ctx->hits, &ctx->counters, &ctx->rows, &ctx->rows_out, &ctx->jobs,
-                            &ctx->job_out, &ctx->trace, &ctx->tjobs, &ctx->tjob_out, &ctx->cigar, &ctx->user_text, &ctx->user_text_rev})
-        b->release();
-    if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
+    for (auto& lane : ctx->lanes) { (void)hipStreamSynchronize(lane->stream); lane->release_all(); }
+    for (DeviceBuffer* b : {&ctx->occ0, &ctx->occ1, &ctx->sa, &ctx->text, &ctx->text_rev}) b->release();
     delete ctx;
 }
 
 int flx_ctx_set_stream(flx_ctx* ctx, void* hip_stream) {
     if (!ctx) { set_error("null context"); return FLX_ERR_INVALID; }
-    int rc = ctx->sync();
+    int rc = ctx->sync_all();
     if (rc) return rc;
-    ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+    Lane* l0 = ctx->lane0();
+    l0->stream = hip_stream ? (hipStream_t)hip_stream : l0->own_stream;
+    ctx->external_stream = hip_stream != nullptr;      // with a caller-owned stream every launch goes to that stream only
     return FLX_OK;
 }
 
 int flx_ctx_enable_kernel_timing(flx_ctx* ctx, int enable) {
     if (!ctx) { set_error("null context"); return FLX_ERR_INVALID; }
-    int rc = ctx->sync();
+    int rc = ctx->sync_all();
     if (rc) return rc;
     ctx->timing = enable != 0;
     return FLX_OK;
 }
 int flx_ctx_reset_kernel_stats(flx_ctx* ctx) {
     if (!ctx) { set_error("null context"); return FLX_ERR_INVALID; }
-    int rc = ctx->sync();
+    int rc = ctx->sync_all();
     if (rc) return rc;
+    std::lock_guard<std::mutex> g(ctx->mu);
     ctx->stats.clear();
     ctx->stat_order.clear();
     return FLX_OK;
 }
 int flx_ctx_get_kernel_stats(flx_ctx* ctx, flx_kernel_stat* out, uint32_t* n) {
     if (!ctx || !n) { set_error("null argument"); return FLX_ERR_INVALID; }
-    int rc = ctx->sync();
+    int rc = ctx->sync_all();
     if (rc) return rc;
+    std::lock_guard<std::mutex> g(ctx->mu);
     uint32_t const cap = *n;
     *n = (uint32_t)ctx->stat_order.size();
     if (ctx->stat_order.size() > cap || (!out && cap)) { set_error("stat buffer too small"); return FLX_ERR_CAPACITY; }

@@ -4,6 +4,8 @@
 #include <hip/hip_runtime.h>
 
 #include <map>
+#include <memory>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -34,45 +36,61 @@ struct PendingTiming { std::string name; hipEvent_t start, stop; u64 bytes, unit
 
 struct flx_index { flx::HostIndex* host = nullptr; };
 
+struct flx_ctx;
+
+namespace flx {
+// One execution lane: a HIP stream with its own grow-only workspaces. A context runs the slices of a read batch on several
+// lanes concurrently (one host thread each) so that the host-side phases of one slice overlap the kernels of the others.
+struct Lane {
+    flx_ctx* ctx = nullptr;
+    int id = 0;
+    hipStream_t own_stream = nullptr, stream = nullptr;
+    DeviceBuffer seq, seq_rev, peq, peq_rev, scheme, seeds, stack, hits, counters, rows, rows_out;
+    DeviceBuffer jobs, job_out, trace, tjobs, tjob_out, cigar, user_text, user_text_rev;
+    size_t trace_budget_bytes = 0;
+    std::vector<PendingTiming> pending;
+    std::vector<hipEvent_t> event_pool;
+    int sync();                      // stream synchronize + fold pending timings into the context's statistics
+    hipEvent_t get_event();
+    void release_all();
+};
+}  // namespace flx
+
 struct flx_ctx {
     int device = 0;
-    hipStream_t own_stream = nullptr, stream = nullptr;
     const flx::HostIndex* hidx = nullptr;
     flx::DevIndex didx{};
     flx::DeviceBuffer occ0, occ1, sa, text, text_rev;
     bool text_rev_ready = false;
-    // workspaces
-    flx::DeviceBuffer seq, seq_rev, peq, peq_rev, scheme, seeds, stack, hits, counters, rows, rows_out;
-    flx::DeviceBuffer jobs, job_out, trace, tjobs, tjob_out, cigar, user_text, user_text_rev;
-    size_t trace_budget_bytes = 0;
+    std::mutex mu;                   // guards text_rev upload and the statistics
+    std::vector<std::unique_ptr<flx::Lane>> lanes;
+    bool external_stream = false;    // a caller-owned stream is installed on lane 0: run on that lane only
     // accounting
     bool timing = false;
-    std::vector<flx::PendingTiming> pending;
-    std::vector<hipEvent_t> event_pool;
     std::map<std::string, flx_kernel_stat> stats;
     std::vector<std::string> stat_order;
 
-    int sync();                      // stream synchronize + fold pending timings
-    void account(const char* name, flx::u64 bytes, flx::u64 units, hipEvent_t start, hipEvent_t stop);
-    hipEvent_t get_event();
+    flx::Lane* lane0() { return lanes[0].get(); }
+    int sync_all();
+    void account(const char* name, flx::u64 bytes, flx::u64 units, hipEvent_t start, hipEvent_t stop);   // caller holds mu
 };
 
 namespace flx {
 
 // brackets a launch with events when timing is enabled
 template <class F>
-int timed_launch(flx_ctx* ctx, const char* name, u64 bytes, u64 units, F&& launch) {
-    if (!ctx->timing) {
+int timed_launch(Lane* lane, const char* name, u64 bytes, u64 units, F&& launch) {
+    if (!lane->ctx->timing) {
         int const rc = launch();
         if (rc != 0) { set_error(std::string(name) + ": launch failed: " + hipGetErrorString((hipError_t)rc)); return FLX_ERR_NO_DEVICE; }
         return FLX_OK;
     }
-    hipEvent_t const a = ctx->get_event(), b = ctx->get_event();
-    FLX_HIP(hipEventRecord(a, ctx->stream));
+    hipEvent_t const a = lane->get_event(), b = lane->get_event();
+    FLX_HIP(hipEventRecord(a, lane->stream));
     int const rc = launch();
-    FLX_HIP(hipEventRecord(b, ctx->stream));
+    FLX_HIP(hipEventRecord(b, lane->stream));
     if (rc != 0) { set_error(std::string(name) + ": launch failed: " + hipGetErrorString((hipError_t)rc)); return FLX_ERR_NO_DEVICE; }
-    ctx->pending.push_back(PendingTiming{name, a, b, bytes, units});
+    lane->pending.push_back(PendingTiming{name, a, b, bytes, units});
     return FLX_OK;
 }
 
@@ -80,7 +98,7 @@ int timed_launch(flx_ctx* ctx, const char* name, u64 bytes, u64 units, F&& launc
 struct HostAnchor { u32 seed_index, leaf, ref_id, errors; u64 pos; };
 struct SeedStats { u32 useful, raw, excluded_soft, fully_excluded; };
 
-int search_seeds_device(flx_ctx* ctx, const u8* d_seq_pool_or_null, const u8* h_seq_pool, u64 pool_len, const flx_seed* seeds,
+int search_seeds_device(Lane* lane, const u8* d_seq_pool_or_null, const u8* h_seq_pool, u64 pool_len, const flx_seed* seeds,
                         u64 n_seeds, const flx_search_config& cfg, std::vector<HostAnchor>& anchors, std::vector<SeedStats>& stats,
                         std::vector<DevHit>* raw_hits, u64 raw_max_hits);
 

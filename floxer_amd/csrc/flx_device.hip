@@ -424,10 +424,10 @@ static int launch_align(hipStream_t s, const u8* d_text, const u64* d_peq, const
     u32 const blocks = (n_jobs + jobs_per_wave - 1) / jobs_per_wave;
     size_t const lds = (size_t)6 * 64 * W * sizeof(u64);
     if (trace) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&ed_align_kernel<W, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ed_align_kernel<W, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL((ed_align_kernel<W, true>), dim3(blocks), dim3(64), lds, s, d_text, d_peq, d_jobs, n_jobs, log2_g, d_trace, d_out);
     } else {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&ed_align_kernel<W, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ed_align_kernel<W, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL((ed_align_kernel<W, false>), dim3(blocks), dim3(64), lds, s, d_text, d_peq, d_jobs, n_jobs, log2_g, d_trace, d_out);
     }
     return (int)hipGetLastError();

@@ -2,6 +2,8 @@
 // (K0/K3/K4/K5, alignment.cpp:83-181) and the level-synchronous PEX verification driver (verification.cpp:8-245) with
 // --threads 1 record order (parallelization.cpp:14-43, 230-276; output.cpp:49-108).
 #include <algorithm>
+#include <chrono>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <map>
@@ -9,6 +11,7 @@
 #include <numeric>
 #include <queue>
 #include <set>
+#include <thread>
 
 #include "flx_context.hpp"
 
@@ -38,20 +41,55 @@ void DeviceBuffer::release() {
 
 using namespace flx;
 
-hipEvent_t flx_ctx::get_event() {
+namespace {
+// FLX_HOST_PROFILE=1 prints wall-clock milliseconds of the host phases of flx_align_reads_resident to stderr
+struct PhaseTimer {
+    bool on;
+    std::chrono::steady_clock::time_point t;
+    std::vector<std::pair<const char*, double>> rows;
+    PhaseTimer() : on(getenv("FLX_HOST_PROFILE") != nullptr), t(std::chrono::steady_clock::now()) {}
+    void mark(const char* name) {
+        if (!on) return;
+        auto const now = std::chrono::steady_clock::now();
+        rows.emplace_back(name, std::chrono::duration<double, std::milli>(now - t).count());
+        t = now;
+    }
+    ~PhaseTimer() {
+        if (!on) return;
+        double total = 0;
+        for (auto& r : rows) total += r.second;
+        fprintf(stderr, "[flx host profile] total %.2f ms:", total);
+        for (auto& r : rows) fprintf(stderr, " %s=%.2f", r.first, r.second);
+        fprintf(stderr, "\n");
+    }
+};
+}  // namespace
+
+hipEvent_t Lane::get_event() {
     if (!event_pool.empty()) { hipEvent_t e = event_pool.back(); event_pool.pop_back(); return e; }
     hipEvent_t e = nullptr;
     (void)hipEventCreate(&e);
     return e;
+}
+void Lane::release_all() {
+    for (DeviceBuffer* b : {&seq, &seq_rev, &peq, &peq_rev, &scheme, &seeds, &stack, &hits, &counters, &rows, &rows_out, &jobs, &job_out,
+                            &trace, &tjobs, &tjob_out, &cigar, &user_text, &user_text_rev})
+        b->release();
+    for (auto& p : pending) { (void)hipEventDestroy(p.start); (void)hipEventDestroy(p.stop); }
+    for (auto e : event_pool) (void)hipEventDestroy(e);
+    pending.clear();
+    event_pool.clear();
+    if (own_stream) (void)hipStreamDestroy(own_stream);
+    own_stream = stream = nullptr;
 }
 void flx_ctx::account(const char* name, u64 bytes, u64 units, hipEvent_t start, hipEvent_t stop) {
     float ms = 0.f;
     (void)hipEventElapsedTime(&ms, start, stop);
     auto it = stats.find(name);
     if (it == stats.end()) {
-        flx_kernel_stat s{};
-        strncpy(s.name, name, sizeof(s.name) - 1);
-        it = stats.emplace(name, s).first;
+        flx_kernel_stat st{};
+        strncpy(st.name, name, sizeof(st.name) - 1);
+        it = stats.emplace(name, st).first;
         stat_order.push_back(name);
     }
     it->second.launches += 1;
@@ -59,32 +97,39 @@ void flx_ctx::account(const char* name, u64 bytes, u64 units, hipEvent_t start, 
     it->second.algorithmic_bytes += bytes;
     it->second.work_units += units;
 }
-int flx_ctx::sync() {
+int Lane::sync() {
     FLX_HIP(hipStreamSynchronize(stream));
-    for (auto& p : pending) {
-        account(p.name.c_str(), p.bytes, p.units, p.start, p.stop);
-        event_pool.push_back(p.start);
-        event_pool.push_back(p.stop);
+    if (!pending.empty()) {
+        std::lock_guard<std::mutex> g(ctx->mu);
+        for (auto& p : pending) {
+            ctx->account(p.name.c_str(), p.bytes, p.units, p.start, p.stop);
+            event_pool.push_back(p.start);
+            event_pool.push_back(p.stop);
+        }
+        pending.clear();
     }
-    pending.clear();
+    return FLX_OK;
+}
+int flx_ctx::sync_all() {
+    for (auto& l : lanes) { int rc = l->sync(); if (rc) return rc; }
     return FLX_OK;
 }
 
 namespace flx {
 
-static int h2d(flx_ctx* ctx, DeviceBuffer& buf, const void* src, size_t bytes, size_t extra_zero_tail = 0) {
+static int h2d(Lane* ctx, DeviceBuffer& buf, const void* src, size_t bytes, size_t extra_zero_tail = 0) {
     int rc = buf.ensure(bytes + extra_zero_tail + 16);
     if (rc) return rc;
     if (bytes) FLX_HIP(hipMemcpyAsync(buf.ptr, src, bytes, hipMemcpyHostToDevice, ctx->stream));
     if (extra_zero_tail) FLX_HIP(hipMemsetAsync((char*)buf.ptr + bytes, 0, extra_zero_tail, ctx->stream));
     return FLX_OK;
 }
-static int d2h(flx_ctx* ctx, void* dst, const void* src, size_t bytes) {
+static int d2h(Lane* ctx, void* dst, const void* src, size_t bytes) {
     if (bytes) FLX_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
     return FLX_OK;
 }
 // upload a byte sequence with TEXT_PAD zero bytes in front and behind; returns pointer to element 0
-static int upload_padded(flx_ctx* ctx, DeviceBuffer& buf, const u8* src, u64 len, const u8** d_first) {
+static int upload_padded(Lane* ctx, DeviceBuffer& buf, const u8* src, u64 len, const u8** d_first) {
     int rc = buf.ensure(len + 2 * TEXT_PAD + 16);
     if (rc) return rc;
     FLX_HIP(hipMemsetAsync(buf.ptr, 0, TEXT_PAD, ctx->stream));
@@ -125,14 +170,14 @@ void erase_useless(std::vector<RefAnchor>& v) {
 
 }  // namespace
 
-int search_seeds_device(flx_ctx* ctx, const u8* d_seq_pool_or_null, const u8* h_seq_pool, u64 pool_len, const flx_seed* seeds,
+int search_seeds_device(Lane* ctx, const u8* d_seq_pool_or_null, const u8* h_seq_pool, u64 pool_len, const flx_seed* seeds,
                         u64 n_seeds, const flx_search_config& cfg, std::vector<HostAnchor>& anchors, std::vector<SeedStats>& stats,
                         std::vector<DevHit>* raw_hits, u64 raw_max_hits) {
     anchors.clear();
     stats.assign(n_seeds, SeedStats{0, 0, 0, 0});
     if (n_seeds == 0) return FLX_OK;
     if (n_seeds >= (1ull << 31)) { set_error("too many seeds in one call"); return FLX_ERR_INVALID; }
-    HostIndex const& H = *ctx->hidx;
+    HostIndex const& H = *ctx->ctx->hidx;
 
     // ---- expanded schemes (search_scheme_cache, search.cpp:328-350) and DFS stack reservations
     std::map<std::pair<u32, u32>, std::pair<u32, u32>> scheme_of;      // (len, k) -> (offset, searches)
@@ -183,7 +228,7 @@ int search_seeds_device(flx_ctx* ctx, const u8* d_seq_pool_or_null, const u8* h_
         if ((rc = ctx->hits.ensure(hit_cap * sizeof(DevHit)))) return rc;
         FLX_HIP(hipMemsetAsync(ctx->counters.ptr, 0, 64, ctx->stream));
         rc = timed_launch(ctx, "fm_search", 0, n_seeds, [&] {
-            return DeviceApi::search(ctx->stream, ctx->didx, d_seq, ctx->scheme.as<u32>(), ctx->seeds.as<DevSeed>(), (u32)n_seeds,
+            return DeviceApi::search(ctx->stream, ctx->ctx->didx, d_seq, ctx->scheme.as<u32>(), ctx->seeds.as<DevSeed>(), (u32)n_seeds,
                                      max_hits, ctx->stack.as<DevFrame>(), ctx->hits.as<DevHit>(), (u32)std::min<u64>(hit_cap, 0xFFFFFFFFu),
                                      ctx->counters.as<u32>());
         });
@@ -196,9 +241,10 @@ int search_seeds_device(flx_ctx* ctx, const u8* d_seq_pool_or_null, const u8* h_
         hit_cap = (u64)counters[0] + 1024;      // exact size is known now; run again
     }
     // fold the extension count into the kernel's accounting: 2 rank positions of one 128-byte block each
-    if (ctx->timing) {
-        auto it = ctx->stats.find("fm_search");
-        if (it != ctx->stats.end()) { it->second.algorithmic_bytes += (u64)counters[2] * 2 * sizeof(OccBlock); it->second.work_units += counters[2]; }
+    if (ctx->ctx->timing) {
+        std::lock_guard<std::mutex> g(ctx->ctx->mu);
+        auto it = ctx->ctx->stats.find("fm_search");
+        if (it != ctx->ctx->stats.end()) { it->second.algorithmic_bytes += (u64)counters[2] * 2 * sizeof(OccBlock); it->second.work_units += counters[2]; }
     }
     u32 const n_hits = counters[0];
     std::vector<DevHit> hits(n_hits);
@@ -278,7 +324,7 @@ int search_seeds_device(flx_ctx* ctx, const u8* d_seq_pool_or_null, const u8* h_
         if ((rc = h2d(ctx, ctx->rows, rows.data(), rows.size() * 4))) return rc;
         if ((rc = ctx->rows_out.ensure(rows.size() * 4))) return rc;
         rc = timed_launch(ctx, "fm_locate", rows.size() * 8, rows.size(), [&] {
-            return DeviceApi::locate(ctx->stream, ctx->didx, ctx->rows.as<u32>(), (u32)rows.size(), ctx->rows_out.as<u32>());
+            return DeviceApi::locate(ctx->stream, ctx->ctx->didx, ctx->rows.as<u32>(), (u32)rows.size(), ctx->rows_out.as<u32>());
         });
         if (rc) return rc;
         if ((rc = d2h(ctx, textpos.data(), ctx->rows_out.ptr, rows.size() * 4))) return rc;
@@ -330,7 +376,7 @@ struct ShapeKey {
 };
 
 // score + end column for every request (no trace)
-int run_score_jobs(flx_ctx* ctx, const u8* d_text, const u64* d_peq, std::vector<AlignRequest> const& reqs,
+int run_score_jobs(Lane* ctx, const u8* d_text, const u64* d_peq, std::vector<AlignRequest> const& reqs,
                    std::vector<DevAlignOut>& outs, const char* kernel_name) {
     outs.assign(reqs.size(), DevAlignOut{0xFFFFFFFFu, 0});
     if (reqs.empty()) return FLX_OK;
@@ -374,7 +420,7 @@ int run_score_jobs(flx_ctx* ctx, const u8* d_text, const u64* d_peq, std::vector
 struct TraceResult { bool exists = false; u32 nm = 0; u32 begin = 0; u64 cigar_off = 0; u32 cigar_len = 0; };
 
 // score, begin position and CIGAR for every request (alignment.cpp:147-180); CIGAR words appended to cigar_pool
-int run_trace_jobs(flx_ctx* ctx, const u8* d_text, const u8* d_query, const u64* d_peq, std::vector<AlignRequest> const& reqs,
+int run_trace_jobs(Lane* ctx, const u8* d_text, const u8* d_query, const u64* d_peq, std::vector<AlignRequest> const& reqs,
                    std::vector<TraceResult>& results, std::vector<u32>& cigar_pool) {
     results.assign(reqs.size(), TraceResult{});
     if (reqs.empty()) return FLX_OK;
@@ -480,21 +526,23 @@ int run_trace_jobs(flx_ctx* ctx, const u8* d_text, const u8* d_query, const u64*
     return FLX_OK;
 }
 
-int build_peq(flx_ctx* ctx, const u8* d_seq, u64 len, DeviceBuffer& peq) {
+int build_peq(Lane* ctx, const u8* d_seq, u64 len, DeviceBuffer& peq) {
     u64 const n_words = len / 64 + 2;
     int rc = peq.ensure(n_words * 6 * 8 + 64);
     if (rc) return rc;
     return timed_launch(ctx, "peq_build", len + n_words * 48, n_words, [&] { return DeviceApi::build_peq(ctx->stream, d_seq, len, peq.as<u64>()); });
 }
 
-int ensure_reversed_text(flx_ctx* ctx) {
+int ensure_reversed_text(Lane* lane) {
+    flx_ctx* ctx = lane->ctx;
+    std::lock_guard<std::mutex> g(ctx->mu);
     if (ctx->text_rev_ready) return FLX_OK;
     HostIndex const& H = *ctx->hidx;
     std::vector<u8> rev(H.text.rbegin(), H.text.rend());
     const u8* first = nullptr;
-    int rc = upload_padded(ctx, ctx->text_rev, rev.data(), rev.size(), &first);
+    int rc = upload_padded(lane, ctx->text_rev, rev.data(), rev.size(), &first);
     if (rc) return rc;
-    if ((rc = ctx->sync())) return rc;
+    FLX_HIP(hipStreamSynchronize(lane->stream));
     ctx->text_rev_ready = true;
     return FLX_OK;
 }
@@ -511,7 +559,7 @@ extern "C" int flx_search_seeds(flx_ctx* ctx, const uint8_t* seq_pool, uint64_t 
     FLX_HIP(hipSetDevice(ctx->device));
     std::vector<HostAnchor> anchors;
     std::vector<SeedStats> stats;
-    int rc = search_seeds_device(ctx, nullptr, seq_pool, seq_pool_len, seeds, n_seeds, *cfg, anchors, stats, nullptr, 0);
+    int rc = search_seeds_device(ctx->lane0(), nullptr, seq_pool, seq_pool_len, seeds, n_seeds, *cfg, anchors, stats, nullptr, 0);
     if (rc) return rc;
     uint64_t const cap = *n_anchors;
     *n_anchors = anchors.size();
@@ -530,7 +578,7 @@ extern "C" int flx_search_groups(flx_ctx* ctx, const uint8_t* seq_pool, uint64_t
     std::vector<SeedStats> stats;
     std::vector<DevHit> hits;
     flx_search_config cfg{};
-    int rc = search_seeds_device(ctx, nullptr, seq_pool, seq_pool_len, seeds, n_seeds, cfg, anchors, stats, &hits, max_hits_per_seed);
+    int rc = search_seeds_device(ctx->lane0(), nullptr, seq_pool, seq_pool_len, seeds, n_seeds, cfg, anchors, stats, &hits, max_hits_per_seed);
     if (rc) return rc;
     uint64_t const cap = *n_out;
     *n_out = hits.size();
@@ -557,29 +605,30 @@ extern "C" int flx_align_batch(flx_ctx* ctx, const uint8_t* ref_pool, uint64_t r
         any_trace |= j.mode == FLX_MODE_WITH_CIGAR;
     }
     int rc;
+    Lane* L = ctx->lane0();
     const u8* d_text = ctx->didx.text;
     const u8* d_text_rev = nullptr;
     std::vector<u8> tmp;
     if (ref_pool) {
-        if ((rc = upload_padded(ctx, ctx->user_text, ref_pool, ref_pool_len, &d_text))) return rc;
+        if ((rc = upload_padded(L, L->user_text, ref_pool, ref_pool_len, &d_text))) return rc;
         if (any_rev) {
             tmp.assign(ref_pool, ref_pool + ref_pool_len);
             std::reverse(tmp.begin(), tmp.end());
-            if ((rc = upload_padded(ctx, ctx->user_text_rev, tmp.data(), tmp.size(), &d_text_rev))) return rc;
-            if ((rc = ctx->sync())) return rc;
+            if ((rc = upload_padded(L, L->user_text_rev, tmp.data(), tmp.size(), &d_text_rev))) return rc;
+            if ((rc = L->sync())) return rc;
         }
     } else if (any_rev) {
-        if ((rc = ensure_reversed_text(ctx))) return rc;
+        if ((rc = ensure_reversed_text(L))) return rc;
         d_text_rev = ctx->text_rev.as<u8>() + TEXT_PAD;
     }
-    if ((rc = h2d(ctx, ctx->seq, query_pool, query_pool_len, 64))) return rc;
-    if ((rc = build_peq(ctx, ctx->seq.as<u8>(), query_pool_len, ctx->peq))) return rc;
+    if ((rc = h2d(L, L->seq, query_pool, query_pool_len, 64))) return rc;
+    if ((rc = build_peq(L, L->seq.as<u8>(), query_pool_len, L->peq))) return rc;
     std::vector<u8> qrev;
     if (any_rev) {
         qrev.assign(query_pool, query_pool + query_pool_len);
         std::reverse(qrev.begin(), qrev.end());
-        if ((rc = h2d(ctx, ctx->seq_rev, qrev.data(), qrev.size(), 64))) return rc;
-        if ((rc = build_peq(ctx, ctx->seq_rev.as<u8>(), query_pool_len, ctx->peq_rev))) return rc;
+        if ((rc = h2d(L, L->seq_rev, qrev.data(), qrev.size(), 64))) return rc;
+        if ((rc = build_peq(L, L->seq_rev.as<u8>(), query_pool_len, L->peq_rev))) return rc;
     }
     std::vector<AlignRequest> score_reqs, rev_reqs, trace_reqs;
     std::vector<u32> score_ids, rev_ids, trace_ids;
@@ -593,10 +642,10 @@ extern "C" int flx_align_batch(flx_ctx* ctx, const uint8_t* ref_pool, uint64_t r
     }
     for (uint64_t i = 0; i < n_jobs; ++i) out[i] = flx_align_result{0, 0, 0, 0, 0, 0};
     std::vector<DevAlignOut> outs;
-    if ((rc = run_score_jobs(ctx, d_text, ctx->peq.as<u64>(), score_reqs, outs, "ed_align_exists"))) return rc;
+    if ((rc = run_score_jobs(L, d_text, L->peq.as<u64>(), score_reqs, outs, "ed_align_exists"))) return rc;
     for (size_t i = 0; i < outs.size(); ++i)
         if (outs[i].score != 0xFFFFFFFFu) { out[score_ids[i]].exists = 1; out[score_ids[i]].num_errors = outs[i].score; }
-    if ((rc = run_score_jobs(ctx, d_text_rev, ctx->peq_rev.as<u64>(), rev_reqs, outs, "ed_align_exists"))) return rc;
+    if ((rc = run_score_jobs(L, d_text_rev, L->peq_rev.as<u64>(), rev_reqs, outs, "ed_align_exists"))) return rc;
     for (size_t i = 0; i < outs.size(); ++i)
         if (outs[i].score != 0xFFFFFFFFu) {
             flx_align_result& r = out[rev_ids[i]];
@@ -604,7 +653,7 @@ extern "C" int flx_align_batch(flx_ctx* ctx, const uint8_t* ref_pool, uint64_t r
         }
     std::vector<TraceResult> tres;
     std::vector<u32> cig;
-    if ((rc = run_trace_jobs(ctx, d_text, ctx->seq.as<u8>(), ctx->peq.as<u64>(), trace_reqs, tres, cig))) return rc;
+    if ((rc = run_trace_jobs(L, d_text, L->seq.as<u8>(), L->peq.as<u64>(), trace_reqs, tres, cig))) return rc;
     uint64_t const cap = cigar_pool_words ? *cigar_pool_words : 0;
     if (cigar_pool_words) *cigar_pool_words = cig.size();
     if (any_trace && (!cigar_pool || cig.size() > cap)) { set_error("cigar pool too small"); return FLX_ERR_CAPACITY; }
@@ -695,25 +744,84 @@ extern "C" void flx_params_default(flx_params* p) {
     p->num_anchors_per_verification_task = 3000;
 }
 
+struct flx_reads {
+    flx_ctx* ctx = nullptr;
+    uint64_t n_reads = 0;
+    std::vector<u64> lens;            // per read
+    std::vector<u64> pool_off;        // per read: offset of the forward sequence; reverse complement follows at +len
+    std::vector<u8> pool;             // host copy (forward + reverse complement per read)
+    flx::DeviceBuffer d_pool;         // HBM-resident copy
+};
+
+extern "C" int flx_reads_upload(flx_ctx* ctx, const uint8_t* read_pool, const uint64_t* read_offsets, uint64_t n_reads, flx_reads** out) {
+    if (!ctx || !out || (n_reads && (!read_pool || !read_offsets))) { set_error("flx_reads_upload: null argument"); return FLX_ERR_INVALID; }
+    FLX_HIP(hipSetDevice(ctx->device));
+    auto rd = std::make_unique<flx_reads>();
+    rd->ctx = ctx;
+    rd->n_reads = n_reads;
+    rd->lens.resize(n_reads);
+    rd->pool_off.resize(n_reads);
+    u64 total = 0;
+    for (u64 i = 0; i < n_reads; ++i) {
+        if (read_offsets[i + 1] < read_offsets[i]) { set_error("read offsets must be non-decreasing"); return FLX_ERR_INVALID; }
+        rd->lens[i] = read_offsets[i + 1] - read_offsets[i];
+        total += 2 * rd->lens[i];
+    }
+    rd->pool.resize(total);
+    u64 off = 0;
+    for (u64 i = 0; i < n_reads; ++i) {
+        u64 const len = rd->lens[i];
+        const u8* src = read_pool + read_offsets[i];
+        for (u64 b = 0; b < len; ++b) if (src[b] > 5) { set_error("read rank > 5"); return FLX_ERR_INVALID; }
+        rd->pool_off[i] = off;
+        memcpy(rd->pool.data() + off, src, len);
+        reverse_complement(src, len, rd->pool.data() + off + len);
+        off += 2 * len;
+    }
+    int rc = rd->d_pool.ensure(total + 128);
+    if (rc) return rc;
+    hipStream_t const s0 = ctx->lane0()->stream;
+    if (total) FLX_HIP(hipMemcpyAsync(rd->d_pool.ptr, rd->pool.data(), total, hipMemcpyHostToDevice, s0));
+    FLX_HIP(hipMemsetAsync((char*)rd->d_pool.ptr + total, 0, 64, s0));
+    FLX_HIP(hipStreamSynchronize(s0));
+    *out = rd.release();
+    return FLX_OK;
+}
+
+extern "C" void flx_reads_free(flx_reads* reads) {
+    if (!reads) return;
+    if (reads->ctx) (void)hipSetDevice(reads->ctx->device);
+    reads->d_pool.release();
+    delete reads;
+}
+
 extern "C" int flx_align_reads(flx_ctx* ctx, const flx_params* P, const uint8_t* read_pool, const uint64_t* read_offsets,
                                uint64_t n_reads, flx_run** out) {
-    if (!ctx || !P || !out || (n_reads && (!read_pool || !read_offsets))) { set_error("flx_align_reads: null argument"); return FLX_ERR_INVALID; }
-    FLX_HIP(hipSetDevice(ctx->device));
-    if (P->query_error_probability < 0 && P->query_num_errors < P->pex_seed_num_errors) { set_error("query errors must be >= seed errors (floxer_cli.cpp:180)"); return FLX_ERR_INVALID; }
-    if (P->pex_seed_num_errors > 3 || P->seed_sampling_step_size == 0 || P->num_anchors_per_verification_task == 0) { set_error("invalid parameters"); return FLX_ERR_INVALID; }
-    if (P->search.max_num_anchors_hard < P->search.max_num_anchors_soft) { set_error("max-anchors-hard must not be smaller than max-anchors-soft"); return FLX_ERR_INVALID; }
-    HostIndex const& H = *ctx->hidx;
-    auto run = std::make_unique<flx_run>();
-    run->skipped.assign(n_reads, 0);
+    flx_reads* rd = nullptr;
+    int rc = flx_reads_upload(ctx, read_pool, read_offsets, n_reads, &rd);
+    if (rc) return rc;
+    rc = flx_align_reads_resident(ctx, P, rd, out);
+    flx_reads_free(rd);
+    return rc;
+}
 
-    // ---- reads -> PEX trees, sequence pool (forward + reverse complement), seeds (parallelization.cpp:77-98)
+namespace {
+
+// one contiguous slice of the batch on one lane; produces the slice's records (read_index relative to the whole batch)
+int align_slice(Lane* lane, const flx_params* P, const flx_reads* RD, u64 first_read, u64 end_read, flx_run* run) {
+    flx_ctx* ctx = lane->ctx;
+    FLX_HIP(hipSetDevice(ctx->device));
+    HostIndex const& H = *ctx->hidx;
+    std::vector<u8> const& pool = RD->pool;
+    PhaseTimer prof;
+
+    // ---- reads -> PEX trees, seeds on the forward and reverse-complement sequence (parallelization.cpp:77-98)
     std::vector<ReadState> reads;
-    std::vector<u8> pool;
     std::vector<flx_seed> seeds;
     struct SeedOwner { u32 read; u8 orientation; };
     std::vector<SeedOwner> seed_owner;
-    for (u64 i = 0; i < n_reads; ++i) {
-        u64 const len = read_offsets[i + 1] - read_offsets[i];
+    for (u64 i = first_read; i < end_read; ++i) {
+        u64 const len = RD->lens[i];
         if (len == 0 || len > 100000) { run->skipped[i] = 1; continue; }                       // input.cpp:95-110
         u64 const k = P->query_error_probability >= 0 ? fp_aware_ceil(len * P->query_error_probability) : P->query_num_errors;
         if (len <= k || k < P->pex_seed_num_errors) { run->skipped[i] = 1; continue; }         // input.cpp:115-129
@@ -723,12 +831,8 @@ extern "C" int flx_align_reads(flx_ctx* ctx, const flx_params* P, const uint8_t*
         rs.len = (u32)len;
         rs.k = (u32)k;
         rs.tree = build_pex_tree(len, k, P->pex_seed_num_errors, P->bottom_up_pex_tree_building != 0);
-        const u8* src = read_pool + read_offsets[i];
-        rs.pool_off[0] = pool.size();
-        pool.insert(pool.end(), src, src + len);
-        rs.pool_off[1] = pool.size();
-        pool.resize(pool.size() + len);
-        reverse_complement(src, len, pool.data() + rs.pool_off[1]);
+        rs.pool_off[0] = RD->pool_off[i];
+        rs.pool_off[1] = RD->pool_off[i] + len;
         for (int o = 0; o < 2; ++o)
             for (u64 l = 0; l < rs.tree.leaves.size(); l += P->seed_sampling_step_size) {      // pex.cpp:258-277
                 flx_pex_node const& leaf = rs.tree.leaves[l];
@@ -737,17 +841,18 @@ extern "C" int flx_align_reads(flx_ctx* ctx, const flx_params* P, const uint8_t*
             }
         reads.push_back(std::move(rs));
     }
-    for (u8 c : pool) if (c > 5) { set_error("read rank > 5"); return FLX_ERR_INVALID; }
 
     int rc;
-    if ((rc = h2d(ctx, ctx->seq, pool.data(), pool.size(), 64))) return rc;
-    const u8* d_pool = ctx->seq.as<u8>();
+    const u8* d_pool = RD->d_pool.as<u8>();
+    prof.mark("pex+seeds");
+
 
     // ---- seeding
     std::vector<HostAnchor> anchors;
     std::vector<SeedStats> sstats;
-    if ((rc = search_seeds_device(ctx, d_pool, pool.data(), pool.size(), seeds.data(), seeds.size(), P->search, anchors, sstats, nullptr, 0))) return rc;
+    if ((rc = search_seeds_device(lane, d_pool, pool.data(), pool.size(), seeds.data(), seeds.size(), P->search, anchors, sstats, nullptr, 0))) return rc;
 
+    prof.mark("search");
     std::vector<AnchorState> A(anchors.size());
     for (size_t a = 0; a < anchors.size(); ++a) {
         SeedOwner const so = seed_owner[anchors[a].seed_index];
@@ -777,8 +882,9 @@ extern "C" int flx_align_reads(flx_ctx* ctx, const flx_params* P, const uint8_t*
             for (u32 j = 0; j < pkgs[pid].second; ++j) exec_order[r].push_back(concat[pkgs[pid].first + j]);
     }
 
+    prof.mark("anchors+order");
     // ---- Peq planes of the whole pool
-    if ((rc = build_peq(ctx, d_pool, pool.size(), ctx->peq))) return rc;
+    if ((rc = build_peq(lane, d_pool, pool.size(), lane->peq))) return rc;
     const u8* d_text = ctx->didx.text;
 
     auto window_request = [&](AnchorState const& a, flx_pex_node const& node, double ratio, Span* span_out) {
@@ -810,7 +916,7 @@ extern "C" int flx_align_reads(flx_ctx* ctx, const flx_params* P, const uint8_t*
         }
         if (reqs.empty()) break;
         std::vector<DevAlignOut> outs;
-        if ((rc = run_score_jobs(ctx, d_text, ctx->peq.as<u64>(), reqs, outs, "ed_align_exists"))) return rc;
+        if ((rc = run_score_jobs(lane, d_text, lane->peq.as<u64>(), reqs, outs, "ed_align_exists"))) return rc;
         for (size_t i = 0; i < outs.size(); ++i) {
             AnchorState& a = A[req_anchor[i]];
             if (outs[i].score == 0xFFFFFFFFu) { a.alive = false; continue; }
@@ -819,6 +925,7 @@ extern "C" int flx_align_reads(flx_ctx* ctx, const flx_params* P, const uint8_t*
         }
     }
 
+    prof.mark("inner-levels");
     // ---- interval pass in verification order (verification.cpp:45, 106-109, 119-136): decides which anchors align the root
     std::vector<AlignRequest> root_reqs;
     std::vector<u32> root_anchor;
@@ -844,30 +951,32 @@ extern "C" int flx_align_reads(flx_ctx* ctx, const flx_params* P, const uint8_t*
         }
     }
 
+    prof.mark("interval-pass");
     // ---- root alignments (alignment.cpp:115-180)
     struct RootAlignment { bool exists = false; u64 start = 0; u32 nm = 0; u64 cigar_off = 0; u32 cigar_len = 0; };
     std::vector<RootAlignment> root_res(root_reqs.size());
     std::vector<u32> cig;
     if (P->without_cigar) {
-        if ((rc = ensure_reversed_text(ctx))) return rc;
+        if ((rc = ensure_reversed_text(lane))) return rc;
         std::vector<u8> qrev(pool.rbegin(), pool.rend());
-        if ((rc = h2d(ctx, ctx->seq_rev, qrev.data(), qrev.size(), 64))) return rc;
-        if ((rc = build_peq(ctx, ctx->seq_rev.as<u8>(), qrev.size(), ctx->peq_rev))) return rc;
+        if ((rc = h2d(lane, lane->seq_rev, qrev.data(), qrev.size(), 64))) return rc;
+        if ((rc = build_peq(lane, lane->seq_rev.as<u8>(), qrev.size(), lane->peq_rev))) return rc;
         std::vector<AlignRequest> rev(root_reqs.size());
         for (size_t i = 0; i < rev.size(); ++i)
             rev[i] = AlignRequest{H.n - root_reqs[i].ref_off - root_reqs[i].n, pool.size() - root_reqs[i].q_off - root_reqs[i].m,
                                   root_reqs[i].n, root_reqs[i].m, root_reqs[i].k};
         std::vector<DevAlignOut> outs;
-        if ((rc = run_score_jobs(ctx, ctx->text_rev.as<u8>() + TEXT_PAD, ctx->peq_rev.as<u64>(), rev, outs, "ed_align_exists"))) return rc;
+        if ((rc = run_score_jobs(lane, ctx->text_rev.as<u8>() + TEXT_PAD, lane->peq_rev.as<u64>(), rev, outs, "ed_align_exists"))) return rc;
         for (size_t i = 0; i < outs.size(); ++i)
             if (outs[i].score != 0xFFFFFFFFu) { root_res[i].exists = true; root_res[i].nm = outs[i].score; root_res[i].start = root_spans[i].offset + (root_reqs[i].n - outs[i].end_col); }
     } else {
         std::vector<TraceResult> tres;
-        if ((rc = run_trace_jobs(ctx, d_text, d_pool, ctx->peq.as<u64>(), root_reqs, tres, cig))) return rc;
+        if ((rc = run_trace_jobs(lane, d_text, d_pool, lane->peq.as<u64>(), root_reqs, tres, cig))) return rc;
         for (size_t i = 0; i < tres.size(); ++i)
             if (tres[i].exists) root_res[i] = RootAlignment{true, root_spans[i].offset + tres[i].begin, tres[i].nm, tres[i].cigar_off, tres[i].cigar_len};
     }
 
+    prof.mark("root-align");
     // ---- records (alignment.cpp:37-79, output.cpp:49-108): per reference in id order, alignments in verification order
     std::vector<std::vector<u32>> roots_of_read(reads.size());
     for (u32 i = 0; i < root_anchor.size(); ++i) roots_of_read[A[root_anchor[i]].read].push_back(i);   // already in verification order
@@ -890,6 +999,51 @@ extern "C" int flx_align_reads(flx_ctx* ctx, const flx_params* P, const uint8_t*
                 run->records.push_back(rec);
             }
         if (!primary_written) run->records.push_back(flx_record{reads[r].read_index, 4u, -1, 0, 0, 0, 0, 0});
+    }
+    prof.mark("records");
+    return FLX_OK;
+}
+
+}  // namespace
+
+extern "C" int flx_align_reads_resident(flx_ctx* ctx, const flx_params* P, const flx_reads* RD, flx_run** out) {
+    if (!ctx || !P || !out || !RD || RD->ctx != ctx) { set_error("flx_align_reads_resident: null argument or reads of another context"); return FLX_ERR_INVALID; }
+    FLX_HIP(hipSetDevice(ctx->device));
+    if (P->query_error_probability < 0 && P->query_num_errors < P->pex_seed_num_errors) { set_error("query errors must be >= seed errors (floxer_cli.cpp:180)"); return FLX_ERR_INVALID; }
+    if (P->pex_seed_num_errors > 3 || P->seed_sampling_step_size == 0 || P->num_anchors_per_verification_task == 0) { set_error("invalid parameters"); return FLX_ERR_INVALID; }
+    if (P->search.max_num_anchors_hard < P->search.max_num_anchors_soft) { set_error("max-anchors-hard must not be smaller than max-anchors-soft"); return FLX_ERR_INVALID; }
+    u64 const n_reads = RD->n_reads;
+    auto run = std::make_unique<flx_run>();
+    run->skipped.assign(n_reads, 0);
+    // contiguous slices, one per lane (reads are independent units: parallelization.cpp:77-87)
+    size_t n_lanes = ctx->external_stream ? 1 : ctx->lanes.size();
+    n_lanes = std::max<size_t>(1, std::min<size_t>(n_lanes, (n_reads + 63) / 64));
+    std::vector<flx_run> parts(n_lanes);
+    std::vector<int> rcs(n_lanes, FLX_OK);
+    std::vector<std::string> errs(n_lanes);
+    auto work = [&](size_t l) {
+        u64 const a = n_reads * l / n_lanes, b = n_reads * (l + 1) / n_lanes;
+        parts[l].skipped.assign(n_reads, 0);
+        rcs[l] = align_slice(ctx->lanes[l].get(), P, RD, a, b, &parts[l]);
+        if (rcs[l]) errs[l] = flx_last_error();
+    };
+    if (n_lanes == 1) work(0);
+    else {
+        std::vector<std::thread> threads;
+        for (size_t l = 0; l < n_lanes; ++l) threads.emplace_back(work, l);
+        for (auto& t : threads) t.join();
+    }
+    for (size_t l = 0; l < n_lanes; ++l)
+        if (rcs[l]) { set_error(errs[l]); return rcs[l]; }
+    size_t nrec = 0, ncig = 0;
+    for (auto const& p : parts) { nrec += p.records.size(); ncig += p.cigars.size(); }
+    run->records.reserve(nrec);
+    run->cigars.reserve(ncig);
+    for (auto& p : parts) {
+        u64 const base = run->cigars.size();
+        run->cigars.insert(run->cigars.end(), p.cigars.begin(), p.cigars.end());
+        for (auto rec : p.records) { rec.cigar_offset += base; run->records.push_back(rec); }
+        for (u64 i = 0; i < n_reads; ++i) run->skipped[i] |= p.skipped[i];
     }
     *out = run.release();
     return FLX_OK;

@@ -184,6 +184,11 @@ typedef struct flx_run flx_run;      /* result of one batch */
  * (filtered reads produce no record and are flagged in the skipped array). */
 int flx_align_reads(flx_ctx* ctx, const flx_params* params, const uint8_t* read_pool, const uint64_t* read_offsets,
                     uint64_t n_reads, flx_run** out);
+/* The same with the reads already resident in HBM (the measured configuration of bench.py): upload once, align many times. */
+typedef struct flx_reads flx_reads;
+int flx_reads_upload(flx_ctx* ctx, const uint8_t* read_pool, const uint64_t* read_offsets, uint64_t n_reads, flx_reads** out);
+void flx_reads_free(flx_reads* reads);
+int flx_align_reads_resident(flx_ctx* ctx, const flx_params* params, const flx_reads* reads, flx_run** out);
 uint64_t flx_run_num_records(const flx_run* run);
 uint64_t flx_run_num_cigar_words(const flx_run* run);
 int flx_run_copy(const flx_run* run, flx_record* records, uint32_t* cigar_words, uint8_t* skipped);
