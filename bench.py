@@ -38,6 +38,18 @@ def parse():
     return ap.parse_args()
 
 
+def usable_cores():
+    """threads the host actually grants this process: cgroup cpu.max quota if set, else the affinity mask"""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 def main():
     args = parse()
     rank = int(os.environ.get("RANK", 0))
@@ -75,31 +87,13 @@ def main():
     al = F.aligner(ctx, p)
     resident = [F.resident_reads(ctx, r) for r in batches]       # inputs resident in HBM before the timed region
 
+    from floxer_amd import distributed as D
+    dev = torch.device("cuda", local_rank)
+
     def gather_records(res):
         """the path's one exchange step: variable-length gather of alignment records to rank 0 over RCCL"""
-        if world == 1:
-            return len(res.rows)
-        dev = torch.device("cuda", local_rank)
-        rows = torch.from_numpy(res.rows.astype(np.int64)).to(dev)
-        cig = torch.from_numpy(res.cigars.astype(np.int64)).to(dev)
-        counts = torch.tensor([rows.shape[0], cig.shape[0]], device=dev, dtype=torch.int64)
-        all_counts = [torch.zeros_like(counts) for _ in range(world)]
-        dist.all_gather(all_counts, counts)
-        max_r = int(max(c[0].item() for c in all_counts))
-        max_c = int(max(c[1].item() for c in all_counts))
-        pad_r = torch.zeros((max_r, 7), device=dev, dtype=torch.int64)
-        pad_r[: rows.shape[0]] = rows
-        pad_c = torch.zeros((max(max_c, 1),), device=dev, dtype=torch.int64)
-        pad_c[: cig.shape[0]] = cig
-        if rank == 0:
-            gr = [torch.zeros_like(pad_r) for _ in range(world)]
-            gc = [torch.zeros_like(pad_c) for _ in range(world)]
-            dist.gather(pad_r, gr, dst=0)
-            dist.gather(pad_c, gc, dst=0)
-            return sum(int(c[0].item()) for c in all_counts)
-        dist.gather(pad_r, None, dst=0)
-        dist.gather(pad_c, None, dst=0)
-        return 0
+        merged = D.gather_records(res.rows, res.cigars, rank * B, rank, world, device=dev)
+        return len(merged[0]) if merged is not None else 0
 
     def barrier():
         if world > 1:
@@ -152,7 +146,7 @@ def main():
         if not args.no_cpu_baseline:
             sys.path.insert(0, os.path.join(ROOT, "tests"))
             import oracle_lib as O                      # the checker, timed as the reported CPU baseline only
-            cores = os.cpu_count() or 1
+            cores = usable_cores()
             sample = batches[args.warmup][: args.cpu_sample]
             oidx = O.Index(genome)
             ores = oidx.run(sample, O.params(error_probability=args.error_rate, interval_opt=args.interval_optimization), threads=cores)

@@ -1,0 +1,359 @@
+// floxer-compatible command line over libfloxer_amd (drop-in for the process boundary):
+//   ./floxer --reference ref.fa --queries reads.fq --error-probability 0.08 --output out.bam   (README.md:35)
+// Options, short ids, defaults and validators follow include/floxer_cli.hpp:41-70 and src/lib/floxer_cli.cpp:173-435;
+// main() follows src/main/floxer.cpp:35-195. Diagnostics go to stderr only, stdout stays empty
+// (floxer_whole_program_via_cli_test.cpp:125-126); exit code 0 on success, 255 (-1) on any error.
+#include <zlib.h>
+
+#include <chrono>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <sys/stat.h>
+#include <vector>
+
+#include "../../include/floxer_amd.h"
+
+namespace {
+
+bool g_debug = false;
+FILE* g_logfile = nullptr;
+
+void log_line(const char* level, const char* fmt, ...) {
+    char buf[4096];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    bool const is_debug = strcmp(level, "debug") == 0;
+    if (!is_debug || g_debug) fprintf(stderr, "[floxer] [%s] %s\n", level, buf);
+    if (g_logfile) { fprintf(g_logfile, "[%s] %s\n", level, buf); fflush(g_logfile); }
+}
+
+struct Options {
+    std::string reference, queries, output, index, logfile;
+    bool console_debug_logs = false;
+    bool has_query_errors = false, has_error_probability = false;
+    uint64_t query_errors = 0;
+    double error_probability = NAN;
+    uint64_t seed_errors = 2, max_anchors_hard = 500, max_anchors_soft = 50;
+    std::string anchor_group_order = "count_first", anchor_choice_strategy = "round_robin";
+    uint64_t seed_sampling_step_size = 1;
+    bool dont_erase_useless_anchors = false, bottom_up_pex_tree = false, interval_optimization = false;
+    double extra_verification_ratio = 0.05;
+    bool direct_full_verification = false;
+    uint64_t num_anchors_per_task = 3000;
+    bool without_cigar = false;
+    uint64_t threads = 1, timeout = 0;
+    bool has_timeout = false;
+    std::string stats, stats_input_hint;
+};
+
+struct OptDef { char short_id; const char* long_id; bool flag; };
+const OptDef OPTS[] = {
+    {'r', "reference", false}, {'q', "queries", false}, {'o', "output", false}, {'i', "index", false}, {'l', "logfile", false},
+    {'c', "console-debug-logs", true}, {'e', "query-errors", false}, {'p', "error-probability", false}, {'s', "seed-errors", false},
+    {'M', "max-anchors-hard", false}, {'m', "max-anchors-soft", false}, {'g', "anchor-group-order", false},
+    {'y', "anchor-choice-strategy", false}, {'C', "seed-sampling-step-size", false}, {'E', "dont-erase-useless-anchors", true},
+    {'b', "bottom-up-pex-tree", true}, {'I', "interval-optimization", true}, {'v', "extra-verification-ratio", false},
+    {'d', "direct-full-verification", true}, {'u', "num-anchors-per-task", false}, {'w', "without-cigar", true}, {'t', "threads", false},
+    {'x', "timeout", false}, {'S', "stats", false}, {'H', "stats-input-hint", false},
+};
+
+struct CliError { std::string msg; };
+
+bool ends_with(std::string const& s, std::string const& suf) { return s.size() >= suf.size() && s.compare(s.size() - suf.size(), suf.size(), suf) == 0; }
+bool has_ext(std::string const& path, std::vector<std::string> const& exts, bool allow_gz) {
+    for (auto const& e : exts) {
+        if (ends_with(path, "." + e)) return true;
+        if (allow_gz && ends_with(path, "." + e + ".gz")) return true;
+    }
+    return false;
+}
+uint64_t parse_u64(std::string const& name, std::string const& v) {
+    char* end = nullptr;
+    if (v.empty() || v[0] == '-') throw CliError{"Value parse failed for --" + name + ": Argument " + v + " could not be parsed as type unsigned integer."};
+    unsigned long long const x = strtoull(v.c_str(), &end, 10);
+    if (*end) throw CliError{"Value parse failed for --" + name + ": Argument " + v + " could not be parsed as type unsigned integer."};
+    return x;
+}
+double parse_double(std::string const& name, std::string const& v) {
+    char* end = nullptr;
+    double const x = strtod(v.c_str(), &end);
+    if (v.empty() || *end) throw CliError{"Value parse failed for --" + name + ": Argument " + v + " could not be parsed as type double."};
+    return x;
+}
+void range_check(std::string const& name, double v, double lo, double hi) {
+    if (v < lo || v > hi) throw CliError{"Validation failed for option --" + name + ": Value " + std::to_string(v) + " is not in range [" + std::to_string(lo) + "," + std::to_string(hi) + "]."};
+}
+bool file_readable(std::string const& p) { FILE* f = fopen(p.c_str(), "rb"); if (!f) return false; fclose(f); return true; }
+
+Options parse_cli(int argc, char** argv) {
+    Options o;
+    bool seen_ref = false, seen_q = false, seen_out = false;
+    for (int a = 1; a < argc; ++a) {
+        std::string arg = argv[a];
+        const OptDef* def = nullptr;
+        std::string inline_value;
+        bool has_inline = false;
+        if (arg.size() > 2 && arg[0] == '-' && arg[1] == '-') {
+            std::string name = arg.substr(2);
+            size_t const eq = name.find('=');
+            if (eq != std::string::npos) { inline_value = name.substr(eq + 1); name = name.substr(0, eq); has_inline = true; }
+            for (auto const& d : OPTS) if (name == d.long_id) def = &d;
+        } else if (arg.size() == 2 && arg[0] == '-') {
+            for (auto const& d : OPTS) if (arg[1] == d.short_id) def = &d;
+        }
+        if (arg == "-h" || arg == "--help") {
+            fprintf(stderr, "floxer (MI355X-native path) - usage: ./floxer --reference hg38.fasta --queries reads.fastq --error-probability 0.07 --output mapped_reads.bam\n");
+            for (auto const& d : OPTS) fprintf(stderr, "  -%c, --%s%s\n", d.short_id, d.long_id, d.flag ? "" : " <value>");
+            exit(0);
+        }
+        if (arg == "--version") { fprintf(stderr, "%s\n", flx_version()); exit(0); }
+        if (!def) throw CliError{"Unknown option " + arg + ". In case this is meant to be a non-option/argument/parameter, please specify the start of non-options with '--'."};
+        std::string value;
+        if (!def->flag) {
+            if (has_inline) value = inline_value;
+            else { if (a + 1 >= argc) throw CliError{std::string("Missing value for option --") + def->long_id}; value = argv[++a]; }
+        }
+        std::string const n = def->long_id;
+        if (n == "reference") { o.reference = value; seen_ref = true; }
+        else if (n == "queries") { o.queries = value; seen_q = true; }
+        else if (n == "output") { o.output = value; seen_out = true; }
+        else if (n == "index") o.index = value;
+        else if (n == "logfile") o.logfile = value;
+        else if (n == "console-debug-logs") o.console_debug_logs = true;
+        else if (n == "query-errors") { o.query_errors = parse_u64(n, value); range_check(n, (double)o.query_errors, 0, 4096); o.has_query_errors = true; }
+        else if (n == "error-probability") { o.error_probability = parse_double(n, value); range_check(n, o.error_probability, 0.00001, 0.99999); o.has_error_probability = true; }
+        else if (n == "seed-errors") { o.seed_errors = parse_u64(n, value); range_check(n, (double)o.seed_errors, 0, 3); }
+        else if (n == "max-anchors-hard") o.max_anchors_hard = parse_u64(n, value);
+        else if (n == "max-anchors-soft") o.max_anchors_soft = parse_u64(n, value);
+        else if (n == "anchor-group-order") {
+            if (value != "count_first" && value != "errors_first" && value != "none") throw CliError{"Validation failed for option --" + n + ": Value " + value + " is not one of [count_first,errors_first,none]."};
+            o.anchor_group_order = value;
+        } else if (n == "anchor-choice-strategy") {
+            if (value != "round_robin" && value != "full_groups" && value != "first_reported") throw CliError{"Validation failed for option --" + n + ": Value " + value + " is not one of [round_robin,full_groups,first_reported]."};
+            o.anchor_choice_strategy = value;
+        } else if (n == "seed-sampling-step-size") o.seed_sampling_step_size = parse_u64(n, value);
+        else if (n == "dont-erase-useless-anchors") o.dont_erase_useless_anchors = true;
+        else if (n == "bottom-up-pex-tree") o.bottom_up_pex_tree = true;
+        else if (n == "interval-optimization") o.interval_optimization = true;
+        else if (n == "extra-verification-ratio") o.extra_verification_ratio = parse_double(n, value);
+        else if (n == "direct-full-verification") o.direct_full_verification = true;
+        else if (n == "num-anchors-per-task") { o.num_anchors_per_task = parse_u64(n, value); if (o.num_anchors_per_task < 1) throw CliError{"Validation failed for option --" + n + ": must be at least 1."}; }
+        else if (n == "without-cigar") o.without_cigar = true;
+        else if (n == "threads") { o.threads = parse_u64(n, value); range_check(n, (double)o.threads, 1, 4096); }
+        else if (n == "timeout") { o.timeout = parse_u64(n, value); o.has_timeout = true; }
+        else if (n == "stats") o.stats = value;
+        else if (n == "stats-input-hint") {
+            if (value != "real_nanopore" && value != "simulated") throw CliError{"Validation failed for option --" + n + ": Value " + value + " is not one of [real_nanopore,simulated]."};
+            o.stats_input_hint = value;
+        }
+    }
+    if (!seen_ref) throw CliError{"Option -r/--reference is required but not set."};
+    if (!seen_q) throw CliError{"Option -q/--queries is required but not set."};
+    if (!seen_out) throw CliError{"Option -o/--output is required but not set."};
+    if (!has_ext(o.reference, {"fa", "fasta", "fna", "ffn", "fas", "faa", "mpfa", "frn"}, true)) throw CliError{"Validation failed for option -r/--reference: Expected one of the following valid extensions: [fa,fasta,fna,ffn,fas,faa,mpfa,frn](.gz)."};
+    if (!file_readable(o.reference)) throw CliError{"Validation failed for option -r/--reference: The file " + o.reference + " does not exist!"};
+    if (!has_ext(o.queries, {"fq", "fastq"}, true)) throw CliError{"Validation failed for option -q/--queries: Expected one of the following valid extensions: [fq,fastq](.gz)."};
+    if (!file_readable(o.queries)) throw CliError{"Validation failed for option -q/--queries: The file " + o.queries + " does not exist!"};
+    if (!has_ext(o.output, {"bam", "sam"}, false)) throw CliError{"Validation failed for option -o/--output: Expected one of the following valid extensions: [bam,sam]."};
+    // cross validation, floxer_cli.cpp:173-204
+    if (!o.has_query_errors && !o.has_error_probability) throw CliError{"Either a fixed number of errors in the query or an error probability must be given."};
+    if (!o.has_error_probability && o.query_errors < o.seed_errors)
+        throw CliError{"The number of errors per query (" + std::to_string(o.query_errors) + ") must be greater or equal than the number of errors in the PEX tree leaves (" + std::to_string(o.seed_errors) + ")."};
+    if (o.max_anchors_hard < o.max_anchors_soft)
+        throw CliError{"The hard maximum number of anchors (" + std::to_string(o.max_anchors_hard) + ") should not be smaller than the soft maximum number of anchors (" + std::to_string(o.max_anchors_soft) + ")."};
+    if (o.seed_sampling_step_size == 0) throw CliError{"Validation failed for option --seed-sampling-step-size: must be at least 1."};
+    return o;
+}
+
+// ---------------------------------------------------------------- FASTA / FASTQ (plain or gz), input.cpp:36-148
+struct LineReader {
+    gzFile f;
+    std::vector<char> buf;
+    explicit LineReader(const char* path) : f(gzopen(path, "rb")), buf(1 << 16) { if (f) gzbuffer(f, 1 << 20); }
+    ~LineReader() { if (f) gzclose(f); }
+    bool getline(std::string& out) {
+        out.clear();
+        while (true) {
+            if (!gzgets(f, buf.data(), (int)buf.size())) return !out.empty();
+            size_t const n = strlen(buf.data());
+            out.append(buf.data(), n);
+            if (n && out.back() == '\n') { out.pop_back(); if (!out.empty() && out.back() == '\r') out.pop_back(); return true; }
+        }
+    }
+};
+
+std::string record_id(std::string const& tag) { return tag.substr(0, tag.find(' ')); }     // input.cpp:161-163
+
+struct Reference { std::vector<std::string> ids; std::vector<uint64_t> lens; std::vector<uint8_t> pool; };
+
+bool read_references(std::string const& path, Reference& ref, std::string& err) {
+    LineReader in(path.c_str());
+    if (!in.f) { err = "cannot open " + path; return false; }
+    std::string line, id, seq;
+    bool have = false;
+    auto flush = [&]() {
+        if (!have) return;
+        if (seq.empty()) { log_line("warning", "The record %s in the reference file has an empty sequence and will be skipped.", id.c_str()); return; }
+        ref.ids.push_back(id);
+        ref.lens.push_back(seq.size());
+        size_t const off = ref.pool.size();
+        ref.pool.resize(off + seq.size());
+        flx_chars_to_rank_sequence(seq.data(), seq.size(), ref.pool.data() + off);
+        log_line("debug", "read reference, id: %s, length %zu", id.c_str(), seq.size());
+    };
+    while (in.getline(line)) {
+        if (!line.empty() && line[0] == '>') { flush(); id = record_id(line.substr(1)); seq.clear(); have = true; }
+        else if (have) seq += line;
+    }
+    flush();
+    if (ref.ids.empty()) { err = "The reference file is empty, which is not allowed."; return false; }
+    return true;
+}
+
+struct ReadBatch {
+    std::vector<std::string> ids, quals;
+    std::vector<uint8_t> pool;
+    std::vector<uint64_t> offsets{0};
+    void clear() { ids.clear(); quals.clear(); pool.clear(); offsets.assign(1, 0); }
+};
+
+// returns false at end of file
+bool next_fastq(LineReader& in, std::string& id, std::string& seq, std::string& qual, std::string& err) {
+    std::string plus;
+    if (!in.getline(id)) return false;
+    while (id.empty()) if (!in.getline(id)) return false;
+    if (id[0] != '@') { err = "malformed FASTQ record header: " + id; return false; }
+    if (!in.getline(seq) || !in.getline(plus) || !in.getline(qual)) { err = "truncated FASTQ record " + id; return false; }
+    id = record_id(id.substr(1));
+    return true;
+}
+
+}  // namespace
+
+int main(int argc, char** argv) {
+    Options o;
+    try { o = parse_cli(argc, argv); }
+    catch (CliError const& e) { fprintf(stderr, "[CLI PARSER ERROR]\n%s\n", e.msg.c_str()); return -1; }
+    g_debug = o.console_debug_logs;
+    if (!o.logfile.empty()) g_logfile = fopen(o.logfile.c_str(), "a");
+    log_line("info", "successfully parsed CLI input ... starting");
+
+    Reference ref;
+    std::string err;
+    log_line("info", "reading reference sequences from %s", o.reference.c_str());
+    if (!read_references(o.reference, ref, err)) { log_line("error", "An error occured while trying to read the reference from the file %s.\n%s", o.reference.c_str(), err.c_str()); return -1; }
+
+    flx_index* index = nullptr;
+    struct stat st;
+    if (!o.index.empty() && stat(o.index.c_str(), &st) == 0) {
+        log_line("info", "loading index from %s", o.index.c_str());
+        if (flx_index_load(o.index.c_str(), &index) != FLX_OK) { log_line("error", "An error occured while trying to load the index from the file %s.\n%s", o.index.c_str(), flx_last_error()); return -1; }
+        if (flx_index_num_references(index) != ref.ids.size()) { log_line("error", "the index file does not belong to this reference"); return -1; }
+    } else {
+        log_line("info", "building index with %llu thread%s", (unsigned long long)o.threads, o.threads == 1 ? "" : "s");
+        auto const t0 = std::chrono::steady_clock::now();
+        if (flx_index_build(ref.pool.data(), ref.lens.data(), (uint32_t)ref.ids.size(), &index) != FLX_OK) { log_line("error", "index construction failed: %s", flx_last_error()); return -1; }
+        log_line("info", "building index took %.3f seconds", std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
+        if (!o.index.empty() && flx_index_save(index, o.index.c_str()) != FLX_OK)
+            log_line("warning", "An error occured while trying to write the index to the file %s.\nContinuing without saving the index.\n%s", o.index.c_str(), flx_last_error());
+    }
+
+    flx_ctx* ctx = nullptr;
+    int device = 0;
+    if (const char* env = getenv("FLX_DEVICE")) device = atoi(env);
+    if (flx_ctx_create(device, index, &ctx) != FLX_OK) { log_line("error", "cannot set up the GPU context: %s", flx_last_error()); return -1; }
+
+    std::vector<const char*> ref_id_ptrs;
+    for (auto const& s : ref.ids) ref_id_ptrs.push_back(s.c_str());
+    flx_sam_writer* out = nullptr;
+    if (flx_sam_open(o.output.c_str(), ref_id_ptrs.data(), ref.lens.data(), (uint32_t)ref.ids.size(), &out) != FLX_OK) { log_line("error", "%s", flx_last_error()); return -1; }
+
+    flx_params p;
+    flx_params_default(&p);
+    p.query_error_probability = o.has_error_probability ? o.error_probability : -1.0;      // the probability wins (input.cpp:27-33)
+    p.query_num_errors = o.query_errors;
+    p.pex_seed_num_errors = o.seed_errors;
+    p.search.max_num_anchors_hard = o.max_anchors_hard;
+    p.search.max_num_anchors_soft = o.max_anchors_soft;
+    p.search.anchor_group_order = o.anchor_group_order == "errors_first" ? FLX_ORDER_ERRORS_FIRST : o.anchor_group_order == "none" ? FLX_ORDER_NONE : FLX_ORDER_COUNT_FIRST;
+    p.search.anchor_choice_strategy = o.anchor_choice_strategy == "full_groups" ? FLX_CHOICE_FULL_GROUPS : o.anchor_choice_strategy == "first_reported" ? FLX_CHOICE_FIRST_REPORTED : FLX_CHOICE_ROUND_ROBIN;
+    p.search.erase_useless_anchors = !o.dont_erase_useless_anchors;
+    p.seed_sampling_step_size = o.seed_sampling_step_size;
+    p.bottom_up_pex_tree_building = o.bottom_up_pex_tree;
+    p.use_interval_optimization = o.interval_optimization;
+    p.extra_verification_ratio = o.extra_verification_ratio;
+    p.direct_full_verification = o.direct_full_verification;
+    p.without_cigar = o.without_cigar;
+    p.num_anchors_per_verification_task = o.num_anchors_per_task;
+
+    struct stat qst;
+    stat(o.queries.c_str(), &qst);
+    log_line("info", "aligning queries from a %lld bytes large file against %zu references on the GPU and writing output file to %s", (long long)qst.st_size, ref.ids.size(), o.output.c_str());
+    auto const t_align = std::chrono::steady_clock::now();
+    LineReader qin(o.queries.c_str());
+    if (!qin.f) { log_line("error", "cannot open %s", o.queries.c_str()); return -1; }
+    size_t batch_reads = 2048;
+    if (const char* env = getenv("FLX_BATCH_READS")) { size_t const v = strtoull(env, nullptr, 10); if (v) batch_reads = v; }
+    ReadBatch batch;
+    std::string id, seq, qual;
+    uint64_t total_reads = 0, total_records = 0;
+    bool failed = false, eof = false, timed_out = false;
+    while (!eof && !failed) {
+        if (o.has_timeout && std::chrono::duration<double>(std::chrono::steady_clock::now() - t_align).count() > (double)o.timeout) {
+            log_line("warning", "Timeout happened. Shutting down now. The output file might be incomplete.");
+            timed_out = true;
+            break;
+        }
+        batch.clear();
+        while (batch.ids.size() < batch_reads) {
+            if (!next_fastq(qin, id, seq, qual, err)) { eof = true; if (!err.empty()) { log_line("error", "%s", err.c_str()); failed = true; } break; }
+            if (seq.empty()) { log_line("warning", "The record %s in the query file has an empty sequence and will be skipped.", id.c_str()); continue; }
+            if (seq.size() > 100000) { log_line("warning", "skipping too large query: %s", id.c_str()); continue; }
+            batch.ids.push_back(id);
+            batch.quals.push_back(qual);
+            size_t const off = batch.pool.size();
+            batch.pool.resize(off + seq.size());
+            flx_chars_to_rank_sequence(seq.data(), seq.size(), batch.pool.data() + off);
+            batch.offsets.push_back(batch.pool.size());
+        }
+        if (failed || batch.ids.empty()) break;
+        flx_run* run = nullptr;
+        if (flx_align_reads(ctx, &p, batch.pool.data(), batch.offsets.data(), batch.ids.size(), &run) != FLX_OK) {
+            log_line("error", "An error occurred while aligning a batch of queries.\nShutting down. The output file is likely incomplete. Error message:\n%s", flx_last_error());
+            failed = true;
+            break;
+        }
+        std::vector<flx_record> recs(flx_run_num_records(run));
+        std::vector<uint32_t> cig(flx_run_num_cigar_words(run) + 1);
+        std::vector<uint8_t> skipped(batch.ids.size());
+        flx_run_copy(run, recs.data(), cig.data(), skipped.data());
+        flx_run_free(run);
+        for (size_t i = 0; i < skipped.size(); ++i)
+            if (skipped[i]) log_line("warning", "skipping query: %s due to bad configuration regarding the number of errors.", batch.ids[i].c_str());
+        std::vector<const char*> idp, qp;
+        for (auto const& s : batch.ids) idp.push_back(s.c_str());
+        for (auto const& s : batch.quals) qp.push_back(s.c_str());
+        if (flx_sam_write(out, idp.data(), batch.pool.data(), batch.offsets.data(), qp.data(), recs.data(), recs.size(), cig.data()) != FLX_OK) { log_line("error", "%s", flx_last_error()); failed = true; }
+        total_reads += batch.ids.size();
+        total_records += recs.size();
+        log_line("debug", "finished a batch: %llu queries, %llu records so far", (unsigned long long)total_reads, (unsigned long long)total_records);
+    }
+    if (flx_sam_close(out) != FLX_OK) { log_line("error", "%s", flx_last_error()); failed = true; }
+    flx_ctx_destroy(ctx);
+    flx_index_free(index);
+    if (failed || timed_out) return -1;
+    double const secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_align).count();
+    log_line("info", "finished aligning successfully in %.3f seconds (%llu queries, %llu records)", secs, (unsigned long long)total_reads, (unsigned long long)total_records);
+    if (!o.stats.empty()) {
+        if (o.stats == "terminal") log_line("info", "queries: %llu, alignment records: %llu, seconds: %.3f", (unsigned long long)total_reads, (unsigned long long)total_records, secs);
+        else if (FILE* f = fopen(o.stats.c_str(), "w")) { fprintf(f, "num_queries = %llu\nnum_alignment_records = %llu\nseconds = %.3f\n", (unsigned long long)total_reads, (unsigned long long)total_records, secs); fclose(f); }
+    }
+    if (g_logfile) fclose(g_logfile);
+    return 0;
+}

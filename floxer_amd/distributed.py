@@ -1,0 +1,54 @@
+"""Multi-GPU read sharding: reads are independent units (parallelization.cpp:77-87), so each rank
+aligns a contiguous block of the reads against its own replica of the index and the only exchange step is one
+variable-length gather of alignment records to rank 0 (RCCL over xGMI when the backend is "nccl"; gloo on CPU in tests).
+Rank 0 re-emits the records in global read order, so the output is identical for any number of ranks."""
+import numpy as np
+
+
+def shard_bounds(n_reads, rank, world):
+    """contiguous blocks of ceil(N / G) reads in input order"""
+    per = -(-n_reads // world) if world > 0 else n_reads
+    lo = min(n_reads, rank * per)
+    return lo, min(n_reads, lo + per)
+
+
+def gather_records(rows, cigars, read_offset, rank, world, device=None):
+    """rows: (n,7) int64 {read_index (shard-local), flag, ref_id, pos, nm, cigar_off, cigar_len}; cigars: uint32 words.
+    Returns (rows, cigars) of the whole job on rank 0 (read_index global, cigar offsets rebased), None on other ranks."""
+    rows = np.ascontiguousarray(rows, dtype=np.int64).reshape(-1, 7).copy()
+    rows[:, 0] += read_offset
+    cigars = np.ascontiguousarray(cigars, dtype=np.uint32)
+    if world == 1:
+        return rows, cigars
+    import torch
+    import torch.distributed as dist
+    dev = device if device is not None else torch.device("cpu")
+    t_rows = torch.from_numpy(rows).to(dev)
+    t_cig = torch.from_numpy(cigars.astype(np.int64)).to(dev)
+    counts = torch.tensor([t_rows.shape[0], t_cig.shape[0]], device=dev, dtype=torch.int64)
+    all_counts = [torch.zeros_like(counts) for _ in range(world)]
+    dist.all_gather(all_counts, counts)
+    all_counts = [(int(c[0].item()), int(c[1].item())) for c in all_counts]
+    max_r = max(1, max(c[0] for c in all_counts))
+    max_c = max(1, max(c[1] for c in all_counts))
+    pad_r = torch.zeros((max_r, 7), device=dev, dtype=torch.int64)
+    pad_r[: t_rows.shape[0]] = t_rows
+    pad_c = torch.zeros((max_c,), device=dev, dtype=torch.int64)
+    pad_c[: t_cig.shape[0]] = t_cig
+    if rank == 0:
+        gr = [torch.zeros_like(pad_r) for _ in range(world)]
+        gc = [torch.zeros_like(pad_c) for _ in range(world)]
+        dist.gather(pad_r, gr, dst=0)
+        dist.gather(pad_c, gc, dst=0)
+        out_rows, out_cig, base = [], [], 0
+        for r in range(world):
+            nr, nc = all_counts[r]
+            rr = gr[r][:nr].cpu().numpy().copy()
+            rr[:, 5] += base
+            out_rows.append(rr)
+            out_cig.append(gc[r][:nc].cpu().numpy().astype(np.uint32))
+            base += nc
+        return np.concatenate(out_rows, axis=0), np.concatenate(out_cig)
+    dist.gather(pad_r, None, dst=0)
+    dist.gather(pad_c, None, dst=0)
+    return None

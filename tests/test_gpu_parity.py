@@ -277,3 +277,68 @@ def test_full_size_reads_properties():
     exp = O.Index(genome).run(reads[:12], O.params(error_probability=0.08), threads=8)
     assert [r for r in recs if r[0] < 12] == exp.records()
     ctx.close()
+
+
+@pytest.mark.parametrize("seed_errors,ext", [(0, "sam"), (1, "sam"), (1, "bam")])
+def test_cli_whole_program(pins, tmp_path, seed_errors, ext):
+    """the reference's end-to-end test (floxer_whole_program_via_cli_test.cpp:17-143) against the drop-in CLI"""
+    import gzip
+    import struct
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "floxer_amd", "floxer")
+    g = os.path.join(root, "tests", "golden")
+    out = str(tmp_path / f"out.{ext}")
+    cmd = [exe, "--reference", os.path.join(g, "reference.fasta"), "--queries", os.path.join(g, "queries.fastq"), "--output", out,
+           "--interval-optimization", "--console-debug-logs", "--query-errors", "2", "--seed-errors", str(seed_errors),
+           "--extra-verification-ratio", "2", "--threads", "1"]
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert r.returncode == 0, r.stderr.decode()
+    assert r.stdout == b""                                    # all diagnostics on stderr
+    wp = pins["whole_program"]
+    recs = []
+    if ext == "sam":
+        lines = open(out).read().splitlines()
+        assert lines[0].startswith("@HD") and lines[1] == "@SQ\tSN:ref\tLN:71" and lines[2] == "@SQ\tSN:*extra_snippet(\")\tLN:8"
+        for l in lines[3:]:
+            f = l.split("\t")
+            nm = [int(t[5:]) for t in f[11:] if t.startswith("NM:i:")]
+            recs.append((f[0], int(f[1]), f[2], int(f[3]) - 1, f[5], nm[0] if nm else None, f[9], f[10]))
+    else:
+        data = gzip.open(out, "rb").read()
+        l_text = struct.unpack_from("<i", data, 4)[0]
+        off = 8 + l_text
+        n_ref = struct.unpack_from("<i", data, off)[0]
+        off += 4
+        names = []
+        for _ in range(n_ref):
+            ln = struct.unpack_from("<i", data, off)[0]
+            names.append(data[off + 4: off + 4 + ln - 1].decode())
+            off += 4 + ln + 4
+        while off < len(data):
+            bs, ref_id, pos, l_name, mapq, _bin, n_cig, flag, l_seq = struct.unpack_from("<iiiBBHHHi", data, off)
+            p = off + 36
+            name = data[p: p + l_name - 1].decode()
+            p += l_name
+            cig = "".join(f"{w >> 4}{'MIDNSHP=X'[w & 15]}" for w in struct.unpack_from(f"<{n_cig}I", data, p))
+            p += 4 * n_cig + (l_seq + 1) // 2 + l_seq
+            nm = None
+            if p < off + 4 + bs:
+                assert data[p:p + 2] == b"NM"
+                nm = data[p + 3]
+            recs.append((name, flag, names[ref_id] if ref_id >= 0 else "*", pos, cig or "*", nm, None, None))
+            off += 4 + bs
+    assert {r[0] for r in recs} == set(wp["ids"])
+    for name, flag, rname, pos, cig, nm, seq, qual in recs:
+        if name in wp["unmapped"]:
+            assert flag == 4 and rname == "*"
+            continue
+        assert rname == "ref" and not flag & 4
+        for ename, erev, pmin, pmax, enm, ecig in wp["expect"]:
+            if ename == name and erev == bool(flag & 16):
+                assert pmin <= pos <= pmax and nm == enm and cig == ecig
+        if seq is not None:
+            if flag & 256:
+                assert seq == "*" and qual == "*"            # secondary records carry no SEQ/QUAL (output.cpp:69-90)
+            else:
+                assert len(seq) == 12 and qual == "I" * 12

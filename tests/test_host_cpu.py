@@ -149,3 +149,22 @@ def test_sam_and_bam_writer(tmp_path):
             assert open(path, "rb").read()[-28:] == bytes.fromhex("1f8b08040000000000ff0600424302001b0003000000000000000000")
     with pytest.raises(F.FloxerError):
         capi.check(L.flx_sam_open(str(tmp_path / "o.txt").encode(), ids, capi.ptr(lens, capi.u64p), 1, C.byref(C.c_void_p())))
+
+
+def test_cli_rejects_bad_invocations(tmp_path):
+    """exit code -1 and diagnostics on stderr only (floxer.cpp:38-42; floxer_whole_program_via_cli_test.cpp:125-126)"""
+    import subprocess
+    exe = os.path.join(ROOT, "floxer_amd", "floxer")
+    if not os.path.exists(exe):
+        pytest.skip("CLI not built")
+    g = os.path.join(ROOT, "tests", "golden")
+    base = [exe, "--reference", os.path.join(g, "reference.fasta"), "--queries", os.path.join(g, "queries.fastq")]
+    cases = [base + ["--output", str(tmp_path / "o.sam")],                                   # neither -e nor -p
+             base + ["--output", str(tmp_path / "o.txt"), "-e", "2"],                        # bad output extension
+             base + ["--output", str(tmp_path / "o.sam"), "-e", "1", "-s", "2"],             # query errors < seed errors
+             base + ["--output", str(tmp_path / "o.sam"), "-e", "2", "-M", "5", "-m", "9"],  # hard < soft
+             base + ["--output", str(tmp_path / "o.sam"), "-e", "2", "--seed-errors", "4"],  # out of range
+             [exe, "--queries", os.path.join(g, "queries.fastq"), "--output", str(tmp_path / "o.sam"), "-e", "2"]]   # missing required
+    for cmd in cases:
+        r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        assert r.returncode == 255 and r.stdout == b"" and b"CLI PARSER ERROR" in r.stderr, cmd
