@@ -8,6 +8,8 @@
 //   K5 ed_traceback   trace walk + CIGAR (alignment.cpp:166-180)
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "flx_internal.hpp"
 
 namespace flx {
@@ -401,35 +403,225 @@ __global__ void __launch_bounds__(64) ed_align_kernel(const u8* __restrict__ tex
     }
 }
 
-AlignShape choose_align_shape(u32 m) {
-    static const u32 ws[] = {1, 2, 3, 4, 6, 8, 13, 25};
+// ------------------------------------------------------------------------------------------------ banded, ring-scheduled form
+// Only cells on diagonals -k <= col - row <= (n - m) + k can lie on an alignment of the whole query inside the window with at
+// most k errors (Ukkonen). The query's 64*W-row word groups g = 0..Lg-1 are therefore only computed for the columns
+// [64W*g - k, 64W*(g+1) - 1 + (n-m) + k]; group g runs on lane (g mod R) of the job's R-lane ring, skewed by g steps, and a lane
+// moves on to group g+R when its window ends (host guarantees the windows of g and g+R do not overlap in time). A group that
+// starts late starts from the all-(+1) column, a group whose predecessor has finished receives horizontal delta +1: both only
+// over-estimate cells outside the band, every cell on a valid path (and the trace bits of its predecessors) stays exact.
+// Each carry word also hands the predecessor's bottom-row value down so that the last group knows D[m][c] absolutely.
+template <int W, bool TRACE>
+__global__ void __launch_bounds__(64) ed_band_kernel(const u8* __restrict__ text, const u64* __restrict__ peq,
+                                                     const DevAlignJob* __restrict__ jobs, u32 n_jobs, u32 log2_r,
+                                                     u64* __restrict__ trace, DevAlignOut* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) u64 lds_eq[];     // [6 symbols][64 lanes][W words]
+    u32 const lane = lane_id();
+    u32 const R = 1u << log2_r;
+    u32 const p = lane & (R - 1u);
+    u32 const jobs_per_wave = 64u >> log2_r;
+    u32 const job_id = blockIdx.x * jobs_per_wave + (lane >> log2_r);
+    bool const valid = job_id < n_jobs;
+    DevAlignJob job;
+    if (valid) job = jobs[job_id];
+    else { job.ref_off = 0; job.q_off = 0; job.trace_off = 0; job.n = 0; job.m = 1; job.k = 0; job.out_index = 0; }
+
+    int const n = (int)job.n, m = (int)job.m, k = (int)job.k;
+    int const nw = (m + 63) >> 6;
+    int const Lg = (nw + W - 1) / W;                      // word groups
+    int const band_hi = n - m + k;                        // largest useful diagonal (col - row, 1-based)
+    u32 const src_lane = (lane & ~(R - 1u)) | ((lane - 1u) & (R - 1u));
+
+    int g = (int)p;                                       // current group of this lane
+    int c_lo = 0, c_hi = -1;
+    u64 vp[W], vn[W];
+    int rows_g = 0;
+    auto enter_group = [&]() {
+        // window of columns (0-based) and equality masks of group g
+        int const r0 = 64 * W * g;
+        int const r1 = min(m, r0 + 64 * W);
+        rows_g = r1 - r0;
+        c_lo = max(0, r0 - k);
+        c_hi = min(n - 1, r1 - 1 + band_hi);
+        u64 const a = job.q_off >> 6;
+        u32 const sh = (u32)(job.q_off & 63u);
+#pragma unroll
+        for (int w = 0; w < W; ++w) {
+            int const gw = g * W + w;
+#pragma unroll
+            for (u32 s = 0; s < 6; ++s) {
+                u64 v = 0;
+                if (gw < nw) {
+                    u64 const lo = peq[(a + gw) * 6 + s];
+                    u64 const hi = peq[(a + gw + 1) * 6 + s];
+                    v = sh ? (lo >> sh) | (hi << (64 - sh)) : lo;
+                    int const rows_left = m - gw * 64;
+                    if (rows_left < 64) v &= (1ull << rows_left) - 1ull;
+                }
+                lds_eq[(s * 64u + lane) * W + w] = v;
+            }
+            vp[w] = ~0ull;
+            vn[w] = 0ull;
+        }
+    };
+    bool has_group = valid && g < Lg;
+    if (has_group) enter_group();
+    else {
+#pragma unroll
+        for (int w = 0; w < W; ++w) { vp[w] = ~0ull; vn[w] = 0ull; }
+    }
+
+    u32 const my_steps = valid ? (u32)(n + Lg - 1) : 0u;
+    u32 const t_max = wave_max_u32(my_steps);
+
+    // reference symbols: this lane needs text[ref_off + (t - g)] at step t; 8 symbols per refill, one refill ahead
+    const u8* __restrict__ ref = text + job.ref_off;
+    auto load8 = [&](int t) -> u64 {
+        int const c = t - g;
+        if (c < -8 || c >= n + 8) return 0ull;            // outside the window (+- guard): never consumed by an active step
+        const u8* const addr = ref + c;
+        uintptr_t const ai = (uintptr_t)addr;
+        const u64* const base = reinterpret_cast<const u64*>(ai & ~(uintptr_t)7);
+        u32 const shb = (u32)(ai & 7u) * 8u;
+        u64 const lo = base[0], hi = base[1];
+        return shb ? (lo >> shb) | (hi << (64u - shb)) : lo;
+    };
+    u64 queue = 0, next_queue = 0;
+    if (has_group) { queue = load8(0); next_queue = load8(8); }
+
+    u32 cout = 2u;                                        // inactive lanes hand down "horizontal +1"
+    int bot = 0;                                          // D[last row of the group][current column]
+    bool started = false;
+    int best = m, best_col = 0;
+    u64 const last_bit = 1ull << ((m - 1) & 63);
+
+    for (u32 t = 0; t < t_max; ++t) {
+        int c = (int)t - g;
+        if (has_group && c > c_hi && g + (int)R < Lg) {
+            // this lane's group is finished: take over group g + R (its window starts strictly later)
+            g += (int)R;
+            enter_group();
+            started = false;
+            c = (int)t - g;
+            int const tb = (int)(t & ~7u);
+            queue = load8(tb) >> (8u * (t & 7u));
+            next_queue = load8(tb + 8);
+        } else if ((t & 7u) == 0u && t > 0u) {
+            queue = next_queue;
+            next_queue = has_group ? load8((int)t + 8) : 0ull;
+        }
+        u32 const sym = (u32)(queue & 7ull);
+        queue >>= 8;
+        u32 const cin_raw = (u32)__shfl((int)cout, (int)src_lane);
+        bool const active = has_group && c >= c_lo && c <= c_hi;
+        if (active) {
+            u32 const cin = g == 0 ? 0u : cin_raw;
+            u64 c_hp = (cin >> 1) & 1u, c_hn = (cin >> 2) & 1u;
+            u64 c_d0 = c_hn;                              // the adder's carry out of a word equals its top horizontal-negative bit
+            if (!started) {
+                // column just left of the window: all vertical deltas +1 below the predecessor's bottom value
+                int const top_prev = g == 0 ? 0 : (int)(cin >> 3) - (int)c_hp + (int)c_hn;
+                bot = top_prev + rows_g;
+                started = true;
+            }
+            bool const is_last_group = g == Lg - 1;
+            int const w_last = (nw - 1) - g * W;
+            const u64* __restrict__ eqp = &lds_eq[(sym * 64u + lane) * W];
+#pragma unroll
+            for (int w = 0; w < W; ++w) {
+                u64 const eq = eqp[w];
+                u64 const pv = vp[w], mv = vn[w];
+                u64 const x = eq | mv;
+                u64 const t1 = pv + (x & pv);
+                u64 const tt = t1 + c_d0;
+                u64 const d0 = (tt ^ pv) | x;
+                u64 const hn = pv & d0;
+                u64 const hp = mv | ~(pv | d0);
+                u64 const xh = (hp << 1) | c_hp;
+                u64 const nvn = xh & d0;
+                u64 const nvp = (hn << 1) | ~(xh | d0) | c_hn;
+                c_hp = hp >> 63;
+                c_hn = hn >> 63;
+                c_d0 = c_hn;
+                vn[w] = nvn;
+                vp[w] = nvp;
+                if (TRACE) {
+                    ulonglong2 v;
+                    v.x = hp;
+                    v.y = nvp;
+                    u64 const slot = job.trace_off + ((u64)t * R + p) * W + (u64)w;
+                    *reinterpret_cast<ulonglong2*>(trace + 2ull * slot) = v;
+                }
+                if (is_last_group && w == w_last) {
+                    bot += (hp & last_bit) ? 1 : 0;
+                    bot -= (hn & last_bit) ? 1 : 0;
+                }
+            }
+            if (!is_last_group) bot += (int)c_hp - (int)c_hn;
+            else if (bot <= best) { best = bot; best_col = c + 1; }
+            cout = ((u32)c_hp << 1) | ((u32)c_hn << 2) | ((u32)bot << 3);
+        } else {
+            cout = 2u;
+        }
+    }
+    if (valid && has_group && g == Lg - 1) {
+        DevAlignOut o;
+        o.score = best <= k ? (u32)best : 0xFFFFFFFFu;
+        o.end_col = (u32)best_col;
+        out[job.out_index] = o;
+    }
+}
+
+static const u32 kWordsPerLane[] = {1, 2, 3, 4, 6, 8, 13, 25};
+
+static bool use_band() {
+    static int const v = getenv("FLX_NO_BAND") ? 0 : 1;
+    return v != 0;
+}
+
+AlignShape choose_align_shape(u32 n, u32 m, u32 k) {
     u32 const nw = (m + 63) / 64;
-    AlignShape best{0, 0};
+    AlignShape best{0, 0, 0};
     u64 best_cost = ~0ull;
-    for (u32 w : ws)
-        for (u32 g = 1; g <= 64; g *= 2) {
-            if ((u64)w * g < nw) continue;
+    bool const band = use_band();
+    i64 const width = (i64)n - (i64)m + 2 * (i64)k;       // diagonals that matter, minus one
+    for (u32 w : kWordsPerLane)
+        for (u32 r = 1; r <= 64; r *= 2) {
+            u32 const groups = (nw + w - 1) / w;
+            bool ok = groups <= r;                        // every group has its own lane
+            if (!ok && band) ok = (i64)64 * w * (r - 1) + r + 1 > width;   // group g + r starts after group g has ended
+            if (!ok) continue;
             // cost ~ wave slots consumed: words per lane times lanes reserved; prefer fewer words per lane on ties
-            u64 const cost = (u64)w * g * 1000 + w;
-            if (cost < best_cost) { best_cost = cost; best = AlignShape{w, g}; }
+            u64 const cost = (u64)w * r * 1000 + w;
+            if (cost < best_cost) { best_cost = cost; best = AlignShape{w, r, band ? 1u : 0u}; }
         }
     return best;
 }
 u32 align_supported_max_query() { return 25u * 64u * 64u; }
 
+u64 align_trace_slots(u32 n, u32 m, AlignShape sh) {
+    u32 const nw = (m + 63) / 64;
+    u64 const groups = (nw + sh.words_per_lane - 1) / sh.words_per_lane;
+    // step-major: (n + groups - 1) steps, `lanes` lanes, W words; for the unbanded kernel lanes == groups rounded up is not
+    // required, the kernel only uses `groups` lanes per step there
+    u64 const lanes = sh.banded ? sh.lanes_per_job : groups;
+    return ((u64)n + groups - 1) * lanes * sh.words_per_lane;
+}
+
 template <int W>
 static int launch_align(hipStream_t s, const u8* d_text, const u64* d_peq, const DevAlignJob* d_jobs, u32 n_jobs, u32 log2_g, bool trace,
-                        u64* d_trace, DevAlignOut* d_out) {
+                        bool banded, u64* d_trace, DevAlignOut* d_out) {
     u32 const jobs_per_wave = 64u >> log2_g;
     u32 const blocks = (n_jobs + jobs_per_wave - 1) / jobs_per_wave;
     size_t const lds = (size_t)6 * 64 * W * sizeof(u64);
-    if (trace) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ed_align_kernel<W, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL((ed_align_kernel<W, true>), dim3(blocks), dim3(64), lds, s, d_text, d_peq, d_jobs, n_jobs, log2_g, d_trace, d_out);
-    } else {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ed_align_kernel<W, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL((ed_align_kernel<W, false>), dim3(blocks), dim3(64), lds, s, d_text, d_peq, d_jobs, n_jobs, log2_g, d_trace, d_out);
-    }
+#define FLX_LAUNCH(KERNEL)                                                                                                           \
+    do {                                                                                                                             \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&KERNEL), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);     \
+        hipLaunchKernelGGL((KERNEL), dim3(blocks), dim3(64), lds, s, d_text, d_peq, d_jobs, n_jobs, log2_g, d_trace, d_out);          \
+    } while (0)
+    if (banded) { if (trace) FLX_LAUNCH((ed_band_kernel<W, true>)); else FLX_LAUNCH((ed_band_kernel<W, false>)); }
+    else { if (trace) FLX_LAUNCH((ed_align_kernel<W, true>)); else FLX_LAUNCH((ed_align_kernel<W, false>)); }
+#undef FLX_LAUNCH
     return (int)hipGetLastError();
 }
 
@@ -439,15 +631,16 @@ int DeviceApi::align(void* stream, const u8* d_text, const u64* d_peq, const Dev
     u32 log2_g = 0;
     while ((1u << log2_g) < shape.lanes_per_job) ++log2_g;
     hipStream_t s = (hipStream_t)stream;
+    bool const b = shape.banded != 0;
     switch (shape.words_per_lane) {
-        case 1: return launch_align<1>(s, d_text, d_peq, d_jobs, n_jobs, log2_g, trace, d_trace, d_out);
-        case 2: return launch_align<2>(s, d_text, d_peq, d_jobs, n_jobs, log2_g, trace, d_trace, d_out);
-        case 3: return launch_align<3>(s, d_text, d_peq, d_jobs, n_jobs, log2_g, trace, d_trace, d_out);
-        case 4: return launch_align<4>(s, d_text, d_peq, d_jobs, n_jobs, log2_g, trace, d_trace, d_out);
-        case 6: return launch_align<6>(s, d_text, d_peq, d_jobs, n_jobs, log2_g, trace, d_trace, d_out);
-        case 8: return launch_align<8>(s, d_text, d_peq, d_jobs, n_jobs, log2_g, trace, d_trace, d_out);
-        case 13: return launch_align<13>(s, d_text, d_peq, d_jobs, n_jobs, log2_g, trace, d_trace, d_out);
-        case 25: return launch_align<25>(s, d_text, d_peq, d_jobs, n_jobs, log2_g, trace, d_trace, d_out);
+        case 1: return launch_align<1>(s, d_text, d_peq, d_jobs, n_jobs, log2_g, trace, b, d_trace, d_out);
+        case 2: return launch_align<2>(s, d_text, d_peq, d_jobs, n_jobs, log2_g, trace, b, d_trace, d_out);
+        case 3: return launch_align<3>(s, d_text, d_peq, d_jobs, n_jobs, log2_g, trace, b, d_trace, d_out);
+        case 4: return launch_align<4>(s, d_text, d_peq, d_jobs, n_jobs, log2_g, trace, b, d_trace, d_out);
+        case 6: return launch_align<6>(s, d_text, d_peq, d_jobs, n_jobs, log2_g, trace, b, d_trace, d_out);
+        case 8: return launch_align<8>(s, d_text, d_peq, d_jobs, n_jobs, log2_g, trace, b, d_trace, d_out);
+        case 13: return launch_align<13>(s, d_text, d_peq, d_jobs, n_jobs, log2_g, trace, b, d_trace, d_out);
+        case 25: return launch_align<25>(s, d_text, d_peq, d_jobs, n_jobs, log2_g, trace, b, d_trace, d_out);
         default: return (int)hipErrorInvalidValue;
     }
 }
@@ -475,7 +668,7 @@ __global__ void __launch_bounds__(64) ed_traceback_kernel(const u8* __restrict__
         else {
             u32 const gw = (i - 1u) >> 6, bit = (i - 1u) & 63u;
             u32 const lgx = gw / W, w = gw - lgx * W;
-            u64 const slot = job.trace_off + ((u64)(j - 1u + lgx) * L + lgx) * W + w;
+            u64 const slot = job.trace_off + ((u64)(j - 1u + lgx) * L + (lgx % L)) * W + w;
             ulonglong2 const v = *reinterpret_cast<const ulonglong2*>(trace + 2ull * slot);
             if ((v.y >> bit) & 1ull) { op = 1u; --i; }                  // up: query symbol unmatched (I)
             else if ((v.x >> bit) & 1ull) { op = 2u; --j; }             // left: reference symbol skipped (D)

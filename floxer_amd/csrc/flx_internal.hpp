@@ -94,8 +94,9 @@ struct DevTraceJob {
 struct DevTraceOut { u32 begin; u32 cigar_start; u32 cigar_len; u32 pad; };   // cigar_start relative to the slab
 
 // launch geometry for one alignment job shape
-struct AlignShape { u32 words_per_lane; u32 lanes_per_job; };
-AlignShape choose_align_shape(u32 m);
+struct AlignShape { u32 words_per_lane; u32 lanes_per_job; u32 banded; };
+AlignShape choose_align_shape(u32 n, u32 m, u32 k);
+u64 align_trace_slots(u32 n, u32 m, AlignShape sh);     // 16-byte trace slots a TRACE launch of this shape needs for one job
 u32 align_supported_max_query();
 
 // ------------------------------------------------------------------------------------------------ device launchers (flx_device.hip)

@@ -364,15 +364,23 @@ namespace {
 
 struct AlignRequest { u64 ref_off, q_off; u32 n, m, k; };
 
-u64 trace_slots(u32 n, u32 m, AlignShape sh) {
-    u32 const nw = (m + 63) / 64;
-    u64 const L = (nw + sh.words_per_lane - 1) / sh.words_per_lane;
-    return ((u64)n + L - 1) * L * sh.words_per_lane;
+// word-steps the launch really performs for one job: the whole matrix, or only the band -k <= col-row <= n-m+k
+u64 job_word_steps(u32 n, u32 m, u32 k, AlignShape sh) {
+    u64 const nw = (m + 63) / 64;
+    if (!sh.banded) return (u64)n * nw;
+    i64 const W = sh.words_per_lane, band_hi = (i64)n - (i64)m + (i64)k;
+    u64 total = 0;
+    for (i64 g = 0; g * W < (i64)nw; ++g) {
+        i64 const r0 = 64 * W * g, r1 = std::min<i64>(m, r0 + 64 * W);
+        i64 const lo = std::max<i64>(0, r0 - (i64)k), hi = std::min<i64>((i64)n - 1, r1 - 1 + band_hi);
+        if (hi >= lo) total += (u64)(hi - lo + 1) * (u64)std::min<i64>(W, (i64)nw - g * W);
+    }
+    return total;
 }
 
 struct ShapeKey {
-    u32 w, g;
-    bool operator<(ShapeKey const& o) const { return w != o.w ? w < o.w : g < o.g; }
+    u32 w, g, banded;
+    bool operator<(ShapeKey const& o) const { return w != o.w ? w < o.w : g != o.g ? g < o.g : banded < o.banded; }
 };
 
 // score + end column for every request (no trace)
@@ -382,9 +390,9 @@ int run_score_jobs(Lane* ctx, const u8* d_text, const u64* d_peq, std::vector<Al
     if (reqs.empty()) return FLX_OK;
     std::map<ShapeKey, std::vector<u32>> by_shape;
     for (u32 i = 0; i < reqs.size(); ++i) {
-        AlignShape const sh = choose_align_shape(reqs[i].m);
+        AlignShape const sh = choose_align_shape(reqs[i].n, reqs[i].m, reqs[i].k);
         if (sh.words_per_lane == 0) { set_error("query longer than the supported maximum"); return FLX_ERR_UNSUPPORTED; }
-        by_shape[ShapeKey{sh.words_per_lane, sh.lanes_per_job}].push_back(i);
+        by_shape[ShapeKey{sh.words_per_lane, sh.lanes_per_job, sh.banded}].push_back(i);
     }
     std::vector<DevAlignJob> jobs;
     jobs.reserve(reqs.size());
@@ -398,7 +406,7 @@ int run_score_jobs(Lane* ctx, const u8* d_text, const u64* d_peq, std::vector<Al
         for (u32 id : ids) {
             AlignRequest const& r = reqs[id];
             jobs.push_back(DevAlignJob{r.ref_off, r.q_off, 0, r.n, r.m, r.k, id});
-            l.word_steps += (u64)r.n * ((r.m + 63) / 64);
+            l.word_steps += job_word_steps(r.n, r.m, r.k, AlignShape{kv.first.w, kv.first.g, kv.first.banded});
             l.bytes += (u64)r.n + r.m;
         }
         launches.push_back(l);
@@ -409,7 +417,7 @@ int run_score_jobs(Lane* ctx, const u8* d_text, const u64* d_peq, std::vector<Al
     for (auto const& l : launches) {
         rc = timed_launch(ctx, kernel_name, l.bytes, l.word_steps, [&] {
             return DeviceApi::align(ctx->stream, d_text, d_peq, ctx->jobs.as<DevAlignJob>() + l.first, l.count,
-                                    AlignShape{l.key.w, l.key.g}, false, nullptr, ctx->job_out.as<DevAlignOut>());
+                                    AlignShape{l.key.w, l.key.g, l.key.banded}, false, nullptr, ctx->job_out.as<DevAlignOut>());
         });
         if (rc) return rc;
     }
@@ -428,9 +436,9 @@ int run_trace_jobs(Lane* ctx, const u8* d_text, const u8* d_query, const u64* d_
     std::vector<u64> slots(reqs.size());
     u64 const budget_slots = std::max<u64>(ctx->trace_budget_bytes / 16, 1);
     for (size_t i = 0; i < reqs.size(); ++i) {
-        shapes[i] = choose_align_shape(reqs[i].m);
+        shapes[i] = choose_align_shape(reqs[i].n, reqs[i].m, reqs[i].k);
         if (shapes[i].words_per_lane == 0) { set_error("query longer than the supported maximum"); return FLX_ERR_UNSUPPORTED; }
-        slots[i] = trace_slots(reqs[i].n, reqs[i].m, shapes[i]);
+        slots[i] = align_trace_slots(reqs[i].n, reqs[i].m, shapes[i]);
         if (slots[i] > budget_slots) { set_error("one alignment needs more trace memory than the configured budget (FLX_TRACE_ARENA_MB)"); return FLX_ERR_CAPACITY; }
     }
     int rc;
@@ -444,7 +452,7 @@ int run_trace_jobs(Lane* ctx, const u8* d_text, const u8* d_query, const u64* d_
         if ((rc = ctx->trace.ensure(used * 16 + 64))) return rc;
 
         std::map<ShapeKey, std::vector<u32>> by_shape;
-        for (size_t i = begin; i < next; ++i) by_shape[ShapeKey{shapes[i].words_per_lane, shapes[i].lanes_per_job}].push_back((u32)i);
+        for (size_t i = begin; i < next; ++i) by_shape[ShapeKey{shapes[i].words_per_lane, shapes[i].lanes_per_job, shapes[i].banded}].push_back((u32)i);
         std::vector<DevAlignJob> jobs;
         std::vector<u64> trace_off(count);
         struct Launch { ShapeKey key; u32 first, count; u64 word_steps, bytes; };
@@ -459,7 +467,7 @@ int run_trace_jobs(Lane* ctx, const u8* d_text, const u8* d_query, const u64* d_
                 trace_off[id - begin] = off;
                 jobs.push_back(DevAlignJob{r.ref_off, r.q_off, off, r.n, r.m, r.k, (u32)(id - begin)});
                 off += slots[id];
-                u64 const ws = (u64)r.n * ((r.m + 63) / 64);
+                u64 const ws = job_word_steps(r.n, r.m, r.k, shapes[id]);
                 l.word_steps += ws;
                 l.bytes += (u64)r.n + r.m + ws * 16;        // reference + query symbols read, 2 trace words written per word-step
             }
@@ -470,7 +478,7 @@ int run_trace_jobs(Lane* ctx, const u8* d_text, const u8* d_query, const u64* d_
         for (auto const& l : launches) {
             rc = timed_launch(ctx, "ed_align_trace", l.bytes, l.word_steps, [&] {
                 return DeviceApi::align(ctx->stream, d_text, d_peq, ctx->jobs.as<DevAlignJob>() + l.first, l.count,
-                                        AlignShape{l.key.w, l.key.g}, true, ctx->trace.as<u64>(), ctx->job_out.as<DevAlignOut>());
+                                        AlignShape{l.key.w, l.key.g, l.key.banded}, true, ctx->trace.as<u64>(), ctx->job_out.as<DevAlignOut>());
             });
             if (rc) return rc;
         }
@@ -488,7 +496,7 @@ int run_trace_jobs(Lane* ctx, const u8* d_text, const u8* d_query, const u64* d_
             AlignRequest const& r = reqs[id];
             AlignShape const sh = shapes[id];
             u32 const nw = (r.m + 63) / 64;
-            u32 const L = (nw + sh.words_per_lane - 1) / sh.words_per_lane;
+            u32 const L = sh.banded ? sh.lanes_per_job : (nw + sh.words_per_lane - 1) / sh.words_per_lane;
             u32 const cap = 2 * outs[c].score + 2;      // runs <= 2*NM + 1
             tjobs.push_back(DevTraceJob{r.ref_off, r.q_off, trace_off[c], cigar_words, r.n, r.m, L, sh.words_per_lane, outs[c].end_col,
                                         cap, (u32)tjob_req.size(), 0});
