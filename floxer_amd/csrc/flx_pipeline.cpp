@@ -514,9 +514,10 @@ int run_trace_jobs(Lane* ctx, const u8* d_text, const u8* d_query, const u64* d_
             });
             if (rc) return rc;
             std::vector<DevTraceOut> touts(tjobs.size());
-            std::vector<u32> cig(cigar_words);
+            size_t const pool_base = cigar_pool.size();
+            cigar_pool.resize(pool_base + cigar_words);          // slabs are kept as they are (gaps included): no host repacking
             if ((rc = d2h(ctx, touts.data(), ctx->tjob_out.ptr, touts.size() * sizeof(DevTraceOut)))) return rc;
-            if ((rc = d2h(ctx, cig.data(), ctx->cigar.ptr, cigar_words * 4))) return rc;
+            if ((rc = d2h(ctx, cigar_pool.data() + pool_base, ctx->cigar.ptr, cigar_words * 4))) return rc;
             if ((rc = ctx->sync())) return rc;
             for (size_t j = 0; j < tjobs.size(); ++j) {
                 if (touts[j].cigar_len == 0xFFFFFFFFu) { set_error("ed_traceback: CIGAR slab overflow"); return FLX_ERR_INTERNAL; }
@@ -524,10 +525,8 @@ int run_trace_jobs(Lane* ctx, const u8* d_text, const u8* d_query, const u64* d_
                 res.exists = true;
                 res.nm = outs[tjob_req[j] - begin].score;
                 res.begin = touts[j].begin;
-                res.cigar_off = cigar_pool.size();
+                res.cigar_off = pool_base + tjobs[j].cigar_off + touts[j].cigar_start;
                 res.cigar_len = touts[j].cigar_len;
-                const u32* src = cig.data() + tjobs[j].cigar_off + touts[j].cigar_start;
-                cigar_pool.insert(cigar_pool.end(), src, src + touts[j].cigar_len);
             }
         }
     }
@@ -733,9 +732,10 @@ struct AnchorState {
 }  // namespace
 
 struct flx_run {
-    std::vector<flx_record> records;
+    std::vector<flx_record> records;     // cigar_offset relative to this object's `cigars`
     std::vector<u32> cigars;
     std::vector<u8> skipped;
+    std::vector<flx_run> parts;          // a batch result is the in-order list of its slices (no concatenation on the host)
 };
 
 extern "C" void flx_params_default(flx_params* p) {
@@ -1001,13 +1001,12 @@ int align_slice(Lane* lane, const flx_params* P, const flx_reads* RD, u64 first_
                 bool const primary = !primary_written && root_res[i].nm == best;
                 if (primary) primary_written = true;
                 else flag |= 256u;
-                flx_record rec{reads[r].read_index, flag, (int32_t)ref, saturate_i32(root_res[i].start), root_res[i].nm, run->cigars.size(),
-                               root_res[i].cigar_len, 0};
-                run->cigars.insert(run->cigars.end(), cig.begin() + root_res[i].cigar_off, cig.begin() + root_res[i].cigar_off + root_res[i].cigar_len);
-                run->records.push_back(rec);
+                run->records.push_back(flx_record{reads[r].read_index, flag, (int32_t)ref, saturate_i32(root_res[i].start), root_res[i].nm,
+                                                  root_res[i].cigar_off, root_res[i].cigar_len, 0});
             }
         if (!primary_written) run->records.push_back(flx_record{reads[r].read_index, 4u, -1, 0, 0, 0, 0, 0});
     }
+    run->cigars = std::move(cig);
     prof.mark("records");
     return FLX_OK;
 }
@@ -1026,7 +1025,8 @@ extern "C" int flx_align_reads_resident(flx_ctx* ctx, const flx_params* P, const
     // contiguous slices, one per lane (reads are independent units: parallelization.cpp:77-87)
     size_t n_lanes = ctx->external_stream ? 1 : ctx->lanes.size();
     n_lanes = std::max<size_t>(1, std::min<size_t>(n_lanes, (n_reads + 63) / 64));
-    std::vector<flx_run> parts(n_lanes);
+    run->parts.resize(n_lanes);
+    std::vector<flx_run>& parts = run->parts;
     std::vector<int> rcs(n_lanes, FLX_OK);
     std::vector<std::string> errs(n_lanes);
     auto work = [&](size_t l) {
@@ -1043,26 +1043,35 @@ extern "C" int flx_align_reads_resident(flx_ctx* ctx, const flx_params* P, const
     }
     for (size_t l = 0; l < n_lanes; ++l)
         if (rcs[l]) { set_error(errs[l]); return rcs[l]; }
-    size_t nrec = 0, ncig = 0;
-    for (auto const& p : parts) { nrec += p.records.size(); ncig += p.cigars.size(); }
-    run->records.reserve(nrec);
-    run->cigars.reserve(ncig);
-    for (auto& p : parts) {
-        u64 const base = run->cigars.size();
-        run->cigars.insert(run->cigars.end(), p.cigars.begin(), p.cigars.end());
-        for (auto rec : p.records) { rec.cigar_offset += base; run->records.push_back(rec); }
+    for (auto& p : parts)
         for (u64 i = 0; i < n_reads; ++i) run->skipped[i] |= p.skipped[i];
-    }
     *out = run.release();
     return FLX_OK;
 }
 
-extern "C" uint64_t flx_run_num_records(const flx_run* run) { return run ? run->records.size() : 0; }
-extern "C" uint64_t flx_run_num_cigar_words(const flx_run* run) { return run ? run->cigars.size() : 0; }
+extern "C" uint64_t flx_run_num_records(const flx_run* run) {
+    if (!run) return 0;
+    uint64_t n = run->records.size();
+    for (auto const& p : run->parts) n += p.records.size();
+    return n;
+}
+extern "C" uint64_t flx_run_num_cigar_words(const flx_run* run) {
+    if (!run) return 0;
+    uint64_t n = run->cigars.size();
+    for (auto const& p : run->parts) n += p.cigars.size();
+    return n;
+}
 extern "C" int flx_run_copy(const flx_run* run, flx_record* records, uint32_t* cigar_words, uint8_t* skipped) {
     if (!run) { set_error("null run"); return FLX_ERR_INVALID; }
-    if (records && !run->records.empty()) memcpy(records, run->records.data(), run->records.size() * sizeof(flx_record));
-    if (cigar_words && !run->cigars.empty()) memcpy(cigar_words, run->cigars.data(), run->cigars.size() * 4);
+    uint64_t rec_base = 0, cig_base = 0;
+    auto emit = [&](flx_run const& part) {
+        if (records) for (size_t i = 0; i < part.records.size(); ++i) { records[rec_base + i] = part.records[i]; records[rec_base + i].cigar_offset += cig_base; }
+        if (cigar_words && !part.cigars.empty()) memcpy(cigar_words + cig_base, part.cigars.data(), part.cigars.size() * 4);
+        rec_base += part.records.size();
+        cig_base += part.cigars.size();
+    };
+    emit(*run);
+    for (auto const& p : run->parts) emit(p);
     if (skipped && !run->skipped.empty()) memcpy(skipped, run->skipped.data(), run->skipped.size());
     return FLX_OK;
 }
