@@ -415,12 +415,15 @@ template <int W, bool TRACE>
 __global__ void __launch_bounds__(64) ed_band_kernel(const u8* __restrict__ text, const u64* __restrict__ peq,
                                                      const DevAlignJob* __restrict__ jobs, u32 n_jobs, u32 log2_r,
                                                      u64* __restrict__ trace, DevAlignOut* __restrict__ out) {
-    extern __shared__ __attribute__((aligned(16))) u64 lds_eq[];     // [6 symbols][64 lanes][W words]
+    // LDS: [6 symbols][64 lanes][W words] equality masks, then one 256-byte ring of reference symbols per job of the wave
+    extern __shared__ __attribute__((aligned(16))) u64 lds_eq[];
+    u8* const lds_sym = reinterpret_cast<u8*>(lds_eq + 6 * 64 * W);
     u32 const lane = lane_id();
     u32 const R = 1u << log2_r;
     u32 const p = lane & (R - 1u);
     u32 const jobs_per_wave = 64u >> log2_r;
-    u32 const job_id = blockIdx.x * jobs_per_wave + (lane >> log2_r);
+    u32 const job_slot = lane >> log2_r;
+    u32 const job_id = blockIdx.x * jobs_per_wave + job_slot;
     bool const valid = job_id < n_jobs;
     DevAlignJob job;
     if (valid) job = jobs[job_id];
@@ -431,6 +434,7 @@ __global__ void __launch_bounds__(64) ed_band_kernel(const u8* __restrict__ text
     int const Lg = (nw + W - 1) / W;                      // word groups
     int const band_hi = n - m + k;                        // largest useful diagonal (col - row, 1-based)
     u32 const src_lane = (lane & ~(R - 1u)) | ((lane - 1u) & (R - 1u));
+    u8* const ring = lds_sym + job_slot * 256u;
 
     int g = (int)p;                                       // current group of this lane
     int c_lo = 0, c_hi = -1;
@@ -474,20 +478,24 @@ __global__ void __launch_bounds__(64) ed_band_kernel(const u8* __restrict__ text
     u32 const my_steps = valid ? (u32)(n + Lg - 1) : 0u;
     u32 const t_max = wave_max_u32(my_steps);
 
-    // reference symbols: this lane needs text[ref_off + (t - g)] at step t; 8 symbols per refill, one refill ahead
+    // Reference symbols travel through the LDS ring (column c at ring[c & 255]) so that the step loop issues no global
+    // loads: a load in the loop would make every step wait for the previous step's trace stores (loads and stores share
+    // vmcnt). The R lanes of a job refill 64 columns at a time, far ahead of the newest column any of them needs.
     const u8* __restrict__ ref = text + job.ref_off;
-    auto load8 = [&](int t) -> u64 {
-        int const c = t - g;
-        if (c < -8 || c >= n + 8) return 0ull;            // outside the window (+- guard): never consumed by an active step
-        const u8* const addr = ref + c;
-        uintptr_t const ai = (uintptr_t)addr;
-        const u64* const base = reinterpret_cast<const u64*>(ai & ~(uintptr_t)7);
-        u32 const shb = (u32)(ai & 7u) * 8u;
-        u64 const lo = base[0], hi = base[1];
-        return shb ? (lo >> shb) | (hi << (64u - shb)) : lo;
+    int loaded = 0;                                       // columns [0, loaded) have been written to the ring (job-uniform)
+    int g_front = 0;                                      // oldest group that is not finished (job-uniform): needs the newest column
+    auto refill = [&]() {
+        u32 const per_lane = 64u >> log2_r;               // R lanes x per_lane bytes = 64 columns
+        for (u32 i = 0; i < per_lane; ++i) {
+            int const c = loaded + (int)(p * per_lane + i);
+            u8 const v = (valid && c < n) ? ref[c] : (u8)7;
+            ring[(u32)c & 255u] = v;
+        }
+        loaded += 64;
     };
-    u64 queue = 0, next_queue = 0;
-    if (has_group) { queue = load8(0); next_queue = load8(8); }
+    refill();
+    refill();
+    __syncthreads();
 
     u32 cout = 2u;                                        // inactive lanes hand down "horizontal +1"
     int bot = 0;                                          // D[last row of the group][current column]
@@ -496,6 +504,13 @@ __global__ void __launch_bounds__(64) ed_band_kernel(const u8* __restrict__ text
     u64 const last_bit = 1ull << ((m - 1) & 63);
 
     for (u32 t = 0; t < t_max; ++t) {
+        // front group: finished once its last column has been passed
+        {
+            int const fr1 = min(m, 64 * W * (g_front + 1));
+            int const f_hi = min(n - 1, fr1 - 1 + band_hi);
+            if ((int)t - g_front > f_hi && g_front + 1 < Lg) ++g_front;
+        }
+        if ((int)t - g_front + 72 > loaded && loaded < n) { refill(); __builtin_amdgcn_s_waitcnt(0); }
         int c = (int)t - g;
         if (has_group && c > c_hi && g + (int)R < Lg) {
             // this lane's group is finished: take over group g + R (its window starts strictly later)
@@ -503,18 +518,11 @@ __global__ void __launch_bounds__(64) ed_band_kernel(const u8* __restrict__ text
             enter_group();
             started = false;
             c = (int)t - g;
-            int const tb = (int)(t & ~7u);
-            queue = load8(tb) >> (8u * (t & 7u));
-            next_queue = load8(tb + 8);
-        } else if ((t & 7u) == 0u && t > 0u) {
-            queue = next_queue;
-            next_queue = has_group ? load8((int)t + 8) : 0ull;
         }
-        u32 const sym = (u32)(queue & 7ull);
-        queue >>= 8;
         u32 const cin_raw = (u32)__shfl((int)cout, (int)src_lane);
         bool const active = has_group && c >= c_lo && c <= c_hi;
         if (active) {
+            u32 const sym = ring[(u32)c & 255u];
             u32 const cin = g == 0 ? 0u : cin_raw;
             u64 c_hp = (cin >> 1) & 1u, c_hn = (cin >> 2) & 1u;
             u64 c_d0 = c_hn;                              // the adder's carry out of a word equals its top horizontal-negative bit
@@ -613,7 +621,7 @@ static int launch_align(hipStream_t s, const u8* d_text, const u64* d_peq, const
                         bool banded, u64* d_trace, DevAlignOut* d_out) {
     u32 const jobs_per_wave = 64u >> log2_g;
     u32 const blocks = (n_jobs + jobs_per_wave - 1) / jobs_per_wave;
-    size_t const lds = (size_t)6 * 64 * W * sizeof(u64);
+    size_t const lds = (size_t)6 * 64 * W * sizeof(u64) + (banded ? (size_t)jobs_per_wave * 256 : 0);
 #define FLX_LAUNCH(KERNEL)                                                                                                           \
     do {                                                                                                                             \
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&KERNEL), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);     \

@@ -12,6 +12,7 @@
 #include <queue>
 #include <set>
 #include <thread>
+#include <unordered_map>
 
 #include "flx_context.hpp"
 
@@ -383,9 +384,36 @@ struct ShapeKey {
     bool operator<(ShapeKey const& o) const { return w != o.w ? w < o.w : g != o.g ? g < o.g : banded < o.banded; }
 };
 
-// score + end column for every request (no trace)
-int run_score_jobs(Lane* ctx, const u8* d_text, const u64* d_peq, std::vector<AlignRequest> const& reqs,
-                   std::vector<DevAlignOut>& outs, const char* kernel_name) {
+// Anchors of one locus produce many identical (window, node) jobs (sibling leaves share their parent's window, anchors with the
+// same indel drift share the root window). Identical inputs give identical outputs, so each distinct job runs once.
+struct ReqKey {
+    u64 ref_off, q_off; u32 n, m, k;
+    bool operator==(ReqKey const& o) const { return ref_off == o.ref_off && q_off == o.q_off && n == o.n && m == o.m && k == o.k; }
+};
+struct ReqKeyHash {
+    size_t operator()(ReqKey const& r) const {
+        u64 h = r.ref_off * 0x9E3779B97F4A7C15ull ^ (r.q_off + 0x7F4A7C15ull) * 0xC2B2AE3D27D4EB4Full;
+        h ^= ((u64)r.n << 40) ^ ((u64)r.m << 20) ^ r.k;
+        h ^= h >> 29;
+        return (size_t)(h * 0xBF58476D1CE4E5B9ull);
+    }
+};
+void dedup_requests(std::vector<AlignRequest> const& reqs, std::vector<AlignRequest>& uniq, std::vector<u32>& uniq_of) {
+    std::unordered_map<ReqKey, u32, ReqKeyHash> seen;
+    seen.reserve(reqs.size() * 2);
+    uniq.clear();
+    uniq_of.resize(reqs.size());
+    for (size_t i = 0; i < reqs.size(); ++i) {
+        AlignRequest const& r = reqs[i];
+        auto ins = seen.emplace(ReqKey{r.ref_off, r.q_off, r.n, r.m, r.k}, (u32)uniq.size());
+        if (ins.second) uniq.push_back(r);
+        uniq_of[i] = ins.first->second;
+    }
+}
+
+// score + end column for every (distinct) request (no trace)
+int run_score_jobs_unique(Lane* ctx, const u8* d_text, const u64* d_peq, std::vector<AlignRequest> const& reqs,
+                          std::vector<DevAlignOut>& outs, const char* kernel_name) {
     outs.assign(reqs.size(), DevAlignOut{0xFFFFFFFFu, 0});
     if (reqs.empty()) return FLX_OK;
     std::map<ShapeKey, std::vector<u32>> by_shape;
@@ -425,11 +453,40 @@ int run_score_jobs(Lane* ctx, const u8* d_text, const u64* d_peq, std::vector<Al
     return ctx->sync();
 }
 
+int run_score_jobs(Lane* ctx, const u8* d_text, const u64* d_peq, std::vector<AlignRequest> const& reqs,
+                   std::vector<DevAlignOut>& outs, const char* kernel_name) {
+    std::vector<AlignRequest> uniq;
+    std::vector<u32> uniq_of;
+    dedup_requests(reqs, uniq, uniq_of);
+    std::vector<DevAlignOut> uouts;
+    int rc = run_score_jobs_unique(ctx, d_text, d_peq, uniq, uouts, kernel_name);
+    if (rc) return rc;
+    outs.resize(reqs.size());
+    for (size_t i = 0; i < reqs.size(); ++i) outs[i] = uouts[uniq_of[i]];
+    return FLX_OK;
+}
+
 struct TraceResult { bool exists = false; u32 nm = 0; u32 begin = 0; u64 cigar_off = 0; u32 cigar_len = 0; };
 
-// score, begin position and CIGAR for every request (alignment.cpp:147-180); CIGAR words appended to cigar_pool
+int run_trace_jobs_unique(Lane* ctx, const u8* d_text, const u8* d_query, const u64* d_peq, std::vector<AlignRequest> const& reqs,
+                          std::vector<TraceResult>& results, std::vector<u32>& cigar_pool);
+
+// score, begin position and CIGAR for every request (alignment.cpp:147-180); CIGAR words land in cigar_pool (shared by duplicates)
 int run_trace_jobs(Lane* ctx, const u8* d_text, const u8* d_query, const u64* d_peq, std::vector<AlignRequest> const& reqs,
                    std::vector<TraceResult>& results, std::vector<u32>& cigar_pool) {
+    std::vector<AlignRequest> uniq;
+    std::vector<u32> uniq_of;
+    dedup_requests(reqs, uniq, uniq_of);
+    std::vector<TraceResult> ures;
+    int rc = run_trace_jobs_unique(ctx, d_text, d_query, d_peq, uniq, ures, cigar_pool);
+    if (rc) return rc;
+    results.resize(reqs.size());
+    for (size_t i = 0; i < reqs.size(); ++i) results[i] = ures[uniq_of[i]];
+    return FLX_OK;
+}
+
+int run_trace_jobs_unique(Lane* ctx, const u8* d_text, const u8* d_query, const u64* d_peq, std::vector<AlignRequest> const& reqs,
+                          std::vector<TraceResult>& results, std::vector<u32>& cigar_pool) {
     results.assign(reqs.size(), TraceResult{});
     if (reqs.empty()) return FLX_OK;
     std::vector<AlignShape> shapes(reqs.size());
