@@ -654,54 +654,94 @@ int DeviceApi::align(void* stream, const u8* d_text, const u64* d_peq, const Dev
 }
 
 // ================================================================================================ K5: traceback + CIGAR
-// One lane walks one job's path from (m, end_col) to row 0 with seqan3's preference up (I) > left (D) > diagonal (=/X).
-// The CIGAR is written backwards into the job's slab so that it ends up in forward order without a reversal pass.
+// One wave walks one job's path from (m, end_col) to row 0 with seqan3's preference up (I) > left (D) > diagonal (=/X).
+// The 64 lanes fetch the trace words and symbols of the next 64 cells along the current diagonal in one go (a path is mostly
+// diagonal: ~2/3 of 8 % errors are indels, i.e. a diagonal change every ~19 cells), wave ballots turn them into three 64-bit
+// masks and the run-length encoding of the diagonal stretch up to the first indel is done on those masks. The CIGAR is written
+// backwards into the job's slab so that it ends up in forward order without a reversal pass.
 __global__ void __launch_bounds__(64) ed_traceback_kernel(const u8* __restrict__ text, const u8* __restrict__ query,
                                                           const u64* __restrict__ trace, const DevTraceJob* __restrict__ jobs, u32 n_jobs,
                                                           u32* __restrict__ cigar, DevTraceOut* __restrict__ out) {
-    u32 const id = blockIdx.x * blockDim.x + threadIdx.x;
+    u32 const id = blockIdx.x;
     if (id >= n_jobs) return;
+    u32 const lane = lane_id();
     DevTraceJob const job = jobs[id];
     const u8* __restrict__ r = text + job.ref_off;
     const u8* __restrict__ q = query + job.q_off;
     u32* __restrict__ slab = cigar + job.cigar_off;
-    u32 wpos = job.cigar_cap;
-    u32 i = job.m, j = job.end_col;
-    u32 cur_op = 0xFFu, cur_len = 0;
     u32 const W = job.words_per_lane, L = job.lanes;
+    u32 wpos = job.cigar_cap;
+    u32 i = job.m, j = job.end_col;                 // wave-uniform walker position
+    u32 cur_op = 0xFFu, cur_len = 0;
     bool overflow = false;
-    while (i > 0) {
-        u32 op;
-        if (j == 0) { op = 1u; --i; }
-        else {
-            u32 const gw = (i - 1u) >> 6, bit = (i - 1u) & 63u;
-            u32 const lgx = gw / W, w = gw - lgx * W;
-            u64 const slot = job.trace_off + ((u64)(j - 1u + lgx) * L + (lgx % L)) * W + w;
-            ulonglong2 const v = *reinterpret_cast<const ulonglong2*>(trace + 2ull * slot);
-            if ((v.y >> bit) & 1ull) { op = 1u; --i; }                  // up: query symbol unmatched (I)
-            else if ((v.x >> bit) & 1ull) { op = 2u; --j; }             // left: reference symbol skipped (D)
-            else { op = q[i - 1u] == r[j - 1u] ? 7u : 8u; --i; --j; }   // diagonal
+    auto emit = [&](u32 op, u32 len) {              // wave-uniform run-length merge; lane 0 stores
+        if (len == 0) return;
+        if (op == cur_op) { cur_len += len; return; }
+        if (cur_len) {
+            if (wpos == 0) overflow = true;
+            else { --wpos; if (lane == 0) slab[wpos] = (cur_len << 4) | cur_op; }
         }
-        if (op == cur_op) ++cur_len;
-        else {
-            if (cur_len) { if (wpos == 0) { overflow = true; break; } slab[--wpos] = (cur_len << 4) | cur_op; }
-            cur_op = op;
-            cur_len = 1;
+        cur_op = op;
+        cur_len = len;
+    };
+    while (i > 0 && !overflow) {
+        if (j == 0) { emit(1u, i); i = 0; break; }                      // only insertions remain
+        // lane l looks at cell (i - l, j - l)
+        bool const in_range = lane < i && lane < j;
+        bool up = false, left = false, eq = false;
+        if (in_range) {
+            u32 const ci = i - lane, cj = j - lane;
+            u32 const gw = (ci - 1u) >> 6, bit = (ci - 1u) & 63u;
+            u32 const g = gw / W, w = gw - g * W;
+            u64 const slot = job.trace_off + ((u64)(cj - 1u + g) * L + (g % L)) * W + w;
+            ulonglong2 const v = *reinterpret_cast<const ulonglong2*>(trace + 2ull * slot);
+            up = (v.y >> bit) & 1ull;
+            left = (v.x >> bit) & 1ull;
+            eq = q[ci - 1u] == r[cj - 1u];
+        }
+        u64 const m_range = __ballot(in_range);
+        u64 const m_indel = __ballot(up || left) & m_range;
+        u64 const m_eq = __ballot(eq);
+        u32 const n_range = (u32)__popcll(m_range);                     // cells available on this diagonal (contiguous from lane 0)
+        u32 const n_diag = m_indel ? (u32)__builtin_ctzll(m_indel) : n_range;   // diagonal cells before the first indel
+        // run-length encode the diagonal stretch [0, n_diag)
+        u32 pos = 0;
+        while (pos < n_diag) {
+            bool const is_eq = (m_eq >> pos) & 1ull;
+            u64 const same = is_eq ? m_eq : ~m_eq;
+            u64 const rest = ~(same >> pos);                            // first position (relative) where the kind changes
+            u32 run = rest ? (u32)__builtin_ctzll(rest) : 64u - pos;
+            if (run > n_diag - pos) run = n_diag - pos;
+            emit(is_eq ? 7u : 8u, run);
+            pos += run;
+        }
+        i -= n_diag;
+        j -= n_diag;
+        if (m_indel) {
+            // the cell at lane n_diag takes an indel: up (I) has priority over left (D)
+            bool const is_up = __shfl((int)up, (int)n_diag) != 0;
+            if (is_up) { emit(1u, 1u); --i; }
+            else { emit(2u, 1u); --j; }
         }
     }
-    if (!overflow && cur_len) { if (wpos == 0) overflow = true; else slab[--wpos] = (cur_len << 4) | cur_op; }
-    DevTraceOut o;
-    o.begin = j;
-    o.cigar_start = wpos;
-    o.cigar_len = overflow ? 0xFFFFFFFFu : job.cigar_cap - wpos;
-    o.pad = 0;
-    out[job.out_index] = o;
+    if (!overflow && cur_len) {
+        if (wpos == 0) overflow = true;
+        else { --wpos; if (lane == 0) slab[wpos] = (cur_len << 4) | cur_op; }
+    }
+    if (lane == 0) {
+        DevTraceOut o;
+        o.begin = j;
+        o.cigar_start = wpos;
+        o.cigar_len = overflow ? 0xFFFFFFFFu : job.cigar_cap - wpos;
+        o.pad = 0;
+        out[job.out_index] = o;
+    }
 }
 
 int DeviceApi::traceback(void* stream, const u8* d_text, const u8* d_query, const u64* d_trace, const DevTraceJob* d_jobs, u32 n_jobs,
                          u32* d_cigar, DevTraceOut* d_out) {
     if (n_jobs == 0) return 0;
-    hipLaunchKernelGGL(ed_traceback_kernel, dim3((n_jobs + 63) / 64), dim3(64), 0, (hipStream_t)stream, d_text, d_query, d_trace, d_jobs,
+    hipLaunchKernelGGL(ed_traceback_kernel, dim3(n_jobs), dim3(64), 0, (hipStream_t)stream, d_text, d_query, d_trace, d_jobs,
                        n_jobs, d_cigar, d_out);
     return (int)hipGetLastError();
 }
