@@ -190,6 +190,14 @@ int search_seeds_device(Lane* ctx, const u8* d_seq_pool_or_null, const u8* h_seq
         if (s.num_errors > 3) { set_error("seed errors must be in [0,3] (floxer_cli.cpp:299)"); return FLX_ERR_INVALID; }
         if (s.length == 0 || s.length > SCH_POS_MASK || s.seq_offset + s.length > pool_len) { set_error("seed outside the sequence pool"); return FLX_ERR_INVALID; }
         auto key = std::make_pair(s.length, s.num_errors);
+        if (i > 0 && seeds[i - 1].length == s.length && seeds[i - 1].num_errors == s.num_errors) {    // consecutive leaves are alike
+            DevSeed& d = dseeds[i];
+            d = dseeds[i - 1];
+            d.seq_off = s.seq_offset;
+            d.stack_off = frames;
+            frames += d.stack_frames;
+            continue;
+        }
         auto it = scheme_of.find(key);
         if (it == scheme_of.end()) {
             std::vector<u32> e = expanded_scheme(s.num_errors, s.length);
@@ -269,7 +277,9 @@ int search_seeds_device(Lane* ctx, const u8* d_seq_pool_or_null, const u8* h_seq
     std::vector<u64> total_raw(n_seeds, 0);
     std::vector<u8> excluded(n_seeds, 0);
     std::vector<Group> groups;
+    std::vector<u32> alive;
     for (u64 si = 0; si < n_seeds; ++si) {
+        if (first[si] == first[si + 1]) continue;               // no hit at all: nothing to select
         groups.clear();
         u64 total = 0;
         for (u32 h = first[si]; h < first[si + 1]; ++h) { groups.push_back(Group{by_seed[h].lb, by_seed[h].len, by_seed[h].errors}); total += by_seed[h].len; }
@@ -292,18 +302,23 @@ int search_seeds_device(Lane* ctx, const u8* d_seq_pool_or_null, const u8* h_seq
         }
         u64 kept = 0;
         if (cfg.anchor_choice_strategy == FLX_CHOICE_ROUND_ROBIN) {
-            std::set<size_t> remaining;
-            for (size_t g = 0; g < groups.size(); ++g) remaining.insert(g);
-            auto it = remaining.begin();
+            // search.cpp:239-272: cycle through the groups that still have rows, taking row lb + round from each; a group leaves
+            // the cycle after its last row. (The reference keeps the remaining indices in a std::set; a compacting vector visits
+            // them in the same ascending order.)
+            alive.resize(groups.size());
+            for (size_t g = 0; g < groups.size(); ++g) alive[g] = (u32)g;
             u64 round = 0;
-            while (kept != cfg.max_num_anchors_soft && !remaining.empty()) {
-                Group const& g = groups[*it];
-                reqs.push_back(RowReq{(u32)si, g.errors, (u32)(g.lb + round)});
-                ++kept;
-                auto prev = it;
-                ++it;
-                if (g.len == round + 1) remaining.erase(prev);
-                if (it == remaining.end()) { it = remaining.begin(); ++round; }
+            while (kept != cfg.max_num_anchors_soft && !alive.empty()) {
+                size_t w = 0;
+                for (size_t a = 0; a < alive.size(); ++a) {
+                    if (kept == cfg.max_num_anchors_soft) { alive[w++] = alive[a]; continue; }
+                    Group const& g = groups[alive[a]];
+                    reqs.push_back(RowReq{(u32)si, g.errors, (u32)(g.lb + round)});
+                    ++kept;
+                    if (g.len != round + 1) alive[w++] = alive[a];
+                }
+                alive.resize(w);
+                ++round;
             }
         } else {
             size_t gi = 0;
@@ -335,27 +350,33 @@ int search_seeds_device(Lane* ctx, const u8* d_seq_pool_or_null, const u8* h_seq
     // ---- per seed: bucket per reference, erase useless anchors, flatten (search.cpp:78-100, 304-318)
     size_t const nref = H.seq_len.size();
     std::vector<std::vector<RefAnchor>> by_ref(nref);
+    std::vector<u32> touched;                    // references that received an anchor of the current seed
     size_t ri = 0;
     for (u64 si = 0; si < n_seeds; ++si) {
         if (excluded[si]) { stats[si] = SeedStats{0, 0, 0, 1}; continue; }
-        for (auto& v : by_ref) v.clear();
+        if (ri >= reqs.size() || reqs[ri].seed != si) continue;      // nothing kept: stats stay zero
+        touched.clear();
         u32 raw = 0;
         while (ri < reqs.size() && reqs[ri].seed == si) {
             u64 const p = textpos[ri];
             if (p >= H.n) { set_error("fm_locate returned a position outside the text"); return FLX_ERR_INTERNAL; }
-            size_t const s = std::upper_bound(H.seq_start.begin(), H.seq_start.end(), p) - H.seq_start.begin() - 1;
+            size_t const s = nref == 1 ? 0 : std::upper_bound(H.seq_start.begin(), H.seq_start.end(), p) - H.seq_start.begin() - 1;
+            if (by_ref[s].empty()) touched.push_back((u32)s);
             by_ref[s].push_back(RefAnchor{p - H.seq_start[s], reqs[ri].errors});
             ++raw;
             ++ri;
         }
+        std::sort(touched.begin(), touched.end());                   // anchors are reported by reference id (search.cpp:78-100)
         u32 useful = raw;
         if (cfg.erase_useless_anchors) {
             useful = 0;
-            for (auto& v : by_ref) { erase_useless(v); useful += (u32)v.size(); }
+            for (u32 r : touched) { erase_useless(by_ref[r]); useful += (u32)by_ref[r].size(); }
         }
         stats[si] = SeedStats{useful, raw, (u32)(total_raw[si] - raw), 0};
-        for (size_t r = 0; r < nref; ++r)
-            for (auto const& a : by_ref[r]) anchors.push_back(HostAnchor{(u32)si, seeds[si].pex_leaf_index, (u32)r, (u32)a.errors, a.pos});
+        for (u32 r : touched) {
+            for (auto const& a : by_ref[r]) anchors.push_back(HostAnchor{(u32)si, seeds[si].pex_leaf_index, r, (u32)a.errors, a.pos});
+            by_ref[r].clear();
+        }
     }
     return FLX_OK;
 }
