@@ -166,11 +166,12 @@ def main():
                     "note": note}
 
         def load_traffic(name, st):
-            """HBM bytes per launch from the committed PMC passes (profiles/*_pmc_traffic.json), if they are of this workload"""
+            """HBM bytes per launch = algorithmic bytes per launch x (PMC bytes / algorithmic bytes) of the committed FETCH_SIZE /
+            WRITE_SIZE passes over this workload (profiles/r01_pmc_traffic.json; launches per pass vary with the trace arena)"""
             try:
                 t = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
                 if t.get("kernel") == name and t.get("reads_per_step") == B:
-                    return t["hbm_bytes_per_launch"]
+                    return int(st["algorithmic_bytes"] / st["launches"] * t["traffic_over_algorithmic"])
             except (OSError, ValueError, KeyError):
                 pass
             return None
