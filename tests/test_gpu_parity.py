@@ -342,3 +342,100 @@ def test_cli_whole_program(pins, tmp_path, seed_errors, ext):
                 assert seq == "*" and qual == "*"            # secondary records carry no SEQ/QUAL (output.cpp:69-90)
             else:
                 assert len(seq) == 12 and qual == "I" * 12
+
+
+def _check_cigars(genome, reads, recs, rate):
+    import re
+    for ridx, flag, ref_id, pos, nm, cig in recs:
+        if flag & 4:
+            continue
+        g = genome[ref_id]
+        q = reads[ridx] if not flag & 16 else F.reverse_complement_rank(reads[ridx])
+        i, j, cost = 0, pos, 0
+        for ln, op in re.findall(r"(\d+)([=XID])", cig):
+            ln = int(ln)
+            if op == "=":
+                assert (q[i:i + ln] == g[j:j + ln]).all(); i += ln; j += ln
+            elif op == "X":
+                assert (q[i:i + ln] != g[j:j + ln]).all(); i += ln; j += ln; cost += ln
+            elif op == "I":
+                i += ln; cost += ln
+            else:
+                j += ln; cost += ln
+        assert i == len(q) and cost == nm and nm <= F.floating_point_error_aware_ceil(len(q) * rate)
+
+
+@pytest.mark.parametrize("length,rate,n_reads", [(10000, 0.08, 12), (20000, 0.02, 8)])
+def test_baseline_read_shapes(length, rate, n_reads):
+    """BASELINE.json configs[2]/[4] read shapes (10 kb @ 8 %, 20 kb @ 2 %) on a small reference: CIGAR consistency, truth position,
+    and record-for-record equality with the oracle."""
+    genome = S.make_genome(600000, 2, seed=71)
+    reads, names, truth = S.make_reads(genome, n_reads, length, rate, seed=72)
+    idx = F.fmindex(genome)
+    ctx = F.context(idx)
+    res = F.aligner(ctx, F.params(error_probability=rate)).align_reads(reads)
+    recs = res.records()
+    _check_cigars(genome, reads, recs, rate)
+    for i, (c, start, rev) in enumerate(truth):
+        prim = [r for r in recs if r[0] == i and not r[1] & 256]
+        assert len(prim) == 1 and not prim[0][1] & 4 and prim[0][2] == c and abs(prim[0][3] - start) <= 0.1 * length
+        assert bool(prim[0][1] & 16) == rev
+    exp = O.Index(genome).run(reads, O.params(error_probability=rate), threads=8)
+    assert recs == exp.records()
+    ctx.close()
+
+
+def test_maximum_length_read_and_reference_edges():
+    """a read close to the 100 000 bp limit (input.hpp:42), one read over it (skipped), and reads hanging over both reference
+    ends (clipped windows)"""
+    genome = S.make_genome(150000, 1, seed=81)
+    g = genome[0]
+    rng = np.random.default_rng(82)
+    long_read = g[20000:20000 + 99000].copy()
+    for p in rng.choice(len(long_read), size=600, replace=False):
+        long_read[p] = long_read[p] % 4 + 1
+    too_long = g[:100001].copy()
+    head = np.concatenate([rng.integers(1, 5, size=40).astype(np.uint8), g[:1500]])          # overhangs the start
+    tail = np.concatenate([g[-1500:], rng.integers(1, 5, size=40).astype(np.uint8)])          # overhangs the end
+    reads = [long_read, too_long, head, tail]
+    idx = F.fmindex(genome)
+    ctx = F.context(idx)
+    p = F.params(error_probability=0.01, interval_optimization=True)       # -I keeps the oracle's root alignments of the 99 kb read few
+    res = F.aligner(ctx, p).align_reads(reads)
+    assert res.skipped.tolist() == [0, 1, 0, 0]
+    exp = O.Index(genome).run(reads, O.params(error_probability=0.01, interval_opt=True), threads=4)
+    assert res.records() == exp.records()
+    prim = [r for r in res.records() if r[0] == 0 and not r[1] & 256][0]
+    assert not prim[1] & 4 and abs(prim[3] - 20000) <= 10
+    p2 = F.params(error_probability=0.04)
+    res2 = F.aligner(ctx, p2).align_reads([head, tail])
+    exp2 = O.Index(genome).run([head, tail], O.params(error_probability=0.04), threads=2)
+    assert res2.records() == exp2.records()
+    assert all(not r[1] & 4 for r in res2.records())
+    ctx.close()
+
+
+def test_many_references_and_n_runs():
+    """many short references (sentinel padding, locate across sequence boundaries), N runs in reads and reference"""
+    rng = np.random.default_rng(91)
+    refs = [rng.integers(1, 5, size=int(rng.integers(700, 4000))).astype(np.uint8) for _ in range(40)]
+    refs[3][100:160] = 5
+    reads = []
+    for i in range(30):
+        r = refs[int(rng.integers(0, len(refs)))]
+        st = int(rng.integers(0, len(r) - 600))
+        q = r[st:st + 600].copy()
+        for pnt in rng.choice(600, size=12, replace=False):
+            q[pnt] = q[pnt] % 4 + 1
+        if i % 7 == 0:
+            q[50:55] = 5
+        if i % 2:
+            q = F.reverse_complement_rank(q)
+        reads.append(q)
+    idx = F.fmindex(refs)
+    ctx = F.context(idx)
+    res = F.aligner(ctx, F.params(error_probability=0.05, interval_optimization=True)).align_reads(reads)
+    exp = O.Index(refs).run(reads, O.params(error_probability=0.05, interval_opt=True), threads=4)
+    assert res.records() == exp.records()
+    assert sum(1 for r in res.records() if not r[1] & 4 and not r[1] & 256) >= 25
+    ctx.close()
