@@ -54,32 +54,58 @@ int DeviceApi::build_peq(void* stream, const u8* d_seq, u64 len, u64* d_peq) {
 }
 
 // ================================================================================================ K1: FM search
-// rank of all six symbols at BWT position i: one 128-byte block (header counts + 3 bit-planes over 256 positions)
-__device__ __forceinline__ void rank_all(const OccBlock* __restrict__ tab, u32 i, u32 out[6]) {
-    const OccBlock* __restrict__ b = tab + (i >> 8);
-    u32 const off = i & 255u;
-    uint4 const h0 = *reinterpret_cast<const uint4*>(&b->cnt[0]);
-    uint2 const h1 = *reinterpret_cast<const uint2*>(&b->cnt[4]);
-    u32 c0 = h0.x, c1 = h0.y, c2 = h0.z, c3 = h0.w, c4 = h1.x, c5 = h1.y;
-#pragma unroll
-    for (u32 w = 0; w < 4; ++w) {
-        // positions of this word that lie below `off`
-        u32 const lo = w * 64;
-        u64 mask;
-        if (off >= lo + 64) mask = ~0ull;
-        else if (off > lo) mask = (1ull << (off - lo)) - 1ull;
-        else mask = 0ull;
-        u64 const p0 = b->planes[w][0], p1 = b->planes[w][1], p2 = b->planes[w][2];
-        u64 const n2 = ~p2 & mask, q2 = p2 & mask;
-        u64 const a00 = ~p1 & ~p0, a01 = ~p1 & p0, a10 = p1 & ~p0, a11 = p1 & p0;
-        c0 += (u32)__popcll(n2 & a00);
-        c1 += (u32)__popcll(n2 & a01);
-        c2 += (u32)__popcll(n2 & a10);
-        c3 += (u32)__popcll(n2 & a11);
-        c4 += (u32)__popcll(q2 & a00);
-        c5 += (u32)__popcll(q2 & a01);
+// ranks of all six symbols at the two ends [lo, hi) of an SA interval. Each end is one 128-byte block (header counts + 3
+// bit-planes over 256 positions); when both ends fall into the same block (the common case once an interval is narrow) the block
+// is read once and the interval's symbol counts come from one masked popcount pass.
+__device__ __forceinline__ void count_word(u64 p0, u64 p1, u64 p2, u64 mask, u32 c[6]) {
+    u64 const n2 = ~p2 & mask, q2 = p2 & mask;
+    u64 const a00 = ~p1 & ~p0, a01 = ~p1 & p0, a10 = p1 & ~p0, a11 = p1 & p0;
+    c[0] += (u32)__popcll(n2 & a00);
+    c[1] += (u32)__popcll(n2 & a01);
+    c[2] += (u32)__popcll(n2 & a10);
+    c[3] += (u32)__popcll(n2 & a11);
+    c[4] += (u32)__popcll(q2 & a00);
+    c[5] += (u32)__popcll(q2 & a01);
+}
+__device__ __forceinline__ u64 below_mask(u32 off, u32 w) {      // positions of word w (64*w ..) that lie below `off`
+    u32 const lo = w * 64;
+    if (off >= lo + 64) return ~0ull;
+    if (off > lo) return (1ull << (off - lo)) - 1ull;
+    return 0ull;
+}
+__device__ __forceinline__ void rank_pair(const OccBlock* __restrict__ tab, u32 lo, u32 hi, u32 a[6], u32 b[6]) {
+    const OccBlock* __restrict__ ba = tab + (lo >> 8);
+    u32 const off_a = lo & 255u;
+    {
+        uint4 const h0 = *reinterpret_cast<const uint4*>(&ba->cnt[0]);
+        uint2 const h1 = *reinterpret_cast<const uint2*>(&ba->cnt[4]);
+        a[0] = h0.x; a[1] = h0.y; a[2] = h0.z; a[3] = h0.w; a[4] = h1.x; a[5] = h1.y;
     }
-    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3; out[4] = c4; out[5] = c5;
+    if ((lo >> 8) == (hi >> 8)) {
+        u32 const off_b = hi & 255u;
+        u32 d[6] = {0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (u32 w = 0; w < 4; ++w) {
+            u64 const p0 = ba->planes[w][0], p1 = ba->planes[w][1], p2 = ba->planes[w][2];
+            u64 const ma = below_mask(off_a, w), mb = below_mask(off_b, w);
+            count_word(p0, p1, p2, ma, a);
+            count_word(p0, p1, p2, mb & ~ma, d);
+        }
+#pragma unroll
+        for (int c = 0; c < 6; ++c) b[c] = a[c] + d[c];
+        return;
+    }
+#pragma unroll
+    for (u32 w = 0; w < 4; ++w) count_word(ba->planes[w][0], ba->planes[w][1], ba->planes[w][2], below_mask(off_a, w), a);
+    const OccBlock* __restrict__ bb = tab + (hi >> 8);
+    u32 const off_b = hi & 255u;
+    {
+        uint4 const h0 = *reinterpret_cast<const uint4*>(&bb->cnt[0]);
+        uint2 const h1 = *reinterpret_cast<const uint2*>(&bb->cnt[4]);
+        b[0] = h0.x; b[1] = h0.y; b[2] = h0.z; b[3] = h0.w; b[4] = h1.x; b[5] = h1.y;
+    }
+#pragma unroll
+    for (u32 w = 0; w < 4; ++w) count_word(bb->planes[w][0], bb->planes[w][1], bb->planes[w][2], below_mask(off_b, w), b);
 }
 
 // frame state word: x:20 | e:3 | linfo:2 | rinfo:2 | next_sym:3 | right:1
@@ -95,161 +121,206 @@ __device__ __forceinline__ u32 st_pack(u32 x, u32 e, u32 li, u32 ri, u32 sym, u3
 #define ST_RIGHT(s) (((s) >> 30) & 1u)
 
 // counters: [0] hits written/reserved, [1] stack overflow flag, [2] cursor extensions (rank pairs), [3] hit overflow
+//
+// One lane runs one seed's search_n at a time. DFS sizes differ by orders of magnitude between seeds, so lanes are not bound to
+// seeds: every wave owns a chunk of FM_CHUNK consecutive seeds and a lane that finishes its seed takes the chunk's next one
+// (an LDS counter), so the wave's lanes stay busy until the chunk is drained. One loop iteration = one DFS step of every busy
+// lane (at most one rank pair), which keeps the divergent part of the loop short.
+constexpr u32 FM_CHUNK = 256;
+
 __global__ void __launch_bounds__(64) fm_search_kernel(DevIndex idx, const u8* __restrict__ seq, const u32* __restrict__ scheme,
                                                        const DevSeed* __restrict__ seeds, u32 n_seeds, u32 max_hits,
                                                        DevFrame* __restrict__ stack, DevHit* __restrict__ hits, u32 hit_cap,
                                                        u32* __restrict__ counters) {
-    u32 const sid = blockIdx.x * blockDim.x + threadIdx.x;
-    if (sid >= n_seeds) return;
-    DevSeed const seed = seeds[sid];
-    const u8* __restrict__ q = seq + seed.seq_off;
-    DevFrame* __restrict__ stk = stack + seed.stack_off;
-    u32 const len = seed.length;
+    __shared__ u32 next_in_chunk;
+    u32 const chunk_base = blockIdx.x * FM_CHUNK;
+    u32 const chunk_n = min(FM_CHUNK, n_seeds - chunk_base);
+    if (threadIdx.x == 0) next_in_chunk = 0;
+    __syncthreads();
+
     u32 n_ext = 0;
-    u32 ct = 0;                     // hits collected for this seed (search_n's counter)
-    bool aborted = false;
-
-    for (u32 srch = 0; srch < seed.num_searches && !aborted; ++srch) {
-        const u32* __restrict__ ex = scheme + seed.scheme_off + (u64)srch * len;
-        u32 const last_entry = ex[len - 1];
-        u32 const l_last = (last_entry >> 20) & 7u, u_last = (last_entry >> 23) & 7u;
-        // node under inspection
-        u32 nlb = 0, nlbr = 0, nlen = idx.n, nx = 0, ne = 0, nli = INFO_M, nri = INFO_M;
-        // top frame (registers)
-        DevFrame F;
-        F.mask = 0;
-        F.lb = F.lb_rev = F.len = F.state = 0;
+    u32 n_iter = 0, n_busy_iter = 0;
+    // ---- per-seed state
+    bool busy = false, exhausted = false;
+    u32 sid = 0, srch = 0, num_searches = 0, len = 0, ct = 0, stack_frames = 0;
+    const u8* __restrict__ q = seq;
+    DevFrame* __restrict__ stk = stack;
+    const u32* __restrict__ ex_base = scheme;
+    // ---- per-search state
+    bool in_search = false;
+    const u32* __restrict__ ex = scheme;
+    u32 l_last = 0, u_last = 0;
+    u32 nlb = 0, nlbr = 0, nlen = 0, nx = 0, ne = 0, nli = INFO_M, nri = INFO_M;
+    DevFrame F;
+    F.mask = 0;
+    F.lb = F.lb_rev = F.len = F.state = 0;
 #pragma unroll
-        for (int c = 0; c < 5; ++c) F.child_abs[c] = 0;
+    for (int c = 0; c < 5; ++c) F.child_abs[c] = 0;
 #pragma unroll
-        for (int c = 0; c < 6; ++c) F.child_len[c] = 0;
-        u32 depth = 0;              // frames stored in memory below F
-        bool have_frame = false;    // F holds a real frame
-        bool need_child = false;
+    for (int c = 0; c < 6; ++c) F.child_len[c] = 0;
+    u32 depth = 0;
+    bool have_frame = false, need_child = false;
 
-        while (true) {
-            if (need_child) {
-                if (!have_frame || F.mask == 0) {
-                    if (depth == 0) break;                  // search exhausted
-                    F = stk[--depth];
-                    have_frame = true;
-                    continue;
-                }
-                u32 const ci = (u32)__ffs((int)F.mask) - 1u;
-                F.mask &= F.mask - 1u;
-                u32 const st = F.state;
-                u32 const right = ST_RIGHT(st);
-                u32 const px = ST_X(st), pe = ST_E(st);
-                u32 info, sym;
-                if (ci == 0) { sym = ST_SYM(st); nx = px + 1; ne = pe; info = INFO_M; }
-                else if (ci == 11) { sym = 0; nx = px + 1; ne = pe + 1; info = INFO_I; }
-                else {
-                    sym = (ci + 1) >> 1;
-                    bool const del = ci & 1u;
-                    nx = del ? px : px + 1;
-                    ne = pe + 1;
-                    info = del ? INFO_D : INFO_S;
-                }
-                if (ci == 11) { nlb = F.lb; nlbr = F.lb_rev; nlen = F.len; }
-                else {
-                    u32 pre = 0, clen = 0, cabs = 0;
-#pragma unroll
-                    for (u32 c = 0; c < 6; ++c) {
-                        if (c < sym) pre += F.child_len[c];
-                        if (c == sym) { clen = F.child_len[c]; cabs = c > 0 ? F.child_abs[c > 0 ? c - 1 : 0] : 0; }
-                    }
-                    nlen = clen;
-                    if (right) { nlbr = cabs; nlb = F.lb + pre; }
-                    else { nlb = cabs; nlbr = F.lb_rev + pre; }
-                }
-                nli = right ? ST_LI(st) : info;
-                nri = right ? info : ST_RI(st);
-                need_child = false;
-            }
+    while (true) {
+        if (!busy && !exhausted) {
+            u32 const k = atomicAdd(&next_in_chunk, 1u);
+            if (k < chunk_n) {
+                sid = chunk_base + k;
+                DevSeed const seed = seeds[sid];
+                q = seq + seed.seq_off;
+                stk = stack + seed.stack_off;
+                len = seed.length;
+                num_searches = seed.num_searches;
+                stack_frames = seed.stack_frames;
+                ex_base = scheme + seed.scheme_off;
+                srch = 0;
+                ct = 0;
+                busy = true;
+                in_search = false;
+            } else exhausted = true;
+        }
+        if (__all(exhausted && !busy)) break;
+        ++n_iter;
+        if (!busy) continue;
+        ++n_busy_iter;
 
-            // ---- inspect node (nlb, nlbr, nlen, nx, ne, nli, nri); nlen > 0 by construction
-            if (nx == len) {
-                bool const ok_l = nli == INFO_M || nli == INFO_I, ok_r = nri == INFO_M || nri == INFO_I;
-                if (ok_l && ok_r && l_last <= ne && ne <= u_last) {
-                    u32 rep = nlen;
-                    if (ct + rep > max_hits) rep = max_hits - ct;        // search_n truncates the last cursor
-                    ct += rep;
-                    u32 const slot = atomicAdd(&counters[0], 1u);
-                    if (slot < hit_cap) hits[slot] = DevHit{sid, nlb, rep, ne};
-                    else atomicOr(&counters[3], 1u);
-                    if (ct == max_hits) { aborted = true; break; }
-                }
-                need_child = true;
+        if (!in_search) {
+            if (srch >= num_searches) { busy = false; continue; }
+            ex = ex_base + (u64)srch * len;
+            u32 const last_entry = ex[len - 1];
+            l_last = (last_entry >> 20) & 7u;
+            u_last = (last_entry >> 23) & 7u;
+            nlb = 0; nlbr = 0; nlen = idx.n; nx = 0; ne = 0; nli = INFO_M; nri = INFO_M;
+            F.mask = 0;
+            depth = 0;
+            have_frame = false;
+            need_child = false;
+            in_search = true;
+        }
+
+        // ---- one DFS step
+        if (need_child) {
+            if (!have_frame || F.mask == 0) {
+                if (depth == 0) { in_search = false; ++srch; continue; }    // search exhausted
+                F = stk[--depth];
+                have_frame = true;
                 continue;
             }
-            u32 const entry = ex[nx];
-            u32 const lower = (entry >> 20) & 7u, upper = (entry >> 23) & 7u, right = (entry >> 26) & 1u;
-            if (ne > upper) { need_child = true; continue; }
-            bool const mismatch_allowed = lower <= ne + 1 && ne + 1 <= upper;
-            bool const match_allowed = lower <= ne && ne <= upper;
-            if (!mismatch_allowed && !match_allowed) { need_child = true; continue; }
-
-            u32 const next_sym = q[entry & SCH_POS_MASK];
-            u32 a[6], b[6];
-            const OccBlock* __restrict__ tab = idx.occ[right];
-            u32 const lo = right ? nlbr : nlb;
-            rank_all(tab, lo, a);
-            rank_all(tab, lo + nlen, b);
-            ++n_ext;
-
-            if (mismatch_allowed) {
-                // this node branches: it becomes the top frame, the previous top goes to memory
-                if (have_frame) {
-                    if (depth >= seed.stack_frames) { atomicOr(&counters[1], 1u); aborted = true; break; }
-                    stk[depth++] = F;
-                }
-                have_frame = true;
-                u32 const tinfo = right ? nri : nli;
-                bool const deletion = tinfo == INFO_M || tinfo == INFO_D;
-                bool const insertion = tinfo == INFO_M || tinfo == INFO_I;
-                F.lb = nlb; F.lb_rev = nlbr; F.len = nlen;
-                F.state = st_pack(nx, ne, nli, nri, next_sym, right);
-                u32 mask = 0;
-#pragma unroll
-                for (u32 c = 0; c < 6; ++c) {
-                    u32 const cl = b[c] - a[c];
-                    F.child_len[c] = cl;
-                    if (c > 0) {
-                        F.child_abs[c - 1] = idx.C[c] + a[c];
-                        if (cl > 0) {
-                            if (deletion) mask |= 1u << (2 * c - 1);
-                            if (c != next_sym) mask |= 1u << (2 * c);
-                            else if (match_allowed) mask |= 1u;
-                        }
-                    }
-                }
-                if (insertion) mask |= 1u << 11;
-                F.mask = mask;
-                need_child = true;
-            } else {
-                // only an exact extension is possible: continue in place (no frame)
+            u32 const ci = (u32)__ffs((int)F.mask) - 1u;
+            F.mask &= F.mask - 1u;
+            u32 const st = F.state;
+            u32 const right = ST_RIGHT(st);
+            u32 const px = ST_X(st), pe = ST_E(st);
+            u32 info, sym;
+            if (ci == 0) { sym = ST_SYM(st); nx = px + 1; ne = pe; info = INFO_M; }
+            else if (ci == 11) { sym = 0; nx = px + 1; ne = pe + 1; info = INFO_I; }
+            else {
+                sym = (ci + 1) >> 1;
+                bool const del = ci & 1u;
+                nx = del ? px : px + 1;
+                ne = pe + 1;
+                info = del ? INFO_D : INFO_S;
+            }
+            if (ci == 11) { nlb = F.lb; nlbr = F.lb_rev; nlen = F.len; }
+            else {
                 u32 pre = 0, clen = 0, cabs = 0;
 #pragma unroll
                 for (u32 c = 0; c < 6; ++c) {
-                    u32 const cl = b[c] - a[c];
-                    if (c < next_sym) pre += cl;
-                    if (c == next_sym) { clen = cl; cabs = idx.C[c] + a[c]; }
+                    if (c < sym) pre += F.child_len[c];
+                    if (c == sym) { clen = F.child_len[c]; cabs = c > 0 ? F.child_abs[c > 0 ? c - 1 : 0] : 0; }
                 }
-                if (clen == 0) { need_child = true; continue; }
-                if (right) { nlbr = cabs; nlb = nlb + pre; nri = INFO_M; }
-                else { nlb = cabs; nlbr = nlbr + pre; nli = INFO_M; }
                 nlen = clen;
-                nx = nx + 1;
+                if (right) { nlbr = cabs; nlb = F.lb + pre; }
+                else { nlb = cabs; nlbr = F.lb_rev + pre; }
             }
+            nli = right ? ST_LI(st) : info;
+            nri = right ? info : ST_RI(st);
+            need_child = false;
+        }
+
+        // ---- inspect node (nlb, nlbr, nlen, nx, ne, nli, nri); nlen > 0 by construction
+        if (nx == len) {
+            bool const ok_l = nli == INFO_M || nli == INFO_I, ok_r = nri == INFO_M || nri == INFO_I;
+            if (ok_l && ok_r && l_last <= ne && ne <= u_last) {
+                u32 rep = nlen;
+                if (ct + rep > max_hits) rep = max_hits - ct;        // search_n truncates the last cursor
+                ct += rep;
+                u32 const slot = atomicAdd(&counters[0], 1u);
+                if (slot < hit_cap) hits[slot] = DevHit{sid, nlb, rep, ne};
+                else atomicOr(&counters[3], 1u);
+                if (ct == max_hits) { busy = false; continue; }      // search_n aborts all remaining searches of the seed
+            }
+            need_child = true;
+            continue;
+        }
+        u32 const entry = ex[nx];
+        u32 const lower = (entry >> 20) & 7u, upper = (entry >> 23) & 7u, right = (entry >> 26) & 1u;
+        if (ne > upper) { need_child = true; continue; }
+        bool const mismatch_allowed = lower <= ne + 1 && ne + 1 <= upper;
+        bool const match_allowed = lower <= ne && ne <= upper;
+        if (!mismatch_allowed && !match_allowed) { need_child = true; continue; }
+
+        u32 const next_sym = q[entry & SCH_POS_MASK];
+        u32 a[6], b[6];
+        const OccBlock* __restrict__ tab = idx.occ[right];
+        u32 const lo = right ? nlbr : nlb;
+        rank_pair(tab, lo, lo + nlen, a, b);
+        ++n_ext;
+
+        if (mismatch_allowed) {
+            // this node branches: it becomes the top frame, the previous top goes to memory
+            if (have_frame) {
+                if (depth >= stack_frames) { atomicOr(&counters[1], 1u); busy = false; continue; }
+                stk[depth++] = F;
+            }
+            have_frame = true;
+            u32 const tinfo = right ? nri : nli;
+            bool const deletion = tinfo == INFO_M || tinfo == INFO_D;
+            bool const insertion = tinfo == INFO_M || tinfo == INFO_I;
+            F.lb = nlb; F.lb_rev = nlbr; F.len = nlen;
+            F.state = st_pack(nx, ne, nli, nri, next_sym, right);
+            u32 mask = 0;
+#pragma unroll
+            for (u32 c = 0; c < 6; ++c) {
+                u32 const cl = b[c] - a[c];
+                F.child_len[c] = cl;
+                if (c > 0) {
+                    F.child_abs[c - 1] = idx.C[c] + a[c];
+                    if (cl > 0) {
+                        if (deletion) mask |= 1u << (2 * c - 1);
+                        if (c != next_sym) mask |= 1u << (2 * c);
+                        else if (match_allowed) mask |= 1u;
+                    }
+                }
+            }
+            if (insertion) mask |= 1u << 11;
+            F.mask = mask;
+            need_child = true;
+        } else {
+            // only an exact extension is possible: continue in place (no frame)
+            u32 pre = 0, clen = 0, cabs = 0;
+#pragma unroll
+            for (u32 c = 0; c < 6; ++c) {
+                u32 const cl = b[c] - a[c];
+                if (c < next_sym) pre += cl;
+                if (c == next_sym) { clen = cl; cabs = idx.C[c] + a[c]; }
+            }
+            if (clen == 0) { need_child = true; continue; }
+            if (right) { nlbr = cabs; nlb = nlb + pre; nri = INFO_M; }
+            else { nlb = cabs; nlbr = nlbr + pre; nli = INFO_M; }
+            nlen = clen;
+            nx = nx + 1;
         }
     }
     atomicAdd(&counters[2], n_ext);
+    if (threadIdx.x == 0) { atomicAdd(&counters[4], n_iter); atomicMax(&counters[5], n_iter); }
+    atomicAdd(&counters[6], n_busy_iter);
 }
 
 int DeviceApi::search(void* stream, const DevIndex& idx, const u8* d_seq, const u32* d_scheme, const DevSeed* d_seeds, u32 n_seeds,
                       u32 max_hits_per_seed, DevFrame* d_stack, DevHit* d_hits, u32 hit_cap, u32* d_counters) {
     if (n_seeds == 0) return 0;
-    hipLaunchKernelGGL(fm_search_kernel, dim3((n_seeds + 63) / 64), dim3(64), 0, (hipStream_t)stream, idx, d_seq, d_scheme, d_seeds,
+    hipLaunchKernelGGL(fm_search_kernel, dim3((n_seeds + FM_CHUNK - 1) / FM_CHUNK), dim3(64), 0, (hipStream_t)stream, idx, d_seq, d_scheme, d_seeds,
                        n_seeds, max_hits_per_seed, d_stack, d_hits, hit_cap, d_counters);
     return (int)hipGetLastError();
 }

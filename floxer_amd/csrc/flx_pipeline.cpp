@@ -232,7 +232,7 @@ int search_seeds_device(Lane* ctx, const u8* d_seq_pool_or_null, const u8* h_seq
                                          ? (u32)cfg.max_num_anchors_soft
                                          : (u32)std::max(cfg.max_num_anchors_hard, cfg.max_num_anchors_hard + 1));
     u64 hit_cap = std::max<u64>(n_seeds * 6, 4096);
-    u32 counters[4];
+    u32 counters[8];
     for (int attempt = 0;; ++attempt) {
         if ((rc = ctx->hits.ensure(hit_cap * sizeof(DevHit)))) return rc;
         FLX_HIP(hipMemsetAsync(ctx->counters.ptr, 0, 64, ctx->stream));
@@ -242,8 +242,9 @@ int search_seeds_device(Lane* ctx, const u8* d_seq_pool_or_null, const u8* h_seq
                                      ctx->counters.as<u32>());
         });
         if (rc) return rc;
-        if ((rc = d2h(ctx, counters, ctx->counters.ptr, 16))) return rc;
+        if ((rc = d2h(ctx, counters, ctx->counters.ptr, 32))) return rc;
         if ((rc = ctx->sync())) return rc;
+        if (getenv("FLX_SEARCH_DEBUG")) fprintf(stderr, "[fm_search] seeds %llu ext %u wave-iterations %u (max per wave %u) busy lane-iterations %u\n", (unsigned long long)n_seeds, counters[2], counters[4], counters[5], counters[6]);
         if (counters[1]) { set_error("fm_search: DFS stack reservation exceeded"); return FLX_ERR_INTERNAL; }
         if (counters[0] <= hit_cap) break;
         if (attempt >= 2) { set_error("fm_search: hit buffer could not be sized"); return FLX_ERR_INTERNAL; }
