@@ -572,75 +572,92 @@ __global__ void __launch_bounds__(64) ed_band_kernel(const u8* __restrict__ text
     int bot = 0;                                          // D[last row of the group][current column]
     bool started = false;
     int best = m, best_col = 0;
-    u64 const last_bit = 1ull << ((m - 1) & 63);
+    u32 const last_shift = (u32)(m - 1) & 63u;
+    int const w_last_of_last = (nw - 1) - (Lg - 1) * W;   // word of the last group that holds row m-1
+    // Trace layout: steps in blocks of S = TRACE_STEP_BLOCK; slot(t, p, w) = trace_off + (((t/S)*R + p)*S + t%S)*W + w. A lane keeps
+    // the S steps of a block in registers and stores them as one run of S*W*16 bytes, so that a job writes R*S*W*16 contiguous
+    // bytes per block (3 KB at W=3, R=16): few, long bursts per DRAM row instead of one 768-byte piece per step.
+    constexpr u32 S = TRACE ? TRACE_STEP_BLOCK : 1u;
+    ulonglong2* __restrict__ tptr = reinterpret_cast<ulonglong2*>(trace) + job.trace_off + (u64)p * S * W;
+    u32 const tstride = R * S * W;
+    ulonglong2 tbuf[S][W];
+    bool any_active_in_block = false;
 
-    for (u32 t = 0; t < t_max; ++t) {
-        // front group: finished once its last column has been passed
-        {
-            int const fr1 = min(m, 64 * W * (g_front + 1));
-            int const f_hi = min(n - 1, fr1 - 1 + band_hi);
-            if ((int)t - g_front > f_hi && g_front + 1 < Lg) ++g_front;
-        }
-        if ((int)t - g_front + 72 > loaded && loaded < n) { refill(); __builtin_amdgcn_s_waitcnt(0); }
-        int c = (int)t - g;
-        if (has_group && c > c_hi && g + (int)R < Lg) {
-            // this lane's group is finished: take over group g + R (its window starts strictly later)
-            g += (int)R;
-            enter_group();
-            started = false;
-            c = (int)t - g;
-        }
-        u32 const cin_raw = (u32)__shfl((int)cout, (int)src_lane);
-        bool const active = has_group && c >= c_lo && c <= c_hi;
-        if (active) {
-            u32 const sym = ring[(u32)c & 255u];
-            u32 const cin = g == 0 ? 0u : cin_raw;
-            u64 c_hp = (cin >> 1) & 1u, c_hn = (cin >> 2) & 1u;
-            u64 c_d0 = c_hn;                              // the adder's carry out of a word equals its top horizontal-negative bit
-            if (!started) {
-                // column just left of the window: all vertical deltas +1 below the predecessor's bottom value
-                int const top_prev = g == 0 ? 0 : (int)(cin >> 3) - (int)c_hp + (int)c_hn;
-                bot = top_prev + rows_g;
-                started = true;
+    for (u32 t0 = 0; t0 < t_max; t0 += S) {
+        if ((t0 & 15u) == 0u) {
+            // every 16 steps: retire finished front groups and keep the symbol ring >= 72 columns ahead of the front group
+            while (g_front + 1 < Lg) {
+                int const fr1 = min(m, 64 * W * (g_front + 1));
+                int const f_hi = min(n - 1, fr1 - 1 + band_hi);
+                if ((int)t0 - g_front > f_hi) ++g_front; else break;
             }
-            bool const is_last_group = g == Lg - 1;
-            int const w_last = (nw - 1) - g * W;
-            const u64* __restrict__ eqp = &lds_eq[(sym * 64u + lane) * W];
+            if ((int)t0 - g_front + 88 > loaded && loaded < n) { refill(); __builtin_amdgcn_s_waitcnt(0); }
+        }
 #pragma unroll
-            for (int w = 0; w < W; ++w) {
-                u64 const eq = eqp[w];
-                u64 const pv = vp[w], mv = vn[w];
-                u64 const x = eq | mv;
-                u64 const t1 = pv + (x & pv);
-                u64 const tt = t1 + c_d0;
-                u64 const d0 = (tt ^ pv) | x;
-                u64 const hn = pv & d0;
-                u64 const hp = mv | ~(pv | d0);
-                u64 const xh = (hp << 1) | c_hp;
-                u64 const nvn = xh & d0;
-                u64 const nvp = (hn << 1) | ~(xh | d0) | c_hn;
-                c_hp = hp >> 63;
-                c_hn = hn >> 63;
-                c_d0 = c_hn;
-                vn[w] = nvn;
-                vp[w] = nvp;
-                if (TRACE) {
-                    ulonglong2 v;
-                    v.x = hp;
-                    v.y = nvp;
-                    u64 const slot = job.trace_off + ((u64)t * R + p) * W + (u64)w;
-                    *reinterpret_cast<ulonglong2*>(trace + 2ull * slot) = v;
-                }
-                if (is_last_group && w == w_last) {
-                    bot += (hp & last_bit) ? 1 : 0;
-                    bot -= (hn & last_bit) ? 1 : 0;
-                }
+        for (u32 s = 0; s < S; ++s) {
+            u32 const t = t0 + s;
+            int c = (int)t - g;
+            if (has_group && c > c_hi && g + (int)R < Lg) {
+                // this lane's group is finished: take over group g + R (its window starts strictly later). Steps of the old group
+                // that are still buffered belong to the current block and are stored with it below.
+                g += (int)R;
+                enter_group();
+                started = false;
+                c = (int)t - g;
             }
-            if (!is_last_group) bot += (int)c_hp - (int)c_hn;
-            else if (bot <= best) { best = bot; best_col = c + 1; }
-            cout = ((u32)c_hp << 1) | ((u32)c_hn << 2) | ((u32)bot << 3);
-        } else {
-            cout = 2u;
+            u32 const cin_raw = (u32)__shfl((int)cout, (int)src_lane);
+            bool const active = has_group && c >= c_lo && c <= c_hi && t < t_max;
+            if (active) {
+                u32 const sym = ring[(u32)c & 255u];
+                u32 const cin = g == 0 ? 0u : cin_raw;
+                u64 c_hp = (cin >> 1) & 1u, c_hn = (cin >> 2) & 1u;
+                if (!started) {
+                    // column just left of the window: all vertical deltas +1 below the predecessor's bottom value
+                    int const top_prev = g == 0 ? 0 : (int)(cin >> 3) - (int)c_hp + (int)c_hn;
+                    bot = top_prev + rows_g;
+                    started = true;
+                }
+                const u64* __restrict__ eqp = &lds_eq[(sym * 64u + lane) * W];
+                u64 hp_keep = 0, hn_keep = 0;             // horizontal deltas of the word that holds row m-1 (last group only)
+#pragma unroll
+                for (int w = 0; w < W; ++w) {
+                    u64 const eq = eqp[w];
+                    u64 const pv = vp[w], mv = vn[w];
+                    u64 const x = eq | mv;
+                    u64 const tt = pv + (x & pv) + c_hn;  // the adder's carry-in is the predecessor word's top horizontal-negative bit
+                    u64 const d0 = (tt ^ pv) | x;
+                    u64 const hn = pv & d0;
+                    u64 const hp = mv | ~(pv | d0);
+                    u64 const xh = (hp << 1) | c_hp;
+                    u64 const nvn = xh & d0;
+                    u64 const nvp = (hn << 1) | ~(xh | d0) | c_hn;
+                    c_hp = hp >> 63;
+                    c_hn = hn >> 63;
+                    vn[w] = nvn;
+                    vp[w] = nvp;
+                    if (TRACE) { tbuf[s][w].x = hp; tbuf[s][w].y = nvp; }
+                    if (w == w_last_of_last) { hp_keep = hp; hn_keep = hn; }
+                }
+                if (g != Lg - 1) bot += (int)c_hp - (int)c_hn;
+                else {
+                    bot += (int)((hp_keep >> last_shift) & 1ull) - (int)((hn_keep >> last_shift) & 1ull);
+                    if (bot <= best) { best = bot; best_col = c + 1; }
+                }
+                cout = ((u32)c_hp << 1) | ((u32)c_hn << 2) | ((u32)bot << 3);
+                any_active_in_block = true;
+            } else {
+                cout = 2u;
+            }
+        }
+        if (TRACE) {
+            if (any_active_in_block) {
+#pragma unroll
+                for (u32 s = 0; s < S; ++s)
+#pragma unroll
+                    for (int w = 0; w < W; ++w) tptr[s * W + w] = tbuf[s][w];
+                any_active_in_block = false;
+            }
+            tptr += tstride;
         }
     }
     if (valid && has_group && g == Lg - 1) {
@@ -684,7 +701,9 @@ u64 align_trace_slots(u32 n, u32 m, AlignShape sh) {
     // step-major: (n + groups - 1) steps, `lanes` lanes, W words; for the unbanded kernel lanes == groups rounded up is not
     // required, the kernel only uses `groups` lanes per step there
     u64 const lanes = sh.banded ? sh.lanes_per_job : groups;
-    return ((u64)n + groups - 1) * lanes * sh.words_per_lane;
+    u64 steps = (u64)n + groups - 1;
+    if (sh.banded) steps = (steps + TRACE_STEP_BLOCK - 1) / TRACE_STEP_BLOCK * TRACE_STEP_BLOCK;
+    return steps * lanes * sh.words_per_lane;
 }
 
 template <int W>
@@ -764,7 +783,8 @@ __global__ void __launch_bounds__(64) ed_traceback_kernel(const u8* __restrict__
             u32 const ci = i - lane, cj = j - lane;
             u32 const gw = (ci - 1u) >> 6, bit = (ci - 1u) & 63u;
             u32 const g = gw / W, w = gw - g * W;
-            u64 const slot = job.trace_off + ((u64)(cj - 1u + g) * L + (g % L)) * W + w;
+            u32 const t = cj - 1u + g, SB = job.step_block;
+            u64 const slot = job.trace_off + (((u64)(t / SB) * L + (g % L)) * SB + (t % SB)) * W + w;
             ulonglong2 const v = *reinterpret_cast<const ulonglong2*>(trace + 2ull * slot);
             up = (v.y >> bit) & 1ull;
             left = (v.x >> bit) & 1ull;

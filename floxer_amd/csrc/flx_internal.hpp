@@ -89,12 +89,14 @@ struct DevAlignOut { u32 score; u32 end_col; };    // score 0xFFFFFFFF: no align
 struct DevTraceJob {
     u64 ref_off, q_off, trace_off, cigar_off;      // cigar_off: first word of this job's CIGAR slab
     u32 n, m, lanes, words_per_lane;
-    u32 end_col, cigar_cap, out_index, pad;
+    u32 end_col, cigar_cap, out_index;
+    u32 step_block;                                // trace layout: steps are stored in blocks of this many (1 = plain step-major)
 };
 struct DevTraceOut { u32 begin; u32 cigar_start; u32 cigar_len; u32 pad; };   // cigar_start relative to the slab
 
 // launch geometry for one alignment job shape
 struct AlignShape { u32 words_per_lane; u32 lanes_per_job; u32 banded; };
+constexpr u32 TRACE_STEP_BLOCK = 4;   // banded TRACE launches: a lane keeps this many steps in registers and stores them as one run
 AlignShape choose_align_shape(u32 n, u32 m, u32 k);
 u64 align_trace_slots(u32 n, u32 m, AlignShape sh);     // 16-byte trace slots a TRACE launch of this shape needs for one job
 u32 align_supported_max_query();

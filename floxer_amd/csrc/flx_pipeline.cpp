@@ -578,7 +578,7 @@ int run_trace_jobs_unique(Lane* ctx, const u8* d_text, const u8* d_query, const 
             u32 const L = sh.banded ? sh.lanes_per_job : (nw + sh.words_per_lane - 1) / sh.words_per_lane;
             u32 const cap = 2 * outs[c].score + 2;      // runs <= 2*NM + 1
             tjobs.push_back(DevTraceJob{r.ref_off, r.q_off, trace_off[c], cigar_words, r.n, r.m, L, sh.words_per_lane, outs[c].end_col,
-                                        cap, (u32)tjob_req.size(), 0});
+                                        cap, (u32)tjob_req.size(), sh.banded ? TRACE_STEP_BLOCK : 1u});
             tjob_req.push_back((u32)id);
             cigar_words += cap;
             path_steps += (u64)r.m + outs[c].score;
