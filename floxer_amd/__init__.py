@@ -310,12 +310,13 @@ def _collect_run(run, n):
     try:
         nr = lib().flx_run_num_records(run)
         nc = lib().flx_run_num_cigar_words(run)
-        recs = (capi.Record * max(1, nr))()
-        cig = np.zeros(max(1, nc), dtype=np.uint32)
+        rec_dtype = np.dtype([("read", "<u8"), ("flag", "<u4"), ("ref", "<i4"), ("pos", "<i4"), ("nm", "<u4"), ("coff", "<u8"),
+                              ("clen", "<u4"), ("res", "<u4")])
+        raw = np.empty(max(1, nr), dtype=rec_dtype)
+        cig = np.empty(max(1, nc), dtype=np.uint32)
         skipped = np.zeros(max(1, n), dtype=np.uint8)
-        check(lib().flx_run_copy(run, recs, ptr(cig, u32p), ptr(skipped, u8p)))
-        raw = np.frombuffer(recs, dtype=np.dtype([("read", "<u8"), ("flag", "<u4"), ("ref", "<i4"), ("pos", "<i4"), ("nm", "<u4"),
-                                                  ("coff", "<u8"), ("clen", "<u4"), ("res", "<u4")]), count=nr)
+        check(lib().flx_run_copy(run, raw.ctypes.data_as(C.POINTER(capi.Record)), ptr(cig, u32p), ptr(skipped, u8p)))
+        raw = raw[:nr]
         rows = np.stack([raw["read"].astype(np.int64), raw["flag"].astype(np.int64), raw["ref"].astype(np.int64),
                          raw["pos"].astype(np.int64), raw["nm"].astype(np.int64), raw["coff"].astype(np.int64),
                          raw["clen"].astype(np.int64)], axis=1) if nr else np.zeros((0, 7), dtype=np.int64)

@@ -421,15 +421,25 @@ struct ReqKeyHash {
     }
 };
 void dedup_requests(std::vector<AlignRequest> const& reqs, std::vector<AlignRequest>& uniq, std::vector<u32>& uniq_of) {
-    std::unordered_map<ReqKey, u32, ReqKeyHash> seen;
-    seen.reserve(reqs.size() * 2);
+    // open-addressing table of indices into `uniq` (power-of-two size, linear probing)
+    size_t cap = 16;
+    while (cap < reqs.size() * 2 + 1) cap <<= 1;
+    std::vector<u32> table(cap, 0xFFFFFFFFu);
+    ReqKeyHash const hasher;
     uniq.clear();
+    uniq.reserve(reqs.size());
     uniq_of.resize(reqs.size());
     for (size_t i = 0; i < reqs.size(); ++i) {
         AlignRequest const& r = reqs[i];
-        auto ins = seen.emplace(ReqKey{r.ref_off, r.q_off, r.n, r.m, r.k}, (u32)uniq.size());
-        if (ins.second) uniq.push_back(r);
-        uniq_of[i] = ins.first->second;
+        ReqKey const key{r.ref_off, r.q_off, r.n, r.m, r.k};
+        size_t h = hasher(key) & (cap - 1);
+        while (true) {
+            u32 const e = table[h];
+            if (e == 0xFFFFFFFFu) { table[h] = (u32)uniq.size(); uniq_of[i] = (u32)uniq.size(); uniq.push_back(r); break; }
+            AlignRequest const& u = uniq[e];
+            if (u.ref_off == r.ref_off && u.q_off == r.q_off && u.n == r.n && u.m == r.m && u.k == r.k) { uniq_of[i] = e; break; }
+            h = (h + 1) & (cap - 1);
+        }
     }
 }
 
@@ -1142,15 +1152,23 @@ extern "C" uint64_t flx_run_num_cigar_words(const flx_run* run) {
 }
 extern "C" int flx_run_copy(const flx_run* run, flx_record* records, uint32_t* cigar_words, uint8_t* skipped) {
     if (!run) { set_error("null run"); return FLX_ERR_INVALID; }
-    uint64_t rec_base = 0, cig_base = 0;
-    auto emit = [&](flx_run const& part) {
-        if (records) for (size_t i = 0; i < part.records.size(); ++i) { records[rec_base + i] = part.records[i]; records[rec_base + i].cigar_offset += cig_base; }
-        if (cigar_words && !part.cigars.empty()) memcpy(cigar_words + cig_base, part.cigars.data(), part.cigars.size() * 4);
-        rec_base += part.records.size();
-        cig_base += part.cigars.size();
+    // the run itself plus its per-lane parts, each copied by its own thread (the CIGAR pools are tens of MB per part)
+    std::vector<const flx_run*> pieces{run};
+    for (auto const& p : run->parts) pieces.push_back(&p);
+    std::vector<uint64_t> rec_base(pieces.size()), cig_base(pieces.size());
+    uint64_t rb = 0, cb = 0;
+    for (size_t i = 0; i < pieces.size(); ++i) { rec_base[i] = rb; cig_base[i] = cb; rb += pieces[i]->records.size(); cb += pieces[i]->cigars.size(); }
+    auto emit = [&](size_t i) {
+        flx_run const& part = *pieces[i];
+        if (records) for (size_t r = 0; r < part.records.size(); ++r) { records[rec_base[i] + r] = part.records[r]; records[rec_base[i] + r].cigar_offset += cig_base[i]; }
+        if (cigar_words && !part.cigars.empty()) memcpy(cigar_words + cig_base[i], part.cigars.data(), part.cigars.size() * 4);
     };
-    emit(*run);
-    for (auto const& p : run->parts) emit(p);
+    if (pieces.size() <= 2) for (size_t i = 0; i < pieces.size(); ++i) emit(i);
+    else {
+        std::vector<std::thread> threads;
+        for (size_t i = 0; i < pieces.size(); ++i) threads.emplace_back(emit, i);
+        for (auto& t : threads) t.join();
+    }
     if (skipped && !run->skipped.empty()) memcpy(skipped, run->skipped.data(), run->skipped.size());
     return FLX_OK;
 }

@@ -3,8 +3,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, ctypes as C
 import floxer_amd as F
 from floxer_amd import simulate as S, capi
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 genome = S.make_genome(4_600_000, 1, seed=S.DEFAULT_SEED)
-reads, _, _ = S.make_reads(genome, 1024, 5000, 0.08, seed=5)
+reads, _, _ = S.make_reads(genome, n, 5000, 0.08, seed=5)
 idx = F.fmindex(genome); ctx = F.context(idx)
 p = F.params(error_probability=0.08); al = F.aligner(ctx, p)
 rr = F.resident_reads(ctx, reads)
