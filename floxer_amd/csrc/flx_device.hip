@@ -54,58 +54,77 @@ int DeviceApi::build_peq(void* stream, const u8* d_seq, u64 len, u64* d_peq) {
 }
 
 // ================================================================================================ K1: FM search
-// ranks of all six symbols at the two ends [lo, hi) of an SA interval. Each end is one 128-byte block (header counts + 3
-// bit-planes over 256 positions); when both ends fall into the same block (the common case once an interval is narrow) the block
-// is read once and the interval's symbol counts come from one masked popcount pass.
-__device__ __forceinline__ void count_word(u64 p0, u64 p1, u64 p2, u64 mask, u32 c[6]) {
-    u64 const n2 = ~p2 & mask, q2 = p2 & mask;
-    u64 const a00 = ~p1 & ~p0, a01 = ~p1 & p0, a10 = p1 & ~p0, a11 = p1 & p0;
-    c[0] += (u32)__popcll(n2 & a00);
-    c[1] += (u32)__popcll(n2 & a01);
-    c[2] += (u32)__popcll(n2 & a10);
-    c[3] += (u32)__popcll(n2 & a11);
-    c[4] += (u32)__popcll(q2 & a00);
-    c[5] += (u32)__popcll(q2 & a01);
+// Four lanes (one DPP quad) serve one seed. A rank query reads one 128-byte block as 4 x 32 bytes (lane q reads quarter q: two
+// 32-position chunks of the three bit-planes plus two of the six block counters), every lane pop-counts its 64 positions for all
+// six symbols, and two quad_perm DPP adds give every lane the six totals; lane q then owns the ranks of symbols 2q and 2q+1.
+// The DFS frame is spread the same way (16 bytes per lane, 64 contiguous bytes per push/pop). Control state is replicated in
+// the quad, so a quad's four lanes never diverge; different quads of a wave do.
+
+__device__ __forceinline__ u32 quad_bcast0(u32 v) { return (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x00 /* quad_perm:[0,0,0,0] */, 0xf, 0xf, false); }
+__device__ __forceinline__ u32 quad_bcast3(u32 v) { return (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0xFF /* quad_perm:[3,3,3,3] */, 0xf, 0xf, false); }
+__device__ __forceinline__ u32 quad_sum(u32 v) {
+    v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1 /* quad_perm:[1,0,3,2] */, 0xf, 0xf, false);
+    v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E /* quad_perm:[2,3,0,1] */, 0xf, 0xf, false);
+    return v;
 }
-__device__ __forceinline__ u64 below_mask(u32 off, u32 w) {      // positions of word w (64*w ..) that lie below `off`
-    u32 const lo = w * 64;
-    if (off >= lo + 64) return ~0ull;
-    if (off > lo) return (1ull << (off - lo)) - 1ull;
-    return 0ull;
+
+// symbol counts of the positions selected by `mask` in one 32-position chunk, added to two packed accumulators
+// (10 bits per symbol: acc0 = c0 | c1<<10 | c2<<20, acc1 = c3 | c4<<10 | c5<<20; a quad total is at most 256)
+__device__ __forceinline__ void count_chunk(u32 p0, u32 p1, u32 p2, u32 mask, u32& acc0, u32& acc1) {
+    u32 const n2 = ~p2 & mask, q2 = p2 & mask;
+    u32 const a00 = ~p1 & ~p0, a01 = ~p1 & p0, a10 = p1 & ~p0, a11 = p1 & p0;
+    acc0 += (u32)__popc(n2 & a00) | ((u32)__popc(n2 & a01) << 10) | ((u32)__popc(n2 & a10) << 20);
+    acc1 += (u32)__popc(n2 & a11) | ((u32)__popc(q2 & a00) << 10) | ((u32)__popc(q2 & a01) << 20);
 }
-__device__ __forceinline__ void rank_pair(const OccBlock* __restrict__ tab, u32 lo, u32 hi, u32 a[6], u32 b[6]) {
-    const OccBlock* __restrict__ ba = tab + (lo >> 8);
+__device__ __forceinline__ u32 below_mask32(u32 off, u32 chunk) {       // positions of chunk (32*chunk ..) below `off`
+    u32 const lo = chunk * 32u;
+    if (off >= lo + 32u) return ~0u;
+    if (off > lo) return (1u << (off - lo)) - 1u;
+    return 0u;
+}
+__device__ __forceinline__ u32 unpack10(u32 acc0, u32 acc1, u32 sym) {
+    u32 const a = sym < 3 ? acc0 : acc1;
+    u32 const sh = ((sym < 3 ? sym : sym - 3u) * 10u) & 31u;      // lanes of quarter 3 own no symbol: their result is unused
+    return (a >> sh) & 1023u;
+}
+
+// ranks at the two ends [lo, hi) of an SA interval for the two symbols this lane owns (sa = 2*ql, sb = 2*ql+1)
+__device__ __forceinline__ void quad_rank_pair(const OccBlock* __restrict__ tab, u32 lo, u32 hi, u32 ql, u32& a_sa, u32& a_sb,
+                                               u32& b_sa, u32& b_sb) {
+    u32 const sa = 2u * ql, sb = sa + 1u;
+    const uint4* __restrict__ qa = reinterpret_cast<const uint4*>(tab + (lo >> 8)) + 2u * ql;
+    uint4 const x0 = qa[0], x1 = qa[1];
     u32 const off_a = lo & 255u;
-    {
-        uint4 const h0 = *reinterpret_cast<const uint4*>(&ba->cnt[0]);
-        uint2 const h1 = *reinterpret_cast<const uint2*>(&ba->cnt[4]);
-        a[0] = h0.x; a[1] = h0.y; a[2] = h0.z; a[3] = h0.w; a[4] = h1.x; a[5] = h1.y;
-    }
+    u32 const ma0 = below_mask32(off_a, sa), ma1 = below_mask32(off_a, sb);
+    u32 acc0 = 0, acc1 = 0;
+    count_chunk(x0.x, x0.y, x0.z, ma0, acc0, acc1);
+    count_chunk(x1.x, x1.y, x1.z, ma1, acc0, acc1);
     if ((lo >> 8) == (hi >> 8)) {
+        // same block: the interval's symbol counts are the positions between the two offsets
         u32 const off_b = hi & 255u;
-        u32 d[6] = {0, 0, 0, 0, 0, 0};
-#pragma unroll
-        for (u32 w = 0; w < 4; ++w) {
-            u64 const p0 = ba->planes[w][0], p1 = ba->planes[w][1], p2 = ba->planes[w][2];
-            u64 const ma = below_mask(off_a, w), mb = below_mask(off_b, w);
-            count_word(p0, p1, p2, ma, a);
-            count_word(p0, p1, p2, mb & ~ma, d);
-        }
-#pragma unroll
-        for (int c = 0; c < 6; ++c) b[c] = a[c] + d[c];
+        u32 d0 = 0, d1 = 0;
+        count_chunk(x0.x, x0.y, x0.z, below_mask32(off_b, sa) & ~ma0, d0, d1);
+        count_chunk(x1.x, x1.y, x1.z, below_mask32(off_b, sb) & ~ma1, d0, d1);
+        acc0 = quad_sum(acc0); acc1 = quad_sum(acc1);
+        d0 = quad_sum(d0); d1 = quad_sum(d1);
+        a_sa = x0.w + unpack10(acc0, acc1, sa);
+        a_sb = x1.w + unpack10(acc0, acc1, sb);
+        b_sa = a_sa + unpack10(d0, d1, sa);
+        b_sb = a_sb + unpack10(d0, d1, sb);
         return;
     }
-#pragma unroll
-    for (u32 w = 0; w < 4; ++w) count_word(ba->planes[w][0], ba->planes[w][1], ba->planes[w][2], below_mask(off_a, w), a);
-    const OccBlock* __restrict__ bb = tab + (hi >> 8);
+    const uint4* __restrict__ qb = reinterpret_cast<const uint4*>(tab + (hi >> 8)) + 2u * ql;
+    uint4 const y0 = qb[0], y1 = qb[1];
     u32 const off_b = hi & 255u;
-    {
-        uint4 const h0 = *reinterpret_cast<const uint4*>(&bb->cnt[0]);
-        uint2 const h1 = *reinterpret_cast<const uint2*>(&bb->cnt[4]);
-        b[0] = h0.x; b[1] = h0.y; b[2] = h0.z; b[3] = h0.w; b[4] = h1.x; b[5] = h1.y;
-    }
-#pragma unroll
-    for (u32 w = 0; w < 4; ++w) count_word(bb->planes[w][0], bb->planes[w][1], bb->planes[w][2], below_mask(off_b, w), b);
+    u32 bcc0 = 0, bcc1 = 0;
+    count_chunk(y0.x, y0.y, y0.z, below_mask32(off_b, sa), bcc0, bcc1);
+    count_chunk(y1.x, y1.y, y1.z, below_mask32(off_b, sb), bcc0, bcc1);
+    acc0 = quad_sum(acc0); acc1 = quad_sum(acc1);
+    bcc0 = quad_sum(bcc0); bcc1 = quad_sum(bcc1);
+    a_sa = x0.w + unpack10(acc0, acc1, sa);
+    a_sb = x1.w + unpack10(acc0, acc1, sb);
+    b_sa = y0.w + unpack10(bcc0, bcc1, sa);
+    b_sb = y1.w + unpack10(bcc0, bcc1, sb);
 }
 
 // frame state word: x:20 | e:3 | linfo:2 | rinfo:2 | next_sym:3 | right:1
@@ -120,13 +139,13 @@ __device__ __forceinline__ u32 st_pack(u32 x, u32 e, u32 li, u32 ri, u32 sym, u3
 #define ST_SYM(s) (((s) >> 27) & 7u)
 #define ST_RIGHT(s) (((s) >> 30) & 1u)
 
-// counters: [0] hits written/reserved, [1] stack overflow flag, [2] cursor extensions (rank pairs), [3] hit overflow
+// counters: [0] hits written/reserved, [1] stack overflow flag, [2] cursor extensions (rank pairs), [3] hit overflow,
+//           [4] wave-iterations, [5] max iterations of a wave, [6] busy quad-iterations
 //
-// One lane runs one seed's search_n at a time. DFS sizes differ by orders of magnitude between seeds, so lanes are not bound to
-// seeds: every wave owns a chunk of FM_CHUNK consecutive seeds and a lane that finishes its seed takes the chunk's next one
-// (an LDS counter), so the wave's lanes stay busy until the chunk is drained. One loop iteration = one DFS step of every busy
-// lane (at most one rank pair), which keeps the divergent part of the loop short.
-constexpr u32 FM_CHUNK = 256;
+// DFS sizes differ by orders of magnitude between seeds, so quads are not bound to seeds: every wave owns a chunk of FM_CHUNK
+// consecutive seeds and a quad that finishes its seed takes the chunk's next one (an LDS counter). One loop iteration = one DFS
+// step of every busy quad (at most one rank pair), which keeps the divergent part of the loop short.
+constexpr u32 FM_CHUNK = 64;
 
 __global__ void __launch_bounds__(64) fm_search_kernel(DevIndex idx, const u8* __restrict__ seq, const u32* __restrict__ scheme,
                                                        const DevSeed* __restrict__ seeds, u32 n_seeds, u32 max_hits,
@@ -137,38 +156,39 @@ __global__ void __launch_bounds__(64) fm_search_kernel(DevIndex idx, const u8* _
     u32 const chunk_n = min(FM_CHUNK, n_seeds - chunk_base);
     if (threadIdx.x == 0) next_in_chunk = 0;
     __syncthreads();
+    u32 const lane = threadIdx.x & 63u;
+    u32 const ql = lane & 3u;                   // lane within the quad
+    u32 const quad_base = lane & ~3u;
+    u32 const sa = 2u * ql, sb = sa + 1u;       // symbols owned by this lane (only ql < 3 owns real symbols)
 
-    u32 n_ext = 0;
-    u32 n_iter = 0, n_busy_iter = 0;
-    // ---- per-seed state
+    u32 n_ext = 0, n_iter = 0, n_busy_iter = 0;
+    // ---- per-seed state (replicated in the quad)
     bool busy = false, exhausted = false;
     u32 sid = 0, srch = 0, num_searches = 0, len = 0, ct = 0, stack_frames = 0;
     const u8* __restrict__ q = seq;
-    DevFrame* __restrict__ stk = stack;
+    uint4* __restrict__ stk = reinterpret_cast<uint4*>(stack);
     const u32* __restrict__ ex_base = scheme;
     // ---- per-search state
     bool in_search = false;
     const u32* __restrict__ ex = scheme;
     u32 l_last = 0, u_last = 0;
     u32 nlb = 0, nlbr = 0, nlen = 0, nx = 0, ne = 0, nli = INFO_M, nri = INFO_M;
-    DevFrame F;
-    F.mask = 0;
-    F.lb = F.lb_rev = F.len = F.state = 0;
-#pragma unroll
-    for (int c = 0; c < 5; ++c) F.child_abs[c] = 0;
-#pragma unroll
-    for (int c = 0; c < 6; ++c) F.child_len[c] = 0;
+    // top frame: replicated node part + this lane's two child cursors
+    u32 f_lb = 0, f_lbr = 0, f_len = 0, f_state = 0, f_mask = 0;
+    u32 f_abs_a = 0, f_len_a = 0, f_abs_b = 0, f_len_b = 0;
     u32 depth = 0;
     bool have_frame = false, need_child = false;
 
     while (true) {
         if (!busy && !exhausted) {
-            u32 const k = atomicAdd(&next_in_chunk, 1u);
+            u32 k = 0;
+            if (ql == 0) k = atomicAdd(&next_in_chunk, 1u);
+            k = quad_bcast0(k);
             if (k < chunk_n) {
                 sid = chunk_base + k;
                 DevSeed const seed = seeds[sid];
                 q = seq + seed.seq_off;
-                stk = stack + seed.stack_off;
+                stk = reinterpret_cast<uint4*>(stack + seed.stack_off);
                 len = seed.length;
                 num_searches = seed.num_searches;
                 stack_frames = seed.stack_frames;
@@ -191,7 +211,7 @@ __global__ void __launch_bounds__(64) fm_search_kernel(DevIndex idx, const u8* _
             l_last = (last_entry >> 20) & 7u;
             u_last = (last_entry >> 23) & 7u;
             nlb = 0; nlbr = 0; nlen = idx.n; nx = 0; ne = 0; nli = INFO_M; nri = INFO_M;
-            F.mask = 0;
+            f_mask = 0;
             depth = 0;
             have_frame = false;
             need_child = false;
@@ -200,15 +220,19 @@ __global__ void __launch_bounds__(64) fm_search_kernel(DevIndex idx, const u8* _
 
         // ---- one DFS step
         if (need_child) {
-            if (!have_frame || F.mask == 0) {
+            if (!have_frame || f_mask == 0) {
                 if (depth == 0) { in_search = false; ++srch; continue; }    // search exhausted
-                F = stk[--depth];
+                --depth;
+                uint4 const v = stk[depth * 4u + ql];
+                f_abs_a = v.x; f_len_a = v.y; f_abs_b = v.z; f_len_b = v.w;
+                f_lb = quad_bcast3(v.x); f_lbr = quad_bcast3(v.y); f_len = quad_bcast3(v.z); f_state = quad_bcast3(v.w);
+                f_mask = quad_bcast0(v.x);
                 have_frame = true;
                 continue;
             }
-            u32 const ci = (u32)__ffs((int)F.mask) - 1u;
-            F.mask &= F.mask - 1u;
-            u32 const st = F.state;
+            u32 const ci = (u32)__ffs((int)f_mask) - 1u;
+            f_mask &= f_mask - 1u;
+            u32 const st = f_state;
             u32 const right = ST_RIGHT(st);
             u32 const px = ST_X(st), pe = ST_E(st);
             u32 info, sym;
@@ -221,17 +245,17 @@ __global__ void __launch_bounds__(64) fm_search_kernel(DevIndex idx, const u8* _
                 ne = pe + 1;
                 info = del ? INFO_D : INFO_S;
             }
-            if (ci == 11) { nlb = F.lb; nlbr = F.lb_rev; nlen = F.len; }
+            if (ci == 11) { nlb = f_lb; nlbr = f_lbr; nlen = f_len; }
             else {
-                u32 pre = 0, clen = 0, cabs = 0;
-#pragma unroll
-                for (u32 c = 0; c < 6; ++c) {
-                    if (c < sym) pre += F.child_len[c];
-                    if (c == sym) { clen = F.child_len[c]; cabs = c > 0 ? F.child_abs[c > 0 ? c - 1 : 0] : 0; }
-                }
+                // child cursor of `sym`: its (abs, len) live in lane sym/2, the prefix sum of smaller symbols is a quad sum
+                u32 const part = ql < 3 ? ((sa < sym ? f_len_a : 0u) + (sb < sym ? f_len_b : 0u)) : 0u;
+                u32 const pre = quad_sum(part);
+                u32 const my_abs = (sym & 1u) ? f_abs_b : f_abs_a, my_len = (sym & 1u) ? f_len_b : f_len_a;
+                u32 const owner = quad_base + (sym >> 1);
+                u32 const cabs = (u32)__shfl((int)my_abs, (int)owner), clen = (u32)__shfl((int)my_len, (int)owner);
                 nlen = clen;
-                if (right) { nlbr = cabs; nlb = F.lb + pre; }
-                else { nlb = cabs; nlbr = F.lb_rev + pre; }
+                if (right) { nlbr = cabs; nlb = f_lb + pre; }
+                else { nlb = cabs; nlbr = f_lbr + pre; }
             }
             nli = right ? ST_LI(st) : info;
             nri = right ? info : ST_RI(st);
@@ -245,9 +269,11 @@ __global__ void __launch_bounds__(64) fm_search_kernel(DevIndex idx, const u8* _
                 u32 rep = nlen;
                 if (ct + rep > max_hits) rep = max_hits - ct;        // search_n truncates the last cursor
                 ct += rep;
-                u32 const slot = atomicAdd(&counters[0], 1u);
-                if (slot < hit_cap) hits[slot] = DevHit{sid, nlb, rep, ne};
-                else atomicOr(&counters[3], 1u);
+                if (ql == 0) {
+                    u32 const slot = atomicAdd(&counters[0], 1u);
+                    if (slot < hit_cap) hits[slot] = DevHit{sid, nlb, rep, ne};
+                    else atomicOr(&counters[3], 1u);
+                }
                 if (ct == max_hits) { busy = false; continue; }      // search_n aborts all remaining searches of the seed
             }
             need_child = true;
@@ -261,60 +287,63 @@ __global__ void __launch_bounds__(64) fm_search_kernel(DevIndex idx, const u8* _
         if (!mismatch_allowed && !match_allowed) { need_child = true; continue; }
 
         u32 const next_sym = q[entry & SCH_POS_MASK];
-        u32 a[6], b[6];
         const OccBlock* __restrict__ tab = idx.occ[right];
         u32 const lo = right ? nlbr : nlb;
-        rank_pair(tab, lo, lo + nlen, a, b);
+        u32 a_sa, a_sb, b_sa, b_sb;
+        quad_rank_pair(tab, lo, lo + nlen, ql, a_sa, a_sb, b_sa, b_sb);
         ++n_ext;
+        u32 const len_a = ql < 3 ? b_sa - a_sa : 0u, len_b = ql < 3 ? b_sb - a_sb : 0u;
+        u32 const abs_a = idx.C[sa] + a_sa, abs_b = idx.C[sb < 6 ? sb : 5] + a_sb;
 
         if (mismatch_allowed) {
-            // this node branches: it becomes the top frame, the previous top goes to memory
+            // this node branches: it becomes the top frame, the previous top goes to memory (16 bytes per lane)
             if (have_frame) {
-                if (depth >= stack_frames) { atomicOr(&counters[1], 1u); busy = false; continue; }
-                stk[depth++] = F;
+                if (depth >= stack_frames) { if (ql == 0) atomicOr(&counters[1], 1u); busy = false; continue; }
+                uint4 v;
+                if (ql < 3) { v.x = ql == 0 ? f_mask : f_abs_a; v.y = f_len_a; v.z = f_abs_b; v.w = f_len_b; }
+                else { v.x = f_lb; v.y = f_lbr; v.z = f_len; v.w = f_state; }
+                stk[depth * 4u + ql] = v;
+                ++depth;
             }
             have_frame = true;
             u32 const tinfo = right ? nri : nli;
             bool const deletion = tinfo == INFO_M || tinfo == INFO_D;
             bool const insertion = tinfo == INFO_M || tinfo == INFO_I;
-            F.lb = nlb; F.lb_rev = nlbr; F.len = nlen;
-            F.state = st_pack(nx, ne, nli, nri, next_sym, right);
-            u32 mask = 0;
-#pragma unroll
-            for (u32 c = 0; c < 6; ++c) {
-                u32 const cl = b[c] - a[c];
-                F.child_len[c] = cl;
-                if (c > 0) {
-                    F.child_abs[c - 1] = idx.C[c] + a[c];
-                    if (cl > 0) {
-                        if (deletion) mask |= 1u << (2 * c - 1);
-                        if (c != next_sym) mask |= 1u << (2 * c);
-                        else if (match_allowed) mask |= 1u;
-                    }
-                }
+            f_lb = nlb; f_lbr = nlbr; f_len = nlen;
+            f_state = st_pack(nx, ne, nli, nri, next_sym, right);
+            f_abs_a = abs_a; f_len_a = len_a; f_abs_b = abs_b; f_len_b = len_b;
+            // children of symbols 1..5 that are not empty: this lane contributes the bits of its two symbols, quad-OR via sum
+            u32 mine = 0;
+            if (sa > 0 && len_a > 0) {
+                if (deletion) mine |= 1u << (2 * sa - 1);
+                if (sa != next_sym) mine |= 1u << (2 * sa);
+                else if (match_allowed) mine |= 1u;
             }
+            if (ql < 3 && len_b > 0) {
+                if (deletion) mine |= 1u << (2 * sb - 1);
+                if (sb != next_sym) mine |= 1u << (2 * sb);
+                else if (match_allowed) mine |= 1u;
+            }
+            u32 mask = quad_sum(mine);              // the four contributions have disjoint bits
             if (insertion) mask |= 1u << 11;
-            F.mask = mask;
+            f_mask = mask;
             need_child = true;
         } else {
             // only an exact extension is possible: continue in place (no frame)
-            u32 pre = 0, clen = 0, cabs = 0;
-#pragma unroll
-            for (u32 c = 0; c < 6; ++c) {
-                u32 const cl = b[c] - a[c];
-                if (c < next_sym) pre += cl;
-                if (c == next_sym) { clen = cl; cabs = idx.C[c] + a[c]; }
-            }
-            if (clen == 0) { need_child = true; continue; }
+            u32 const part = ql < 3 ? ((sa < next_sym ? len_a : 0u) + (sb < next_sym ? len_b : 0u)) : 0u;
+            u32 const pre = quad_sum(part);
+            u32 const my_abs = (next_sym & 1u) ? abs_b : abs_a, my_len = (next_sym & 1u) ? len_b : len_a;
+            u32 const owner = quad_base + (next_sym >> 1);
+            u32 const cabs = (u32)__shfl((int)my_abs, (int)owner), clen = (u32)__shfl((int)my_len, (int)owner);
+            if (clen == 0 || next_sym == 0u || next_sym > 5u) { need_child = true; continue; }   // the sentinel never matches
             if (right) { nlbr = cabs; nlb = nlb + pre; nri = INFO_M; }
             else { nlb = cabs; nlbr = nlbr + pre; nli = INFO_M; }
             nlen = clen;
             nx = nx + 1;
         }
     }
-    atomicAdd(&counters[2], n_ext);
+    if (ql == 0) { atomicAdd(&counters[2], n_ext); atomicAdd(&counters[6], n_busy_iter); }
     if (threadIdx.x == 0) { atomicAdd(&counters[4], n_iter); atomicMax(&counters[5], n_iter); }
-    atomicAdd(&counters[6], n_busy_iter);
 }
 
 int DeviceApi::search(void* stream, const DevIndex& idx, const u8* d_seq, const u32* d_scheme, const DevSeed* d_seeds, u32 n_seeds,

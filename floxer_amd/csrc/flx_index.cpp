@@ -136,18 +136,19 @@ void build_occ_blocks(const std::vector<u8>& bwt, std::vector<OccBlock>& blocks)
     u32 cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     for (u64 b = 0; b < nb; ++b) {
         OccBlock& blk = blocks[b];
-        for (int c = 0; c < 6; ++c) blk.cnt[c] = cnt[c];
-        for (int w = 0; w < 4; ++w) {
-            u64 p0 = 0, p1 = 0, p2 = 0;
-            for (int k = 0; k < 64; ++k) {
-                u64 const pos = b * 256 + (u64)w * 64 + k;
+        for (int c = 0; c < 6; ++c) blk.w[(c >> 1) * 8 + (c & 1) * 4 + 3] = cnt[c];
+        for (int j = 0; j < 8; ++j) {                   // 32-position chunk j lives in quarter j/2, half j%2
+            u32 p0 = 0, p1 = 0, p2 = 0;
+            for (int k = 0; k < 32; ++k) {
+                u64 const pos = b * 256 + (u64)j * 32 + k;
                 u8 const sym = pos < n ? bwt[pos] : 7;
-                p0 |= (u64)(sym & 1) << k;
-                p1 |= (u64)((sym >> 1) & 1) << k;
-                p2 |= (u64)((sym >> 2) & 1) << k;
+                p0 |= (u32)(sym & 1) << k;
+                p1 |= (u32)((sym >> 1) & 1) << k;
+                p2 |= (u32)((sym >> 2) & 1) << k;
                 if (pos < n) cnt[sym]++;
             }
-            blk.planes[w][0] = p0; blk.planes[w][1] = p1; blk.planes[w][2] = p2;
+            u32* q = &blk.w[(j >> 1) * 8 + (j & 1) * 4];
+            q[0] = p0; q[1] = p1; q[2] = p2;
         }
     }
 }
@@ -192,7 +193,7 @@ HostIndex* build_host_index(const u8* concat, const u64* lens, u32 n_refs) {
 
 // ---------------------------------------------------------------- own index file format (replaces the cereal archive)
 namespace {
-constexpr char MAGIC[8] = {'F', 'L', 'X', 'I', 'D', 'X', '0', '1'};
+constexpr char MAGIC[8] = {'F', 'L', 'X', 'I', 'D', 'X', '0', '2'};
 template <class T> bool wr(FILE* f, const std::vector<T>& v) {
     u64 const n = v.size();
     return fwrite(&n, 8, 1, f) == 1 && (n == 0 || fwrite(v.data(), sizeof(T), n, f) == n);

@@ -19,16 +19,14 @@ using i64 = int64_t;
 void set_error(const std::string& msg);
 
 // ------------------------------------------------------------------------------------------------ HBM data layout
-// Occurrence table block: 256 BWT positions in one 128-byte line (one L2 line / one HBM request on gfx950).
-//   cnt[c]        = number of symbol c in bwt[0, 256*b)           (absolute; text < 2^32 symbols)
-//   planes[w][p]  = bit p of the symbols bwt[256*b + 64*w + 0..63]  (3 bit-planes, symbols 0..5; tail filled with 7)
+// Occurrence table block: 256 BWT positions in one 128-byte line (one L2 line / one HBM request on gfx950), cut into four
+// 32-byte quarters so that the four lanes that serve one seed each read one quarter with two 16-byte loads (coalesced 128 B):
+//   quarter q = { p0[2q], p1[2q], p2[2q], cnt[2q],  p0[2q+1], p1[2q+1], p2[2q+1], cnt[2q+1] }        (8 x u32)
+//   pk[j]  = bit-plane k (symbol bit k) of the 32 positions bwt[256*b + 32*j ..+31]   (symbols 0..5; tail filled with 7)
+//   cnt[c] = number of symbol c in bwt[0, 256*b) for c < 6 (absolute; text < 2^32 symbols); cnt[6], cnt[7] unused
 struct alignas(128) OccBlock {
-    u32 cnt[6];
-    u32 pad[2];
-    u64 planes[4][3];
+    u32 w[32];
 };
-static_assert(sizeof(OccBlock) == 128, "occ block must be one 128-byte line");
-
 constexpr u32 TEXT_PAD = 128;     // bytes of padding in front of and behind the device copy of a reference text
 
 struct HostIndex {
@@ -65,12 +63,11 @@ struct DevSeed {
     u32 stack_frames;   // frames reserved
 };
 
-struct DevFrame {       // 64 bytes: one branching node of the DFS
-    u32 lb, lb_rev, len;        // cursor of the node
-    u32 state;                  // x:20 | e:3 | linfo:2 | rinfo:2 | next_sym:3 | right:1
-    u32 child_abs[5];           // for symbols 1..5: absolute lb on the side that was extended (C[c] + occ)
-    u32 child_len[6];           // for symbols 0..5
-    u32 mask;                   // remaining children (bit ci)
+struct DevFrame {       // 64 bytes: one branching node of the DFS, 16 bytes per lane of the seed's quad
+    // lane q < 3: { abs[2q], len[2q], abs[2q+1], len[2q+1] } of the child cursors for symbols 2q, 2q+1 (abs = C[c] + occ on the
+    //             extended side; abs[0] is unused by the search and carries the mask of remaining children instead)
+    // lane 3:     { lb, lb_rev, len, state } of the node itself; state = x:20 | e:3 | linfo:2 | rinfo:2 | next_sym:3 | right:1
+    u32 v[16];
 };
 static_assert(sizeof(DevFrame) == 64, "frame is one 64-byte line");
 

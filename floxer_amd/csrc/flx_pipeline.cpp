@@ -22,7 +22,7 @@ namespace flx {
 int DeviceBuffer::ensure(size_t bytes) {
     if (bytes <= cap && ptr) return FLX_OK;
     release();
-    size_t const want = std::max<size_t>(bytes + bytes / 4, 4096);
+    size_t const want = std::max<size_t>(bytes + bytes / 2, 4096);       // 50 % slack: batches of a run differ by a few per cent
     void* p = nullptr;
     hipError_t e = hipMalloc(&p, want);
     size_t got = want;
@@ -538,7 +538,8 @@ int run_trace_jobs_unique(Lane* ctx, const u8* d_text, const u8* d_query, const 
         u64 used = 0;
         while (next < reqs.size() && used + slots[next] <= budget_slots) { used += slots[next]; ++next; }
         size_t const count = next - begin;
-        if ((rc = ctx->trace.ensure(used * 16 + 64))) return rc;
+        // the arena is taken whole on first use (its size is the configured budget): no reallocation between batches
+        if ((rc = ctx->trace.ensure(std::max<size_t>(used * 16 + 64, ctx->trace.ptr ? 0 : std::min<size_t>(ctx->trace_budget_bytes, (size_t)budget_slots * 16) / 3 * 2)))) return rc;
 
         std::map<ShapeKey, std::vector<u32>> by_shape;
         for (size_t i = begin; i < next; ++i) by_shape[ShapeKey{shapes[i].words_per_lane, shapes[i].lanes_per_job, shapes[i].banded}].push_back((u32)i);
