@@ -704,12 +704,9 @@ static bool use_band() {
     return v != 0;
 }
 
-AlignShape choose_align_shape(u32 n, u32 m, u32 k) {
-    u32 const nw = (m + 63) / 64;
+static AlignShape choose_align_shape_uncached(u32 nw, i64 width, bool band) {
     AlignShape best{0, 0, 0};
     u64 best_cost = ~0ull;
-    bool const band = use_band();
-    i64 const width = (i64)n - (i64)m + 2 * (i64)k;       // diagonals that matter, minus one
     for (u32 w : kWordsPerLane)
         for (u32 r = 1; r <= 64; r *= 2) {
             u32 const groups = (nw + w - 1) / w;
@@ -721,6 +718,19 @@ AlignShape choose_align_shape(u32 n, u32 m, u32 k) {
             if (cost < best_cost) { best_cost = cost; best = AlignShape{w, r, band ? 1u : 0u}; }
         }
     return best;
+}
+
+AlignShape choose_align_shape(u32 n, u32 m, u32 k) {
+    u32 const nw = (m + 63) / 64;
+    bool const band = use_band();
+    i64 const width = (i64)n - (i64)m + 2 * (i64)k;       // diagonals that matter, minus one
+    // the jobs of one verification level repeat a handful of (words, band width) pairs: small direct-mapped memo per thread
+    struct Entry { u32 nw; i64 width; AlignShape shape; bool valid; };
+    thread_local Entry memo[256] = {};
+    Entry& e = memo[(nw * 31u + (u32)width) & 255u];
+    if (e.valid && e.nw == nw && e.width == width) return e.shape;
+    e = Entry{nw, width, choose_align_shape_uncached(nw, width, band), true};
+    return e.shape;
 }
 u32 align_supported_max_query() { return 25u * 64u * 64u; }
 

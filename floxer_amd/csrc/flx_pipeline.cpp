@@ -460,8 +460,6 @@ int run_score_jobs_unique(Lane* ctx, const u8* d_text, const u64* d_peq, std::ve
     std::vector<Launch> launches;
     for (auto& kv : by_shape) {
         auto& ids = kv.second;
-        // longest windows first so that the waves of one launch finish together
-        std::stable_sort(ids.begin(), ids.end(), [&](u32 a, u32 b) { return reqs[a].n > reqs[b].n; });
         Launch l{kv.first, (u32)jobs.size(), (u32)ids.size(), 0, 0};
         for (u32 id : ids) {
             AlignRequest const& r = reqs[id];
@@ -1003,24 +1001,23 @@ int align_slice(Lane* lane, const flx_params* P, const flx_reads* RD, u64 first_
         a.node = leaf.parent_id;
         if (rs.tree.inner[a.node].parent_id == FLX_NULL_ID) a.at_root = true;
     }
-    while (true) {
-        std::vector<AlignRequest> reqs;
-        std::vector<u32> req_anchor;
-        for (u32 ai = 0; ai < A.size(); ++ai) {
-            AnchorState& a = A[ai];
-            if (!a.alive || a.at_root) continue;
-            reqs.push_back(window_request(a, reads[a.read].tree.inner[a.node], 0.0, nullptr));
-            req_anchor.push_back(ai);
-        }
-        if (reqs.empty()) break;
-        std::vector<DevAlignOut> outs;
+    std::vector<u32> climbing;                       // anchors that still have an inner node to test
+    for (u32 ai = 0; ai < A.size(); ++ai) if (A[ai].alive && !A[ai].at_root) climbing.push_back(ai);
+    std::vector<AlignRequest> reqs;
+    std::vector<DevAlignOut> outs;
+    while (!climbing.empty()) {
+        reqs.clear();
+        for (u32 ai : climbing) reqs.push_back(window_request(A[ai], reads[A[ai].read].tree.inner[A[ai].node], 0.0, nullptr));
         if ((rc = run_score_jobs(lane, d_text, lane->peq.as<u64>(), reqs, outs, "ed_align_exists"))) return rc;
+        size_t keep = 0;
         for (size_t i = 0; i < outs.size(); ++i) {
-            AnchorState& a = A[req_anchor[i]];
+            AnchorState& a = A[climbing[i]];
             if (outs[i].score == 0xFFFFFFFFu) { a.alive = false; continue; }
             a.node = reads[a.read].tree.inner[a.node].parent_id;
             if (reads[a.read].tree.inner[a.node].parent_id == FLX_NULL_ID) a.at_root = true;
+            else climbing[keep++] = climbing[i];
         }
+        climbing.resize(keep);
     }
 
     prof.mark("inner-levels");
