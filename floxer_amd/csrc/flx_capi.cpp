@@ -63,7 +63,7 @@ uint32_t flx_index_num_references(const flx_index* index) { return index ? (uint
 uint64_t flx_index_device_bytes(const flx_index* index) {
     if (!index) return 0;
     HostIndex const& h = *index->host;
-    return (h.occ[0].size() + h.occ[1].size()) * sizeof(OccBlock) + h.sa.size() * 4 + h.text.size() + 2 * TEXT_PAD;
+    return (h.occ[0].size() + h.occ[1].size()) * sizeof(OccBlock) + h.sa.size() * 4 + h.text.size() + 2 * TEXT_PAD + h.kmer_table.size() * 4;
 }
 int flx_index_copy_sa(const flx_index* index, uint64_t* out) {
     if (!index || !out) { set_error("null argument"); return FLX_ERR_INVALID; }
@@ -112,6 +112,7 @@ int flx_ctx_create(int hip_device, const flx_index* index, flx_ctx** out) {
     if ((rc = up(ctx->occ0, H.occ[0].data(), H.occ[0].size() * sizeof(OccBlock)))) return rc;
     if ((rc = up(ctx->occ1, H.occ[1].data(), H.occ[1].size() * sizeof(OccBlock)))) return rc;
     if ((rc = up(ctx->sa, H.sa.data(), H.sa.size() * 4))) return rc;
+    if ((rc = up(ctx->kmer, H.kmer_table.data(), H.kmer_table.size() * 4))) return rc;
     if ((rc = ctx->text.ensure(H.n + 2 * TEXT_PAD + 16))) return rc;
     FLX_HIP(hipMemsetAsync(ctx->text.ptr, 0, ctx->text.cap, s0));
     FLX_HIP(hipMemcpyAsync((char*)ctx->text.ptr + TEXT_PAD, H.text.data(), H.n, hipMemcpyHostToDevice, s0));
@@ -119,6 +120,7 @@ int flx_ctx_create(int hip_device, const flx_index* index, flx_ctx** out) {
     ctx->didx.occ[0] = ctx->occ0.as<OccBlock>();
     ctx->didx.occ[1] = ctx->occ1.as<OccBlock>();
     ctx->didx.sa = ctx->sa.as<u32>();
+    ctx->didx.kmer = ctx->kmer.as<u32>();
     ctx->didx.text = ctx->text.as<u8>() + TEXT_PAD;
     for (int c = 0; c < 7; ++c) ctx->didx.C[c] = (u32)H.C[c];
     ctx->didx.n = (u32)H.n;
@@ -137,7 +139,7 @@ void flx_ctx_destroy(flx_ctx* ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     for (auto& lane : ctx->lanes) { (void)hipStreamSynchronize(lane->stream); lane->release_all(); }
-    for (DeviceBuffer* b : {&ctx->occ0, &ctx->occ1, &ctx->sa, &ctx->text, &ctx->text_rev}) b->release();
+    for (DeviceBuffer* b : {&ctx->occ0, &ctx->occ1, &ctx->sa, &ctx->text, &ctx->text_rev, &ctx->kmer}) b->release();
     delete ctx;
 }
 

@@ -60,7 +60,7 @@ struct flx_ctx {
     int device = 0;
     const flx::HostIndex* hidx = nullptr;
     flx::DevIndex didx{};
-    flx::DeviceBuffer occ0, occ1, sa, text, text_rev;
+    flx::DeviceBuffer occ0, occ1, sa, text, text_rev, kmer;
     bool text_rev_ready = false;
     std::mutex mu;                   // guards text_rev upload and the statistics
     std::vector<std::unique_ptr<flx::Lane>> lanes;

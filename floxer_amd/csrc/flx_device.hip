@@ -216,6 +216,24 @@ __global__ void __launch_bounds__(64) fm_search_kernel(DevIndex idx, const u8* _
             have_frame = false;
             need_child = false;
             in_search = true;
+            // the exact, rightward first part of the search starts from the KMER_Q-mer table when it is long enough and free of N
+            if (len >= KMER_Q && ((ex[KMER_Q - 1] >> 27) & 1u)) {
+                u32 const p0 = ex[0] & SCH_POS_MASK;
+                u32 code = 0;
+                bool ok = true;
+#pragma unroll
+                for (u32 j = 0; j < KMER_Q; ++j) {
+                    u32 const c = q[p0 + j];
+                    ok = ok && c >= 1u && c <= 4u;
+                    code = (code << 2) | ((c - 1u) & 3u);
+                }
+                if (ok) {
+                    const u32* __restrict__ e = idx.kmer + 3u * code;
+                    nlb = e[0]; nlbr = e[1]; nlen = e[2];
+                    nx = KMER_Q;
+                    if (nlen == 0) { in_search = false; ++srch; continue; }     // the k-mer does not occur: this search finds nothing
+                }
+            }
         }
 
         // ---- one DFS step

@@ -133,7 +133,8 @@ std::vector<u32> expanded_scheme(u32 k, u32 len) {
             for (u32 j = 0; j < counts[part]; ++j) {
                 u32 const pos = right ? starts[part] + j : starts[part] + counts[part] - 1 - j;
                 bool const last = j + 1 == counts[part];
-                out.push_back(sch_pack(pos, last ? s.l[i] : lower_before_end, s.u[i], right));
+                bool const exact_prefix = i == 0 && s.u[0] == 0 && s.l[0] == 0;       // first part of every optimum search
+                out.push_back(sch_pack(pos, last ? s.l[i] : lower_before_end, s.u[i], right, exact_prefix));
             }
         }
     }

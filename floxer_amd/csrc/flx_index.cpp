@@ -153,6 +153,51 @@ void build_occ_blocks(const std::vector<u8>& bwt, std::vector<OccBlock>& blocks)
     }
 }
 
+// rank of all symbols at position i on the host (same block layout the device reads)
+void host_rank_all(const std::vector<OccBlock>& tab, u64 i, u64 out[6]) {
+    OccBlock const& b = tab[i >> 8];
+    u32 const off = (u32)(i & 255);
+    for (int c = 0; c < 6; ++c) out[c] = b.w[(c >> 1) * 8 + (c & 1) * 4 + 3];
+    for (u32 j = 0; j < 8; ++j) {
+        if (off <= j * 32) break;
+        u32 const take = std::min<u32>(32, off - j * 32);
+        u32 const mask = take == 32 ? ~0u : ((1u << take) - 1u);
+        const u32* q = &b.w[(j >> 1) * 8 + (j & 1) * 4];
+        for (u32 k = 0; k < 32; ++k) {
+            if (!((mask >> k) & 1)) continue;
+            u32 const sym = ((q[0] >> k) & 1) | (((q[1] >> k) & 1) << 1) | (((q[2] >> k) & 1) << 2);
+            if (sym < 6) out[sym]++;
+        }
+    }
+}
+
+// cursor of every KMER_Q-mer, built level by level with BiFMIndexCursor::extendRight semantics
+void build_kmer_table(HostIndex& idx) {
+    struct Cur { u64 lb, lb_rev, len; };
+    std::vector<Cur> level{Cur{0, 0, idx.n}};
+    for (u32 d = 0; d < KMER_Q; ++d) {
+        std::vector<Cur> next(level.size() * 4);
+        for (size_t i = 0; i < level.size(); ++i) {
+            Cur const& c = level[i];
+            u64 a[6] = {0, 0, 0, 0, 0, 0}, b[6] = {0, 0, 0, 0, 0, 0};
+            if (c.len) { host_rank_all(idx.occ[1], c.lb_rev, a); host_rank_all(idx.occ[1], c.lb_rev + c.len, b); }
+            u64 acc = c.lb + (b[0] - a[0]);
+            for (int sym = 1; sym <= 4; ++sym) {
+                u64 const len = b[sym] - a[sym];
+                next[i * 4 + (sym - 1)] = Cur{acc, idx.C[sym] + a[sym], len};
+                acc += len;
+            }
+        }
+        level.swap(next);
+    }
+    idx.kmer_table.resize(level.size() * 3);
+    for (size_t i = 0; i < level.size(); ++i) {
+        idx.kmer_table[i * 3] = (u32)level[i].lb;
+        idx.kmer_table[i * 3 + 1] = (u32)level[i].lb_rev;
+        idx.kmer_table[i * 3 + 2] = (u32)level[i].len;
+    }
+}
+
 }  // namespace
 
 HostIndex* build_host_index(const u8* concat, const u64* lens, u32 n_refs) {
@@ -188,12 +233,13 @@ HostIndex* build_host_index(const u8* concat, const u64* lens, u32 n_refs) {
     for (int c = 0; c < 6; ++c) idx->C[c + 1] = idx->C[c] + cnt[c];
     build_occ_blocks(idx->bwt[0], idx->occ[0]);
     build_occ_blocks(idx->bwt[1], idx->occ[1]);
+    build_kmer_table(*idx);
     return idx.release();
 }
 
 // ---------------------------------------------------------------- own index file format (replaces the cereal archive)
 namespace {
-constexpr char MAGIC[8] = {'F', 'L', 'X', 'I', 'D', 'X', '0', '2'};
+constexpr char MAGIC[8] = {'F', 'L', 'X', 'I', 'D', 'X', '0', '3'};
 template <class T> bool wr(FILE* f, const std::vector<T>& v) {
     u64 const n = v.size();
     return fwrite(&n, 8, 1, f) == 1 && (n == 0 || fwrite(v.data(), sizeof(T), n, f) == n);
@@ -211,7 +257,7 @@ int save_host_index(const HostIndex& idx, const char* path) {
     if (!f) { set_error(std::string("cannot open index file for writing: ") + path); return FLX_ERR_IO; }
     bool ok = fwrite(MAGIC, 8, 1, f) == 1 && fwrite(&idx.n, 8, 1, f) == 1 && fwrite(idx.C, 8, 7, f) == 7 && wr(f, idx.text) &&
               wr(f, idx.seq_start) && wr(f, idx.seq_len) && wr(f, idx.sa) && wr(f, idx.occ[0]) && wr(f, idx.occ[1]) &&
-              wr(f, idx.bwt[0]) && wr(f, idx.bwt[1]);
+              wr(f, idx.bwt[0]) && wr(f, idx.bwt[1]) && wr(f, idx.kmer_table);
     ok = (fclose(f) == 0) && ok;
     if (!ok) { set_error("short write while saving the index"); return FLX_ERR_IO; }
     return FLX_OK;
@@ -224,7 +270,7 @@ HostIndex* load_host_index(const char* path) {
     char magic[8];
     bool ok = fread(magic, 8, 1, f) == 1 && memcmp(magic, MAGIC, 8) == 0 && fread(&idx->n, 8, 1, f) == 1 &&
               fread(idx->C, 8, 7, f) == 7 && rd(f, idx->text) && rd(f, idx->seq_start) && rd(f, idx->seq_len) && rd(f, idx->sa) &&
-              rd(f, idx->occ[0]) && rd(f, idx->occ[1]) && rd(f, idx->bwt[0]) && rd(f, idx->bwt[1]);
+              rd(f, idx->occ[0]) && rd(f, idx->occ[1]) && rd(f, idx->bwt[0]) && rd(f, idx->bwt[1]) && rd(f, idx->kmer_table);
     fclose(f);
     if (!ok || idx->text.size() != idx->n || idx->sa.size() != idx->n) { set_error("index file is corrupt or of another version"); return nullptr; }
     return idx.release();

@@ -37,22 +37,30 @@ struct HostIndex {
     std::vector<OccBlock> occ[2];         // 0: BWT of text (extendLeft), 1: BWT of reversed text (extendRight)
     u64 C[7] = {0, 0, 0, 0, 0, 0, 0};
     std::vector<u8> bwt[2];               // kept for tests (flx_index_copy_bwt); not uploaded
+    // bidirectional cursors {lb, lb_rev, len} of every KMER_Q-mer over A,C,G,T (first symbol most significant): the exact first
+    // part of a search starts from a table entry instead of KMER_Q rank pairs
+    std::vector<u32> kmer_table;
 };
+constexpr u32 KMER_Q = 8;
 
 // Device-side view handed to kernels (plain pointers into HBM)
 struct DevIndex {
     const OccBlock* occ[2];
     const u32* sa;
     const u8* text;        // points at text[0]; TEXT_PAD readable bytes on both sides
+    const u32* kmer;       // KMER_Q-mer cursor table, 3 words per entry
     u32 C[7];
     u32 n;
 };
 
 // ------------------------------------------------------------------------------------------------ K1: FM search
 // Expanded search-scheme entry for one query character in search order (search_schemes::expand):
-//   bits 0..19 query position, 20..22 lower bound, 23..25 upper bound, 26 extension direction (1 = right)
+//   bits 0..19 query position, 20..22 lower bound, 23..25 upper bound, 26 extension direction (1 = right),
+//   27 set while the entry belongs to the leading run of exact (lower = upper = 0), rightward, consecutive characters
 constexpr u32 SCH_POS_MASK = 0xFFFFF;
-inline u32 sch_pack(u32 pos, u32 l, u32 u, bool right) { return pos | (l << 20) | (u << 23) | ((right ? 1u : 0u) << 26); }
+inline u32 sch_pack(u32 pos, u32 l, u32 u, bool right, bool exact_prefix) {
+    return pos | (l << 20) | (u << 23) | ((right ? 1u : 0u) << 26) | ((exact_prefix ? 1u : 0u) << 27);
+}
 
 struct DevSeed {
     u64 seq_off;        // into the device sequence pool
