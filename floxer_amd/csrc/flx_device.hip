@@ -621,90 +621,94 @@ __global__ void __launch_bounds__(64) ed_band_kernel(const u8* __restrict__ text
     int best = m, best_col = 0;
     u32 const last_shift = (u32)(m - 1) & 63u;
     int const w_last_of_last = (nw - 1) - (Lg - 1) * W;   // word of the last group that holds row m-1
-    // Trace layout: steps in blocks of S = TRACE_STEP_BLOCK; slot(t, p, w) = trace_off + (((t/S)*R + p)*S + t%S)*W + w. A lane keeps
-    // the S steps of a block in registers and stores them as one run of S*W*16 bytes, so that a job writes R*S*W*16 contiguous
-    // bytes per block (3 KB at W=3, R=16): few, long bursts per DRAM row instead of one 768-byte piece per step.
-    constexpr u32 S = TRACE ? TRACE_STEP_BLOCK : 1u;
-    ulonglong2* __restrict__ tptr = reinterpret_cast<ulonglong2*>(trace) + job.trace_off + (u64)p * S * W;
-    u32 const tstride = R * S * W;
-    ulonglong2 tbuf[S][W];
-    bool any_active_in_block = false;
+    // TRACE: nothing of the trace itself is stored. Per step and word the two carry bits entering the word from above are
+    // collected (16 steps per u32) and every TRACE_CKPT steps the lane's {vp, vn} are written out; ed_traceback_ckpt_kernel
+    // recomputes the trace words it needs from those (see TraceLayout).
+    TraceLayout const tl = ckpt_trace_layout(job.n, job.m, (u32)W, R);
+    u32* __restrict__ carry_out = reinterpret_cast<u32*>(reinterpret_cast<ulonglong2*>(trace) + job.trace_off);
+    ulonglong2* __restrict__ ckpt_out = reinterpret_cast<ulonglong2*>(trace) + job.trace_off + tl.carry_slots;
+    u32 cbits[W];
+#pragma unroll
+    for (int w = 0; w < W; ++w) cbits[w] = 0;
 
-    for (u32 t0 = 0; t0 < t_max; t0 += S) {
-        if ((t0 & 15u) == 0u) {
+    for (u32 t = 0; t < t_max; ++t) {
+        if ((t & 15u) == 0u) {
             // every 16 steps: retire finished front groups and keep the symbol ring >= 72 columns ahead of the front group
             while (g_front + 1 < Lg) {
                 int const fr1 = min(m, 64 * W * (g_front + 1));
                 int const f_hi = min(n - 1, fr1 - 1 + band_hi);
-                if ((int)t0 - g_front > f_hi) ++g_front; else break;
+                if ((int)t - g_front > f_hi) ++g_front; else break;
             }
-            if ((int)t0 - g_front + 88 > loaded && loaded < n) { refill(); __builtin_amdgcn_s_waitcnt(0); }
+            if ((int)t - g_front + 88 > loaded && loaded < n) { refill(); __builtin_amdgcn_s_waitcnt(0); }
         }
-#pragma unroll
-        for (u32 s = 0; s < S; ++s) {
-            u32 const t = t0 + s;
-            int c = (int)t - g;
-            if (has_group && c > c_hi && g + (int)R < Lg) {
-                // this lane's group is finished: take over group g + R (its window starts strictly later). Steps of the old group
-                // that are still buffered belong to the current block and are stored with it below.
-                g += (int)R;
-                enter_group();
-                started = false;
-                c = (int)t - g;
-            }
-            u32 const cin_raw = (u32)__shfl((int)cout, (int)src_lane);
-            bool const active = has_group && c >= c_lo && c <= c_hi && t < t_max;
-            if (active) {
-                u32 const sym = ring[(u32)c & 255u];
-                u32 const cin = g == 0 ? 0u : cin_raw;
-                u64 c_hp = (cin >> 1) & 1u, c_hn = (cin >> 2) & 1u;
-                if (!started) {
-                    // column just left of the window: all vertical deltas +1 below the predecessor's bottom value
-                    int const top_prev = g == 0 ? 0 : (int)(cin >> 3) - (int)c_hp + (int)c_hn;
-                    bot = top_prev + rows_g;
-                    started = true;
-                }
-                const u64* __restrict__ eqp = &lds_eq[(sym * 64u + lane) * W];
-                u64 hp_keep = 0, hn_keep = 0;             // horizontal deltas of the word that holds row m-1 (last group only)
-#pragma unroll
-                for (int w = 0; w < W; ++w) {
-                    u64 const eq = eqp[w];
-                    u64 const pv = vp[w], mv = vn[w];
-                    u64 const x = eq | mv;
-                    u64 const tt = pv + (x & pv) + c_hn;  // the adder's carry-in is the predecessor word's top horizontal-negative bit
-                    u64 const d0 = (tt ^ pv) | x;
-                    u64 const hn = pv & d0;
-                    u64 const hp = mv | ~(pv | d0);
-                    u64 const xh = (hp << 1) | c_hp;
-                    u64 const nvn = xh & d0;
-                    u64 const nvp = (hn << 1) | ~(xh | d0) | c_hn;
-                    c_hp = hp >> 63;
-                    c_hn = hn >> 63;
-                    vn[w] = nvn;
-                    vp[w] = nvp;
-                    if (TRACE) { tbuf[s][w].x = hp; tbuf[s][w].y = nvp; }
-                    if (w == w_last_of_last) { hp_keep = hp; hn_keep = hn; }
-                }
-                if (g != Lg - 1) bot += (int)c_hp - (int)c_hn;
-                else {
-                    bot += (int)((hp_keep >> last_shift) & 1ull) - (int)((hn_keep >> last_shift) & 1ull);
-                    if (bot <= best) { best = bot; best_col = c + 1; }
-                }
-                cout = ((u32)c_hp << 1) | ((u32)c_hn << 2) | ((u32)bot << 3);
-                any_active_in_block = true;
-            } else {
-                cout = 2u;
-            }
+        int c = (int)t - g;
+        if (has_group && c > c_hi && g + (int)R < Lg) {
+            // this lane's group is finished: take over group g + R (its window starts strictly later)
+            g += (int)R;
+            enter_group();
+            started = false;
+            c = (int)t - g;
         }
-        if (TRACE) {
-            if (any_active_in_block) {
+        if (TRACE && (t % TRACE_CKPT) == 0u && valid && t < my_steps) {
+            // state of the group this lane holds, before step t
+            ulonglong2* __restrict__ dst = ckpt_out + ((u64)(t / TRACE_CKPT) * R + p) * W;
 #pragma unroll
-                for (u32 s = 0; s < S; ++s)
-#pragma unroll
-                    for (int w = 0; w < W; ++w) tptr[s * W + w] = tbuf[s][w];
-                any_active_in_block = false;
+            for (int w = 0; w < W; ++w) { ulonglong2 v; v.x = vp[w]; v.y = vn[w]; dst[w] = v; }
+        }
+        u32 const cin_raw = (u32)__shfl((int)cout, (int)src_lane);
+        bool const active = has_group && c >= c_lo && c <= c_hi;
+        if (active) {
+            u32 const sym = ring[(u32)c & 255u];
+            u32 const cin = g == 0 ? 0u : cin_raw;
+            u64 c_hp = (cin >> 1) & 1u, c_hn = (cin >> 2) & 1u;
+            if (!started) {
+                // column just left of the window: all vertical deltas +1 below the predecessor's bottom value
+                int const top_prev = g == 0 ? 0 : (int)(cin >> 3) - (int)c_hp + (int)c_hn;
+                bot = top_prev + rows_g;
+                started = true;
             }
-            tptr += tstride;
+            const u64* __restrict__ eqp = &lds_eq[(sym * 64u + lane) * W];
+            u64 hp_keep = 0, hn_keep = 0;                 // horizontal deltas of the word that holds row m-1 (last group only)
+            u32 const cshift = 2u * (t % TRACE_CARRY_STEPS);
+#pragma unroll
+            for (int w = 0; w < W; ++w) {
+                if (TRACE) cbits[w] |= ((u32)c_hp | ((u32)c_hn << 1)) << cshift;
+                u64 const eq = eqp[w];
+                u64 const pv = vp[w], mv = vn[w];
+                u64 const x = eq | mv;
+                u64 const tt = pv + (x & pv) + c_hn;      // the adder's carry-in is the predecessor word's top horizontal-negative bit
+                u64 const d0 = (tt ^ pv) | x;
+                u64 const hn = pv & d0;
+                u64 const hp = mv | ~(pv | d0);
+                u64 const xh = (hp << 1) | c_hp;
+                u64 const nvn = xh & d0;
+                u64 const nvp = (hn << 1) | ~(xh | d0) | c_hn;
+                c_hp = hp >> 63;
+                c_hn = hn >> 63;
+                vn[w] = nvn;
+                vp[w] = nvp;
+                if (w == w_last_of_last) { hp_keep = hp; hn_keep = hn; }
+            }
+            if (g != Lg - 1) bot += (int)c_hp - (int)c_hn;
+            else {
+                bot += (int)((hp_keep >> last_shift) & 1ull) - (int)((hn_keep >> last_shift) & 1ull);
+                if (bot <= best) { best = bot; best_col = c + 1; }
+            }
+            cout = ((u32)c_hp << 1) | ((u32)c_hn << 2) | ((u32)bot << 3);
+        } else {
+            cout = 2u;
+        }
+        if (TRACE && ((t % TRACE_CARRY_STEPS) == TRACE_CARRY_STEPS - 1u || t + 1u == t_max)) {
+            if (valid && t < my_steps + TRACE_CARRY_STEPS) {
+                u64 const blk = t / TRACE_CARRY_STEPS;
+                if (blk * TRACE_CARRY_STEPS < my_steps) {
+                    u32* __restrict__ dst = carry_out + (blk * R + p) * W;
+#pragma unroll
+                    for (int w = 0; w < W; ++w) dst[w] = cbits[w];
+                }
+            }
+#pragma unroll
+            for (int w = 0; w < W; ++w) cbits[w] = 0;
         }
     }
     if (valid && has_group && g == Lg - 1) {
@@ -753,14 +757,14 @@ AlignShape choose_align_shape(u32 n, u32 m, u32 k) {
 u32 align_supported_max_query() { return 25u * 64u * 64u; }
 
 u64 align_trace_slots(u32 n, u32 m, AlignShape sh) {
+    if (sh.banded) {
+        TraceLayout const tl = ckpt_trace_layout(n, m, sh.words_per_lane, sh.lanes_per_job);
+        return tl.carry_slots + tl.ckpt_slots;
+    }
+    // full trace, step-major: (n + groups - 1) steps x groups lanes x W words of {hp, vp}
     u32 const nw = (m + 63) / 64;
     u64 const groups = (nw + sh.words_per_lane - 1) / sh.words_per_lane;
-    // step-major: (n + groups - 1) steps, `lanes` lanes, W words; for the unbanded kernel lanes == groups rounded up is not
-    // required, the kernel only uses `groups` lanes per step there
-    u64 const lanes = sh.banded ? sh.lanes_per_job : groups;
-    u64 steps = (u64)n + groups - 1;
-    if (sh.banded) steps = (steps + TRACE_STEP_BLOCK - 1) / TRACE_STEP_BLOCK * TRACE_STEP_BLOCK;
-    return steps * lanes * sh.words_per_lane;
+    return ((u64)n + groups - 1) * groups * sh.words_per_lane;
 }
 
 template <int W>
@@ -840,8 +844,7 @@ __global__ void __launch_bounds__(64) ed_traceback_kernel(const u8* __restrict__
             u32 const ci = i - lane, cj = j - lane;
             u32 const gw = (ci - 1u) >> 6, bit = (ci - 1u) & 63u;
             u32 const g = gw / W, w = gw - g * W;
-            u32 const t = cj - 1u + g, SB = job.step_block;
-            u64 const slot = job.trace_off + (((u64)(t / SB) * L + (g % L)) * SB + (t % SB)) * W + w;
+            u64 const slot = job.trace_off + ((u64)(cj - 1u + g) * L + (g % L)) * W + w;
             ulonglong2 const v = *reinterpret_cast<const ulonglong2*>(trace + 2ull * slot);
             up = (v.y >> bit) & 1ull;
             left = (v.x >> bit) & 1ull;
@@ -886,11 +889,153 @@ __global__ void __launch_bounds__(64) ed_traceback_kernel(const u8* __restrict__
     }
 }
 
-int DeviceApi::traceback(void* stream, const u8* d_text, const u8* d_query, const u64* d_trace, const DevTraceJob* d_jobs, u32 n_jobs,
-                         u32* d_cigar, DevTraceOut* d_out) {
+// ------------------------------------------------------------------------------------------------ K5': traceback over a checkpointed trace
+// One lane walks one job. The trace bits of the word under the walker are recomputed on demand: from the word's nearest
+// checkpoint at or before step t - TRACE_CKPT + 1 up to the walker's step t, with the stored carry-in bits standing in for the
+// rest of the column, and the last TRACE_CKPT steps of {hp, vp} are kept in LDS. All lanes of a wave alternate between the
+// same two phases (recompute, then walk until the window or the word is left), so the wave stays converged.
+__global__ void __launch_bounds__(64) ed_traceback_ckpt_kernel(const u8* __restrict__ text, const u8* __restrict__ query,
+                                                               const u64* __restrict__ peq, const u64* __restrict__ trace,
+                                                               const DevTraceJob* __restrict__ jobs, u32 n_jobs,
+                                                               u32* __restrict__ cigar, DevTraceOut* __restrict__ out) {
+    __shared__ ulonglong2 win[TRACE_CKPT][64];      // {hp, vp} of step t at win[t % TRACE_CKPT][lane]
+    __shared__ u64 eqc[6][64];                      // equality masks of the cached word
+    u32 const lane = threadIdx.x & 63u;
+    u32 const id = blockIdx.x * 64u + lane;
+    bool const live = id < n_jobs;
+    DevTraceJob job;
+    if (live) job = jobs[id];
+    else { job.ref_off = job.q_off = job.trace_off = job.cigar_off = 0; job.n = 0; job.m = 0; job.lanes = 1; job.words_per_lane = 1; job.end_col = 0; job.cigar_cap = 0; job.out_index = 0; job.k = 0; }
+    const u8* __restrict__ r = text + job.ref_off;
+    const u8* __restrict__ q = query + job.q_off;
+    u32* __restrict__ slab = cigar + job.cigar_off;
+    int const W = (int)job.words_per_lane, R = (int)job.lanes;
+    int const n = (int)job.n, m = (int)job.m, k = (int)job.k;
+    int const band_hi = n - m + k;
+    TraceLayout const tl = ckpt_trace_layout(job.n, job.m ? job.m : 1u, (u32)W, (u32)R);
+    const u32* __restrict__ carry = reinterpret_cast<const u32*>(reinterpret_cast<const ulonglong2*>(trace) + job.trace_off);
+    const ulonglong2* __restrict__ ckpt = reinterpret_cast<const ulonglong2*>(trace) + job.trace_off + tl.carry_slots;
+
+    u32 wpos = job.cigar_cap;
+    int i = m, j = (int)job.end_col;
+    u32 cur_op = 0xFFu, cur_len = 0;
+    bool overflow = false;
+    bool done = !live || i == 0;
+    int win_gw = -1, win_lo = 0, win_hi = -1;       // cached word and the steps [win_lo, win_hi] held in `win`
+    int eq_gw = -1;
+    auto emit = [&](u32 op, u32 len) {
+        if (op == cur_op) { cur_len += len; return; }
+        if (cur_len) { if (wpos == 0) overflow = true; else slab[--wpos] = (cur_len << 4) | cur_op; }
+        cur_op = op;
+        cur_len = len;
+    };
+
+    while (true) {
+        if (!done && j == 0) { emit(1u, (u32)i); i = 0; done = true; }       // only insertions remain
+        if (overflow) done = true;
+        if (__all(done)) break;
+        // ---- phase 1: lanes whose walker left the cached window recompute it
+        int gw = 0, g = 0, w = 0, t = 0;
+        bool need = false;
+        if (!done) {
+            gw = (i - 1) >> 6;
+            g = gw / W;
+            w = gw - g * W;
+            t = (j - 1) + g;
+            need = !(gw == win_gw && t >= win_lo && t <= win_hi);
+        }
+        if (need) {
+            int const p = g % R;
+            int const r0 = 64 * W * g, r1 = min(m, r0 + 64 * W);
+            int const c_lo = max(0, r0 - k), c_hi = min(n - 1, r1 - 1 + band_hi);
+            int const t_first = c_lo + g;
+            // equality masks of the word
+            if (gw != eq_gw) {
+                u64 const a = job.q_off >> 6;
+                u32 const sh = (u32)(job.q_off & 63u);
+                int const rows_left = m - gw * 64;
+#pragma unroll
+                for (u32 s = 0; s < 6; ++s) {
+                    u64 const lo = peq[(a + (u64)gw) * 6 + s];
+                    u64 const hi = peq[(a + (u64)gw + 1) * 6 + s];
+                    u64 v = sh ? (lo >> sh) | (hi << (64 - sh)) : lo;
+                    if (rows_left < 64) v &= (1ull << rows_left) - 1ull;
+                    eqc[s][lane] = v;
+                }
+                eq_gw = gw;
+            }
+            // start from the checkpoint at or before t - TRACE_CKPT + 1 (or from the word's initial state if its window starts later)
+            int const want_lo = max(0, t - (int)TRACE_CKPT + 1);
+            int t0 = (want_lo / (int)TRACE_CKPT) * (int)TRACE_CKPT;
+            u64 pv = ~0ull, mv = 0ull;
+            if (t_first <= t0) {
+                ulonglong2 const v = ckpt[((u64)(t0 / (int)TRACE_CKPT) * R + p) * W + w];
+                pv = v.x;
+                mv = v.y;
+            } else t0 = max(t0, min(t_first, want_lo));     // nothing happens to this word before its window starts
+            u32 cw = 0;
+            int cw_block = -1;
+            for (int tt = t0; tt <= t; ++tt) {
+                int const cc = tt - g;
+                if (cc >= c_lo && cc <= c_hi) {
+                    int const blk = tt / (int)TRACE_CARRY_STEPS;
+                    if (blk != cw_block) { cw = carry[((u64)blk * R + p) * W + w]; cw_block = blk; }
+                    u32 const cb = (cw >> (2u * ((u32)tt % TRACE_CARRY_STEPS))) & 3u;
+                    u64 const c_hp = cb & 1u, c_hn = cb >> 1;
+                    u64 const eq = eqc[r[cc] & 7u][lane];
+                    u64 const x = eq | mv;
+                    u64 const sum = pv + (x & pv) + c_hn;
+                    u64 const d0 = (sum ^ pv) | x;
+                    u64 const hn = pv & d0;
+                    u64 const hp = mv | ~(pv | d0);
+                    u64 const xh = (hp << 1) | c_hp;
+                    mv = xh & d0;
+                    pv = (hn << 1) | ~(xh | d0) | c_hn;
+                    ulonglong2 o;
+                    o.x = hp;
+                    o.y = pv;
+                    win[(u32)tt % TRACE_CKPT][lane] = o;
+                }
+            }
+            win_gw = gw;
+            win_lo = want_lo;
+            win_hi = t;
+        }
+        // ---- phase 2: walk while the cached window covers the walker
+        while (!done) {
+            if (j == 0) break;
+            int const cgw = (i - 1) >> 6;
+            int const cg = cgw / W;
+            int const ct = (j - 1) + cg;
+            if (cgw != win_gw || ct < win_lo || ct > win_hi) break;
+            u32 const bit = (u32)(i - 1) & 63u;
+            ulonglong2 const v = win[(u32)ct % TRACE_CKPT][lane];
+            if ((v.y >> bit) & 1ull) { emit(1u, 1u); --i; }                        // up: query symbol unmatched (I)
+            else if ((v.x >> bit) & 1ull) { emit(2u, 1u); --j; }                   // left: reference symbol skipped (D)
+            else { emit(q[i - 1] == r[j - 1] ? 7u : 8u, 1u); --i; --j; }           // diagonal
+            if (i == 0 || overflow) done = true;
+        }
+    }
+    if (live) {
+        if (!overflow && cur_len) { if (wpos == 0) overflow = true; else slab[--wpos] = (cur_len << 4) | cur_op; }
+        DevTraceOut o;
+        o.begin = (u32)j;
+        o.cigar_start = wpos;
+        o.cigar_len = overflow ? 0xFFFFFFFFu : job.cigar_cap - wpos;
+        o.pad = 0;
+        out[job.out_index] = o;
+    }
+}
+
+int DeviceApi::traceback(void* stream, const u8* d_text, const u8* d_query, const u64* d_peq, const u64* d_trace, const DevTraceJob* d_jobs,
+                         u32 n_jobs, bool checkpointed, u32* d_cigar, DevTraceOut* d_out) {
     if (n_jobs == 0) return 0;
-    hipLaunchKernelGGL(ed_traceback_kernel, dim3(n_jobs), dim3(64), 0, (hipStream_t)stream, d_text, d_query, d_trace, d_jobs,
-                       n_jobs, d_cigar, d_out);
+    if (checkpointed)
+        hipLaunchKernelGGL(ed_traceback_ckpt_kernel, dim3((n_jobs + 63) / 64), dim3(64), 0, (hipStream_t)stream, d_text, d_query, d_peq,
+                           d_trace, d_jobs, n_jobs, d_cigar, d_out);
+    else
+        hipLaunchKernelGGL(ed_traceback_kernel, dim3(n_jobs), dim3(64), 0, (hipStream_t)stream, d_text, d_query, d_trace, d_jobs,
+                           n_jobs, d_cigar, d_out);
     return (int)hipGetLastError();
 }
 

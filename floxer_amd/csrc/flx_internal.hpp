@@ -95,13 +95,34 @@ struct DevTraceJob {
     u64 ref_off, q_off, trace_off, cigar_off;      // cigar_off: first word of this job's CIGAR slab
     u32 n, m, lanes, words_per_lane;
     u32 end_col, cigar_cap, out_index;
-    u32 step_block;                                // trace layout: steps are stored in blocks of this many (1 = plain step-major)
+    u32 k;                                         // allowed errors (band of the checkpointed trace)
 };
 struct DevTraceOut { u32 begin; u32 cigar_start; u32 cigar_len; u32 pad; };   // cigar_start relative to the slab
 
 // launch geometry for one alignment job shape
 struct AlignShape { u32 words_per_lane; u32 lanes_per_job; u32 banded; };
-constexpr u32 TRACE_STEP_BLOCK = 4;   // banded TRACE launches: a lane keeps this many steps in registers and stores them as one run
+
+// Banded TRACE launches do not store the trace itself. Per (step, ring lane, word) they keep the two horizontal-delta bits that
+// enter the word from above (16 steps per u32), and every TRACE_CKPT steps the word's vertical delta vectors {vp, vn}. Any word's
+// trace bits over any step range can be recomputed from that by the traceback kernel (2.25 B instead of 48 B per step and lane).
+constexpr u32 TRACE_CARRY_STEPS = 16;   // steps per u32 of carry bits
+constexpr u32 TRACE_CKPT = 32;          // steps between two checkpoints
+struct TraceLayout { u64 steps, carry_words, carry_slots, ckpt_slots; };   // slots = 16-byte units; carry region first
+#if defined(__HIPCC__)
+#define FLX_HD __host__ __device__
+#else
+#define FLX_HD
+#endif
+FLX_HD inline TraceLayout ckpt_trace_layout(u32 n, u32 m, u32 W, u32 R) {
+    u64 const nw = (m + 63u) / 64u, groups = (nw + W - 1) / W;
+    TraceLayout l;
+    l.steps = (u64)n + groups - 1;
+    u64 const carry_blocks = (l.steps + TRACE_CARRY_STEPS - 1) / TRACE_CARRY_STEPS;
+    l.carry_words = carry_blocks * R * W;
+    l.carry_slots = (l.carry_words + 3) / 4;
+    l.ckpt_slots = ((l.steps + TRACE_CKPT - 1) / TRACE_CKPT) * R * W;
+    return l;
+}
 AlignShape choose_align_shape(u32 n, u32 m, u32 k);
 u64 align_trace_slots(u32 n, u32 m, AlignShape sh);     // 16-byte trace slots a TRACE launch of this shape needs for one job
 u32 align_supported_max_query();
@@ -117,8 +138,8 @@ struct DeviceApi {
     static int locate(void* stream, const DevIndex& idx, const u32* d_rows, u32 n, u32* d_out);
     static int align(void* stream, const u8* d_text, const u64* d_peq, const DevAlignJob* d_jobs, u32 n_jobs, AlignShape shape,
                      bool trace, u64* d_trace, DevAlignOut* d_out);
-    static int traceback(void* stream, const u8* d_text, const u8* d_query, const u64* d_trace, const DevTraceJob* d_jobs,
-                         u32 n_jobs, u32* d_cigar, DevTraceOut* d_out);
+    static int traceback(void* stream, const u8* d_text, const u8* d_query, const u64* d_peq, const u64* d_trace,
+                         const DevTraceJob* d_jobs, u32 n_jobs, bool checkpointed, u32* d_cigar, DevTraceOut* d_out);
 };
 
 // ------------------------------------------------------------------------------------------------ host logic

@@ -557,7 +557,12 @@ int run_trace_jobs_unique(Lane* ctx, const u8* d_text, const u8* d_query, const 
                 off += slots[id];
                 u64 const ws = job_word_steps(r.n, r.m, r.k, shapes[id]);
                 l.word_steps += ws;
-                l.bytes += (u64)r.n + r.m + ws * 16;        // reference + query symbols read, 2 trace words written per word-step
+                // reference + query symbols read; trace written: full form 16 B per word-step, checkpointed form its carry and
+                // checkpoint regions
+                if (shapes[id].banded) {
+                    TraceLayout const tl = ckpt_trace_layout(r.n, r.m, shapes[id].words_per_lane, shapes[id].lanes_per_job);
+                    l.bytes += (u64)r.n + r.m + (tl.carry_slots + tl.ckpt_slots) * 16;
+                } else l.bytes += (u64)r.n + r.m + ws * 16;
             }
             launches.push_back(l);
         }
@@ -587,7 +592,7 @@ int run_trace_jobs_unique(Lane* ctx, const u8* d_text, const u8* d_query, const 
             u32 const L = sh.banded ? sh.lanes_per_job : (nw + sh.words_per_lane - 1) / sh.words_per_lane;
             u32 const cap = 2 * outs[c].score + 2;      // runs <= 2*NM + 1
             tjobs.push_back(DevTraceJob{r.ref_off, r.q_off, trace_off[c], cigar_words, r.n, r.m, L, sh.words_per_lane, outs[c].end_col,
-                                        cap, (u32)tjob_req.size(), sh.banded ? TRACE_STEP_BLOCK : 1u});
+                                        cap, (u32)tjob_req.size(), r.k});
             tjob_req.push_back((u32)id);
             cigar_words += cap;
             path_steps += (u64)r.m + outs[c].score;
@@ -597,8 +602,8 @@ int run_trace_jobs_unique(Lane* ctx, const u8* d_text, const u8* d_query, const 
             if ((rc = ctx->tjob_out.ensure(tjobs.size() * sizeof(DevTraceOut)))) return rc;
             if ((rc = ctx->cigar.ensure(cigar_words * 4 + 16))) return rc;
             rc = timed_launch(ctx, "ed_traceback", path_steps * 18, path_steps, [&] {
-                return DeviceApi::traceback(ctx->stream, d_text, d_query, ctx->trace.as<u64>(), ctx->tjobs.as<DevTraceJob>(),
-                                            (u32)tjobs.size(), ctx->cigar.as<u32>(), ctx->tjob_out.as<DevTraceOut>());
+                return DeviceApi::traceback(ctx->stream, d_text, d_query, d_peq, ctx->trace.as<u64>(), ctx->tjobs.as<DevTraceJob>(),
+                                            (u32)tjobs.size(), shapes[begin].banded != 0, ctx->cigar.as<u32>(), ctx->tjob_out.as<DevTraceOut>());
             });
             if (rc) return rc;
             std::vector<DevTraceOut> touts(tjobs.size());
