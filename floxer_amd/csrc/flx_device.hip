@@ -900,6 +900,9 @@ __global__ void __launch_bounds__(64) ed_traceback_ckpt_kernel(const u8* __restr
                                                                u32* __restrict__ cigar, DevTraceOut* __restrict__ out) {
     __shared__ ulonglong2 win[TRACE_CKPT][64];      // {hp, vp} of step t at win[t % TRACE_CKPT][lane]
     __shared__ u64 eqc[6][64];                      // equality masks of the cached word
+    __shared__ u64 qc[8][64];                       // the 64 query symbols of the cached word
+    __shared__ u64 refc[10][64];                    // reference symbols of the columns the cached window was computed over
+    int ref_base = 0;                               // column of refc[0] byte 0 (multiple of 8, may be negative)
     u32 const lane = threadIdx.x & 63u;
     u32 const id = blockIdx.x * 64u + lane;
     bool const live = id < n_jobs;
@@ -962,6 +965,20 @@ __global__ void __launch_bounds__(64) ed_traceback_ckpt_kernel(const u8* __restr
                     if (rows_left < 64) v &= (1ull << rows_left) - 1ull;
                     eqc[s][lane] = v;
                 }
+                {
+                    // query symbols of rows 64*gw .. +63 (unaligned 8-byte reads assembled from aligned ones; the pool is padded)
+                    const u8* const addr = q + 64 * gw;
+                    uintptr_t const ai = (uintptr_t)addr;
+                    const u64* const base = reinterpret_cast<const u64*>(ai & ~(uintptr_t)7);
+                    u32 const shb = (u32)(ai & 7u) * 8u;
+                    u64 prev = base[0];
+#pragma unroll
+                    for (int x = 0; x < 8; ++x) {
+                        u64 const nxt = base[x + 1];
+                        qc[x][lane] = shb ? (prev >> shb) | (nxt << (64u - shb)) : prev;
+                        prev = nxt;
+                    }
+                }
                 eq_gw = gw;
             }
             // start from the checkpoint at or before t - TRACE_CKPT + 1 (or from the word's initial state if its window starts later)
@@ -973,6 +990,20 @@ __global__ void __launch_bounds__(64) ed_traceback_ckpt_kernel(const u8* __restr
                 pv = v.x;
                 mv = v.y;
             } else t0 = max(t0, min(t_first, want_lo));     // nothing happens to this word before its window starts
+            {
+                // reference symbols of columns t0-g .. t-g (at most 2*TRACE_CKPT-1 of them) into LDS in 8-byte pieces
+                int const first_col = max(t0 - g, 0);            // columns left of the window start are never active
+                ref_base = first_col & ~7;
+                const u64* const base = reinterpret_cast<const u64*>(((uintptr_t)(r + ref_base)) & ~(uintptr_t)7);
+                u32 const shb = (u32)(((uintptr_t)(r + ref_base)) & 7u) * 8u;
+                int const pieces = ((t - g) - ref_base) / 8 + 1;
+                u64 prev = base[0];
+                for (int x = 0; x < pieces && x < 10; ++x) {
+                    u64 const nxt = base[x + 1];
+                    refc[x][lane] = shb ? (prev >> shb) | (nxt << (64u - shb)) : prev;
+                    prev = nxt;
+                }
+            }
             u32 cw = 0;
             int cw_block = -1;
             for (int tt = t0; tt <= t; ++tt) {
@@ -982,7 +1013,9 @@ __global__ void __launch_bounds__(64) ed_traceback_ckpt_kernel(const u8* __restr
                     if (blk != cw_block) { cw = carry[((u64)blk * R + p) * W + w]; cw_block = blk; }
                     u32 const cb = (cw >> (2u * ((u32)tt % TRACE_CARRY_STEPS))) & 3u;
                     u64 const c_hp = cb & 1u, c_hn = cb >> 1;
-                    u64 const eq = eqc[r[cc] & 7u][lane];
+                    u32 const ro = (u32)(cc - ref_base);
+                    u32 const rsym = (u32)(refc[ro >> 3][lane] >> (8u * (ro & 7u))) & 7u;
+                    u64 const eq = eqc[rsym][lane];
                     u64 const x = eq | mv;
                     u64 const sum = pv + (x & pv) + c_hn;
                     u64 const d0 = (sum ^ pv) | x;
@@ -1012,7 +1045,14 @@ __global__ void __launch_bounds__(64) ed_traceback_ckpt_kernel(const u8* __restr
             ulonglong2 const v = win[(u32)ct % TRACE_CKPT][lane];
             if ((v.y >> bit) & 1ull) { emit(1u, 1u); --i; }                        // up: query symbol unmatched (I)
             else if ((v.x >> bit) & 1ull) { emit(2u, 1u); --j; }                   // left: reference symbol skipped (D)
-            else { emit(q[i - 1] == r[j - 1] ? 7u : 8u, 1u); --i; --j; }           // diagonal
+            else {                                                                    // diagonal: '=' or 'X' from the cached symbols
+                u32 const ro = (u32)((j - 1) - ref_base), qo = (u32)(i - 1) & 63u;
+                u32 const rsym = (u32)(refc[ro >> 3][lane] >> (8u * (ro & 7u))) & 0xFFu;
+                u32 const qsym = (u32)(qc[qo >> 3][lane] >> (8u * (qo & 7u))) & 0xFFu;
+                emit(qsym == rsym ? 7u : 8u, 1u);
+                --i;
+                --j;
+            }
             if (i == 0 || overflow) done = true;
         }
     }

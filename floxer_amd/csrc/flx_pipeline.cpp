@@ -721,7 +721,7 @@ extern "C" int flx_align_batch(flx_ctx* ctx, const uint8_t* ref_pool, uint64_t r
         if ((rc = ensure_reversed_text(L))) return rc;
         d_text_rev = ctx->text_rev.as<u8>() + TEXT_PAD;
     }
-    if ((rc = h2d(L, L->seq, query_pool, query_pool_len, 64))) return rc;
+    if ((rc = h2d(L, L->seq, query_pool, query_pool_len, 192))) return rc;
     if ((rc = build_peq(L, L->seq.as<u8>(), query_pool_len, L->peq))) return rc;
     std::vector<u8> qrev;
     if (any_rev) {
@@ -879,11 +879,11 @@ extern "C" int flx_reads_upload(flx_ctx* ctx, const uint8_t* read_pool, const ui
         reverse_complement(src, len, rd->pool.data() + off + len);
         off += 2 * len;
     }
-    int rc = rd->d_pool.ensure(total + 128);
+    int rc = rd->d_pool.ensure(total + 256);
     if (rc) return rc;
     hipStream_t const s0 = ctx->lane0()->stream;
     if (total) FLX_HIP(hipMemcpyAsync(rd->d_pool.ptr, rd->pool.data(), total, hipMemcpyHostToDevice, s0));
-    FLX_HIP(hipMemsetAsync((char*)rd->d_pool.ptr + total, 0, 64, s0));
+    FLX_HIP(hipMemsetAsync((char*)rd->d_pool.ptr + total, 0, 192, s0));
     FLX_HIP(hipStreamSynchronize(s0));
     *out = rd.release();
     return FLX_OK;
