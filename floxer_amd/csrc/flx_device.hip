@@ -146,12 +146,17 @@ __device__ __forceinline__ u32 st_pack(u32 x, u32 e, u32 li, u32 ri, u32 sym, u3
 // consecutive seeds and a quad that finishes its seed takes the chunk's next one (an LDS counter). One loop iteration = one DFS
 // step of every busy quad (at most one rank pair), which keeps the divergent part of the loop short.
 constexpr u32 FM_CHUNK = 64;
+constexpr u32 FM_STAGE = 64;
 
 __global__ void __launch_bounds__(64) fm_search_kernel(DevIndex idx, const u8* __restrict__ seq, const u32* __restrict__ scheme,
                                                        const DevSeed* __restrict__ seeds, u32 n_seeds, u32 max_hits,
                                                        DevFrame* __restrict__ stack, DevHit* __restrict__ hits, u32 hit_cap,
                                                        u32* __restrict__ counters) {
     __shared__ u32 next_in_chunk;
+    // per quad: the current search's expanded scheme entries with the query symbol folded into bits 28..30, for seeds of at most
+    // FM_STAGE characters (longer seeds read scheme and query from global memory): one LDS read per DFS step instead of two
+    // dependent global loads
+    __shared__ u32 lds_ann[16][FM_STAGE];
     u32 const chunk_base = blockIdx.x * FM_CHUNK;
     u32 const chunk_n = min(FM_CHUNK, n_seeds - chunk_base);
     if (threadIdx.x == 0) next_in_chunk = 0;
@@ -169,8 +174,9 @@ __global__ void __launch_bounds__(64) fm_search_kernel(DevIndex idx, const u8* _
     uint4* __restrict__ stk = reinterpret_cast<uint4*>(stack);
     const u32* __restrict__ ex_base = scheme;
     // ---- per-search state
-    bool in_search = false;
+    bool in_search = false, staged = false;
     const u32* __restrict__ ex = scheme;
+    u32* const my_ann = lds_ann[lane >> 2];
     u32 l_last = 0, u_last = 0;
     u32 nlb = 0, nlbr = 0, nlen = 0, nx = 0, ne = 0, nli = INFO_M, nri = INFO_M;
     // top frame: replicated node part + this lane's two child cursors
@@ -216,6 +222,14 @@ __global__ void __launch_bounds__(64) fm_search_kernel(DevIndex idx, const u8* _
             have_frame = false;
             need_child = false;
             in_search = true;
+            staged = len <= FM_STAGE;
+            if (staged) {
+                for (u32 x = ql; x < len; x += 4u) {
+                    u32 const e = ex[x];
+                    my_ann[x] = (e & 0x0FFFFFFFu) | ((u32)q[e & SCH_POS_MASK] << 28);
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
             // the exact, rightward first part of the search starts from the KMER_Q-mer table when it is long enough and free of N
             if (len >= KMER_Q && ((ex[KMER_Q - 1] >> 27) & 1u)) {
                 u32 const p0 = ex[0] & SCH_POS_MASK;
@@ -297,14 +311,16 @@ __global__ void __launch_bounds__(64) fm_search_kernel(DevIndex idx, const u8* _
             need_child = true;
             continue;
         }
-        u32 const entry = ex[nx];
+        u32 entry;
+        if (staged) entry = my_ann[nx];
+        else { u32 const e = ex[nx]; entry = (e & 0x0FFFFFFFu) | ((u32)q[e & SCH_POS_MASK] << 28); }
         u32 const lower = (entry >> 20) & 7u, upper = (entry >> 23) & 7u, right = (entry >> 26) & 1u;
         if (ne > upper) { need_child = true; continue; }
         bool const mismatch_allowed = lower <= ne + 1 && ne + 1 <= upper;
         bool const match_allowed = lower <= ne && ne <= upper;
         if (!mismatch_allowed && !match_allowed) { need_child = true; continue; }
 
-        u32 const next_sym = q[entry & SCH_POS_MASK];
+        u32 const next_sym = (entry >> 28) & 7u;
         const OccBlock* __restrict__ tab = idx.occ[right];
         u32 const lo = right ? nlbr : nlb;
         u32 a_sa, a_sb, b_sa, b_sb;
