@@ -54,77 +54,63 @@ int DeviceApi::build_peq(void* stream, const u8* d_seq, u64 len, u64* d_peq) {
 }
 
 // ================================================================================================ K1: FM search
-// Four lanes (one DPP quad) serve one seed. A rank query reads one 128-byte block as 4 x 32 bytes (lane q reads quarter q: two
-// 32-position chunks of the three bit-planes plus two of the six block counters), every lane pop-counts its 64 positions for all
-// six symbols, and two quad_perm DPP adds give every lane the six totals; lane q then owns the ranks of symbols 2q and 2q+1.
-// The DFS frame is spread the same way (16 bytes per lane, 64 contiguous bytes per push/pop). Control state is replicated in
-// the quad, so a quad's four lanes never diverge; different quads of a wave do.
+// Two lanes (a DPP pair) serve one seed. A rank query reads one 128-byte block as 2 x 64 bytes (lane h reads quarters 2h, 2h+1:
+// four 32-position chunks of the three bit-planes plus four of the eight counter slots), every lane pop-counts its 128 positions
+// for all six symbols, one quad_perm DPP add gives both lanes the six totals; lane 0 then owns the ranks of symbols 0..3, lane 1
+// those of symbols 4, 5. The DFS frame is spread the same way (32 bytes per lane, 64 contiguous bytes per push/pop). Control
+// state is replicated in the pair, so a pair never diverges; different pairs of a wave do. (One lane per seed made every load
+// touch 64 different lines and was bound by the L1; four lanes per seed replicated the control flow four times and was bound by
+// instruction issue: two lanes balance the two.)
 
-__device__ __forceinline__ u32 quad_bcast0(u32 v) { return (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x00 /* quad_perm:[0,0,0,0] */, 0xf, 0xf, false); }
-__device__ __forceinline__ u32 quad_bcast3(u32 v) { return (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0xFF /* quad_perm:[3,3,3,3] */, 0xf, 0xf, false); }
-__device__ __forceinline__ u32 quad_sum(u32 v) {
-    v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1 /* quad_perm:[1,0,3,2] */, 0xf, 0xf, false);
-    v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E /* quad_perm:[2,3,0,1] */, 0xf, 0xf, false);
-    return v;
-}
+__device__ __forceinline__ u32 pair_even(u32 v) { return (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0xA0 /* quad_perm:[0,0,2,2] */, 0xf, 0xf, false); }
+__device__ __forceinline__ u32 pair_odd(u32 v) { return (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0xF5 /* quad_perm:[1,1,3,3] */, 0xf, 0xf, false); }
+__device__ __forceinline__ u32 pair_sum(u32 v) { return v + (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1 /* quad_perm:[1,0,3,2] */, 0xf, 0xf, false); }
+__device__ __forceinline__ u32 pair_from(u32 v, u32 owner) { u32 const e = pair_even(v), o = pair_odd(v); return owner ? o : e; }
 
-// symbol counts of the positions selected by `mask` in one 32-position chunk, added to two packed accumulators
-// (10 bits per symbol: acc0 = c0 | c1<<10 | c2<<20, acc1 = c3 | c4<<10 | c5<<20; a quad total is at most 256)
-__device__ __forceinline__ void count_chunk(u32 p0, u32 p1, u32 p2, u32 mask, u32& acc0, u32& acc1) {
+// symbol counts of the positions selected by `mask` in one 32-position chunk, added to six accumulators (v_bcnt accumulates)
+__device__ __forceinline__ void count_chunk(u32 p0, u32 p1, u32 p2, u32 mask, u32 acc[6]) {
     u32 const n2 = ~p2 & mask, q2 = p2 & mask;
-    u32 const a00 = ~p1 & ~p0, a01 = ~p1 & p0, a10 = p1 & ~p0, a11 = p1 & p0;
-    acc0 += (u32)__popc(n2 & a00) | ((u32)__popc(n2 & a01) << 10) | ((u32)__popc(n2 & a10) << 20);
-    acc1 += (u32)__popc(n2 & a11) | ((u32)__popc(q2 & a00) << 10) | ((u32)__popc(q2 & a01) << 20);
+    u32 const a00 = ~(p1 | p0), a01 = ~p1 & p0, a10 = p1 & ~p0, a11 = p1 & p0;
+    acc[0] += (u32)__popc(n2 & a00);
+    acc[1] += (u32)__popc(n2 & a01);
+    acc[2] += (u32)__popc(n2 & a10);
+    acc[3] += (u32)__popc(n2 & a11);
+    acc[4] += (u32)__popc(q2 & a00);
+    acc[5] += (u32)__popc(q2 & a01);
 }
 __device__ __forceinline__ u32 below_mask32(u32 off, u32 chunk) {       // positions of chunk (32*chunk ..) below `off`
-    u32 const lo = chunk * 32u;
-    if (off >= lo + 32u) return ~0u;
-    if (off > lo) return (1u << (off - lo)) - 1u;
-    return 0u;
-}
-__device__ __forceinline__ u32 unpack10(u32 acc0, u32 acc1, u32 sym) {
-    u32 const a = sym < 3 ? acc0 : acc1;
-    u32 const sh = ((sym < 3 ? sym : sym - 3u) * 10u) & 31u;      // lanes of quarter 3 own no symbol: their result is unused
-    return (a >> sh) & 1023u;
+    int const w = min(max((int)off - (int)(chunk * 32u), 0), 32);       // v_med3_i32
+    return (u32)(0xFFFFFFFFull >> (32 - w));                            // w = 0 -> 0, w = 32 -> all ones
 }
 
-// ranks at the two ends [lo, hi) of an SA interval for the two symbols this lane owns (sa = 2*ql, sb = 2*ql+1)
-__device__ __forceinline__ void quad_rank_pair(const OccBlock* __restrict__ tab, u32 lo, u32 hi, u32 ql, u32& a_sa, u32& a_sb,
-                                               u32& b_sa, u32& b_sb) {
-    u32 const sa = 2u * ql, sb = sa + 1u;
-    const uint4* __restrict__ qa = reinterpret_cast<const uint4*>(tab + (lo >> 8)) + 2u * ql;
-    uint4 const x0 = qa[0], x1 = qa[1];
-    u32 const off_a = lo & 255u;
-    u32 const ma0 = below_mask32(off_a, sa), ma1 = below_mask32(off_a, sb);
-    u32 acc0 = 0, acc1 = 0;
-    count_chunk(x0.x, x0.y, x0.z, ma0, acc0, acc1);
-    count_chunk(x1.x, x1.y, x1.z, ma1, acc0, acc1);
-    if ((lo >> 8) == (hi >> 8)) {
-        // same block: the interval's symbol counts are the positions between the two offsets
-        u32 const off_b = hi & 255u;
-        u32 d0 = 0, d1 = 0;
-        count_chunk(x0.x, x0.y, x0.z, below_mask32(off_b, sa) & ~ma0, d0, d1);
-        count_chunk(x1.x, x1.y, x1.z, below_mask32(off_b, sb) & ~ma1, d0, d1);
-        acc0 = quad_sum(acc0); acc1 = quad_sum(acc1);
-        d0 = quad_sum(d0); d1 = quad_sum(d1);
-        a_sa = x0.w + unpack10(acc0, acc1, sa);
-        a_sb = x1.w + unpack10(acc0, acc1, sb);
-        b_sa = a_sa + unpack10(d0, d1, sa);
-        b_sb = a_sb + unpack10(d0, d1, sb);
-        return;
-    }
-    const uint4* __restrict__ qb = reinterpret_cast<const uint4*>(tab + (hi >> 8)) + 2u * ql;
-    uint4 const y0 = qb[0], y1 = qb[1];
-    u32 const off_b = hi & 255u;
-    u32 bcc0 = 0, bcc1 = 0;
-    count_chunk(y0.x, y0.y, y0.z, below_mask32(off_b, sa), bcc0, bcc1);
-    count_chunk(y1.x, y1.y, y1.z, below_mask32(off_b, sb), bcc0, bcc1);
-    acc0 = quad_sum(acc0); acc1 = quad_sum(acc1);
-    bcc0 = quad_sum(bcc0); bcc1 = quad_sum(bcc1);
-    a_sa = x0.w + unpack10(acc0, acc1, sa);
-    a_sb = x1.w + unpack10(acc0, acc1, sb);
-    b_sa = y0.w + unpack10(bcc0, bcc1, sa);
-    b_sb = y1.w + unpack10(bcc0, bcc1, sb);
+// symbol counts of bwt[256*block, pos) restricted to this lane's half of the block, pair-summed, plus this lane's four absolute
+// counter slots: r[j] = rank of symbol 4h+j at `pos` (slots of lane 1 beyond symbol 5 are dummies)
+__device__ __forceinline__ void pair_rank(const OccBlock* __restrict__ tab, u32 pos, u32 h, u32 r[4]) {
+    const uint4* __restrict__ qa = reinterpret_cast<const uint4*>(tab + (pos >> 8)) + 4u * h;
+    uint4 const x0 = qa[0], x1 = qa[1], x2 = qa[2], x3 = qa[3];
+    u32 const off = pos & 255u, c0 = 4u * h;
+    u32 acc[6] = {0, 0, 0, 0, 0, 0};
+    count_chunk(x0.x, x0.y, x0.z, below_mask32(off, c0), acc);
+    count_chunk(x1.x, x1.y, x1.z, below_mask32(off, c0 + 1), acc);
+    count_chunk(x2.x, x2.y, x2.z, below_mask32(off, c0 + 2), acc);
+    count_chunk(x3.x, x3.y, x3.z, below_mask32(off, c0 + 3), acc);
+#pragma unroll
+    for (u32 c = 0; c < 6; ++c) acc[c] = pair_sum(acc[c]);
+    r[0] = x0.w + (h ? acc[4] : acc[0]);
+    r[1] = x1.w + (h ? acc[5] : acc[1]);
+    r[2] = x2.w + acc[2];
+    r[3] = x3.w + acc[3];
+}
+
+// ranks at the two ends [lo, hi) of an SA interval for the four counter slots this lane owns (slot j = symbol 4*h + j).
+// a[j] = rank at lo, d[j] = number of that symbol inside [lo, hi). Both ends take the same path also when they fall into one
+// block (the second read then hits the L1): in a divergent wave the union of the paths is what costs.
+__device__ __forceinline__ void pair_rank_pair(const OccBlock* __restrict__ tab, u32 lo, u32 hi, u32 h, u32 a[4], u32 d[4]) {
+    u32 b[4];
+    pair_rank(tab, lo, h, a);
+    pair_rank(tab, hi, h, b);
+#pragma unroll
+    for (u32 j = 0; j < 4; ++j) d[j] = b[j] - a[j];
 }
 
 // frame state word: x:20 | e:3 | linfo:2 | rinfo:2 | next_sym:3 | right:1
@@ -139,71 +125,130 @@ __device__ __forceinline__ u32 st_pack(u32 x, u32 e, u32 li, u32 ri, u32 sym, u3
 #define ST_SYM(s) (((s) >> 27) & 7u)
 #define ST_RIGHT(s) (((s) >> 30) & 1u)
 
-// counters: [0] hits written/reserved, [1] stack overflow flag, [2] cursor extensions (rank pairs), [3] hit overflow,
-//           [4] wave-iterations, [5] max iterations of a wave, [6] busy quad-iterations
+// counters: [0] hit slots reserved, [1] stack overflow flag, [2] cursor extensions (rank pairs), [3] unused,
+//           [4] wave-iterations, [5] max iterations of a wave, [6] busy pair-iterations
 //
-// DFS sizes differ by orders of magnitude between seeds, so quads are not bound to seeds: every wave owns a chunk of FM_CHUNK
-// consecutive seeds and a quad that finishes its seed takes the chunk's next one (an LDS counter). One loop iteration = one DFS
-// step of every busy quad (at most one rank pair), which keeps the divergent part of the loop short.
-constexpr u32 FM_CHUNK = 64;
-constexpr u32 FM_STAGE = 64;
+// DFS sizes differ by orders of magnitude between seeds, so neither pairs nor waves are bound to seeds: the launch is a fixed
+// number of waves, a wave takes FM_GRAB consecutive seeds at a time from a global counter (counters[7]) and hands them to its pairs
+// as they finish (wave-uniform bookkeeping in scalar registers). One loop iteration = one DFS step of every busy pair (at most one
+// rank pair), which keeps the divergent part of the loop short. (Per-wave chunks of seeds left half of the pairs idle behind
+// the heaviest seed of their chunk.)
+constexpr u32 FM_GRAB = 32;
+constexpr u32 FM_HIT_GRAB = 64;
+constexpr u32 FM_MAX_WAVES = 4096;
 
 __global__ void __launch_bounds__(64) fm_search_kernel(DevIndex idx, const u8* __restrict__ seq, const u32* __restrict__ scheme,
                                                        const DevSeed* __restrict__ seeds, u32 n_seeds, u32 max_hits,
                                                        DevFrame* __restrict__ stack, DevHit* __restrict__ hits, u32 hit_cap,
                                                        u32* __restrict__ counters) {
-    __shared__ u32 next_in_chunk;
-    // per quad: the current search's expanded scheme entries with the query symbol folded into bits 28..30, for seeds of at most
-    // FM_STAGE characters (longer seeds read scheme and query from global memory): one LDS read per DFS step instead of two
-    // dependent global loads
-    __shared__ u32 lds_ann[16][FM_STAGE];
-    u32 const chunk_base = blockIdx.x * FM_CHUNK;
-    u32 const chunk_n = min(FM_CHUNK, n_seeds - chunk_base);
-    if (threadIdx.x == 0) next_in_chunk = 0;
-    __syncthreads();
+    u32 q_next = 0, q_end = 0;                  // wave-uniform: the unserved rest of the last grabbed seed range
+    bool queue_done = false;
+    u32 h_next = 0, h_end = 0;                  // wave-uniform: the unwritten rest of the last reserved range of hit slots
     u32 const lane = threadIdx.x & 63u;
-    u32 const ql = lane & 3u;                   // lane within the quad
-    u32 const quad_base = lane & ~3u;
-    u32 const sa = 2u * ql, sb = sa + 1u;       // symbols owned by this lane (only ql < 3 owns real symbols)
+    u32 const h = lane & 1u;                    // lane within the pair
+    u32 const sym0 = 4u * h;                    // first counter slot / symbol owned by this lane
 
     u32 n_ext = 0, n_iter = 0, n_busy_iter = 0;
-    // ---- per-seed state (replicated in the quad)
+    // ---- per-seed state (replicated in the pair)
     bool busy = false, exhausted = false;
     u32 sid = 0, srch = 0, num_searches = 0, len = 0, ct = 0, stack_frames = 0;
     const u8* __restrict__ q = seq;
     uint4* __restrict__ stk = reinterpret_cast<uint4*>(stack);
     const u32* __restrict__ ex_base = scheme;
     // ---- per-search state
-    bool in_search = false, staged = false;
+    bool in_search = false;
     const u32* __restrict__ ex = scheme;
-    u32* const my_ann = lds_ann[lane >> 2];
     u32 l_last = 0, u_last = 0;
     u32 nlb = 0, nlbr = 0, nlen = 0, nx = 0, ne = 0, nli = INFO_M, nri = INFO_M;
-    // top frame: replicated node part + this lane's two child cursors
+    // top frame: replicated node part + this lane's four child-cursor slots (extended side, other side, length)
     u32 f_lb = 0, f_lbr = 0, f_len = 0, f_state = 0, f_mask = 0;
-    u32 f_abs_a = 0, f_len_a = 0, f_abs_b = 0, f_len_b = 0;
+    u32 f_abs[4] = {0, 0, 0, 0}, f_oth[4] = {0, 0, 0, 0}, f_cl[4] = {0, 0, 0, 0};
     u32 depth = 0;
     bool have_frame = false, need_child = false;
+    bool hit_pending = false;                   // a hit of this pair (sid, nlb, hit_rep, ne) waits for its slot
+    u32 hit_rep = 0;
+
+    // child cursor of symbol `sym` out of per-lane slot arrays, from the lane that owns the symbol
+    auto child_of = [&](const u32 abs_s[4], const u32 oth_s[4], const u32 len_s[4], u32 sym, u32& cabs, u32& coth, u32& clen) {
+        u32 const j = sym & 3u;
+        u32 const my_abs = j == 0 ? abs_s[0] : j == 1 ? abs_s[1] : j == 2 ? abs_s[2] : abs_s[3];
+        u32 const my_oth = j == 0 ? oth_s[0] : j == 1 ? oth_s[1] : j == 2 ? oth_s[2] : oth_s[3];
+        u32 const my_len = j == 0 ? len_s[0] : j == 1 ? len_s[1] : j == 2 ? len_s[2] : len_s[3];
+        u32 const owner = sym >> 2;
+        cabs = pair_from(my_abs, owner);
+        coth = pair_from(my_oth, owner);
+        clen = pair_from(my_len, owner);
+    };
+
+    // hit slots are reserved FM_HIT_GRAB at a time per wave (one global atomic per range instead of one per hit, all on one
+    // address); the unused rest of a range is filled with entries of seed FLX_NO_SEED, which the host skips
+    auto fill_rest = [&]() {
+        u32 const at = h_next + lane;
+        if (at < h_end && at < hit_cap) hits[at] = DevHit{0xFFFFFFFFu, 0u, 0u, 0u};
+    };
 
     while (true) {
-        if (!busy && !exhausted) {
-            u32 k = 0;
-            if (ql == 0) k = atomicAdd(&next_in_chunk, 1u);
-            k = quad_bcast0(k);
-            if (k < chunk_n) {
-                sid = chunk_base + k;
-                DevSeed const seed = seeds[sid];
-                q = seq + seed.seq_off;
-                stk = reinterpret_cast<uint4*>(stack + seed.stack_off);
-                len = seed.length;
-                num_searches = seed.num_searches;
-                stack_frames = seed.stack_frames;
-                ex_base = scheme + seed.scheme_off;
-                srch = 0;
-                ct = 0;
-                busy = true;
-                in_search = false;
-            } else exhausted = true;
+        u64 const emit = __ballot(hit_pending && h == 0u);
+        if (emit) {                                                     // wave-uniform
+            u32 const n_emit = (u32)__popcll(emit);
+            if (h_end - h_next < n_emit) {
+                fill_rest();
+                u32 b = 0;
+                if (lane == 0) b = atomicAdd(&counters[0], FM_HIT_GRAB);
+                h_next = (u32)__builtin_amdgcn_readfirstlane((int)b);
+                h_end = h_next + FM_HIT_GRAB;
+            }
+            if (hit_pending && h == 0u) {
+                u32 const slot = h_next + (u32)__popcll(emit & ((1ull << lane) - 1ull));
+                if (slot < hit_cap) hits[slot] = DevHit{sid, nlb, hit_rep, ne};
+            }
+            h_next += n_emit;
+            hit_pending = false;
+        }
+        bool const want = !busy && !exhausted;
+        u64 const idle = __ballot(want && h == 0u);
+        if (idle) {                                                     // wave-uniform
+            u32 const n_idle = (u32)__popcll(idle);
+            u32 const avail = q_end - q_next;
+            u32 new_base = 0;
+            bool grabbed = false;
+            if (avail < n_idle && !queue_done) {
+                u32 b = 0;
+                if (lane == 0) b = atomicAdd(&counters[7], FM_GRAB);
+                new_base = (u32)__builtin_amdgcn_readfirstlane((int)b);
+                grabbed = true;
+            }
+            u32 const r = (u32)__popcll(idle & ((1ull << lane) - 1ull));   // rank of this pair among the idle ones
+            u32 k = 0xFFFFFFFFu;
+            if (want && h == 0u) {
+                if (r < avail) k = q_next + r;
+                else if (grabbed && new_base + (r - avail) < n_seeds) k = new_base + (r - avail);
+            }
+            k = pair_even(k);
+            if (grabbed) {
+                if (new_base >= n_seeds) { q_next = 0; q_end = 0; queue_done = true; }
+                else {
+                    q_end = min(new_base + FM_GRAB, n_seeds);
+                    q_next = min(new_base + (n_idle - avail), q_end);
+                    queue_done = new_base + FM_GRAB >= n_seeds;
+                }
+            } else q_next += min(n_idle, avail);
+            if (want) {
+                if (k != 0xFFFFFFFFu) {
+                    sid = k;
+                    DevSeed const seed = seeds[sid];
+                    q = seq + seed.seq_off;
+                    stk = reinterpret_cast<uint4*>(stack + seed.stack_off);
+                    len = seed.length;
+                    num_searches = seed.num_searches;
+                    stack_frames = seed.stack_frames;
+                    ex_base = scheme + seed.scheme_off;
+                    srch = 0;
+                    ct = 0;
+                    busy = true;
+                    in_search = false;
+                } else exhausted = true;
+            }
         }
         if (__all(exhausted && !busy)) break;
         ++n_iter;
@@ -222,26 +267,15 @@ __global__ void __launch_bounds__(64) fm_search_kernel(DevIndex idx, const u8* _
             have_frame = false;
             need_child = false;
             in_search = true;
-            staged = len <= FM_STAGE;
-            if (staged) {
-                for (u32 x = ql; x < len; x += 4u) {
-                    u32 const e = ex[x];
-                    my_ann[x] = (e & 0x0FFFFFFFu) | ((u32)q[e & SCH_POS_MASK] << 28);
-                }
-                __builtin_amdgcn_wave_barrier();
-            }
             // the exact, rightward first part of the search starts from the KMER_Q-mer table when it is long enough and free of N
             if (len >= KMER_Q && ((ex[KMER_Q - 1] >> 27) & 1u)) {
                 u32 const p0 = ex[0] & SCH_POS_MASK;
-                u32 code = 0;
-                bool ok = true;
-#pragma unroll
-                for (u32 j = 0; j < KMER_Q; ++j) {
-                    u32 const c = q[p0 + j];
-                    ok = ok && c >= 1u && c <= 4u;
-                    code = (code << 2) | ((c - 1u) & 3u);
-                }
-                if (ok) {
+                u32 w[2];
+                __builtin_memcpy(w, q + p0, 8);                                  // eight ranks, first character in the low byte
+                u32 const t0 = w[0] - 0x01010101u, t1 = w[1] - 0x01010101u;      // A,C,G,T -> 0..3; anything else leaves bits 2..7 set
+                if (((t0 | t1) & 0xFCFCFCFCu) == 0u) {
+                    // gather the four 2-bit fields of a word, first character most significant: b0<<6 | b1<<4 | b2<<2 | b3
+                    u32 const code = (((t0 * 0x40100401u) >> 24) << 8) | ((t1 * 0x40100401u) >> 24);
                     const u32* __restrict__ e = idx.kmer + 3u * code;
                     nlb = e[0]; nlbr = e[1]; nlen = e[2];
                     nx = KMER_Q;
@@ -255,10 +289,14 @@ __global__ void __launch_bounds__(64) fm_search_kernel(DevIndex idx, const u8* _
             if (!have_frame || f_mask == 0) {
                 if (depth == 0) { in_search = false; ++srch; continue; }    // search exhausted
                 --depth;
-                uint4 const v = stk[depth * 4u + ql];
-                f_abs_a = v.x; f_len_a = v.y; f_abs_b = v.z; f_len_b = v.w;
-                f_lb = quad_bcast3(v.x); f_lbr = quad_bcast3(v.y); f_len = quad_bcast3(v.z); f_state = quad_bcast3(v.w);
-                f_mask = quad_bcast0(v.x);
+                const uint4* __restrict__ fr = stk + depth * 6u + 3u * h;
+                uint4 const v0 = fr[0], v1 = fr[1], v2 = fr[2];
+                f_abs[0] = v0.x; f_oth[0] = v0.y; f_cl[0] = v0.z; f_abs[1] = v0.w;
+                f_oth[1] = v1.x; f_cl[1] = v1.y;
+                if (h == 0) { f_abs[2] = v1.z; f_oth[2] = v1.w; f_cl[2] = v2.x; f_abs[3] = v2.y; f_oth[3] = v2.z; f_cl[3] = v2.w; }
+                else { f_abs[2] = 0; f_oth[2] = 0; f_cl[2] = 0; f_abs[3] = 0; f_oth[3] = 0; f_cl[3] = 0; }
+                f_lb = pair_odd(v1.z); f_lbr = pair_odd(v1.w); f_len = pair_odd(v2.x); f_state = pair_odd(v2.y);
+                f_mask = pair_even(v0.x);
                 have_frame = true;
                 continue;
             }
@@ -277,18 +315,10 @@ __global__ void __launch_bounds__(64) fm_search_kernel(DevIndex idx, const u8* _
                 ne = pe + 1;
                 info = del ? INFO_D : INFO_S;
             }
+            u32 cabs, coth, clen;
+            child_of(f_abs, f_oth, f_cl, sym, cabs, coth, clen);
             if (ci == 11) { nlb = f_lb; nlbr = f_lbr; nlen = f_len; }
-            else {
-                // child cursor of `sym`: its (abs, len) live in lane sym/2, the prefix sum of smaller symbols is a quad sum
-                u32 const part = ql < 3 ? ((sa < sym ? f_len_a : 0u) + (sb < sym ? f_len_b : 0u)) : 0u;
-                u32 const pre = quad_sum(part);
-                u32 const my_abs = (sym & 1u) ? f_abs_b : f_abs_a, my_len = (sym & 1u) ? f_len_b : f_len_a;
-                u32 const owner = quad_base + (sym >> 1);
-                u32 const cabs = (u32)__shfl((int)my_abs, (int)owner), clen = (u32)__shfl((int)my_len, (int)owner);
-                nlen = clen;
-                if (right) { nlbr = cabs; nlb = f_lb + pre; }
-                else { nlb = cabs; nlbr = f_lbr + pre; }
-            }
+            else { nlen = clen; nlb = right ? coth : cabs; nlbr = right ? cabs : coth; }
             nli = right ? ST_LI(st) : info;
             nri = right ? info : ST_RI(st);
             need_child = false;
@@ -301,42 +331,49 @@ __global__ void __launch_bounds__(64) fm_search_kernel(DevIndex idx, const u8* _
                 u32 rep = nlen;
                 if (ct + rep > max_hits) rep = max_hits - ct;        // search_n truncates the last cursor
                 ct += rep;
-                if (ql == 0) {
-                    u32 const slot = atomicAdd(&counters[0], 1u);
-                    if (slot < hit_cap) hits[slot] = DevHit{sid, nlb, rep, ne};
-                    else atomicOr(&counters[3], 1u);
-                }
+                hit_pending = true;                                  // written at the top of the next iteration
+                hit_rep = rep;
                 if (ct == max_hits) { busy = false; continue; }      // search_n aborts all remaining searches of the seed
             }
             need_child = true;
             continue;
         }
-        u32 entry;
-        if (staged) entry = my_ann[nx];
-        else { u32 const e = ex[nx]; entry = (e & 0x0FFFFFFFu) | ((u32)q[e & SCH_POS_MASK] << 28); }
-        u32 const lower = (entry >> 20) & 7u, upper = (entry >> 23) & 7u, right = (entry >> 26) & 1u;
+        u32 const sch = ex[nx];
+        u32 const lower = (sch >> 20) & 7u, upper = (sch >> 23) & 7u, right = (sch >> 26) & 1u;
         if (ne > upper) { need_child = true; continue; }
         bool const mismatch_allowed = lower <= ne + 1 && ne + 1 <= upper;
         bool const match_allowed = lower <= ne && ne <= upper;
         if (!mismatch_allowed && !match_allowed) { need_child = true; continue; }
 
-        u32 const next_sym = (entry >> 28) & 7u;
+        u32 const next_sym = q[sch & SCH_POS_MASK];
         const OccBlock* __restrict__ tab = idx.occ[right];
-        u32 const lo = right ? nlbr : nlb;
-        u32 a_sa, a_sb, b_sa, b_sb;
-        quad_rank_pair(tab, lo, lo + nlen, ql, a_sa, a_sb, b_sa, b_sb);
+        u32 const lo = right ? nlbr : nlb, other = right ? nlb : nlbr;
+        u32 ra[4], cl[4], s_abs[4], s_oth[4];
+        pair_rank_pair(tab, lo, lo + nlen, h, ra, cl);
         ++n_ext;
-        u32 const len_a = ql < 3 ? b_sa - a_sa : 0u, len_b = ql < 3 ? b_sb - a_sb : 0u;
-        u32 const abs_a = idx.C[sa] + a_sa, abs_b = idx.C[sb < 6 ? sb : 5] + a_sb;
+        if (h) { cl[2] = 0; cl[3] = 0; }                     // dummy slots of lane 1
+        // other-side bounds: the lengths of all smaller symbols come first (exclusive prefix over the six symbols)
+        u32 const e1 = cl[0], e2 = e1 + cl[1], e3 = e2 + cl[2], tot = e3 + cl[3];
+        u32 const tot0 = pair_even(tot);                     // all lanes execute the DPP move (not under a lane-dependent select)
+        u32 const base = other + (tot0 & (0u - h));
+        s_oth[0] = base; s_oth[1] = base + e1; s_oth[2] = base + e2; s_oth[3] = base + e3;
+#pragma unroll
+        for (u32 j = 0; j < 4; ++j) {
+            u32 const c = sym0 + j;
+            s_abs[j] = idx.C[c < 6u ? c : 5u] + ra[j];
+        }
 
         if (mismatch_allowed) {
-            // this node branches: it becomes the top frame, the previous top goes to memory (16 bytes per lane)
+            // this node branches: it becomes the top frame, the previous top goes to memory (48 bytes per lane)
             if (have_frame) {
-                if (depth >= stack_frames) { if (ql == 0) atomicOr(&counters[1], 1u); busy = false; continue; }
-                uint4 v;
-                if (ql < 3) { v.x = ql == 0 ? f_mask : f_abs_a; v.y = f_len_a; v.z = f_abs_b; v.w = f_len_b; }
-                else { v.x = f_lb; v.y = f_lbr; v.z = f_len; v.w = f_state; }
-                stk[depth * 4u + ql] = v;
+                if (depth >= stack_frames) { if (h == 0) atomicOr(&counters[1], 1u); busy = false; continue; }
+                uint4 v0, v1, v2;
+                v0.x = h ? f_abs[0] : f_mask; v0.y = f_oth[0]; v0.z = f_cl[0]; v0.w = f_abs[1];
+                v1.x = f_oth[1]; v1.y = f_cl[1];
+                if (h == 0) { v1.z = f_abs[2]; v1.w = f_oth[2]; v2.x = f_cl[2]; v2.y = f_abs[3]; v2.z = f_oth[3]; v2.w = f_cl[3]; }
+                else { v1.z = f_lb; v1.w = f_lbr; v2.x = f_len; v2.y = f_state; v2.z = 0; v2.w = 0; }
+                uint4* __restrict__ fr = stk + depth * 6u + 3u * h;
+                fr[0] = v0; fr[1] = v1; fr[2] = v2;
                 ++depth;
             }
             have_frame = true;
@@ -345,45 +382,46 @@ __global__ void __launch_bounds__(64) fm_search_kernel(DevIndex idx, const u8* _
             bool const insertion = tinfo == INFO_M || tinfo == INFO_I;
             f_lb = nlb; f_lbr = nlbr; f_len = nlen;
             f_state = st_pack(nx, ne, nli, nri, next_sym, right);
-            f_abs_a = abs_a; f_len_a = len_a; f_abs_b = abs_b; f_len_b = len_b;
-            // children of symbols 1..5 that are not empty: this lane contributes the bits of its two symbols, quad-OR via sum
+            // children of symbols 1..5 that are not empty: this lane contributes the bits of its symbols, pair-OR via sum
             u32 mine = 0;
-            if (sa > 0 && len_a > 0) {
-                if (deletion) mine |= 1u << (2 * sa - 1);
-                if (sa != next_sym) mine |= 1u << (2 * sa);
-                else if (match_allowed) mine |= 1u;
+#pragma unroll
+            for (u32 j = 0; j < 4; ++j) {
+                u32 const c = sym0 + j;
+                f_abs[j] = s_abs[j];
+                f_oth[j] = s_oth[j];
+                f_cl[j] = cl[j];
+                if (c >= 1u && c < 6u && cl[j] > 0u) {
+                    if (deletion) mine |= 1u << (2u * c - 1u);
+                    if (c != next_sym) mine |= 1u << (2u * c);
+                    else if (match_allowed) mine |= 1u;
+                }
             }
-            if (ql < 3 && len_b > 0) {
-                if (deletion) mine |= 1u << (2 * sb - 1);
-                if (sb != next_sym) mine |= 1u << (2 * sb);
-                else if (match_allowed) mine |= 1u;
-            }
-            u32 mask = quad_sum(mine);              // the four contributions have disjoint bits
+            u32 mask = pair_sum(mine);              // the two contributions have disjoint bits
             if (insertion) mask |= 1u << 11;
             f_mask = mask;
             need_child = true;
         } else {
             // only an exact extension is possible: continue in place (no frame)
-            u32 const part = ql < 3 ? ((sa < next_sym ? len_a : 0u) + (sb < next_sym ? len_b : 0u)) : 0u;
-            u32 const pre = quad_sum(part);
-            u32 const my_abs = (next_sym & 1u) ? abs_b : abs_a, my_len = (next_sym & 1u) ? len_b : len_a;
-            u32 const owner = quad_base + (next_sym >> 1);
-            u32 const cabs = (u32)__shfl((int)my_abs, (int)owner), clen = (u32)__shfl((int)my_len, (int)owner);
-            if (clen == 0 || next_sym == 0u || next_sym > 5u) { need_child = true; continue; }   // the sentinel never matches
-            if (right) { nlbr = cabs; nlb = nlb + pre; nri = INFO_M; }
-            else { nlb = cabs; nlbr = nlbr + pre; nli = INFO_M; }
+            if (next_sym == 0u || next_sym > 5u) { need_child = true; continue; }       // the sentinel never matches
+            u32 cabs, coth, clen;
+            child_of(s_abs, s_oth, cl, next_sym, cabs, coth, clen);
+            if (clen == 0) { need_child = true; continue; }
+            nlb = right ? coth : cabs;
+            nlbr = right ? cabs : coth;
+            if (right) nri = INFO_M; else nli = INFO_M;
             nlen = clen;
             nx = nx + 1;
         }
     }
-    if (ql == 0) { atomicAdd(&counters[2], n_ext); atomicAdd(&counters[6], n_busy_iter); }
+    fill_rest();
+    if (h == 0) { atomicAdd(&counters[2], n_ext); atomicAdd(&counters[6], n_busy_iter); }
     if (threadIdx.x == 0) { atomicAdd(&counters[4], n_iter); atomicMax(&counters[5], n_iter); }
 }
 
 int DeviceApi::search(void* stream, const DevIndex& idx, const u8* d_seq, const u32* d_scheme, const DevSeed* d_seeds, u32 n_seeds,
                       u32 max_hits_per_seed, DevFrame* d_stack, DevHit* d_hits, u32 hit_cap, u32* d_counters) {
     if (n_seeds == 0) return 0;
-    hipLaunchKernelGGL(fm_search_kernel, dim3((n_seeds + FM_CHUNK - 1) / FM_CHUNK), dim3(64), 0, (hipStream_t)stream, idx, d_seq, d_scheme, d_seeds,
+    hipLaunchKernelGGL(fm_search_kernel, dim3(std::min<u32>((n_seeds + FM_GRAB - 1) / FM_GRAB, FM_MAX_WAVES)), dim3(64), 0, (hipStream_t)stream, idx, d_seq, d_scheme, d_seeds,
                        n_seeds, max_hits_per_seed, d_stack, d_hits, hit_cap, d_counters);
     return (int)hipGetLastError();
 }

@@ -20,7 +20,7 @@ void set_error(const std::string& msg);
 
 // ------------------------------------------------------------------------------------------------ HBM data layout
 // Occurrence table block: 256 BWT positions in one 128-byte line (one L2 line / one HBM request on gfx950), cut into four
-// 32-byte quarters so that the four lanes that serve one seed each read one quarter with two 16-byte loads (coalesced 128 B):
+// 32-byte quarters so that the two lanes that serve one seed each read two quarters with four 16-byte loads (coalesced 128 B):
 //   quarter q = { p0[2q], p1[2q], p2[2q], cnt[2q],  p0[2q+1], p1[2q+1], p2[2q+1], cnt[2q+1] }        (8 x u32)
 //   pk[j]  = bit-plane k (symbol bit k) of the 32 positions bwt[256*b + 32*j ..+31]   (symbols 0..5; tail filled with 7)
 //   cnt[c] = number of symbol c in bwt[0, 256*b) for c < 6 (absolute; text < 2^32 symbols); cnt[6], cnt[7] unused
@@ -71,13 +71,14 @@ struct DevSeed {
     u32 stack_frames;   // frames reserved
 };
 
-struct DevFrame {       // 64 bytes: one branching node of the DFS, 16 bytes per lane of the seed's quad
-    // lane q < 3: { abs[2q], len[2q], abs[2q+1], len[2q+1] } of the child cursors for symbols 2q, 2q+1 (abs = C[c] + occ on the
-    //             extended side; abs[0] is unused by the search and carries the mask of remaining children instead)
-    // lane 3:     { lb, lb_rev, len, state } of the node itself; state = x:20 | e:3 | linfo:2 | rinfo:2 | next_sym:3 | right:1
-    u32 v[16];
+struct DevFrame {       // 96 bytes: one branching node of the DFS, 48 bytes per lane of the seed's pair
+    // lane 0: { abs, oth, len } of the child cursors for symbols 0..3 (abs = C[c] + occ on the extended side, oth = bound on the
+    //         other side; symbol 0 is never a child and its abs carries the mask of remaining children instead)
+    // lane 1: { abs, oth, len } for symbols 4, 5, then { lb, lb_rev, len, state } of the node itself and 8 unused bytes;
+    //         state = x:20 | e:3 | linfo:2 | rinfo:2 | next_sym:3 | right:1
+    u32 v[24];
 };
-static_assert(sizeof(DevFrame) == 64, "frame is one 64-byte line");
+static_assert(sizeof(DevFrame) == 96, "frame is six 16-byte slots");
 
 struct DevHit { u32 seed, lb, len, errors; };
 

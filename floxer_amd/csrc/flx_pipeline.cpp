@@ -231,7 +231,8 @@ int search_seeds_device(Lane* ctx, const u8* d_seq_pool_or_null, const u8* h_seq
                                   : (cfg.anchor_choice_strategy == FLX_CHOICE_FIRST_REPORTED
                                          ? (u32)cfg.max_num_anchors_soft
                                          : (u32)std::max(cfg.max_num_anchors_hard, cfg.max_num_anchors_hard + 1));
-    u64 hit_cap = std::max<u64>(n_seeds * 6, 4096);
+    u64 const hit_slack = 4096 * 64;            // unused ends of the per-wave slot ranges (FM_MAX_WAVES x FM_HIT_GRAB)
+    u64 hit_cap = n_seeds * 6 + hit_slack;
     u32 counters[8];
     for (int attempt = 0;; ++attempt) {
         if ((rc = ctx->hits.ensure(hit_cap * sizeof(DevHit)))) return rc;
@@ -248,7 +249,7 @@ int search_seeds_device(Lane* ctx, const u8* d_seq_pool_or_null, const u8* h_seq
         if (counters[1]) { set_error("fm_search: DFS stack reservation exceeded"); return FLX_ERR_INTERNAL; }
         if (counters[0] <= hit_cap) break;
         if (attempt >= 2) { set_error("fm_search: hit buffer could not be sized"); return FLX_ERR_INTERNAL; }
-        hit_cap = (u64)counters[0] + 1024;      // exact size is known now; run again
+        hit_cap = (u64)counters[0] + hit_slack;      // the number of hits is known now; run again
     }
     // fold the extension count into the kernel's accounting: 2 rank positions of one 128-byte block each
     if (ctx->ctx->timing) {
@@ -256,19 +257,21 @@ int search_seeds_device(Lane* ctx, const u8* d_seq_pool_or_null, const u8* h_seq
         auto it = ctx->ctx->stats.find("fm_search");
         if (it != ctx->ctx->stats.end()) { it->second.algorithmic_bytes += (u64)counters[2] * 2 * sizeof(OccBlock); it->second.work_units += counters[2]; }
     }
-    u32 const n_hits = counters[0];
-    std::vector<DevHit> hits(n_hits);
-    if ((rc = d2h(ctx, hits.data(), ctx->hits.ptr, (size_t)n_hits * sizeof(DevHit)))) return rc;
+    u32 const n_slots = counters[0];          // reserved slots; unused ones carry seed 0xFFFFFFFF
+    std::vector<DevHit> hits(n_slots);
+    if ((rc = d2h(ctx, hits.data(), ctx->hits.ptr, (size_t)n_slots * sizeof(DevHit)))) return rc;
     if ((rc = ctx->sync())) return rc;
 
-    // group by seed, keeping each seed's emission order (a lane's slots are reserved in increasing order)
+    // group by seed, keeping each seed's emission order (a seed stays on one wave, whose slot ranges and slots within a range
+    // are handed out in increasing order)
     std::vector<u32> first(n_seeds + 1, 0);
-    for (auto const& h : hits) first[h.seed + 1]++;
+    for (auto const& h : hits) if (h.seed != 0xFFFFFFFFu) first[h.seed + 1]++;
     for (u64 i = 0; i < n_seeds; ++i) first[i + 1] += first[i];
+    u32 const n_hits = first[n_seeds];
     std::vector<DevHit> by_seed(n_hits);
     {
         std::vector<u32> cursor(first.begin(), first.end() - 1);
-        for (auto const& h : hits) by_seed[cursor[h.seed]++] = h;
+        for (auto const& h : hits) if (h.seed != 0xFFFFFFFFu) by_seed[cursor[h.seed]++] = h;
     }
     if (raw_hits) { *raw_hits = std::move(by_seed); return FLX_OK; }
 
