@@ -1,6 +1,7 @@
 // C ABI: host arithmetic, PEX trees, index lifetime, device context, kernel accounting.
 #include <cstdlib>
 #include <cstring>
+#include <malloc.h>
 #include <memory>
 
 #include "flx_context.hpp"
@@ -91,6 +92,14 @@ int flx_ctx_create(int hip_device, const flx_index* index, flx_ctx** out) {
     auto ctx = std::make_unique<flx_ctx>();
     ctx->device = hip_device;
     ctx->hidx = index->host;
+    // Every batch builds and drops some hundred MB of host-side lists per lane. With glibc's defaults those go back to the
+    // kernel on free and fault in again on the next batch; keep them in the heap instead (FLX_KEEP_MALLOC_DEFAULTS=1 leaves the
+    // process-wide malloc settings alone).
+    if (!getenv("FLX_KEEP_MALLOC_DEFAULTS")) {
+        mallopt(M_MMAP_THRESHOLD, 32 << 20);
+        mallopt(M_TRIM_THRESHOLD, 1 << 30);
+        mallopt(M_TOP_PAD, 256 << 20);
+    }
     size_t n_lanes = 4;
     if (const char* env = getenv("FLX_LANES")) { size_t const v = strtoull(env, nullptr, 10); if (v >= 1 && v <= 16) n_lanes = v; }
     for (size_t l = 0; l < n_lanes; ++l) {

@@ -136,6 +136,7 @@ __device__ __forceinline__ u32 st_pack(u32 x, u32 e, u32 li, u32 ri, u32 sym, u3
 constexpr u32 FM_GRAB = 32;
 constexpr u32 FM_HIT_GRAB = 64;
 constexpr u32 FM_MAX_WAVES = 4096;
+constexpr u32 FM_SEEDS_PER_WAVE = 256;      // a launch has at most n_seeds / this many waves, so that every wave gets several ranges
 
 __global__ void __launch_bounds__(64) fm_search_kernel(DevIndex idx, const u8* __restrict__ seq, const u32* __restrict__ scheme,
                                                        const DevSeed* __restrict__ seeds, u32 n_seeds, u32 max_hits,
@@ -421,7 +422,7 @@ __global__ void __launch_bounds__(64) fm_search_kernel(DevIndex idx, const u8* _
 int DeviceApi::search(void* stream, const DevIndex& idx, const u8* d_seq, const u32* d_scheme, const DevSeed* d_seeds, u32 n_seeds,
                       u32 max_hits_per_seed, DevFrame* d_stack, DevHit* d_hits, u32 hit_cap, u32* d_counters) {
     if (n_seeds == 0) return 0;
-    hipLaunchKernelGGL(fm_search_kernel, dim3(std::min<u32>((n_seeds + FM_GRAB - 1) / FM_GRAB, FM_MAX_WAVES)), dim3(64), 0, (hipStream_t)stream, idx, d_seq, d_scheme, d_seeds,
+    hipLaunchKernelGGL(fm_search_kernel, dim3(std::min<u32>((n_seeds + FM_SEEDS_PER_WAVE - 1) / FM_SEEDS_PER_WAVE, FM_MAX_WAVES)), dim3(64), 0, (hipStream_t)stream, idx, d_seq, d_scheme, d_seeds,
                        n_seeds, max_hits_per_seed, d_stack, d_hits, hit_cap, d_counters);
     return (int)hipGetLastError();
 }
@@ -780,7 +781,7 @@ static bool use_band() {
     return v != 0;
 }
 
-static AlignShape choose_align_shape_uncached(u32 nw, i64 width, bool band) {
+static AlignShape choose_align_shape_uncached(u32 nw, i64 width, bool band, bool parallel) {
     AlignShape best{0, 0, 0};
     u64 best_cost = ~0ull;
     for (u32 w : kWordsPerLane)
@@ -789,23 +790,24 @@ static AlignShape choose_align_shape_uncached(u32 nw, i64 width, bool band) {
             bool ok = groups <= r;                        // every group has its own lane
             if (!ok && band) ok = (i64)64 * w * (r - 1) + r + 1 > width;   // group g + r starts after group g has ended
             if (!ok) continue;
-            // cost ~ wave slots consumed: words per lane times lanes reserved; prefer fewer words per lane on ties
-            u64 const cost = (u64)w * r * 1000 + w;
+            // throughput form: cost ~ wave slots consumed (words per lane times lanes reserved), fewer words per lane on ties;
+            // parallel form: fewest words per lane first (shortest dependent chain per step, most waves), then fewest lanes
+            u64 const cost = parallel ? (u64)w * 1000 + r : (u64)w * r * 1000 + w;
             if (cost < best_cost) { best_cost = cost; best = AlignShape{w, r, band ? 1u : 0u}; }
         }
     return best;
 }
 
-AlignShape choose_align_shape(u32 n, u32 m, u32 k) {
+AlignShape choose_align_shape(u32 n, u32 m, u32 k, bool parallel) {
     u32 const nw = (m + 63) / 64;
     bool const band = use_band();
     i64 const width = (i64)n - (i64)m + 2 * (i64)k;       // diagonals that matter, minus one
     // the jobs of one verification level repeat a handful of (words, band width) pairs: small direct-mapped memo per thread
     struct Entry { u32 nw; i64 width; AlignShape shape; bool valid; };
-    thread_local Entry memo[256] = {};
-    Entry& e = memo[(nw * 31u + (u32)width) & 255u];
+    thread_local Entry memo[2][256] = {};
+    Entry& e = memo[parallel ? 1 : 0][(nw * 31u + (u32)width) & 255u];
     if (e.valid && e.nw == nw && e.width == width) return e.shape;
-    e = Entry{nw, width, choose_align_shape_uncached(nw, width, band), true};
+    e = Entry{nw, width, choose_align_shape_uncached(nw, width, band, parallel), true};
     return e.shape;
 }
 u32 align_supported_max_query() { return 25u * 64u * 64u; }

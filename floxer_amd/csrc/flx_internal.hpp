@@ -124,7 +124,9 @@ FLX_HD inline TraceLayout ckpt_trace_layout(u32 n, u32 m, u32 W, u32 R) {
     l.ckpt_slots = ((l.steps + TRACE_CKPT - 1) / TRACE_CKPT) * R * W;
     return l;
 }
-AlignShape choose_align_shape(u32 n, u32 m, u32 k);
+// parallel = false: the shape that occupies the fewest wave slots (launches with many jobs); true: the shape with the shortest
+// per-step chain and the most waves (launches whose jobs would not fill the GPU otherwise)
+AlignShape choose_align_shape(u32 n, u32 m, u32 k, bool parallel = false);
 u64 align_trace_slots(u32 n, u32 m, AlignShape sh);     // 16-byte trace slots a TRACE launch of this shape needs for one job
 u32 align_supported_max_query();
 

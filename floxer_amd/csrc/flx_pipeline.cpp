@@ -2,6 +2,7 @@
 // (K0/K3/K4/K5, alignment.cpp:83-181) and the level-synchronous PEX verification driver (verification.cpp:8-245) with
 // --threads 1 record order (parallelization.cpp:14-43, 230-276; output.cpp:49-108).
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -48,7 +49,8 @@ struct PhaseTimer {
     bool on;
     std::chrono::steady_clock::time_point t;
     std::vector<std::pair<const char*, double>> rows;
-    PhaseTimer() : on(getenv("FLX_HOST_PROFILE") != nullptr), t(std::chrono::steady_clock::now()) {}
+    const char* what;
+    explicit PhaseTimer(const char* what_ = "slice") : on(getenv("FLX_HOST_PROFILE") != nullptr), t(std::chrono::steady_clock::now()), what(what_) {}
     void mark(const char* name) {
         if (!on) return;
         auto const now = std::chrono::steady_clock::now();
@@ -59,7 +61,7 @@ struct PhaseTimer {
         if (!on) return;
         double total = 0;
         for (auto& r : rows) total += r.second;
-        fprintf(stderr, "[flx host profile] total %.2f ms:", total);
+        fprintf(stderr, "[flx host profile] %s total %.2f ms:", what, total);
         for (auto& r : rows) fprintf(stderr, " %s=%.2f", r.first, r.second);
         fprintf(stderr, "\n");
     }
@@ -179,6 +181,7 @@ int search_seeds_device(Lane* ctx, const u8* d_seq_pool_or_null, const u8* h_seq
     if (n_seeds == 0) return FLX_OK;
     if (n_seeds >= (1ull << 31)) { set_error("too many seeds in one call"); return FLX_ERR_INVALID; }
     HostIndex const& H = *ctx->ctx->hidx;
+    PhaseTimer sprof("search");
 
     // ---- expanded schemes (search_scheme_cache, search.cpp:328-350) and DFS stack reservations
     std::map<std::pair<u32, u32>, std::pair<u32, u32>> scheme_of;      // (len, k) -> (offset, searches)
@@ -216,6 +219,7 @@ int search_seeds_device(Lane* ctx, const u8* d_seq_pool_or_null, const u8* h_seq
     }
     if (scheme_table.empty()) scheme_table.push_back(0);
 
+    sprof.mark("prep");
     int rc;
     const u8* d_seq = d_seq_pool_or_null;
     if (!d_seq) {
@@ -257,11 +261,13 @@ int search_seeds_device(Lane* ctx, const u8* d_seq_pool_or_null, const u8* h_seq
         auto it = ctx->ctx->stats.find("fm_search");
         if (it != ctx->ctx->stats.end()) { it->second.algorithmic_bytes += (u64)counters[2] * 2 * sizeof(OccBlock); it->second.work_units += counters[2]; }
     }
+    sprof.mark("kernel");
     u32 const n_slots = counters[0];          // reserved slots; unused ones carry seed 0xFFFFFFFF
     std::vector<DevHit> hits(n_slots);
     if ((rc = d2h(ctx, hits.data(), ctx->hits.ptr, (size_t)n_slots * sizeof(DevHit)))) return rc;
     if ((rc = ctx->sync())) return rc;
 
+    sprof.mark("d2h-hits");
     // group by seed, keeping each seed's emission order (a seed stays on one wave, whose slot ranges and slots within a range
     // are handed out in increasing order)
     std::vector<u32> first(n_seeds + 1, 0);
@@ -275,6 +281,7 @@ int search_seeds_device(Lane* ctx, const u8* d_seq_pool_or_null, const u8* h_seq
     }
     if (raw_hits) { *raw_hits = std::move(by_seed); return FLX_OK; }
 
+    sprof.mark("group");
     // ---- hard cap, group order, anchor choice (search.cpp:190-302)
     struct RowReq { u32 seed, errors, row; };
     std::vector<RowReq> reqs;
@@ -337,6 +344,7 @@ int search_seeds_device(Lane* ctx, const u8* d_seq_pool_or_null, const u8* h_seq
         }
     }
 
+    sprof.mark("select");
     // ---- locate (search.cpp:253, 284) as one SA gather
     std::vector<u32> rows(reqs.size()), textpos(reqs.size());
     for (size_t i = 0; i < reqs.size(); ++i) rows[i] = reqs[i].row;
@@ -351,6 +359,7 @@ int search_seeds_device(Lane* ctx, const u8* d_seq_pool_or_null, const u8* h_seq
         if ((rc = ctx->sync())) return rc;
     }
 
+    sprof.mark("locate");
     // ---- per seed: bucket per reference, erase useless anchors, flatten (search.cpp:78-100, 304-318)
     size_t const nref = H.seq_len.size();
     std::vector<std::vector<RefAnchor>> by_ref(nref);
@@ -382,6 +391,7 @@ int search_seeds_device(Lane* ctx, const u8* d_seq_pool_or_null, const u8* h_seq
             by_ref[r].clear();
         }
     }
+    sprof.mark("erase+flatten");
     return FLX_OK;
 }
 
@@ -446,16 +456,46 @@ void dedup_requests(std::vector<AlignRequest> const& reqs, std::vector<AlignRequ
     }
 }
 
+// Shapes for the jobs of one call. Many jobs: each gets the shape that costs the fewest wave slots. Few jobs (they would leave
+// most SIMDs without a wave): all get one common shape with the fewest words per lane, i.e. more, shorter-running waves and a
+// single launch.
+constexpr u64 ALIGN_FEW_WAVES = 2048;
+int choose_shapes(std::vector<AlignRequest> const& reqs, std::vector<AlignShape>& shapes) {
+    shapes.resize(reqs.size());
+    u64 lanes = 0;
+    for (size_t i = 0; i < reqs.size(); ++i) {
+        shapes[i] = choose_align_shape(reqs[i].n, reqs[i].m, reqs[i].k);
+        if (shapes[i].words_per_lane == 0) { set_error("query longer than the supported maximum"); return FLX_ERR_UNSUPPORTED; }
+        lanes += shapes[i].lanes_per_job;
+    }
+    if (reqs.empty() || lanes / 64 >= ALIGN_FEW_WAVES) return FLX_OK;
+    AlignShape common{0, 0, shapes[0].banded};
+    for (size_t i = 0; i < reqs.size(); ++i) {
+        AlignShape const p = choose_align_shape(reqs[i].n, reqs[i].m, reqs[i].k, true);
+        if (p.words_per_lane > common.words_per_lane) common.words_per_lane = p.words_per_lane;
+    }
+    // lanes each job needs at the common words per lane
+    for (size_t i = 0; i < reqs.size(); ++i) {
+        u32 const nw = (reqs[i].m + 63) / 64, W = common.words_per_lane;
+        i64 const width = (i64)reqs[i].n - (i64)reqs[i].m + 2 * (i64)reqs[i].k;
+        u32 r = 1;
+        while (r < 64 && !((nw + W - 1) / W <= r || (common.banded && (i64)64 * W * (r - 1) + r + 1 > width))) r *= 2;
+        if (r > common.lanes_per_job) common.lanes_per_job = r;
+    }
+    for (auto& sh : shapes) sh = common;
+    return FLX_OK;
+}
+
 // score + end column for every (distinct) request (no trace)
 int run_score_jobs_unique(Lane* ctx, const u8* d_text, const u64* d_peq, std::vector<AlignRequest> const& reqs,
                           std::vector<DevAlignOut>& outs, const char* kernel_name) {
     outs.assign(reqs.size(), DevAlignOut{0xFFFFFFFFu, 0});
     if (reqs.empty()) return FLX_OK;
     std::map<ShapeKey, std::vector<u32>> by_shape;
-    for (u32 i = 0; i < reqs.size(); ++i) {
-        AlignShape const sh = choose_align_shape(reqs[i].n, reqs[i].m, reqs[i].k);
-        if (sh.words_per_lane == 0) { set_error("query longer than the supported maximum"); return FLX_ERR_UNSUPPORTED; }
-        by_shape[ShapeKey{sh.words_per_lane, sh.lanes_per_job, sh.banded}].push_back(i);
+    {
+        std::vector<AlignShape> shapes;
+        if (int const rc = choose_shapes(reqs, shapes)) return rc;
+        for (u32 i = 0; i < reqs.size(); ++i) by_shape[ShapeKey{shapes[i].words_per_lane, shapes[i].lanes_per_job, shapes[i].banded}].push_back(i);
     }
     std::vector<DevAlignJob> jobs;
     jobs.reserve(reqs.size());
@@ -476,6 +516,7 @@ int run_score_jobs_unique(Lane* ctx, const u8* d_text, const u64* d_peq, std::ve
     if ((rc = h2d(ctx, ctx->jobs, jobs.data(), jobs.size() * sizeof(DevAlignJob)))) return rc;
     if ((rc = ctx->job_out.ensure(reqs.size() * sizeof(DevAlignOut)))) return rc;
     for (auto const& l : launches) {
+        if (getenv("FLX_ALIGN_DEBUG")) fprintf(stderr, "[%s] W %u R %u banded %u jobs %u word-steps %llu n0 %u m0 %u k0 %u\n", kernel_name, l.key.w, l.key.g, l.key.banded, l.count, (unsigned long long)l.word_steps, jobs[l.first].n, jobs[l.first].m, jobs[l.first].k);
         rc = timed_launch(ctx, kernel_name, l.bytes, l.word_steps, [&] {
             return DeviceApi::align(ctx->stream, d_text, d_peq, ctx->jobs.as<DevAlignJob>() + l.first, l.count,
                                     AlignShape{l.key.w, l.key.g, l.key.banded}, false, nullptr, ctx->job_out.as<DevAlignOut>());
@@ -522,12 +563,11 @@ int run_trace_jobs_unique(Lane* ctx, const u8* d_text, const u8* d_query, const 
                           std::vector<TraceResult>& results, std::vector<u32>& cigar_pool) {
     results.assign(reqs.size(), TraceResult{});
     if (reqs.empty()) return FLX_OK;
-    std::vector<AlignShape> shapes(reqs.size());
+    std::vector<AlignShape> shapes;
+    if (int const src = choose_shapes(reqs, shapes)) return src;
     std::vector<u64> slots(reqs.size());
     u64 const budget_slots = std::max<u64>(ctx->trace_budget_bytes / 16, 1);
     for (size_t i = 0; i < reqs.size(); ++i) {
-        shapes[i] = choose_align_shape(reqs[i].n, reqs[i].m, reqs[i].k);
-        if (shapes[i].words_per_lane == 0) { set_error("query longer than the supported maximum"); return FLX_ERR_UNSUPPORTED; }
         slots[i] = align_trace_slots(reqs[i].n, reqs[i].m, shapes[i]);
         if (slots[i] > budget_slots) { set_error("one alignment needs more trace memory than the configured budget (FLX_TRACE_ARENA_MB)"); return FLX_ERR_CAPACITY; }
     }
@@ -572,6 +612,7 @@ int run_trace_jobs_unique(Lane* ctx, const u8* d_text, const u8* d_query, const 
         if ((rc = h2d(ctx, ctx->jobs, jobs.data(), jobs.size() * sizeof(DevAlignJob)))) return rc;
         if ((rc = ctx->job_out.ensure(count * sizeof(DevAlignOut)))) return rc;
         for (auto const& l : launches) {
+            if (getenv("FLX_ALIGN_DEBUG")) fprintf(stderr, "[ed_align_trace] W %u R %u banded %u jobs %u word-steps %llu n0 %u m0 %u k0 %u\n", l.key.w, l.key.g, l.key.banded, l.count, (unsigned long long)l.word_steps, jobs[l.first].n, jobs[l.first].m, jobs[l.first].k);
             rc = timed_launch(ctx, "ed_align_trace", l.bytes, l.word_steps, [&] {
                 return DeviceApi::align(ctx->stream, d_text, d_peq, ctx->jobs.as<DevAlignJob>() + l.first, l.count,
                                         AlignShape{l.key.w, l.key.g, l.key.banded}, true, ctx->trace.as<u64>(), ctx->job_out.as<DevAlignOut>());
@@ -1115,20 +1156,32 @@ extern "C" int flx_align_reads_resident(flx_ctx* ctx, const flx_params* P, const
     if (P->pex_seed_num_errors > 3 || P->seed_sampling_step_size == 0 || P->num_anchors_per_verification_task == 0) { set_error("invalid parameters"); return FLX_ERR_INVALID; }
     if (P->search.max_num_anchors_hard < P->search.max_num_anchors_soft) { set_error("max-anchors-hard must not be smaller than max-anchors-soft"); return FLX_ERR_INVALID; }
     u64 const n_reads = RD->n_reads;
+    PhaseTimer dprof("dispatch");
     auto run = std::make_unique<flx_run>();
     run->skipped.assign(n_reads, 0);
-    // contiguous slices, one per lane (reads are independent units: parallelization.cpp:77-87)
+    // reads are independent units (parallelization.cpp:77-87): the batch is cut into contiguous chunks and every lane (a host
+    // thread with its own stream and workspaces) takes the next chunk when it is done with its last one.
     size_t n_lanes = ctx->external_stream ? 1 : ctx->lanes.size();
     n_lanes = std::max<size_t>(1, std::min<size_t>(n_lanes, (n_reads + 63) / 64));
-    run->parts.resize(n_lanes);
+    // a chunk's kernels last as long as their longest job whatever the number of jobs, so chunks must not be small: one per
+    // lane up to 1024 reads, more than one per lane beyond that
+    u64 chunk_reads = std::max<u64>(64, std::min<u64>(1024, (n_reads + n_lanes - 1) / n_lanes));
+    if (const char* env = getenv("FLX_CHUNK_READS")) { u64 const v = strtoull(env, nullptr, 10); if (v >= 1) chunk_reads = v; }
+    if (n_lanes == 1) chunk_reads = std::max<u64>(n_reads, 1);
+    size_t const n_chunks = std::max<size_t>(1, (n_reads + chunk_reads - 1) / chunk_reads);
+    run->parts.resize(n_chunks);
     std::vector<flx_run>& parts = run->parts;
-    std::vector<int> rcs(n_lanes, FLX_OK);
-    std::vector<std::string> errs(n_lanes);
+    std::vector<int> rcs(n_chunks, FLX_OK);
+    std::vector<std::string> errs(n_chunks);
+    std::atomic<size_t> next_chunk{0};
+    std::atomic<bool> failed{false};
     auto work = [&](size_t l) {
-        u64 const a = n_reads * l / n_lanes, b = n_reads * (l + 1) / n_lanes;
-        parts[l].skipped.assign(n_reads, 0);
-        rcs[l] = align_slice(ctx->lanes[l].get(), P, RD, a, b, &parts[l]);
-        if (rcs[l]) errs[l] = flx_last_error();
+        for (size_t c; (c = next_chunk.fetch_add(1)) < n_chunks && !failed.load();) {
+            u64 const a = c * chunk_reads, b = std::min<u64>(n_reads, a + chunk_reads);
+            parts[c].skipped.assign(n_reads, 0);
+            rcs[c] = align_slice(ctx->lanes[l].get(), P, RD, a, b, &parts[c]);
+            if (rcs[c]) { errs[c] = flx_last_error(); failed.store(true); }
+        }
     };
     if (n_lanes == 1) work(0);
     else {
@@ -1136,11 +1189,13 @@ extern "C" int flx_align_reads_resident(flx_ctx* ctx, const flx_params* P, const
         for (size_t l = 0; l < n_lanes; ++l) threads.emplace_back(work, l);
         for (auto& t : threads) t.join();
     }
-    for (size_t l = 0; l < n_lanes; ++l)
-        if (rcs[l]) { set_error(errs[l]); return rcs[l]; }
+    dprof.mark("lanes");
+    for (size_t c = 0; c < n_chunks; ++c)
+        if (rcs[c]) { set_error(errs[c]); return rcs[c]; }
     for (auto& p : parts)
         for (u64 i = 0; i < n_reads; ++i) run->skipped[i] |= p.skipped[i];
     *out = run.release();
+    dprof.mark("merge");
     return FLX_OK;
 }
 
@@ -1158,6 +1213,7 @@ extern "C" uint64_t flx_run_num_cigar_words(const flx_run* run) {
 }
 extern "C" int flx_run_copy(const flx_run* run, flx_record* records, uint32_t* cigar_words, uint8_t* skipped) {
     if (!run) { set_error("null run"); return FLX_ERR_INVALID; }
+    PhaseTimer cprof("run_copy");
     // the run itself plus its per-lane parts, each copied by its own thread (the CIGAR pools are tens of MB per part)
     std::vector<const flx_run*> pieces{run};
     for (auto const& p : run->parts) pieces.push_back(&p);
@@ -1171,11 +1227,18 @@ extern "C" int flx_run_copy(const flx_run* run, flx_record* records, uint32_t* c
     };
     if (pieces.size() <= 2) for (size_t i = 0; i < pieces.size(); ++i) emit(i);
     else {
+        size_t const n_threads = std::min<size_t>(8, pieces.size());
         std::vector<std::thread> threads;
-        for (size_t i = 0; i < pieces.size(); ++i) threads.emplace_back(emit, i);
+        for (size_t t = 0; t < n_threads; ++t)
+            threads.emplace_back([&, t] { for (size_t i = t; i < pieces.size(); i += n_threads) emit(i); });
         for (auto& t : threads) t.join();
     }
     if (skipped && !run->skipped.empty()) memcpy(skipped, run->skipped.data(), run->skipped.size());
+    cprof.mark("copy");
     return FLX_OK;
 }
-extern "C" void flx_run_free(flx_run* run) { delete run; }
+extern "C" void flx_run_free(flx_run* run) {
+    PhaseTimer fprof("run_free");
+    delete run;
+    fprof.mark("free");
+}
