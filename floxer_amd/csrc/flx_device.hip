@@ -774,7 +774,7 @@ __global__ void __launch_bounds__(64) ed_band_kernel(const u8* __restrict__ text
     }
 }
 
-static const u32 kWordsPerLane[] = {1, 2, 3, 4, 6, 8, 13, 25};
+static const u32 kWordsPerLane[] = {1, 2, 3, 4, 5, 6, 8, 13, 25};
 
 static bool use_band() {
     static int const v = getenv("FLX_NO_BAND") ? 0 : 1;
@@ -852,6 +852,7 @@ int DeviceApi::align(void* stream, const u8* d_text, const u64* d_peq, const Dev
         case 2: return launch_align<2>(s, d_text, d_peq, d_jobs, n_jobs, log2_g, trace, b, d_trace, d_out);
         case 3: return launch_align<3>(s, d_text, d_peq, d_jobs, n_jobs, log2_g, trace, b, d_trace, d_out);
         case 4: return launch_align<4>(s, d_text, d_peq, d_jobs, n_jobs, log2_g, trace, b, d_trace, d_out);
+        case 5: return launch_align<5>(s, d_text, d_peq, d_jobs, n_jobs, log2_g, trace, b, d_trace, d_out);
         case 6: return launch_align<6>(s, d_text, d_peq, d_jobs, n_jobs, log2_g, trace, b, d_trace, d_out);
         case 8: return launch_align<8>(s, d_text, d_peq, d_jobs, n_jobs, log2_g, trace, b, d_trace, d_out);
         case 13: return launch_align<13>(s, d_text, d_peq, d_jobs, n_jobs, log2_g, trace, b, d_trace, d_out);

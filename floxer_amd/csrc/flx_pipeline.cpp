@@ -468,7 +468,32 @@ int choose_shapes(std::vector<AlignRequest> const& reqs, std::vector<AlignShape>
         if (shapes[i].words_per_lane == 0) { set_error("query longer than the supported maximum"); return FLX_ERR_UNSUPPORTED; }
         lanes += shapes[i].lanes_per_job;
     }
-    if (reqs.empty() || lanes / 64 >= ALIGN_FEW_WAVES) return FLX_OK;
+    auto fits = [](AlignRequest const& r, AlignShape const& sh) {
+        u32 const nw = (r.m + 63) / 64, W = sh.words_per_lane, R = sh.lanes_per_job;
+        i64 const width = (i64)r.n - (i64)r.m + 2 * (i64)r.k;
+        return (nw + W - 1) / W <= R || (sh.banded && (i64)64 * W * (R - 1) + R + 1 > width);
+    };
+    if (!reqs.empty() && lanes / 64 >= ALIGN_FEW_WAVES) {
+        // a launch lasts at least as long as its longest job: a handful of jobs with a shape of their own join the most common
+        // shape that can hold them instead of getting a launch
+        std::map<ShapeKey, u32> count;
+        for (auto const& sh : shapes) count[ShapeKey{sh.words_per_lane, sh.lanes_per_job, sh.banded}]++;
+        if (count.size() > 1) {
+            for (size_t i = 0; i < reqs.size(); ++i) {
+                ShapeKey const mine{shapes[i].words_per_lane, shapes[i].lanes_per_job, shapes[i].banded};
+                if (count[mine] >= 64) continue;
+                u32 best_n = 0;
+                AlignShape best = shapes[i];
+                for (auto const& kv : count) {
+                    AlignShape const cand{kv.first.w, kv.first.g, kv.first.banded};
+                    if (kv.second >= 64 && kv.second > best_n && fits(reqs[i], cand)) { best_n = kv.second; best = cand; }
+                }
+                shapes[i] = best;
+            }
+        }
+        return FLX_OK;
+    }
+    if (reqs.empty()) return FLX_OK;
     AlignShape common{0, 0, shapes[0].banded};
     for (size_t i = 0; i < reqs.size(); ++i) {
         AlignShape const p = choose_align_shape(reqs[i].n, reqs[i].m, reqs[i].k, true);
