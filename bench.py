@@ -17,6 +17,10 @@ import time
 
 import numpy as np
 
+# The lanes of a context are HIP streams; ROCm multiplexes a process's streams onto GPU_MAX_HW_QUEUES hardware queues (default 4)
+# and kernels of streams that share a queue do not overlap. Read by the HIP runtime when it initialises.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
@@ -28,8 +32,9 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--reads-per-step", type=int, default=int(os.environ.get("FLX_BENCH_READS", 4096)), help="per GPU")
-    ap.add_argument("--lanes", type=int, default=int(os.environ.get("FLX_LANES", 8)), help="concurrent lanes (stream + host thread) per GPU")
+    ap.add_argument("--reads-per-step", type=int, default=int(os.environ.get("FLX_BENCH_READS", 16384)), help="per GPU")
+    ap.add_argument("--lanes", type=int, default=int(os.environ.get("FLX_LANES", 0)),
+                    help="concurrent lanes (stream + host thread) per GPU; 0 = one per host core this rank can use, 4..16")
     ap.add_argument("--isolated-only", action="store_true",
                     help="only the one-lane instrumented pass (used under rocprofv3 so that its per-kernel averages are those of roofline_isolated)")
     ap.add_argument("--genome", type=int, default=4_600_000, help="synthetic reference length (E. coli K-12 size)")
@@ -60,6 +65,10 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", 1))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+
+    if args.lanes <= 0:
+        local_world = int(os.environ.get("LOCAL_WORLD_SIZE", world))
+        args.lanes = max(4, min(16, usable_cores() // max(1, local_world)))
 
     import torch
     import torch.distributed as dist
@@ -173,10 +182,11 @@ def main():
 
         def load_traffic(name, st):
             """HBM bytes per launch = algorithmic bytes per launch x (PMC bytes / algorithmic bytes) of the committed FETCH_SIZE /
-            WRITE_SIZE passes over this workload (profiles/r01_pmc_traffic.json; launches per pass vary with the trace arena)"""
+            WRITE_SIZE passes over this workload (profiles/r01_pmc_traffic_<kernel>.json; launches per pass vary with the trace
+            arena, the ratio does not)"""
             try:
-                t = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
-                if t.get("kernel") == name and t.get("reads_per_step") == B:
+                t = json.load(open(os.path.join(ROOT, "profiles", f"r01_pmc_traffic_{name}.json")))
+                if t.get("kernel") == name and t.get("read_length") == args.read_length:
                     return int(st["algorithmic_bytes"] / st["launches"] * t["traffic_over_algorithmic"])
             except (OSError, ValueError, KeyError):
                 pass

@@ -298,7 +298,7 @@ int main(int argc, char** argv) {
     auto const t_align = std::chrono::steady_clock::now();
     LineReader qin(o.queries.c_str());
     if (!qin.f) { log_line("error", "cannot open %s", o.queries.c_str()); return -1; }
-    size_t batch_reads = 2048;
+    size_t batch_reads = 16384;      // 1024 reads per lane and chunk (see flx_align_reads_resident)
     if (const char* env = getenv("FLX_BATCH_READS")) { size_t const v = strtoull(env, nullptr, 10); if (v) batch_reads = v; }
     ReadBatch batch;
     std::string id, seq, qual;

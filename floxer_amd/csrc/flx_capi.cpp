@@ -1,8 +1,10 @@
 // C ABI: host arithmetic, PEX trees, index lifetime, device context, kernel accounting.
+#include <algorithm>
 #include <cstdlib>
 #include <cstring>
 #include <malloc.h>
 #include <memory>
+#include <thread>
 
 #include "flx_context.hpp"
 
@@ -79,6 +81,11 @@ int flx_index_copy_bwt(const flx_index* index, int reversed, uint8_t* out) {
 }
 
 // ---------------------------------------------------------------- context
+// ROCm multiplexes a process's HIP streams onto GPU_MAX_HW_QUEUES hardware queues (default 4); kernels of lanes that share a
+// queue do not overlap. The HIP runtime reads the variable when it initialises, so it is set when this library is loaded (an
+// existing value wins). A host program that initialises HIP before loading the library sets it itself.
+__attribute__((constructor)) static void flx_default_hw_queues() { setenv("GPU_MAX_HW_QUEUES", "16", 0); }
+
 int flx_ctx_create(int hip_device, const flx_index* index, flx_ctx** out) {
     if (!index || !out) { set_error("flx_ctx_create: null argument"); return FLX_ERR_INVALID; }
     int count = 0;
@@ -100,7 +107,8 @@ int flx_ctx_create(int hip_device, const flx_index* index, flx_ctx** out) {
         mallopt(M_TRIM_THRESHOLD, 1 << 30);
         mallopt(M_TOP_PAD, 256 << 20);
     }
-    size_t n_lanes = 4;
+    // one lane per host thread the process may use, at most 16 (FLX_LANES overrides)
+    size_t n_lanes = std::max<size_t>(4, std::min<size_t>(16, std::thread::hardware_concurrency()));
     if (const char* env = getenv("FLX_LANES")) { size_t const v = strtoull(env, nullptr, 10); if (v >= 1 && v <= 16) n_lanes = v; }
     for (size_t l = 0; l < n_lanes; ++l) {
         auto lane = std::make_unique<Lane>();
