@@ -35,6 +35,9 @@ def parse():
     ap.add_argument("--reads-per-step", type=int, default=int(os.environ.get("FLX_BENCH_READS", 16384)), help="per GPU")
     ap.add_argument("--lanes", type=int, default=int(os.environ.get("FLX_LANES", 0)),
                     help="concurrent lanes (stream + host thread) per GPU; 0 = one per host core this rank can use, 4..16")
+    ap.add_argument("--inflight", type=int, default=int(os.environ.get("FLX_BENCH_INFLIGHT", 2)),
+                    help="steps submitted to the context at a time (host threads calling align_reads); every step still runs in "
+                         "full inside the timed region")
     ap.add_argument("--isolated-only", action="store_true",
                     help="only the one-lane instrumented pass (used under rocprofv3 so that its per-kernel averages are those of roofline_isolated)")
     ap.add_argument("--genome", type=int, default=4_600_000, help="synthetic reference length (E. coli K-12 size)")
@@ -122,13 +125,20 @@ def main():
         ctx.enable_kernel_timing(True)
         ctx.reset_kernel_stats()
 
+        from concurrent.futures import ThreadPoolExecutor
+        pool = ThreadPoolExecutor(max_workers=max(1, args.inflight))
+
         barrier()
         t_start = time.perf_counter()
-        for s in range(args.steps):
-            res = al.align_reads(resident[args.warmup + s])
-            n_records += gather_records(res)
+        # a step = the whole hot path over one batch. Batches are independent (floxer itself streams reads through a thread
+        # pool without a barrier between them), so up to --inflight steps are in the context at once: while one batch's lanes
+        # are in a host phase another batch's kernels keep the GPU busy. All K steps start and finish inside the timed region.
+        futures = [pool.submit(al.align_reads, resident[args.warmup + s]) for s in range(args.steps)]
+        for f in futures:
+            n_records += gather_records(f.result())
         barrier()
         elapsed = time.perf_counter() - t_start
+        pool.shutdown()
         if world > 1:
             t = torch.tensor([elapsed], device=torch.device("cuda", local_rank), dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -224,7 +234,7 @@ def main():
                                    f"@ {args.error_rate:.0%} error (BASELINE.json configs[1] shape; E. coli itself is not available offline)",
                        "reads_per_step_per_gpu": B, "mean_read_length": round(mean_len, 1), "cli_flags": "defaults (-s 2 -M 500 -m 50 "
                        "-g count_first -y round_robin -v 0.05)" + (" -I" if args.interval_optimization else ""),
-                       "lanes_per_gpu": args.lanes, "parallelism": f"read-sharded x{world}, index replicated"},
+                       "lanes_per_gpu": args.lanes, "steps_in_flight": args.inflight, "parallelism": f"read-sharded x{world}, index replicated"},
             "gbases_per_s": round(value * mean_len / 1e9, 5), "records": n_records, "index_build_s": round(index_s, 2),
             "roofline": roofline, "roofline_isolated": roofline_iso, "cpu_baseline": cpu, "kernels": kernels,
             "kernels_isolated": {k: {"launches": v["launches"], "device_ms": round(v["device_ms"], 3),

@@ -117,7 +117,9 @@ int flx_ctx_create(int hip_device, const flx_index* index, flx_ctx** out) {
         FLX_HIP(hipStreamCreateWithFlags(&lane->own_stream, hipStreamNonBlocking));
         lane->stream = lane->own_stream;
         ctx->lanes.push_back(std::move(lane));
+        ctx->free_lanes.push_back((int)l);
     }
+    FLX_HIP(hipStreamCreateWithFlags(&ctx->upload_stream, hipStreamNonBlocking));
     hipStream_t const s0 = ctx->lanes[0]->stream;
     HostIndex const& H = *index->host;
     int rc;
@@ -157,6 +159,7 @@ void flx_ctx_destroy(flx_ctx* ctx) {
     (void)hipSetDevice(ctx->device);
     for (auto& lane : ctx->lanes) { (void)hipStreamSynchronize(lane->stream); lane->release_all(); }
     for (DeviceBuffer* b : {&ctx->occ0, &ctx->occ1, &ctx->sa, &ctx->text, &ctx->text_rev, &ctx->kmer}) b->release();
+    if (ctx->upload_stream) (void)hipStreamDestroy(ctx->upload_stream);
     delete ctx;
 }
 

@@ -3,6 +3,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <condition_variable>
 #include <map>
 #include <memory>
 #include <mutex>
@@ -64,11 +65,19 @@ struct flx_ctx {
     bool text_rev_ready = false;
     std::mutex mu;                   // guards text_rev upload and the statistics
     std::vector<std::unique_ptr<flx::Lane>> lanes;
+    hipStream_t upload_stream = nullptr;   // flx_reads_upload copies here, so that it can run while the lanes are busy
     bool external_stream = false;    // a caller-owned stream is installed on lane 0: run on that lane only
     // accounting
     bool timing = false;
     std::map<std::string, flx_kernel_stat> stats;
     std::vector<std::string> stat_order;
+
+    // lanes are handed out one holder at a time, so calls on one context may overlap (each waits for a free lane)
+    std::mutex lane_mu;
+    std::condition_variable lane_cv;
+    std::vector<int> free_lanes;     // indices into `lanes`
+    flx::Lane* acquire_lane(int wanted = -1);   // blocks; wanted >= 0: that lane
+    void release_lane(flx::Lane* lane);
 
     flx::Lane* lane0() { return lanes[0].get(); }
     int sync_all();
@@ -76,6 +85,15 @@ struct flx_ctx {
 };
 
 namespace flx {
+
+struct LaneLease {
+    flx_ctx* ctx;
+    Lane* lane;
+    explicit LaneLease(flx_ctx* c, int wanted = -1) : ctx(c), lane(c->acquire_lane(wanted)) {}
+    ~LaneLease() { ctx->release_lane(lane); }
+    LaneLease(LaneLease const&) = delete;
+    LaneLease& operator=(LaneLease const&) = delete;
+};
 
 // brackets a launch with events when timing is enabled
 template <class F>

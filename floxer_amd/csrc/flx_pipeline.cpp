@@ -113,6 +113,22 @@ int Lane::sync() {
     }
     return FLX_OK;
 }
+flx::Lane* flx_ctx::acquire_lane(int wanted) {
+    std::unique_lock<std::mutex> g(lane_mu);
+    while (true) {
+        for (size_t i = 0; i < free_lanes.size(); ++i)
+            if (wanted < 0 || free_lanes[i] == wanted) {
+                int const id = free_lanes[i];
+                free_lanes.erase(free_lanes.begin() + (long)i);
+                return lanes[(size_t)id].get();
+            }
+        lane_cv.wait(g);
+    }
+}
+void flx_ctx::release_lane(flx::Lane* lane) {
+    { std::lock_guard<std::mutex> g(lane_mu); free_lanes.push_back(lane->id); }
+    lane_cv.notify_all();
+}
 int flx_ctx::sync_all() {
     for (auto& l : lanes) { int rc = l->sync(); if (rc) return rc; }
     return FLX_OK;
@@ -588,6 +604,7 @@ int run_trace_jobs_unique(Lane* ctx, const u8* d_text, const u8* d_query, const 
                           std::vector<TraceResult>& results, std::vector<u32>& cigar_pool) {
     results.assign(reqs.size(), TraceResult{});
     if (reqs.empty()) return FLX_OK;
+    PhaseTimer tprof("trace-jobs");
     std::vector<AlignShape> shapes;
     if (int const src = choose_shapes(reqs, shapes)) return src;
     std::vector<u64> slots(reqs.size());
@@ -634,6 +651,7 @@ int run_trace_jobs_unique(Lane* ctx, const u8* d_text, const u8* d_query, const 
             }
             launches.push_back(l);
         }
+        tprof.mark("prep");
         if ((rc = h2d(ctx, ctx->jobs, jobs.data(), jobs.size() * sizeof(DevAlignJob)))) return rc;
         if ((rc = ctx->job_out.ensure(count * sizeof(DevAlignOut)))) return rc;
         for (auto const& l : launches) {
@@ -647,6 +665,7 @@ int run_trace_jobs_unique(Lane* ctx, const u8* d_text, const u8* d_query, const 
         std::vector<DevAlignOut> outs(count);
         if ((rc = d2h(ctx, outs.data(), ctx->job_out.ptr, count * sizeof(DevAlignOut)))) return rc;
         if ((rc = ctx->sync())) return rc;
+        tprof.mark("K4");
 
         // ---- traceback for the jobs that have an alignment within k
         std::vector<DevTraceJob> tjobs;
@@ -675,12 +694,15 @@ int run_trace_jobs_unique(Lane* ctx, const u8* d_text, const u8* d_query, const 
                                             (u32)tjobs.size(), shapes[begin].banded != 0, ctx->cigar.as<u32>(), ctx->tjob_out.as<DevTraceOut>());
             });
             if (rc) return rc;
+            tprof.mark("tb-prep");
             std::vector<DevTraceOut> touts(tjobs.size());
             size_t const pool_base = cigar_pool.size();
             cigar_pool.resize(pool_base + cigar_words);          // slabs are kept as they are (gaps included): no host repacking
+            tprof.mark("pool-resize");
             if ((rc = d2h(ctx, touts.data(), ctx->tjob_out.ptr, touts.size() * sizeof(DevTraceOut)))) return rc;
             if ((rc = d2h(ctx, cigar_pool.data() + pool_base, ctx->cigar.ptr, cigar_words * 4))) return rc;
             if ((rc = ctx->sync())) return rc;
+            tprof.mark("K5+d2h");
             for (size_t j = 0; j < tjobs.size(); ++j) {
                 if (touts[j].cigar_len == 0xFFFFFFFFu) { set_error("ed_traceback: CIGAR slab overflow"); return FLX_ERR_INTERNAL; }
                 TraceResult& res = results[tjob_req[j]];
@@ -728,7 +750,8 @@ extern "C" int flx_search_seeds(flx_ctx* ctx, const uint8_t* seq_pool, uint64_t 
     FLX_HIP(hipSetDevice(ctx->device));
     std::vector<HostAnchor> anchors;
     std::vector<SeedStats> stats;
-    int rc = search_seeds_device(ctx->lane0(), nullptr, seq_pool, seq_pool_len, seeds, n_seeds, *cfg, anchors, stats, nullptr, 0);
+    LaneLease lease(ctx, ctx->external_stream ? 0 : -1);
+    int rc = search_seeds_device(lease.lane, nullptr, seq_pool, seq_pool_len, seeds, n_seeds, *cfg, anchors, stats, nullptr, 0);
     if (rc) return rc;
     uint64_t const cap = *n_anchors;
     *n_anchors = anchors.size();
@@ -747,7 +770,8 @@ extern "C" int flx_search_groups(flx_ctx* ctx, const uint8_t* seq_pool, uint64_t
     std::vector<SeedStats> stats;
     std::vector<DevHit> hits;
     flx_search_config cfg{};
-    int rc = search_seeds_device(ctx->lane0(), nullptr, seq_pool, seq_pool_len, seeds, n_seeds, cfg, anchors, stats, &hits, max_hits_per_seed);
+    LaneLease lease(ctx, ctx->external_stream ? 0 : -1);
+    int rc = search_seeds_device(lease.lane, nullptr, seq_pool, seq_pool_len, seeds, n_seeds, cfg, anchors, stats, &hits, max_hits_per_seed);
     if (rc) return rc;
     uint64_t const cap = *n_out;
     *n_out = hits.size();
@@ -774,7 +798,8 @@ extern "C" int flx_align_batch(flx_ctx* ctx, const uint8_t* ref_pool, uint64_t r
         any_trace |= j.mode == FLX_MODE_WITH_CIGAR;
     }
     int rc;
-    Lane* L = ctx->lane0();
+    LaneLease lease(ctx, ctx->external_stream ? 0 : -1);
+    Lane* L = lease.lane;
     const u8* d_text = ctx->didx.text;
     const u8* d_text_rev = nullptr;
     std::vector<u8> tmp;
@@ -950,7 +975,7 @@ extern "C" int flx_reads_upload(flx_ctx* ctx, const uint8_t* read_pool, const ui
     }
     int rc = rd->d_pool.ensure(total + 256);
     if (rc) return rc;
-    hipStream_t const s0 = ctx->lane0()->stream;
+    hipStream_t const s0 = ctx->external_stream ? ctx->lane0()->stream : ctx->upload_stream;
     if (total) FLX_HIP(hipMemcpyAsync(rd->d_pool.ptr, rd->pool.data(), total, hipMemcpyHostToDevice, s0));
     FLX_HIP(hipMemsetAsync((char*)rd->d_pool.ptr + total, 0, 192, s0));
     FLX_HIP(hipStreamSynchronize(s0));
@@ -1200,18 +1225,20 @@ extern "C" int flx_align_reads_resident(flx_ctx* ctx, const flx_params* P, const
     std::vector<std::string> errs(n_chunks);
     std::atomic<size_t> next_chunk{0};
     std::atomic<bool> failed{false};
-    auto work = [&](size_t l) {
+    auto work = [&]() {
         for (size_t c; (c = next_chunk.fetch_add(1)) < n_chunks && !failed.load();) {
             u64 const a = c * chunk_reads, b = std::min<u64>(n_reads, a + chunk_reads);
             parts[c].skipped.assign(n_reads, 0);
-            rcs[c] = align_slice(ctx->lanes[l].get(), P, RD, a, b, &parts[c]);
+            LaneLease lease(ctx, ctx->external_stream ? 0 : -1);      // waits while other calls on this context hold all lanes
+            rcs[c] = align_slice(lease.lane, P, RD, a, b, &parts[c]);
             if (rcs[c]) { errs[c] = flx_last_error(); failed.store(true); }
         }
     };
-    if (n_lanes == 1) work(0);
+    size_t const n_workers = std::min(n_lanes, n_chunks);
+    if (n_workers == 1) work();
     else {
         std::vector<std::thread> threads;
-        for (size_t l = 0; l < n_lanes; ++l) threads.emplace_back(work, l);
+        for (size_t l = 0; l < n_workers; ++l) threads.emplace_back(work);
         for (auto& t : threads) t.join();
     }
     dprof.mark("lanes");

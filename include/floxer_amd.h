@@ -5,8 +5,11 @@
  * below replaces one of those seams and cites it. Conventions: caller owns every buffer; plain pointers + sizes; no
  * exceptions cross the boundary — every function returns FLX_OK (0) or a negative flx_status and flx_last_error()
  * describes the failure (the reference throws C++ exceptions that its task wrappers turn into a stop flag,
- * parallelization.cpp:149-157). A flx_ctx owns one HIP device, one stream and its HBM-resident index; calls on
- * different contexts are independent, calls on one context must not overlap.
+ * parallelization.cpp:149-157). A flx_ctx owns one HIP device, its HBM-resident index and a set of lanes (a HIP stream with
+ * its workspaces each); calls on different contexts are independent. The compute calls (flx_search_seeds, flx_search_groups,
+ * flx_align_batch, flx_align_reads*, flx_reads_upload) may be issued from several host threads on one context: each takes a
+ * free lane and waits when there is none, so batches overlap on the GPU. Configuration calls (flx_ctx_set_stream,
+ * flx_ctx_enable_kernel_timing, flx_ctx_reset_kernel_stats, flx_ctx_destroy) must not overlap anything else.
  *
  * Sequences are rank sequences as the reference stores them (input.cpp:165-176): $=0 A=1 C=2 G=3 T=4 N/other=5.
  * CIGARs are BAM words (len<<4|op) with ops I=1 D=2 '='=7 X=8 (extended CIGAR, alignment.cpp:178).
