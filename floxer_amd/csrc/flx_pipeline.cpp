@@ -475,7 +475,10 @@ void dedup_requests(std::vector<AlignRequest> const& reqs, std::vector<AlignRequ
 // Shapes for the jobs of one call. Many jobs: each gets the shape that costs the fewest wave slots. Few jobs (they would leave
 // most SIMDs without a wave): all get one common shape with the fewest words per lane, i.e. more, shorter-running waves and a
 // single launch.
-constexpr u64 ALIGN_FEW_WAVES = 2048;
+u64 align_few_waves() {          // FLX_ALIGN_FEW_WAVES overrides the threshold (tests force either form)
+    const char* env = getenv("FLX_ALIGN_FEW_WAVES");
+    return env ? strtoull(env, nullptr, 10) : 2048;
+}
 int choose_shapes(std::vector<AlignRequest> const& reqs, std::vector<AlignShape>& shapes) {
     shapes.resize(reqs.size());
     u64 lanes = 0;
@@ -489,7 +492,7 @@ int choose_shapes(std::vector<AlignRequest> const& reqs, std::vector<AlignShape>
         i64 const width = (i64)r.n - (i64)r.m + 2 * (i64)r.k;
         return (nw + W - 1) / W <= R || (sh.banded && (i64)64 * W * (R - 1) + R + 1 > width);
     };
-    if (!reqs.empty() && lanes / 64 >= ALIGN_FEW_WAVES) {
+    if (!reqs.empty() && lanes / 64 >= align_few_waves()) {
         // a launch lasts at least as long as its longest job: a handful of jobs with a shape of their own join the most common
         // shape that can hold them instead of getting a launch
         std::map<ShapeKey, u32> count;

@@ -439,3 +439,66 @@ def test_many_references_and_n_runs():
     assert res.records() == exp.records()
     assert sum(1 for r in res.records() if not r[1] & 4 and not r[1] & 256) >= 25
     ctx.close()
+
+
+# ---------------------------------------------------------------- scheduling must not change results
+def _run_with_env(genome, reads, env, **kw):
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
+    try:
+        idx = F.fmindex(genome)
+        ctx = F.context(idx)                      # FLX_LANES is read here, the other variables per call
+        res = F.aligner(ctx, F.params(error_probability=0.07, **kw)).align_reads(reads)
+        out = (res.skipped.tolist(), res.records())
+        ctx.close()
+        return out
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+@pytest.mark.parametrize("kw", [dict(), dict(interval_optimization=True)])
+def test_lanes_chunks_and_launch_forms_give_the_same_records(kw):
+    """one lane / several lanes with small chunks; alignment launches forced to the wave-slot-minimal or to the parallel form"""
+    genome = S.make_genome(300000, 2, seed=31)
+    reads, _, _ = S.make_reads(genome, 200, 1500, 0.07, seed=32)
+    base = _run_with_env(genome, reads, {"FLX_LANES": "1"}, **kw)
+    assert sum(1 for r in base[1] if not r[1] & 4) >= 150
+    assert _run_with_env(genome, reads, {"FLX_LANES": "4", "FLX_CHUNK_READS": "16"}, **kw) == base
+    assert _run_with_env(genome, reads, {"FLX_LANES": "3", "FLX_CHUNK_READS": "70"}, **kw) == base
+    assert _run_with_env(genome, reads, {"FLX_LANES": "2", "FLX_ALIGN_FEW_WAVES": "0"}, **kw) == base
+    assert _run_with_env(genome, reads, {"FLX_LANES": "2", "FLX_ALIGN_FEW_WAVES": "1000000000"}, **kw) == base
+    exp = O.Index(genome).run(reads[:40], O.params(error_probability=0.07, interval_opt=kw.get("interval_optimization", False)), threads=8)
+    assert [r for r in base[1] if r[0] < 40] == exp.records()
+
+
+def test_overlapping_calls_on_one_context():
+    """compute calls from several host threads share the context's lanes; every call returns what it returns alone"""
+    from concurrent.futures import ThreadPoolExecutor
+    genome = S.make_genome(300000, 1, seed=41)
+    batches = [S.make_reads(genome, 150, 1200, 0.06, seed=42 + b)[0] for b in range(4)]
+    old = os.environ.get("FLX_LANES")
+    os.environ["FLX_LANES"] = "3"
+    try:
+        idx = F.fmindex(genome)
+        ctx = F.context(idx)
+    finally:
+        if old is None:
+            os.environ.pop("FLX_LANES", None)
+        else:
+            os.environ["FLX_LANES"] = old
+    al = F.aligner(ctx, F.params(error_probability=0.06))
+    resident = [F.resident_reads(ctx, b) for b in batches]
+    alone = [al.align_reads(r).records() for r in resident]
+    with ThreadPoolExecutor(max_workers=4) as pool:
+        together = [f.result().records() for f in [pool.submit(al.align_reads, r) for r in resident]]
+        uploads = [f.result() for f in [pool.submit(F.resident_reads, ctx, b) for b in batches]]      # uploads while nothing else runs
+        mixed = [f.result().records() for f in [pool.submit(al.align_reads, r) for r in uploads + resident]]
+    assert together == alone
+    assert mixed == alone + alone
+    for r in resident + uploads:
+        r.close()
+    ctx.close()
