@@ -126,7 +126,8 @@ __device__ __forceinline__ u32 st_pack(u32 x, u32 e, u32 li, u32 ri, u32 sym, u3
 #define ST_RIGHT(s) (((s) >> 30) & 1u)
 
 // counters: [0] hit slots reserved, [1] stack overflow flag, [2] cursor extensions (rank pairs), [3] unused,
-//           [4] wave-iterations, [5] max iterations of a wave, [6] busy pair-iterations
+//           [4] wave-iterations, [5] max iterations of a wave, [6] busy pair-iterations, [7] seed queue head,
+//           [8] wave-iterations after the seed queue ran dry, [9] their maximum over the waves
 //
 // DFS sizes differ by orders of magnitude between seeds, so neither pairs nor waves are bound to seeds: the launch is a fixed
 // number of waves, a wave takes FM_GRAB consecutive seeds at a time from a global counter (counters[7]) and hands them to its pairs
@@ -149,7 +150,7 @@ __global__ void __launch_bounds__(64) fm_search_kernel(DevIndex idx, const u8* _
     u32 const h = lane & 1u;                    // lane within the pair
     u32 const sym0 = 4u * h;                    // first counter slot / symbol owned by this lane
 
-    u32 n_ext = 0, n_iter = 0, n_busy_iter = 0;
+    u32 n_ext = 0, n_iter = 0, n_busy_iter = 0, n_tail_iter = 0;
     // ---- per-seed state (replicated in the pair)
     bool busy = false, exhausted = false;
     u32 sid = 0, srch = 0, num_searches = 0, len = 0, ct = 0, stack_frames = 0;
@@ -253,6 +254,7 @@ __global__ void __launch_bounds__(64) fm_search_kernel(DevIndex idx, const u8* _
         }
         if (__all(exhausted && !busy)) break;
         ++n_iter;
+        if (queue_done && q_next == q_end) ++n_tail_iter;
         if (!busy) continue;
         ++n_busy_iter;
 
@@ -297,9 +299,8 @@ __global__ void __launch_bounds__(64) fm_search_kernel(DevIndex idx, const u8* _
                 if (h == 0) { f_abs[2] = v1.z; f_oth[2] = v1.w; f_cl[2] = v2.x; f_abs[3] = v2.y; f_oth[3] = v2.z; f_cl[3] = v2.w; }
                 else { f_abs[2] = 0; f_oth[2] = 0; f_cl[2] = 0; f_abs[3] = 0; f_oth[3] = 0; f_cl[3] = 0; }
                 f_lb = pair_odd(v1.z); f_lbr = pair_odd(v1.w); f_len = pair_odd(v2.x); f_state = pair_odd(v2.y);
-                f_mask = pair_even(v0.x);
+                f_mask = pair_even(v0.x);                                  // never empty: exhausted frames are not pushed
                 have_frame = true;
-                continue;
             }
             u32 const ci = (u32)__ffs((int)f_mask) - 1u;
             f_mask &= f_mask - 1u;
@@ -365,8 +366,9 @@ __global__ void __launch_bounds__(64) fm_search_kernel(DevIndex idx, const u8* _
         }
 
         if (mismatch_allowed) {
-            // this node branches: it becomes the top frame, the previous top goes to memory (48 bytes per lane)
-            if (have_frame) {
+            // this node branches: it becomes the top frame, the previous top goes to memory (48 bytes per lane) unless all
+            // of its children have been taken already
+            if (have_frame && f_mask != 0u) {
                 if (depth >= stack_frames) { if (h == 0) atomicOr(&counters[1], 1u); busy = false; continue; }
                 uint4 v0, v1, v2;
                 v0.x = h ? f_abs[0] : f_mask; v0.y = f_oth[0]; v0.z = f_cl[0]; v0.w = f_abs[1];
@@ -416,7 +418,7 @@ __global__ void __launch_bounds__(64) fm_search_kernel(DevIndex idx, const u8* _
     }
     fill_rest();
     if (h == 0) { atomicAdd(&counters[2], n_ext); atomicAdd(&counters[6], n_busy_iter); }
-    if (threadIdx.x == 0) { atomicAdd(&counters[4], n_iter); atomicMax(&counters[5], n_iter); }
+    if (threadIdx.x == 0) { atomicAdd(&counters[4], n_iter); atomicMax(&counters[5], n_iter); atomicAdd(&counters[8], n_tail_iter); atomicMax(&counters[9], n_tail_iter); }
 }
 
 int DeviceApi::search(void* stream, const DevIndex& idx, const u8* d_seq, const u32* d_scheme, const DevSeed* d_seeds, u32 n_seeds,
@@ -1061,30 +1063,38 @@ __global__ void __launch_bounds__(64) ed_traceback_ckpt_kernel(const u8* __restr
                     prev = nxt;
                 }
             }
-            u32 cw = 0;
-            int cw_block = -1;
-            for (int tt = t0; tt <= t; ++tt) {
-                int const cc = tt - g;
-                if (cc >= c_lo && cc <= c_hi) {
-                    int const blk = tt / (int)TRACE_CARRY_STEPS;
-                    if (blk != cw_block) { cw = carry[((u64)blk * R + p) * W + w]; cw_block = blk; }
-                    u32 const cb = (cw >> (2u * ((u32)tt % TRACE_CARRY_STEPS))) & 3u;
-                    u64 const c_hp = cb & 1u, c_hn = cb >> 1;
-                    u32 const ro = (u32)(cc - ref_base);
-                    u32 const rsym = (u32)(refc[ro >> 3][lane] >> (8u * (ro & 7u))) & 7u;
-                    u64 const eq = eqc[rsym][lane];
-                    u64 const x = eq | mv;
-                    u64 const sum = pv + (x & pv) + c_hn;
-                    u64 const d0 = (sum ^ pv) | x;
-                    u64 const hn = pv & d0;
-                    u64 const hp = mv | ~(pv | d0);
-                    u64 const xh = (hp << 1) | c_hp;
-                    mv = xh & d0;
-                    pv = (hn << 1) | ~(xh | d0) | c_hn;
-                    ulonglong2 o;
-                    o.x = hp;
-                    o.y = pv;
-                    win[(u32)tt % TRACE_CKPT][lane] = o;
+            // the carry words of all 16-step blocks the recomputation touches (at most 2*TRACE_CKPT-1 steps: five blocks) are
+            // fetched up front, together with the checkpoint and the symbols: one memory latency per window instead of one per block
+            int const b0 = t0 / (int)TRACE_CARRY_STEPS, b1 = t / (int)TRACE_CARRY_STEPS;
+            u32 cwv[5];
+#pragma unroll
+            for (int x = 0; x < 5; ++x) cwv[x] = b0 + x <= b1 ? carry[((u64)(b0 + x) * R + p) * W + w] : 0u;
+#pragma unroll
+            for (int x = 0; x < 5; ++x) {
+                int const blk = b0 + x;
+                u32 const cw = cwv[x];
+                int const tt_hi = min(t, blk * (int)TRACE_CARRY_STEPS + (int)TRACE_CARRY_STEPS - 1);
+                for (int tt = max(t0, blk * (int)TRACE_CARRY_STEPS); tt <= tt_hi; ++tt) {
+                    int const cc = tt - g;
+                    if (cc >= c_lo && cc <= c_hi) {
+                        u32 const cb = (cw >> (2u * ((u32)tt % TRACE_CARRY_STEPS))) & 3u;
+                        u64 const c_hp = cb & 1u, c_hn = cb >> 1;
+                        u32 const ro = (u32)(cc - ref_base);
+                        u32 const rsym = (u32)(refc[ro >> 3][lane] >> (8u * (ro & 7u))) & 7u;
+                        u64 const eq = eqc[rsym][lane];
+                        u64 const x_ = eq | mv;
+                        u64 const sum = pv + (x_ & pv) + c_hn;
+                        u64 const d0 = (sum ^ pv) | x_;
+                        u64 const hn = pv & d0;
+                        u64 const hp = mv | ~(pv | d0);
+                        u64 const xh = (hp << 1) | c_hp;
+                        mv = xh & d0;
+                        pv = (hn << 1) | ~(xh | d0) | c_hn;
+                        ulonglong2 o;
+                        o.x = hp;
+                        o.y = pv;
+                        win[(u32)tt % TRACE_CKPT][lane] = o;
+                    }
                 }
             }
             win_gw = gw;

@@ -253,7 +253,7 @@ int search_seeds_device(Lane* ctx, const u8* d_seq_pool_or_null, const u8* h_seq
                                          : (u32)std::max(cfg.max_num_anchors_hard, cfg.max_num_anchors_hard + 1));
     u64 const hit_slack = 4096 * 64;            // unused ends of the per-wave slot ranges (FM_MAX_WAVES x FM_HIT_GRAB)
     u64 hit_cap = n_seeds * 6 + hit_slack;
-    u32 counters[8];
+    u32 counters[16];
     for (int attempt = 0;; ++attempt) {
         if ((rc = ctx->hits.ensure(hit_cap * sizeof(DevHit)))) return rc;
         FLX_HIP(hipMemsetAsync(ctx->counters.ptr, 0, 64, ctx->stream));
@@ -263,9 +263,9 @@ int search_seeds_device(Lane* ctx, const u8* d_seq_pool_or_null, const u8* h_seq
                                      ctx->counters.as<u32>());
         });
         if (rc) return rc;
-        if ((rc = d2h(ctx, counters, ctx->counters.ptr, 32))) return rc;
+        if ((rc = d2h(ctx, counters, ctx->counters.ptr, 64))) return rc;
         if ((rc = ctx->sync())) return rc;
-        if (getenv("FLX_SEARCH_DEBUG")) fprintf(stderr, "[fm_search] seeds %llu ext %u wave-iterations %u (max per wave %u) busy lane-iterations %u\n", (unsigned long long)n_seeds, counters[2], counters[4], counters[5], counters[6]);
+        if (getenv("FLX_SEARCH_DEBUG")) fprintf(stderr, "[fm_search] seeds %llu ext %u wave-iterations %u (max per wave %u) busy pair-iterations %u, after the queue ran dry %u (max %u)\n", (unsigned long long)n_seeds, counters[2], counters[4], counters[5], counters[6], counters[8], counters[9]);
         if (counters[1]) { set_error("fm_search: DFS stack reservation exceeded"); return FLX_ERR_INTERNAL; }
         if (counters[0] <= hit_cap) break;
         if (attempt >= 2) { set_error("fm_search: hit buffer could not be sized"); return FLX_ERR_INTERNAL; }

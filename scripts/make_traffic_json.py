@@ -1,22 +1,31 @@
-"""Builds profiles/<round>_pmc_traffic.json from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; separate runs as the
-MI355X guide prescribes) of `bench.py --isolated-only`. gfx950 corrections (MI355X_MICROARCH.md, HBM): counters are in KiB;
-FETCH_SIZE reports half of the bytes of wide coalesced reads (doubled here); WRITE_SIZE is exact for 16-B-per-lane stores."""
-import csv, json, sys
-fetch_csv, write_csv, kernel_substr, out_path, reads_per_step, algorithmic_bytes_per_pass, kernel_name = sys.argv[1:8]
-def total(path, counter):
+"""Builds profiles/<round>_pmc_traffic_<kernel>.json from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; separate runs as the
+MI355X guide prescribes) of `bench.py --isolated-only` and that run's JSON line. gfx950 corrections (MI355X_MICROARCH.md, HBM):
+counters are in KiB; FETCH_SIZE reports half of the bytes of wide coalesced reads (doubled here); WRITE_SIZE is exact for
+16-B-per-lane stores.
+Usage: make_traffic_json.py fetch.csv write.csv isolated.json out_dir prefix"""
+import csv, json, os, sys
+fetch_csv, write_csv, iso_json, out_dir, prefix = sys.argv[1:6]
+iso = json.load(open(iso_json))
+KERNELS = {"fm_search": "fm_search_kernel", "ed_align_trace": "true>(", "ed_align_exists": "false>(", "ed_traceback": "traceback"}
+def total(path, sub, counter):
     t, n = 0.0, 0
     for row in csv.DictReader(open(path)):
-        if kernel_substr in row["Kernel_Name"] and row["Counter_Name"] == counter:
+        if sub in row["Kernel_Name"] and row["Counter_Name"] == counter:
             t += float(row["Counter_Value"]); n += 1
     return t, n
-f, nf = total(fetch_csv, "FETCH_SIZE")
-w, nw = total(write_csv, "WRITE_SIZE")
 passes = 2           # --isolated-only runs the batch twice (warm + measured)
-hbm = (2.0 * f + w) * 1024.0 / passes
-alg = float(algorithmic_bytes_per_pass)
-json.dump({"kernel": kernel_name, "kernel_symbol": kernel_substr, "reads_per_step": int(reads_per_step),
+for name, sub in KERNELS.items():
+    st = iso["kernels_isolated"].get(name)
+    if not st:
+        continue
+    alg = st["GBps"] * 1e6 * st["device_ms"]           # algorithmic bytes of the measured pass
+    f, nf = total(fetch_csv, sub, "FETCH_SIZE")
+    w, nw = total(write_csv, sub, "WRITE_SIZE")
+    hbm = (2.0 * f + w) * 1024.0 / passes
+    out = {"kernel": name, "kernel_symbol": sub, "reads_per_step": iso["config"]["reads_per_step_per_gpu"],
+           "read_length": int(round(iso["config"]["mean_read_length"], -2)),
            "dispatches_seen": {"fetch_pass": nf, "write_pass": nw}, "FETCH_SIZE_KiB_total": f, "WRITE_SIZE_KiB_total": w,
            "corrections": "bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024 (gfx950: FETCH_SIZE counts 64 B per 128-B request)",
-           "hbm_bytes_per_pass": hbm, "algorithmic_bytes_per_pass": alg, "traffic_over_algorithmic": hbm / alg},
-          open(out_path, "w"), indent=1)
-print(open(out_path).read())
+           "hbm_bytes_per_pass": hbm, "algorithmic_bytes_per_pass": alg, "traffic_over_algorithmic": hbm / alg}
+    json.dump(out, open(os.path.join(out_dir, f"{prefix}_pmc_traffic_{name}.json"), "w"), indent=1)
+    print(name, "traffic/algorithmic", round(hbm / alg, 3))
