@@ -188,7 +188,16 @@ def main():
                     "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": load_traffic(name, st),
                     "avg_launch_ms": round(st["device_ms"] / st["launches"], 4),
                     "algorithmic_bytes_per_launch": int(st["algorithmic_bytes"] / st["launches"]), "launches": st["launches"],
-                    "note": note}
+                    # the path is integer bit-vector work: what binds these kernels is VALU issue, not HBM and not MFMA. The
+                    # fraction of VALU issue slots in use comes from the committed SQ counter pass over this workload.
+                    "valu_busy_frac": load_valu(name), "note": note}
+
+        def load_valu(name):
+            try:
+                t = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_valu.json")))
+                return t["kernels"][name]["valu_busy_frac"]
+            except (OSError, ValueError, KeyError):
+                return None
 
         def load_traffic(name, st):
             """HBM bytes per launch = algorithmic bytes per launch x (PMC bytes / algorithmic bytes) of the committed FETCH_SIZE /
