@@ -3,8 +3,9 @@
 
 One "step" = one pass of the whole path (PEX seeding -> FM search -> hierarchical verification -> root alignment with
 CIGAR -> records) over one batch of synthetic long reads that is already resident in HBM. Reads shard across ranks with
-no data-path collective (FM index replicated per GPU); the only exchange is the gather of alignment records to rank 0
-(RCCL) at the end of every step. Prints ONE JSON line on rank 0.
+no data-path collective (FM index replicated per GPU); every rank keeps its part of the output (the job's output is the parts
+in rank order) and the ranks exchange only the sizes of their parts (RCCL all-gather) at the end of every step. Prints ONE JSON
+line on rank 0.
 
   python bench.py --gpus 1 --steps K --warmup W
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
@@ -106,10 +107,11 @@ def main():
     from floxer_amd import distributed as D
     dev = torch.device("cuda", local_rank)
 
-    def gather_records(res):
-        """the path's one exchange step: variable-length gather of alignment records to rank 0 over RCCL"""
-        merged = D.gather_records(res.rows, res.cigars, rank * B, rank, world, device=dev)
-        return len(merged[0]) if merged is not None else 0
+    def exchange(res):
+        """the only exchange between ranks: the sizes of the ranks' parts (= where each part goes in the job's output, which is the
+        parts in rank order); every rank keeps its own records. Returns the job's record count of this step."""
+        counts = D.exchange_counts(len(res.rows), len(res.cigars), rank, world, device=dev)
+        return int(counts[:, 0].sum())
 
     def barrier():
         if world > 1:
@@ -121,7 +123,7 @@ def main():
     stats = {}
     if not args.isolated_only:
         for w in range(args.warmup):
-            gather_records(al.align_reads(resident[w]))
+            exchange(al.align_reads(resident[w]))
         ctx.enable_kernel_timing(True)
         ctx.reset_kernel_stats()
 
@@ -135,7 +137,7 @@ def main():
         # are in a host phase another batch's kernels keep the GPU busy. All K steps start and finish inside the timed region.
         futures = [pool.submit(al.align_reads, resident[args.warmup + s]) for s in range(args.steps)]
         for f in futures:
-            n_records += gather_records(f.result())
+            n_records += exchange(f.result())
         barrier()
         elapsed = time.perf_counter() - t_start
         pool.shutdown()

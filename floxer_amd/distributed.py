@@ -1,7 +1,13 @@
 """Multi-GPU read sharding: reads are independent units (parallelization.cpp:77-87), so each rank
-aligns a contiguous block of the reads against its own replica of the index and the only exchange step is one
-variable-length gather of alignment records to rank 0 (RCCL over xGMI when the backend is "nccl"; gloo on CPU in tests).
-Rank 0 re-emits the records in global read order, so the output is identical for any number of ranks."""
+aligns a contiguous block of the reads against its own replica of the index; there is no collective on the data path.
+
+Output is in input order, so the job's output is the concatenation of the ranks' parts in rank order. Two ways to get there:
+  * `exchange_counts` (what `bench.py` times): every rank keeps (writes) its own part and the ranks exchange only the sizes of
+    their parts, i.e. the offsets at which the parts are concatenated. Without `-I` a 5-kb read yields ~32 KB of CIGAR words, so
+    funnelling all parts through one rank would make that rank's host the bottleneck of the whole job.
+  * `gather_records`: one variable-length gather of all records to rank 0 (RCCL over xGMI when the backend is "nccl"; gloo on
+    CPU in tests) for callers that want a single stream; rank 0 re-emits the records in global read order, so the result is
+    identical for any number of ranks."""
 import numpy as np
 
 
@@ -10,6 +16,20 @@ def shard_bounds(n_reads, rank, world):
     per = -(-n_reads // world) if world > 0 else n_reads
     lo = min(n_reads, rank * per)
     return lo, min(n_reads, lo + per)
+
+
+def exchange_counts(n_records, n_cigar_words, rank, world, device=None):
+    """all-gather of every part's (records, CIGAR words). Returns an int64 array (world, 2): row r = sizes of rank r's part; the
+    running sums are the offsets of the parts in the job's output."""
+    if world == 1:
+        return np.array([[n_records, n_cigar_words]], dtype=np.int64)
+    import torch
+    import torch.distributed as dist
+    dev = device if device is not None else torch.device("cpu")
+    mine = torch.tensor([n_records, n_cigar_words], device=dev, dtype=torch.int64)
+    parts = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(parts, mine)
+    return torch.stack(parts).cpu().numpy()
 
 
 def gather_records(rows, cigars, read_offset, rank, world, device=None):
@@ -24,7 +44,7 @@ def gather_records(rows, cigars, read_offset, rank, world, device=None):
     import torch.distributed as dist
     dev = device if device is not None else torch.device("cpu")
     t_rows = torch.from_numpy(rows).to(dev)
-    t_cig = torch.from_numpy(cigars.astype(np.int64)).to(dev)
+    t_cig = torch.from_numpy(cigars.view(np.int32)).to(dev)          # the same 32 bits; torch has no uint32 collectives
     counts = torch.tensor([t_rows.shape[0], t_cig.shape[0]], device=dev, dtype=torch.int64)
     all_counts = [torch.zeros_like(counts) for _ in range(world)]
     dist.all_gather(all_counts, counts)
@@ -33,7 +53,7 @@ def gather_records(rows, cigars, read_offset, rank, world, device=None):
     max_c = max(1, max(c[1] for c in all_counts))
     pad_r = torch.zeros((max_r, 7), device=dev, dtype=torch.int64)
     pad_r[: t_rows.shape[0]] = t_rows
-    pad_c = torch.zeros((max_c,), device=dev, dtype=torch.int64)
+    pad_c = torch.zeros((max_c,), device=dev, dtype=torch.int32)
     pad_c[: t_cig.shape[0]] = t_cig
     if rank == 0:
         gr = [torch.zeros_like(pad_r) for _ in range(world)]
@@ -46,7 +66,7 @@ def gather_records(rows, cigars, read_offset, rank, world, device=None):
             rr = gr[r][:nr].cpu().numpy().copy()
             rr[:, 5] += base
             out_rows.append(rr)
-            out_cig.append(gc[r][:nc].cpu().numpy().astype(np.uint32))
+            out_cig.append(gc[r][:nc].cpu().numpy().view(np.uint32))
             base += nc
         return np.concatenate(out_rows, axis=0), np.concatenate(out_cig)
     dist.gather(pad_r, None, dst=0)

@@ -25,8 +25,11 @@ def main():
     reads.append(np.zeros(0, np.uint8))      # a filtered read inside the last shard
     lo, hi = D.shard_bounds(len(reads), rank, world)
     res = O.Index(genome).run(reads[lo:hi], O.params(error_probability=0.05))
+    counts = D.exchange_counts(len(res.rows), len(res.cigars), rank, world)     # every rank learns every part's size
+    assert counts.shape == (world, 2) and tuple(counts[rank]) == (len(res.rows), len(res.cigars))
     merged = D.gather_records(res.rows, res.cigars, lo, rank, world)
     if rank == 0:
+        assert counts[:, 0].sum() == len(merged[0]) and counts[:, 1].sum() == len(merged[1])
         np.savez(out_path, rows=merged[0], cigars=merged[1])
     else:
         assert merged is None
