@@ -1103,23 +1103,33 @@ int align_slice(Lane* lane, const flx_params* P, const flx_reads* RD, u64 first_
         a.node = leaf.parent_id;
         if (rs.tree.inner[a.node].parent_id == FLX_NULL_ID) a.at_root = true;
     }
-    std::vector<u32> climbing;                       // anchors that still have an inner node to test
+    // Anchors do not wait for each other and their tests do not depend on any order, so a round tests the anchors whose
+    // current node is in the smallest size class still pending (PEX trees are unbalanced: the same node is reached after a
+    // different number of steps from different leaves). All tests of a node size then share one launch, and identical
+    // (window, node) tests requested by anchors that started at different depths are found by the de-duplication.
+    std::vector<u32> climbing, selected, waiting;    // anchors that still have an inner node to test
     for (u32 ai = 0; ai < A.size(); ++ai) if (A[ai].alive && !A[ai].at_root) climbing.push_back(ai);
     std::vector<AlignRequest> reqs;
     std::vector<DevAlignOut> outs;
+    auto node_rows = [&](AnchorState const& a) { flx_pex_node const& nd = reads[a.read].tree.inner[a.node]; return nd.to - nd.from + 1; };
     while (!climbing.empty()) {
+        u32 smallest = 0xFFFFFFFFu;
+        for (u32 ai : climbing) smallest = std::min(smallest, node_rows(A[ai]));
+        u64 const limit = (u64)smallest + smallest / 2;
+        selected.clear();
+        waiting.clear();
+        for (u32 ai : climbing) (node_rows(A[ai]) <= limit ? selected : waiting).push_back(ai);
         reqs.clear();
-        for (u32 ai : climbing) reqs.push_back(window_request(A[ai], reads[A[ai].read].tree.inner[A[ai].node], 0.0, nullptr));
+        for (u32 ai : selected) reqs.push_back(window_request(A[ai], reads[A[ai].read].tree.inner[A[ai].node], 0.0, nullptr));
         if ((rc = run_score_jobs(lane, d_text, lane->peq.as<u64>(), reqs, outs, "ed_align_exists"))) return rc;
-        size_t keep = 0;
         for (size_t i = 0; i < outs.size(); ++i) {
-            AnchorState& a = A[climbing[i]];
+            AnchorState& a = A[selected[i]];
             if (outs[i].score == 0xFFFFFFFFu) { a.alive = false; continue; }
             a.node = reads[a.read].tree.inner[a.node].parent_id;
             if (reads[a.read].tree.inner[a.node].parent_id == FLX_NULL_ID) a.at_root = true;
-            else climbing[keep++] = climbing[i];
+            else waiting.push_back(selected[i]);
         }
-        climbing.resize(keep);
+        climbing.swap(waiting);
     }
 
     prof.mark("inner-levels");
