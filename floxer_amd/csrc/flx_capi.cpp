@@ -109,7 +109,7 @@ int flx_ctx_create(int hip_device, const flx_index* index, flx_ctx** out) {
     }
     // one lane per host thread the process may use, at most 16 (FLX_LANES overrides)
     size_t n_lanes = std::max<size_t>(4, std::min<size_t>(16, std::thread::hardware_concurrency()));
-    if (const char* env = getenv("FLX_LANES")) { size_t const v = strtoull(env, nullptr, 10); if (v >= 1 && v <= 16) n_lanes = v; }
+    if (const char* env = getenv("FLX_LANES")) { size_t const v = strtoull(env, nullptr, 10); if (v >= 1 && v <= 64) n_lanes = v; }
     for (size_t l = 0; l < n_lanes; ++l) {
         auto lane = std::make_unique<Lane>();
         lane->ctx = ctx.get();

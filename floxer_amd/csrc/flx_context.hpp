@@ -51,6 +51,7 @@ struct Lane {
     size_t trace_budget_bytes = 0;
     std::vector<PendingTiming> pending;
     std::vector<hipEvent_t> event_pool;
+    hipEvent_t sync_event = nullptr;
     int sync();                      // stream synchronize + fold pending timings into the context's statistics
     hipEvent_t get_event();
     void release_all();

@@ -22,6 +22,8 @@ namespace flx {
 // ================================================================================================ buffers / context
 int DeviceBuffer::ensure(size_t bytes) {
     if (bytes <= cap && ptr) return FLX_OK;
+    static int const debug = getenv("FLX_ALLOC_DEBUG") ? 1 : 0;
+    if (debug) fprintf(stderr, "[flx alloc] %.3f device buffer grows %zu -> %zu bytes\n", std::chrono::duration<double>(std::chrono::system_clock::now().time_since_epoch()).count(), cap, bytes);
     release();
     size_t const want = std::max<size_t>(bytes + bytes / 2, 4096);       // 50 % slack: batches of a run differ by a few per cent
     void* p = nullptr;
@@ -101,7 +103,12 @@ void flx_ctx::account(const char* name, u64 bytes, u64 units, hipEvent_t start, 
     it->second.work_units += units;
 }
 int Lane::sync() {
-    FLX_HIP(hipStreamSynchronize(stream));
+    static int const blocking = getenv("FLX_BLOCKING_SYNC") ? 1 : 0;
+    if (blocking) {
+        if (!sync_event) FLX_HIP(hipEventCreateWithFlags(&sync_event, hipEventBlockingSync | hipEventDisableTiming));
+        FLX_HIP(hipEventRecord(sync_event, stream));
+        FLX_HIP(hipEventSynchronize(sync_event));
+    } else FLX_HIP(hipStreamSynchronize(stream));
     if (!pending.empty()) {
         std::lock_guard<std::mutex> g(ctx->mu);
         for (auto& p : pending) {
