@@ -237,13 +237,13 @@ __global__ void __launch_bounds__(64) fm_search_kernel(DevIndex idx, const u8* _
             } else q_next += min(n_idle, avail);
             if (want) {
                 if (k != 0xFFFFFFFFu) {
-                    sid = k;
-                    DevSeed const seed = seeds[sid];
+                    DevSeed const seed = seeds[k];
+                    sid = seed.id;
                     q = seq + seed.seq_off;
                     stk = reinterpret_cast<uint4*>(stack + seed.stack_off);
                     len = seed.length;
-                    num_searches = seed.num_searches;
-                    stack_frames = seed.stack_frames;
+                    num_searches = seed.frames_searches >> 24;
+                    stack_frames = seed.frames_searches & 0xFFFFFFu;
                     ex_base = scheme + seed.scheme_off;
                     srch = 0;
                     ct = 0;

@@ -67,8 +67,8 @@ struct DevSeed {
     u64 stack_off;      // first frame of this seed's DFS stack
     u32 length;
     u32 scheme_off;     // first entry of this (length, errors) expanded scheme; searches are consecutive, `length` entries each
-    u32 num_searches;
-    u32 stack_frames;   // frames reserved
+    u32 frames_searches;// frames reserved for the DFS stack (bits 0..23) | number of searches (bits 24..)
+    u32 id;             // index of the seed in the caller's list (the launch order is by expected cost, see search_seeds_device)
 };
 
 struct DevFrame {       // 96 bytes: one branching node of the DFS, 48 bytes per lane of the seed's pair

@@ -221,7 +221,8 @@ int search_seeds_device(Lane* ctx, const u8* d_seq_pool_or_null, const u8* h_seq
             d = dseeds[i - 1];
             d.seq_off = s.seq_offset;
             d.stack_off = frames;
-            frames += d.stack_frames;
+            d.id = (u32)i;
+            frames += d.frames_searches & 0xFFFFFFu;
             continue;
         }
         auto it = scheme_of.find(key);
@@ -235,10 +236,30 @@ int search_seeds_device(Lane* ctx, const u8* d_seq_pool_or_null, const u8* h_seq
         d.seq_off = s.seq_offset;
         d.length = s.length;
         d.scheme_off = it->second.first;
-        d.num_searches = it->second.second;
-        d.stack_frames = s.length + s.num_errors + 2;
+        d.frames_searches = (s.length + s.num_errors + 2) | (it->second.second << 24);
         d.stack_off = frames;
-        frames += d.stack_frames;
+        d.id = (u32)i;
+        frames += s.length + s.num_errors + 2;
+    }
+    // Launch order = expected cost, heaviest class first (more errors, then shorter): the work of a seed grows steeply with its
+    // errors (k = 2 leaves of a 5-kb read cost 4x the k = 1 leaves), and what a wave still holds when the seed queue runs dry
+    // is the tail of the kernel. Within a class the caller's order is kept. Hits carry the seed's id, not its launch position.
+    {
+        std::map<u32, u32> first_of_class;                      // key -> number of seeds, then first launch position
+        auto class_key = [&](u64 i) { return ((3u - seeds[i].num_errors) << 24) | std::min<u32>(seeds[i].length, 0xFFFFFFu); };
+        for (u64 i = 0; i < n_seeds; ++i) first_of_class[class_key(i)]++;
+        if (first_of_class.size() > 1) {
+            u32 pos = 0;
+            for (auto& kv : first_of_class) { u32 const n = kv.second; kv.second = pos; pos += n; }
+            std::vector<DevSeed> ordered(n_seeds);
+            u32 last_key = 0xFFFFFFFFu, *cursor = nullptr;
+            for (u64 i = 0; i < n_seeds; ++i) {
+                u32 const key = class_key(i);
+                if (key != last_key) { cursor = &first_of_class[key]; last_key = key; }
+                ordered[(*cursor)++] = dseeds[i];
+            }
+            dseeds.swap(ordered);
+        }
     }
     if (scheme_table.empty()) scheme_table.push_back(0);
 
