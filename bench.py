@@ -4,8 +4,9 @@
 One "step" = one pass of the whole path (PEX seeding -> FM search -> hierarchical verification -> root alignment with
 CIGAR -> records) over one batch of synthetic long reads that is already resident in HBM. Reads shard across ranks with
 no data-path collective (FM index replicated per GPU); every rank keeps its part of the output (the job's output is the parts
-in rank order) and the ranks exchange only the sizes of their parts (RCCL all-gather) at the end of every step. Prints ONE JSON
-line on rank 0.
+in rank order), the ranks exchange the sizes of their parts (RCCL all-gather) at the end of every step and the fixed-size
+alignment records of the whole job are gathered to rank 0 once at the end (RCCL gather, inside the timed region). Prints ONE
+JSON line on rank 0.
 
   python bench.py --gpus 1 --steps K --warmup W
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
@@ -139,8 +140,22 @@ def main():
         # pool without a barrier between them), so up to --inflight steps are in the context at once: while one batch's lanes
         # are in a host phase another batch's kernels keep the GPU busy. All K steps start and finish inside the timed region.
         futures = [pool.submit(al.align_reads, resident[args.warmup + s]) for s in range(args.steps)]
-        for f in futures:
-            n_records += exchange(f.result())
+        kept_rows, my_rows = [], 0
+        for si, f in enumerate(futures):
+            res = f.result()
+            n_records += exchange(res)
+            if world > 1:
+                rows = res.rows.copy()
+                rows[:, 0] += (si * world + rank) * B          # global read index of this step's shard
+                kept_rows.append(rows)
+                my_rows += len(rows)
+        if world > 1:
+            # the job's one gather (RCCL over xGMI): the fixed-size alignment records of all K steps go to rank 0 and stay in its
+            # HBM; CIGAR words stay in the owners' parts (see floxer_amd/distributed.py)
+            totals = D.exchange_counts(my_rows, 0, rank, world, device=dev)
+            table = D.gather_rows(np.concatenate(kept_rows, axis=0) if kept_rows else np.zeros((0, 7), np.int64), totals, rank, world, device=dev)
+            if rank == 0:
+                assert sum(int(t.shape[0]) for t in table) == n_records
         barrier()
         elapsed = time.perf_counter() - t_start
         if os.environ.get("FLX_ALLOC_DEBUG"):

@@ -32,6 +32,28 @@ def exchange_counts(n_records, n_cigar_words, rank, world, device=None):
     return torch.stack(parts).cpu().numpy()
 
 
+def gather_rows(rows, counts, rank, world, device=None):
+    """Final gather of the fixed-size alignment records (read, flag, reference, position, NM, CIGAR offset/length in the owner's
+    part) to rank 0 — the job's mapping table; the CIGAR words stay in the owners' parts. rows: (n,7) int64 of this rank (read
+    index already global); counts: exchange_counts-style (world, >=1) array whose column 0 is every rank's number of rows.
+    Returns on rank 0 a list of `world` tensors (left on `device`: over RCCL nothing passes through a host), None elsewhere."""
+    import torch
+    rows = np.ascontiguousarray(rows, dtype=np.int64).reshape(-1, 7)
+    if world == 1:
+        return [torch.from_numpy(rows)]
+    import torch.distributed as dist
+    dev = device if device is not None else torch.device("cpu")
+    n_max = max(1, int(np.max(np.asarray(counts)[:, 0])))
+    mine = torch.zeros((n_max, 7), device=dev, dtype=torch.int64)
+    mine[: rows.shape[0]] = torch.from_numpy(rows).to(dev)
+    if rank == 0:
+        parts = [torch.zeros_like(mine) for _ in range(world)]
+        dist.gather(mine, parts, dst=0)
+        return [parts[r][: int(counts[r][0])] for r in range(world)]
+    dist.gather(mine, None, dst=0)
+    return None
+
+
 def gather_records(rows, cigars, read_offset, rank, world, device=None):
     """rows: (n,7) int64 {read_index (shard-local), flag, ref_id, pos, nm, cigar_off, cigar_len}; cigars: uint32 words.
     Returns (rows, cigars) of the whole job on rank 0 (read_index global, cigar offsets rebased), None on other ranks."""

@@ -27,9 +27,17 @@ def main():
     res = O.Index(genome).run(reads[lo:hi], O.params(error_probability=0.05))
     counts = D.exchange_counts(len(res.rows), len(res.cigars), rank, world)     # every rank learns every part's size
     assert counts.shape == (world, 2) and tuple(counts[rank]) == (len(res.rows), len(res.cigars))
+    shifted = res.rows.copy()
+    shifted[:, 0] += lo
+    table = D.gather_rows(shifted, counts, rank, world)                          # final gather of the fixed-size records only
     merged = D.gather_records(res.rows, res.cigars, lo, rank, world)
     if rank == 0:
         assert counts[:, 0].sum() == len(merged[0]) and counts[:, 1].sum() == len(merged[1])
+        got = np.concatenate([t.numpy() for t in table], axis=0)
+        assert (got[:, :5] == merged[0][:, :5]).all() and (got[:, 6] == merged[0][:, 6]).all()
+    else:
+        assert table is None
+    if rank == 0:
         np.savez(out_path, rows=merged[0], cigars=merged[1])
     else:
         assert merged is None
