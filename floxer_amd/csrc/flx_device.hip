@@ -957,10 +957,11 @@ __global__ void __launch_bounds__(64) ed_traceback_ckpt_kernel(const u8* __restr
                                                                const u64* __restrict__ peq, const u64* __restrict__ trace,
                                                                const DevTraceJob* __restrict__ jobs, u32 n_jobs,
                                                                u32* __restrict__ cigar, DevTraceOut* __restrict__ out) {
-    __shared__ ulonglong2 win[TRACE_CKPT][64];      // {hp, vp} of step t at win[t % TRACE_CKPT][lane]
+    // 22.5 KB of LDS per wave: seven waves per CU (with a 32-step window and the query symbols cached it was 44 KB, three waves
+    // per CU, and the kernel is bound by the latency of its lanes' serial chains)
+    __shared__ ulonglong2 win[TB_WIN][64];          // {hp, vp} of step t at win[t % TB_WIN][lane]
     __shared__ u64 eqc[6][64];                      // equality masks of the cached word
-    __shared__ u64 qc[8][64];                       // the 64 query symbols of the cached word
-    __shared__ u64 refc[10][64];                    // reference symbols of the columns the cached window was computed over
+    __shared__ u64 refc[8][64];                     // reference symbols of the columns the cached window was computed over
     int ref_base = 0;                               // column of refc[0] byte 0 (multiple of 8, may be negative)
     u32 const lane = threadIdx.x & 63u;
     u32 const id = blockIdx.x * 64u + lane;
@@ -969,7 +970,6 @@ __global__ void __launch_bounds__(64) ed_traceback_ckpt_kernel(const u8* __restr
     if (live) job = jobs[id];
     else { job.ref_off = job.q_off = job.trace_off = job.cigar_off = 0; job.n = 0; job.m = 0; job.lanes = 1; job.words_per_lane = 1; job.end_col = 0; job.cigar_cap = 0; job.out_index = 0; job.k = 0; }
     const u8* __restrict__ r = text + job.ref_off;
-    const u8* __restrict__ q = query + job.q_off;
     u32* __restrict__ slab = cigar + job.cigar_off;
     int const W = (int)job.words_per_lane, R = (int)job.lanes;
     int const n = (int)job.n, m = (int)job.m, k = (int)job.k;
@@ -1024,24 +1024,10 @@ __global__ void __launch_bounds__(64) ed_traceback_ckpt_kernel(const u8* __restr
                     if (rows_left < 64) v &= (1ull << rows_left) - 1ull;
                     eqc[s][lane] = v;
                 }
-                {
-                    // query symbols of rows 64*gw .. +63 (unaligned 8-byte reads assembled from aligned ones; the pool is padded)
-                    const u8* const addr = q + 64 * gw;
-                    uintptr_t const ai = (uintptr_t)addr;
-                    const u64* const base = reinterpret_cast<const u64*>(ai & ~(uintptr_t)7);
-                    u32 const shb = (u32)(ai & 7u) * 8u;
-                    u64 prev = base[0];
-#pragma unroll
-                    for (int x = 0; x < 8; ++x) {
-                        u64 const nxt = base[x + 1];
-                        qc[x][lane] = shb ? (prev >> shb) | (nxt << (64u - shb)) : prev;
-                        prev = nxt;
-                    }
-                }
                 eq_gw = gw;
             }
             // start from the checkpoint at or before t - TRACE_CKPT + 1 (or from the word's initial state if its window starts later)
-            int const want_lo = max(0, t - (int)TRACE_CKPT + 1);
+            int const want_lo = max(0, t - (int)TB_WIN + 1);
             int t0 = (want_lo / (int)TRACE_CKPT) * (int)TRACE_CKPT;
             u64 pv = ~0ull, mv = 0ull;
             if (t_first <= t0) {
@@ -1057,20 +1043,20 @@ __global__ void __launch_bounds__(64) ed_traceback_ckpt_kernel(const u8* __restr
                 u32 const shb = (u32)(((uintptr_t)(r + ref_base)) & 7u) * 8u;
                 int const pieces = ((t - g) - ref_base) / 8 + 1;
                 u64 prev = base[0];
-                for (int x = 0; x < pieces && x < 10; ++x) {
+                for (int x = 0; x < pieces && x < 8; ++x) {
                     u64 const nxt = base[x + 1];
                     refc[x][lane] = shb ? (prev >> shb) | (nxt << (64u - shb)) : prev;
                     prev = nxt;
                 }
             }
-            // the carry words of all 16-step blocks the recomputation touches (at most 2*TRACE_CKPT-1 steps: five blocks) are
+            // the carry words of all 16-step blocks the recomputation touches (at most TRACE_CKPT+TB_WIN-1 steps: four blocks) are
             // fetched up front, together with the checkpoint and the symbols: one memory latency per window instead of one per block
             int const b0 = t0 / (int)TRACE_CARRY_STEPS, b1 = t / (int)TRACE_CARRY_STEPS;
-            u32 cwv[5];
+            u32 cwv[4];
 #pragma unroll
-            for (int x = 0; x < 5; ++x) cwv[x] = b0 + x <= b1 ? carry[((u64)(b0 + x) * R + p) * W + w] : 0u;
+            for (int x = 0; x < 4; ++x) cwv[x] = b0 + x <= b1 ? carry[((u64)(b0 + x) * R + p) * W + w] : 0u;
 #pragma unroll
-            for (int x = 0; x < 5; ++x) {
+            for (int x = 0; x < 4; ++x) {
                 int const blk = b0 + x;
                 u32 const cw = cwv[x];
                 int const tt_hi = min(t, blk * (int)TRACE_CARRY_STEPS + (int)TRACE_CARRY_STEPS - 1);
@@ -1093,7 +1079,7 @@ __global__ void __launch_bounds__(64) ed_traceback_ckpt_kernel(const u8* __restr
                         ulonglong2 o;
                         o.x = hp;
                         o.y = pv;
-                        win[(u32)tt % TRACE_CKPT][lane] = o;
+                        win[(u32)tt % TB_WIN][lane] = o;
                     }
                 }
             }
@@ -1109,14 +1095,14 @@ __global__ void __launch_bounds__(64) ed_traceback_ckpt_kernel(const u8* __restr
             int const ct = (j - 1) + cg;
             if (cgw != win_gw || ct < win_lo || ct > win_hi) break;
             u32 const bit = (u32)(i - 1) & 63u;
-            ulonglong2 const v = win[(u32)ct % TRACE_CKPT][lane];
+            ulonglong2 const v = win[(u32)ct % TB_WIN][lane];
             if ((v.y >> bit) & 1ull) { emit(1u, 1u); --i; }                        // up: query symbol unmatched (I)
             else if ((v.x >> bit) & 1ull) { emit(2u, 1u); --j; }                   // left: reference symbol skipped (D)
-            else {                                                                    // diagonal: '=' or 'X' from the cached symbols
-                u32 const ro = (u32)((j - 1) - ref_base), qo = (u32)(i - 1) & 63u;
-                u32 const rsym = (u32)(refc[ro >> 3][lane] >> (8u * (ro & 7u))) & 0xFFu;
-                u32 const qsym = (u32)(qc[qo >> 3][lane] >> (8u * (qo & 7u))) & 0xFFu;
-                emit(qsym == rsym ? 7u : 8u, 1u);
+            else {                                                                    // diagonal: '=' or 'X' from the cached masks
+                u32 const ro = (u32)((j - 1) - ref_base);
+                u32 const rsym = (u32)(refc[ro >> 3][lane] >> (8u * (ro & 7u))) & 7u;
+                bool const same = rsym < 6u && ((eqc[rsym][lane] >> bit) & 1ull);     // Eq bit of this row = (query symbol == rsym)
+                emit(same ? 7u : 8u, 1u);
                 --i;
                 --j;
             }

@@ -108,6 +108,7 @@ struct AlignShape { u32 words_per_lane; u32 lanes_per_job; u32 banded; };
 // trace bits over any step range can be recomputed from that by the traceback kernel (2.25 B instead of 48 B per step and lane).
 constexpr u32 TRACE_CARRY_STEPS = 16;   // steps per u32 of carry bits
 constexpr u32 TRACE_CKPT = 32;          // steps between two checkpoints
+constexpr u32 TB_WIN = 16;              // steps of recomputed trace the traceback keeps per job (LDS)
 struct TraceLayout { u64 steps, carry_words, carry_slots, ckpt_slots; };   // slots = 16-byte units; carry region first
 #if defined(__HIPCC__)
 #define FLX_HD __host__ __device__
