@@ -950,8 +950,8 @@ __global__ void __launch_bounds__(64) ed_traceback_kernel(const u8* __restrict__
 
 // ------------------------------------------------------------------------------------------------ K5': traceback over a checkpointed trace
 // One lane walks one job. The trace bits of the word under the walker are recomputed on demand: from the word's nearest
-// checkpoint at or before step t - TRACE_CKPT + 1 up to the walker's step t, with the stored carry-in bits standing in for the
-// rest of the column, and the last TRACE_CKPT steps of {hp, vp} are kept in LDS. All lanes of a wave alternate between the
+// checkpoint at or before step t - TB_WIN + 1 up to the walker's step t, with the stored carry-in bits standing in for the
+// rest of the column, and the last TB_WIN steps of {hp, vp} are kept in LDS. All lanes of a wave alternate between the
 // same two phases (recompute, then walk until the window or the word is left), so the wave stays converged.
 __global__ void __launch_bounds__(64) ed_traceback_ckpt_kernel(const u8* __restrict__ text, const u8* __restrict__ query,
                                                                const u64* __restrict__ peq, const u64* __restrict__ trace,
@@ -1026,7 +1026,7 @@ __global__ void __launch_bounds__(64) ed_traceback_ckpt_kernel(const u8* __restr
                 }
                 eq_gw = gw;
             }
-            // start from the checkpoint at or before t - TRACE_CKPT + 1 (or from the word's initial state if its window starts later)
+            // start from the checkpoint at or before t - TB_WIN + 1 (or from the word's initial state if its window starts later)
             int const want_lo = max(0, t - (int)TB_WIN + 1);
             int t0 = (want_lo / (int)TRACE_CKPT) * (int)TRACE_CKPT;
             u64 pv = ~0ull, mv = 0ull;
@@ -1036,7 +1036,7 @@ __global__ void __launch_bounds__(64) ed_traceback_ckpt_kernel(const u8* __restr
                 mv = v.y;
             } else t0 = max(t0, min(t_first, want_lo));     // nothing happens to this word before its window starts
             {
-                // reference symbols of columns t0-g .. t-g (at most 2*TRACE_CKPT-1 of them) into LDS in 8-byte pieces
+                // reference symbols of columns t0-g .. t-g (at most TRACE_CKPT+TB_WIN-1 of them) into LDS in 8-byte pieces
                 int const first_col = max(t0 - g, 0);            // columns left of the window start are never active
                 ref_base = first_col & ~7;
                 const u64* const base = reinterpret_cast<const u64*>(((uintptr_t)(r + ref_base)) & ~(uintptr_t)7);

@@ -105,9 +105,9 @@ struct AlignShape { u32 words_per_lane; u32 lanes_per_job; u32 banded; };
 
 // Banded TRACE launches do not store the trace itself. Per (step, ring lane, word) they keep the two horizontal-delta bits that
 // enter the word from above (16 steps per u32), and every TRACE_CKPT steps the word's vertical delta vectors {vp, vn}. Any word's
-// trace bits over any step range can be recomputed from that by the traceback kernel (2.25 B instead of 48 B per step and lane).
+// trace bits over any step range can be recomputed from that by the traceback kernel (3.25 B instead of 48 B per step and lane).
 constexpr u32 TRACE_CARRY_STEPS = 16;   // steps per u32 of carry bits
-constexpr u32 TRACE_CKPT = 32;          // steps between two checkpoints
+constexpr u32 TRACE_CKPT = 16;          // steps between two checkpoints
 constexpr u32 TB_WIN = 16;              // steps of recomputed trace the traceback keeps per job (LDS)
 struct TraceLayout { u64 steps, carry_words, carry_slots, ckpt_slots; };   // slots = 16-byte units; carry region first
 #if defined(__HIPCC__)
