@@ -133,6 +133,8 @@ def main():
         pool = ThreadPoolExecutor(max_workers=max(1, args.inflight))
 
         barrier()
+        import resource
+        ru0 = resource.getrusage(resource.RUSAGE_SELF)
         if os.environ.get("FLX_ALLOC_DEBUG"):
             print(f"[bench] {time.time():.3f} timed region starts", file=sys.stderr, flush=True)
         t_start = time.perf_counter()
@@ -158,8 +160,11 @@ def main():
                 assert sum(int(t.shape[0]) for t in table) == n_records
         barrier()
         elapsed = time.perf_counter() - t_start
+        ru1 = resource.getrusage(resource.RUSAGE_SELF)
         if os.environ.get("FLX_ALLOC_DEBUG"):
             print(f"[bench] {time.time():.3f} timed region ends", file=sys.stderr, flush=True)
+            print(f"[bench] timed region: minor page faults {ru1.ru_minflt - ru0.ru_minflt}, user {ru1.ru_utime - ru0.ru_utime:.3f} s, "
+                  f"system {ru1.ru_stime - ru0.ru_stime:.3f} s, wall {elapsed:.3f} s", file=sys.stderr, flush=True)
         pool.shutdown()
         if world > 1:
             t = torch.tensor([elapsed], device=torch.device("cuda", local_rank), dtype=torch.float64)
