@@ -977,6 +977,12 @@ struct flx_reads {
     std::vector<u64> pool_off;        // per read: offset of the forward sequence; reverse complement follows at +len
     std::vector<u8> pool;             // host copy (forward + reverse complement per read)
     flx::DeviceBuffer d_pool;         // HBM-resident copy
+    // Peq planes of the whole pool (K0), built by the first flx_align_reads_resident call on these reads and shared by all
+    // lanes and later calls (they depend on the pool only)
+    mutable std::mutex peq_mu;
+    mutable bool peq_built = false;
+    mutable flx::DeviceBuffer d_peq;
+    mutable hipEvent_t peq_event = nullptr;      // recorded behind K0; every lane's stream waits for it before its first DP launch
 };
 
 extern "C" int flx_reads_upload(flx_ctx* ctx, const uint8_t* read_pool, const uint64_t* read_offsets, uint64_t n_reads, flx_reads** out) {
@@ -1018,6 +1024,8 @@ extern "C" void flx_reads_free(flx_reads* reads) {
     if (!reads) return;
     if (reads->ctx) (void)hipSetDevice(reads->ctx->device);
     reads->d_pool.release();
+    reads->d_peq.release();
+    if (reads->peq_event) (void)hipEventDestroy(reads->peq_event);
     delete reads;
 }
 
@@ -1110,7 +1118,8 @@ int align_slice(Lane* lane, const flx_params* P, const flx_reads* RD, u64 first_
 
     prof.mark("anchors+order");
     // ---- Peq planes of the whole pool
-    if ((rc = build_peq(lane, d_pool, pool.size(), lane->peq))) return rc;
+    const u64* const d_peq = RD->d_peq.as<u64>();              // built once per resident read set (flx_align_reads_resident)
+    FLX_HIP(hipStreamWaitEvent(lane->stream, RD->peq_event, 0));
     const u8* d_text = ctx->didx.text;
 
     auto window_request = [&](AnchorState const& a, flx_pex_node const& node, double ratio, Span* span_out) {
@@ -1149,7 +1158,7 @@ int align_slice(Lane* lane, const flx_params* P, const flx_reads* RD, u64 first_
         for (u32 ai : climbing) (node_rows(A[ai]) <= limit ? selected : waiting).push_back(ai);
         reqs.clear();
         for (u32 ai : selected) reqs.push_back(window_request(A[ai], reads[A[ai].read].tree.inner[A[ai].node], 0.0, nullptr));
-        if ((rc = run_score_jobs(lane, d_text, lane->peq.as<u64>(), reqs, outs, "ed_align_exists"))) return rc;
+        if ((rc = run_score_jobs(lane, d_text, d_peq, reqs, outs, "ed_align_exists"))) return rc;
         for (size_t i = 0; i < outs.size(); ++i) {
             AnchorState& a = A[selected[i]];
             if (outs[i].score == 0xFFFFFFFFu) { a.alive = false; continue; }
@@ -1206,7 +1215,7 @@ int align_slice(Lane* lane, const flx_params* P, const flx_reads* RD, u64 first_
             if (outs[i].score != 0xFFFFFFFFu) { root_res[i].exists = true; root_res[i].nm = outs[i].score; root_res[i].start = root_spans[i].offset + (root_reqs[i].n - outs[i].end_col); }
     } else {
         std::vector<TraceResult> tres;
-        if ((rc = run_trace_jobs(lane, d_text, d_pool, lane->peq.as<u64>(), root_reqs, tres, cig))) return rc;
+        if ((rc = run_trace_jobs(lane, d_text, d_pool, d_peq, root_reqs, tres, cig))) return rc;
         for (size_t i = 0; i < tres.size(); ++i)
             if (tres[i].exists) root_res[i] = RootAlignment{true, root_spans[i].offset + tres[i].begin, tres[i].nm, tres[i].cigar_off, tres[i].cigar_len};
     }
@@ -1264,6 +1273,17 @@ extern "C" int flx_align_reads_resident(flx_ctx* ctx, const flx_params* P, const
     std::vector<flx_run>& parts = run->parts;
     std::vector<int> rcs(n_chunks, FLX_OK);
     std::vector<std::string> errs(n_chunks);
+    {
+        std::lock_guard<std::mutex> g(RD->peq_mu);
+        if (!RD->peq_built && n_reads) {
+            LaneLease lease(ctx, ctx->external_stream ? 0 : -1);
+            int const rc = build_peq(lease.lane, RD->d_pool.as<u8>(), RD->pool.size(), RD->d_peq);
+            if (rc) return rc;
+            if (!RD->peq_event) FLX_HIP(hipEventCreateWithFlags(&RD->peq_event, hipEventDisableTiming));
+            FLX_HIP(hipEventRecord(RD->peq_event, lease.lane->stream));
+            RD->peq_built = true;
+        }
+    }
     std::atomic<size_t> next_chunk{0};
     std::atomic<bool> failed{false};
     auto work = [&]() {
