@@ -502,3 +502,25 @@ def test_overlapping_calls_on_one_context():
     for r in resident + uploads:
         r.close()
     ctx.close()
+
+
+def test_full_size_reads_both_launch_forms_match_oracle():
+    """5 kb @ 8 % reads through the wave-slot-minimal launch form (what a full batch uses: five words per lane, eight lanes per
+    root) and through the parallel form (what a small batch uses), both record-for-record equal to the oracle."""
+    genome = S.make_genome(800000, 1, seed=51)
+    reads, _, _ = S.make_reads(genome, 16, 5000, 0.08, seed=52)
+    exp = O.Index(genome).run(reads, O.params(error_probability=0.08), threads=8)
+    old = os.environ.get("FLX_ALIGN_FEW_WAVES")
+    try:
+        for few_waves in ("0", "1000000000"):
+            os.environ["FLX_ALIGN_FEW_WAVES"] = few_waves
+            ctx = F.context(F.fmindex(genome))
+            res = F.aligner(ctx, F.params(error_probability=0.08)).align_reads(reads)
+            assert res.skipped.tolist() == exp.skipped.tolist()
+            assert res.records() == exp.records(), few_waves
+            ctx.close()
+    finally:
+        if old is None:
+            os.environ.pop("FLX_ALIGN_FEW_WAVES", None)
+        else:
+            os.environ["FLX_ALIGN_FEW_WAVES"] = old
