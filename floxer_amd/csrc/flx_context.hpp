@@ -118,7 +118,7 @@ struct HostAnchor { u32 seed_index, leaf, ref_id, errors; u64 pos; };
 struct SeedStats { u32 useful, raw, excluded_soft, fully_excluded; };
 
 int search_seeds_device(Lane* lane, const u8* d_seq_pool_or_null, const u8* h_seq_pool, u64 pool_len, const flx_seed* seeds,
-                        u64 n_seeds, const flx_search_config& cfg, std::vector<HostAnchor>& anchors, std::vector<SeedStats>& stats,
-                        std::vector<DevHit>* raw_hits, u64 raw_max_hits);
+                        u64 n_seeds, const flx_search_config& cfg, hvec<HostAnchor>& anchors, hvec<SeedStats>& stats,
+                        hvec<DevHit>* raw_hits, u64 raw_max_hits);
 
 }  // namespace flx

@@ -1,6 +1,9 @@
 // Host-side integer/double arithmetic of the path that defines seeds and windows: must be bit-identical to the reference,
 // so it stays on the host in IEEE double. math.hpp, input.cpp, pex.cpp, search-scheme expansion.
 #include <cmath>
+#include <cstdlib>
+#include <new>
+#include <vector>
 #include <limits>
 #include <map>
 #include <mutex>
@@ -12,6 +15,58 @@ namespace flx {
 static thread_local std::string g_last_error;
 void set_error(const std::string& msg) { g_last_error = msg; }
 const char* last_error_cstr() { return g_last_error.c_str(); }
+
+// ---------------------------------------------------------------- host block pool (flx_internal.hpp)
+namespace {
+constexpr size_t POOL_MIN = 256 << 10;
+size_t pool_class(size_t bytes) {           // next multiple of an eighth of the enclosing power of two (at most 12.5 % over)
+    size_t p2 = POOL_MIN;
+    while (p2 < bytes) p2 <<= 1;
+    size_t const step = p2 / 16;
+    return (bytes + step - 1) / step * step;
+}
+struct BlockPool {
+    std::mutex mu;
+    std::map<size_t, std::vector<void*>> free_blocks;
+    size_t kept = 0, cap;
+    BlockPool() {
+        const char* env = getenv("FLX_HOST_POOL_MB");
+        cap = (env ? strtoull(env, nullptr, 10) : 16384) << 20;
+    }
+    ~BlockPool() { for (auto& kv : free_blocks) for (void* p : kv.second) free(p); }
+};
+BlockPool& block_pool() { static BlockPool* p = new BlockPool(); return *p; }    // never destroyed: lists may outlive static teardown
+}  // namespace
+
+void* host_pool_get(size_t bytes) {
+    if (bytes < POOL_MIN) { void* p = malloc(bytes ? bytes : 1); if (!p) throw std::bad_alloc(); return p; }
+    size_t const cls = pool_class(bytes);
+    BlockPool& bp = block_pool();
+    {
+        std::lock_guard<std::mutex> g(bp.mu);
+        auto it = bp.free_blocks.find(cls);
+        if (it != bp.free_blocks.end() && !it->second.empty()) {
+            void* p = it->second.back();
+            it->second.pop_back();
+            bp.kept -= cls;
+            return p;
+        }
+    }
+    void* p = malloc(cls);
+    if (!p) throw std::bad_alloc();
+    return p;
+}
+void host_pool_put(void* p, size_t bytes) {
+    if (!p) return;
+    if (bytes < POOL_MIN) { free(p); return; }
+    size_t const cls = pool_class(bytes);
+    BlockPool& bp = block_pool();
+    {
+        std::lock_guard<std::mutex> g(bp.mu);
+        if (bp.kept + cls <= bp.cap) { bp.free_blocks[cls].push_back(p); bp.kept += cls; return; }
+    }
+    free(p);
+}
 
 // ---------------------------------------------------------------- math.hpp:10-27
 u64 ceil_div(u64 a, u64 b) { return (a % b) ? a / b + 1 : a / b; }

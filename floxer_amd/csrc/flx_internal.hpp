@@ -18,6 +18,26 @@ using i64 = int64_t;
 
 void set_error(const std::string& msg);
 
+// ------------------------------------------------------------------------------------------------ host block pool
+// The per-batch lists of the host pipeline (hits, anchors, requests, CIGAR slabs) are tens of MB each and are built and dropped
+// once per chunk. Blocks of 256 KB and more come from a process-wide pool of size classes and go back to it when a list is
+// destroyed, so after the first batches nothing is mapped, faulted in or unmapped any more (glibc maps every block above 32 MB
+// afresh, and concurrent page faults of 16 lanes serialise on the process's mmap lock). FLX_HOST_POOL_MB caps what the pool keeps
+// (default 16384).
+void* host_pool_get(size_t bytes);
+void host_pool_put(void* p, size_t bytes);
+template <class T>
+struct PoolAlloc {
+    using value_type = T;
+    PoolAlloc() = default;
+    template <class U> PoolAlloc(PoolAlloc<U> const&) {}
+    T* allocate(size_t n) { return static_cast<T*>(host_pool_get(n * sizeof(T))); }
+    void deallocate(T* p, size_t n) { host_pool_put(p, n * sizeof(T)); }
+    template <class U> bool operator==(PoolAlloc<U> const&) const { return true; }
+    template <class U> bool operator!=(PoolAlloc<U> const&) const { return false; }
+};
+template <class T> using hvec = std::vector<T, PoolAlloc<T>>;
+
 // ------------------------------------------------------------------------------------------------ HBM data layout
 // Occurrence table block: 256 BWT positions in one 128-byte line (one L2 line / one HBM request on gfx950), cut into four
 // 32-byte quarters so that the two lanes that serve one seed each read two quarters with four 16-byte loads (coalesced 128 B):

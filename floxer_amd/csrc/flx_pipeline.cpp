@@ -50,7 +50,7 @@ namespace {
 struct PhaseTimer {
     bool on;
     std::chrono::steady_clock::time_point t;
-    std::vector<std::pair<const char*, double>> rows;
+    hvec<std::pair<const char*, double>> rows;
     const char* what;
     explicit PhaseTimer(const char* what_ = "slice") : on(getenv("FLX_HOST_PROFILE") != nullptr), t(std::chrono::steady_clock::now()), what(what_) {}
     void mark(const char* name) {
@@ -179,7 +179,7 @@ constexpr u64 ERASED = ~0ull;
 struct RefAnchor { u64 pos; u64 errors; };
 
 // search.cpp:352-389 for one (seed, reference) bucket
-void erase_useless(std::vector<RefAnchor>& v) {
+void erase_useless(hvec<RefAnchor>& v) {
     if (v.empty()) return;
     std::sort(v.begin(), v.end(), [](RefAnchor const& a, RefAnchor const& b) { return a.pos < b.pos; });
     for (size_t cur = 0; cur + 1 < v.size();) {
@@ -197,8 +197,8 @@ void erase_useless(std::vector<RefAnchor>& v) {
 }  // namespace
 
 int search_seeds_device(Lane* ctx, const u8* d_seq_pool_or_null, const u8* h_seq_pool, u64 pool_len, const flx_seed* seeds,
-                        u64 n_seeds, const flx_search_config& cfg, std::vector<HostAnchor>& anchors, std::vector<SeedStats>& stats,
-                        std::vector<DevHit>* raw_hits, u64 raw_max_hits) {
+                        u64 n_seeds, const flx_search_config& cfg, hvec<HostAnchor>& anchors, hvec<SeedStats>& stats,
+                        hvec<DevHit>* raw_hits, u64 raw_max_hits) {
     anchors.clear();
     stats.assign(n_seeds, SeedStats{0, 0, 0, 0});
     if (n_seeds == 0) return FLX_OK;
@@ -208,8 +208,8 @@ int search_seeds_device(Lane* ctx, const u8* d_seq_pool_or_null, const u8* h_seq
 
     // ---- expanded schemes (search_scheme_cache, search.cpp:328-350) and DFS stack reservations
     std::map<std::pair<u32, u32>, std::pair<u32, u32>> scheme_of;      // (len, k) -> (offset, searches)
-    std::vector<u32> scheme_table;
-    std::vector<DevSeed> dseeds(n_seeds);
+    hvec<u32> scheme_table;
+    hvec<DevSeed> dseeds(n_seeds);
     u64 frames = 0;
     for (u64 i = 0; i < n_seeds; ++i) {
         flx_seed const& s = seeds[i];
@@ -227,7 +227,7 @@ int search_seeds_device(Lane* ctx, const u8* d_seq_pool_or_null, const u8* h_seq
         }
         auto it = scheme_of.find(key);
         if (it == scheme_of.end()) {
-            std::vector<u32> e = expanded_scheme(s.num_errors, s.length);
+            auto const e = expanded_scheme(s.num_errors, s.length);
             u32 const nsearch = e.empty() ? 0 : (u32)(e.size() / s.length);
             it = scheme_of.emplace(key, std::make_pair((u32)scheme_table.size(), nsearch)).first;
             scheme_table.insert(scheme_table.end(), e.begin(), e.end());
@@ -251,7 +251,7 @@ int search_seeds_device(Lane* ctx, const u8* d_seq_pool_or_null, const u8* h_seq
         if (first_of_class.size() > 1) {
             u32 pos = 0;
             for (auto& kv : first_of_class) { u32 const n = kv.second; kv.second = pos; pos += n; }
-            std::vector<DevSeed> ordered(n_seeds);
+            hvec<DevSeed> ordered(n_seeds);
             u32 last_key = 0xFFFFFFFFu, *cursor = nullptr;
             for (u64 i = 0; i < n_seeds; ++i) {
                 u32 const key = class_key(i);
@@ -307,20 +307,20 @@ int search_seeds_device(Lane* ctx, const u8* d_seq_pool_or_null, const u8* h_seq
     }
     sprof.mark("kernel");
     u32 const n_slots = counters[0];          // reserved slots; unused ones carry seed 0xFFFFFFFF
-    std::vector<DevHit> hits(n_slots);
+    hvec<DevHit> hits(n_slots);
     if ((rc = d2h(ctx, hits.data(), ctx->hits.ptr, (size_t)n_slots * sizeof(DevHit)))) return rc;
     if ((rc = ctx->sync())) return rc;
 
     sprof.mark("d2h-hits");
     // group by seed, keeping each seed's emission order (a seed stays on one wave, whose slot ranges and slots within a range
     // are handed out in increasing order)
-    std::vector<u32> first(n_seeds + 1, 0);
+    hvec<u32> first(n_seeds + 1, 0);
     for (auto const& h : hits) if (h.seed != 0xFFFFFFFFu) first[h.seed + 1]++;
     for (u64 i = 0; i < n_seeds; ++i) first[i + 1] += first[i];
     u32 const n_hits = first[n_seeds];
-    std::vector<DevHit> by_seed(n_hits);
+    hvec<DevHit> by_seed(n_hits);
     {
-        std::vector<u32> cursor(first.begin(), first.end() - 1);
+        hvec<u32> cursor(first.begin(), first.end() - 1);
         for (auto const& h : hits) if (h.seed != 0xFFFFFFFFu) by_seed[cursor[h.seed]++] = h;
     }
     if (raw_hits) { *raw_hits = std::move(by_seed); return FLX_OK; }
@@ -328,11 +328,11 @@ int search_seeds_device(Lane* ctx, const u8* d_seq_pool_or_null, const u8* h_seq
     sprof.mark("group");
     // ---- hard cap, group order, anchor choice (search.cpp:190-302)
     struct RowReq { u32 seed, errors, row; };
-    std::vector<RowReq> reqs;
-    std::vector<u64> total_raw(n_seeds, 0);
-    std::vector<u8> excluded(n_seeds, 0);
-    std::vector<Group> groups;
-    std::vector<u32> alive;
+    hvec<RowReq> reqs;
+    hvec<u64> total_raw(n_seeds, 0);
+    hvec<u8> excluded(n_seeds, 0);
+    hvec<Group> groups;
+    hvec<u32> alive;
     for (u64 si = 0; si < n_seeds; ++si) {
         if (first[si] == first[si + 1]) continue;               // no hit at all: nothing to select
         groups.clear();
@@ -390,7 +390,7 @@ int search_seeds_device(Lane* ctx, const u8* d_seq_pool_or_null, const u8* h_seq
 
     sprof.mark("select");
     // ---- locate (search.cpp:253, 284) as one SA gather
-    std::vector<u32> rows(reqs.size()), textpos(reqs.size());
+    hvec<u32> rows(reqs.size()), textpos(reqs.size());
     for (size_t i = 0; i < reqs.size(); ++i) rows[i] = reqs[i].row;
     if (!reqs.empty()) {
         if ((rc = h2d(ctx, ctx->rows, rows.data(), rows.size() * 4))) return rc;
@@ -406,8 +406,8 @@ int search_seeds_device(Lane* ctx, const u8* d_seq_pool_or_null, const u8* h_seq
     sprof.mark("locate");
     // ---- per seed: bucket per reference, erase useless anchors, flatten (search.cpp:78-100, 304-318)
     size_t const nref = H.seq_len.size();
-    std::vector<std::vector<RefAnchor>> by_ref(nref);
-    std::vector<u32> touched;                    // references that received an anchor of the current seed
+    hvec<hvec<RefAnchor>> by_ref(nref);
+    hvec<u32> touched;                    // references that received an anchor of the current seed
     size_t ri = 0;
     for (u64 si = 0; si < n_seeds; ++si) {
         if (excluded[si]) { stats[si] = SeedStats{0, 0, 0, 1}; continue; }
@@ -477,11 +477,11 @@ struct ReqKeyHash {
         return (size_t)(h * 0xBF58476D1CE4E5B9ull);
     }
 };
-void dedup_requests(std::vector<AlignRequest> const& reqs, std::vector<AlignRequest>& uniq, std::vector<u32>& uniq_of) {
+void dedup_requests(hvec<AlignRequest> const& reqs, hvec<AlignRequest>& uniq, hvec<u32>& uniq_of) {
     // open-addressing table of indices into `uniq` (power-of-two size, linear probing)
     size_t cap = 16;
     while (cap < reqs.size() * 2 + 1) cap <<= 1;
-    std::vector<u32> table(cap, 0xFFFFFFFFu);
+    hvec<u32> table(cap, 0xFFFFFFFFu);
     ReqKeyHash const hasher;
     uniq.clear();
     uniq.reserve(reqs.size());
@@ -507,7 +507,7 @@ u64 align_few_waves() {          // FLX_ALIGN_FEW_WAVES overrides the threshold 
     const char* env = getenv("FLX_ALIGN_FEW_WAVES");
     return env ? strtoull(env, nullptr, 10) : 2048;
 }
-int choose_shapes(std::vector<AlignRequest> const& reqs, std::vector<AlignShape>& shapes) {
+int choose_shapes(hvec<AlignRequest> const& reqs, hvec<AlignShape>& shapes) {
     shapes.resize(reqs.size());
     u64 lanes = 0;
     for (size_t i = 0; i < reqs.size(); ++i) {
@@ -559,20 +559,20 @@ int choose_shapes(std::vector<AlignRequest> const& reqs, std::vector<AlignShape>
 }
 
 // score + end column for every (distinct) request (no trace)
-int run_score_jobs_unique(Lane* ctx, const u8* d_text, const u64* d_peq, std::vector<AlignRequest> const& reqs,
-                          std::vector<DevAlignOut>& outs, const char* kernel_name) {
+int run_score_jobs_unique(Lane* ctx, const u8* d_text, const u64* d_peq, hvec<AlignRequest> const& reqs,
+                          hvec<DevAlignOut>& outs, const char* kernel_name) {
     outs.assign(reqs.size(), DevAlignOut{0xFFFFFFFFu, 0});
     if (reqs.empty()) return FLX_OK;
-    std::map<ShapeKey, std::vector<u32>> by_shape;
+    std::map<ShapeKey, hvec<u32>> by_shape;
     {
-        std::vector<AlignShape> shapes;
+        hvec<AlignShape> shapes;
         if (int const rc = choose_shapes(reqs, shapes)) return rc;
         for (u32 i = 0; i < reqs.size(); ++i) by_shape[ShapeKey{shapes[i].words_per_lane, shapes[i].lanes_per_job, shapes[i].banded}].push_back(i);
     }
-    std::vector<DevAlignJob> jobs;
+    hvec<DevAlignJob> jobs;
     jobs.reserve(reqs.size());
     struct Launch { ShapeKey key; u32 first, count; u64 word_steps, bytes; };
-    std::vector<Launch> launches;
+    hvec<Launch> launches;
     for (auto& kv : by_shape) {
         auto& ids = kv.second;
         Launch l{kv.first, (u32)jobs.size(), (u32)ids.size(), 0, 0};
@@ -599,12 +599,12 @@ int run_score_jobs_unique(Lane* ctx, const u8* d_text, const u64* d_peq, std::ve
     return ctx->sync();
 }
 
-int run_score_jobs(Lane* ctx, const u8* d_text, const u64* d_peq, std::vector<AlignRequest> const& reqs,
-                   std::vector<DevAlignOut>& outs, const char* kernel_name) {
-    std::vector<AlignRequest> uniq;
-    std::vector<u32> uniq_of;
+int run_score_jobs(Lane* ctx, const u8* d_text, const u64* d_peq, hvec<AlignRequest> const& reqs,
+                   hvec<DevAlignOut>& outs, const char* kernel_name) {
+    hvec<AlignRequest> uniq;
+    hvec<u32> uniq_of;
     dedup_requests(reqs, uniq, uniq_of);
-    std::vector<DevAlignOut> uouts;
+    hvec<DevAlignOut> uouts;
     int rc = run_score_jobs_unique(ctx, d_text, d_peq, uniq, uouts, kernel_name);
     if (rc) return rc;
     outs.resize(reqs.size());
@@ -614,16 +614,16 @@ int run_score_jobs(Lane* ctx, const u8* d_text, const u64* d_peq, std::vector<Al
 
 struct TraceResult { bool exists = false; u32 nm = 0; u32 begin = 0; u64 cigar_off = 0; u32 cigar_len = 0; };
 
-int run_trace_jobs_unique(Lane* ctx, const u8* d_text, const u8* d_query, const u64* d_peq, std::vector<AlignRequest> const& reqs,
-                          std::vector<TraceResult>& results, std::vector<u32>& cigar_pool);
+int run_trace_jobs_unique(Lane* ctx, const u8* d_text, const u8* d_query, const u64* d_peq, hvec<AlignRequest> const& reqs,
+                          hvec<TraceResult>& results, hvec<u32>& cigar_pool);
 
 // score, begin position and CIGAR for every request (alignment.cpp:147-180); CIGAR words land in cigar_pool (shared by duplicates)
-int run_trace_jobs(Lane* ctx, const u8* d_text, const u8* d_query, const u64* d_peq, std::vector<AlignRequest> const& reqs,
-                   std::vector<TraceResult>& results, std::vector<u32>& cigar_pool) {
-    std::vector<AlignRequest> uniq;
-    std::vector<u32> uniq_of;
+int run_trace_jobs(Lane* ctx, const u8* d_text, const u8* d_query, const u64* d_peq, hvec<AlignRequest> const& reqs,
+                   hvec<TraceResult>& results, hvec<u32>& cigar_pool) {
+    hvec<AlignRequest> uniq;
+    hvec<u32> uniq_of;
     dedup_requests(reqs, uniq, uniq_of);
-    std::vector<TraceResult> ures;
+    hvec<TraceResult> ures;
     int rc = run_trace_jobs_unique(ctx, d_text, d_query, d_peq, uniq, ures, cigar_pool);
     if (rc) return rc;
     results.resize(reqs.size());
@@ -631,14 +631,14 @@ int run_trace_jobs(Lane* ctx, const u8* d_text, const u8* d_query, const u64* d_
     return FLX_OK;
 }
 
-int run_trace_jobs_unique(Lane* ctx, const u8* d_text, const u8* d_query, const u64* d_peq, std::vector<AlignRequest> const& reqs,
-                          std::vector<TraceResult>& results, std::vector<u32>& cigar_pool) {
+int run_trace_jobs_unique(Lane* ctx, const u8* d_text, const u8* d_query, const u64* d_peq, hvec<AlignRequest> const& reqs,
+                          hvec<TraceResult>& results, hvec<u32>& cigar_pool) {
     results.assign(reqs.size(), TraceResult{});
     if (reqs.empty()) return FLX_OK;
     PhaseTimer tprof("trace-jobs");
-    std::vector<AlignShape> shapes;
+    hvec<AlignShape> shapes;
     if (int const src = choose_shapes(reqs, shapes)) return src;
-    std::vector<u64> slots(reqs.size());
+    hvec<u64> slots(reqs.size());
     u64 const budget_slots = std::max<u64>(ctx->trace_budget_bytes / 16, 1);
     for (size_t i = 0; i < reqs.size(); ++i) {
         slots[i] = align_trace_slots(reqs[i].n, reqs[i].m, shapes[i]);
@@ -655,12 +655,12 @@ int run_trace_jobs_unique(Lane* ctx, const u8* d_text, const u8* d_query, const 
         // the arena is taken whole on first use (its size is the configured budget): no reallocation between batches
         if ((rc = ctx->trace.ensure(std::max<size_t>(used * 16 + 64, ctx->trace.ptr ? 0 : std::min<size_t>(ctx->trace_budget_bytes, (size_t)budget_slots * 16) / 3 * 2)))) return rc;
 
-        std::map<ShapeKey, std::vector<u32>> by_shape;
+        std::map<ShapeKey, hvec<u32>> by_shape;
         for (size_t i = begin; i < next; ++i) by_shape[ShapeKey{shapes[i].words_per_lane, shapes[i].lanes_per_job, shapes[i].banded}].push_back((u32)i);
-        std::vector<DevAlignJob> jobs;
-        std::vector<u64> trace_off(count);
+        hvec<DevAlignJob> jobs;
+        hvec<u64> trace_off(count);
         struct Launch { ShapeKey key; u32 first, count; u64 word_steps, bytes; };
-        std::vector<Launch> launches;
+        hvec<Launch> launches;
         u64 off = 0;
         for (auto& kv : by_shape) {
             auto& ids = kv.second;
@@ -693,14 +693,14 @@ int run_trace_jobs_unique(Lane* ctx, const u8* d_text, const u8* d_query, const 
             });
             if (rc) return rc;
         }
-        std::vector<DevAlignOut> outs(count);
+        hvec<DevAlignOut> outs(count);
         if ((rc = d2h(ctx, outs.data(), ctx->job_out.ptr, count * sizeof(DevAlignOut)))) return rc;
         if ((rc = ctx->sync())) return rc;
         tprof.mark("K4");
 
         // ---- traceback for the jobs that have an alignment within k
-        std::vector<DevTraceJob> tjobs;
-        std::vector<u32> tjob_req;
+        hvec<DevTraceJob> tjobs;
+        hvec<u32> tjob_req;
         u64 cigar_words = 0, path_steps = 0;
         for (size_t c = 0; c < count; ++c) {
             if (outs[c].score == 0xFFFFFFFFu) continue;
@@ -726,7 +726,7 @@ int run_trace_jobs_unique(Lane* ctx, const u8* d_text, const u8* d_query, const 
             });
             if (rc) return rc;
             tprof.mark("tb-prep");
-            std::vector<DevTraceOut> touts(tjobs.size());
+            hvec<DevTraceOut> touts(tjobs.size());
             size_t const pool_base = cigar_pool.size();
             cigar_pool.resize(pool_base + cigar_words);          // slabs are kept as they are (gaps included): no host repacking
             tprof.mark("pool-resize");
@@ -760,7 +760,7 @@ int ensure_reversed_text(Lane* lane) {
     std::lock_guard<std::mutex> g(ctx->mu);
     if (ctx->text_rev_ready) return FLX_OK;
     HostIndex const& H = *ctx->hidx;
-    std::vector<u8> rev(H.text.rbegin(), H.text.rend());
+    hvec<u8> rev(H.text.rbegin(), H.text.rend());
     const u8* first = nullptr;
     int rc = upload_padded(lane, ctx->text_rev, rev.data(), rev.size(), &first);
     if (rc) return rc;
@@ -779,8 +779,8 @@ extern "C" int flx_search_seeds(flx_ctx* ctx, const uint8_t* seq_pool, uint64_t 
     if (!ctx || !cfg || !n_anchors || (n_seeds && (!seeds || !seq_pool))) { set_error("flx_search_seeds: null argument"); return FLX_ERR_INVALID; }
     if (cfg->max_num_anchors_hard < cfg->max_num_anchors_soft) { set_error("max-anchors-hard must not be smaller than max-anchors-soft (floxer_cli.cpp:194)"); return FLX_ERR_INVALID; }
     FLX_HIP(hipSetDevice(ctx->device));
-    std::vector<HostAnchor> anchors;
-    std::vector<SeedStats> stats;
+    hvec<HostAnchor> anchors;
+    hvec<SeedStats> stats;
     LaneLease lease(ctx, ctx->external_stream ? 0 : -1);
     int rc = search_seeds_device(lease.lane, nullptr, seq_pool, seq_pool_len, seeds, n_seeds, *cfg, anchors, stats, nullptr, 0);
     if (rc) return rc;
@@ -797,9 +797,9 @@ extern "C" int flx_search_groups(flx_ctx* ctx, const uint8_t* seq_pool, uint64_t
                                  uint64_t max_hits_per_seed, flx_hit_group* out, uint64_t* n_out) {
     if (!ctx || !n_out || (n_seeds && (!seeds || !seq_pool))) { set_error("flx_search_groups: null argument"); return FLX_ERR_INVALID; }
     FLX_HIP(hipSetDevice(ctx->device));
-    std::vector<HostAnchor> anchors;
-    std::vector<SeedStats> stats;
-    std::vector<DevHit> hits;
+    hvec<HostAnchor> anchors;
+    hvec<SeedStats> stats;
+    hvec<DevHit> hits;
     flx_search_config cfg{};
     LaneLease lease(ctx, ctx->external_stream ? 0 : -1);
     int rc = search_seeds_device(lease.lane, nullptr, seq_pool, seq_pool_len, seeds, n_seeds, cfg, anchors, stats, &hits, max_hits_per_seed);
@@ -833,7 +833,7 @@ extern "C" int flx_align_batch(flx_ctx* ctx, const uint8_t* ref_pool, uint64_t r
     Lane* L = lease.lane;
     const u8* d_text = ctx->didx.text;
     const u8* d_text_rev = nullptr;
-    std::vector<u8> tmp;
+    hvec<u8> tmp;
     if (ref_pool) {
         if ((rc = upload_padded(L, L->user_text, ref_pool, ref_pool_len, &d_text))) return rc;
         if (any_rev) {
@@ -848,15 +848,15 @@ extern "C" int flx_align_batch(flx_ctx* ctx, const uint8_t* ref_pool, uint64_t r
     }
     if ((rc = h2d(L, L->seq, query_pool, query_pool_len, 192))) return rc;
     if ((rc = build_peq(L, L->seq.as<u8>(), query_pool_len, L->peq))) return rc;
-    std::vector<u8> qrev;
+    hvec<u8> qrev;
     if (any_rev) {
         qrev.assign(query_pool, query_pool + query_pool_len);
         std::reverse(qrev.begin(), qrev.end());
         if ((rc = h2d(L, L->seq_rev, qrev.data(), qrev.size(), 64))) return rc;
         if ((rc = build_peq(L, L->seq_rev.as<u8>(), query_pool_len, L->peq_rev))) return rc;
     }
-    std::vector<AlignRequest> score_reqs, rev_reqs, trace_reqs;
-    std::vector<u32> score_ids, rev_ids, trace_ids;
+    hvec<AlignRequest> score_reqs, rev_reqs, trace_reqs;
+    hvec<u32> score_ids, rev_ids, trace_ids;
     for (uint64_t i = 0; i < n_jobs; ++i) {
         flx_align_job const& j = jobs[i];
         if (j.mode == FLX_MODE_EXISTS) { score_reqs.push_back({j.ref_offset, j.query_offset, j.ref_length, j.query_length, j.num_allowed_errors}); score_ids.push_back((u32)i); }
@@ -866,7 +866,7 @@ extern "C" int flx_align_batch(flx_ctx* ctx, const uint8_t* ref_pool, uint64_t r
         } else { trace_reqs.push_back({j.ref_offset, j.query_offset, j.ref_length, j.query_length, j.num_allowed_errors}); trace_ids.push_back((u32)i); }
     }
     for (uint64_t i = 0; i < n_jobs; ++i) out[i] = flx_align_result{0, 0, 0, 0, 0, 0};
-    std::vector<DevAlignOut> outs;
+    hvec<DevAlignOut> outs;
     if ((rc = run_score_jobs(L, d_text, L->peq.as<u64>(), score_reqs, outs, "ed_align_exists"))) return rc;
     for (size_t i = 0; i < outs.size(); ++i)
         if (outs[i].score != 0xFFFFFFFFu) { out[score_ids[i]].exists = 1; out[score_ids[i]].num_errors = outs[i].score; }
@@ -876,8 +876,8 @@ extern "C" int flx_align_batch(flx_ctx* ctx, const uint8_t* ref_pool, uint64_t r
             flx_align_result& r = out[rev_ids[i]];
             r.exists = 1; r.num_errors = outs[i].score; r.begin = rev_reqs[i].n - outs[i].end_col;      // alignment.cpp:135
         }
-    std::vector<TraceResult> tres;
-    std::vector<u32> cig;
+    hvec<TraceResult> tres;
+    hvec<u32> cig;
     if ((rc = run_trace_jobs(L, d_text, L->seq.as<u8>(), L->peq.as<u64>(), trace_reqs, tres, cig))) return rc;
     uint64_t const cap = cigar_pool_words ? *cigar_pool_words : 0;
     if (cigar_pool_words) *cigar_pool_words = cig.size();
@@ -901,7 +901,7 @@ half_open trim_both(half_open a, u64 amount) {                                  
     return {new_start, new_end};
 }
 struct VerifiedIntervals {                                                                     // intervals.cpp:84-127
-    std::vector<half_open> ivs;
+    hvec<half_open> ivs;
     bool contains(half_open t) const {
         for (auto const& e : ivs) if (e.start <= t.start && e.end >= t.end) return true;      // equal or contains
         return false;
@@ -921,11 +921,11 @@ Span compute_span(u64 anchor_pos, flx_pex_node const& node, u64 leaf_from, u64 r
 
 struct pr_task { int priority; int id; bool operator<(pr_task const& o) const { return priority < o.priority; } };
 // order in which one worker runs the verification packages of a read (BS::thread_pool's priority queue), parallelization.cpp:131-148
-std::vector<int> package_order(int n) {
+hvec<int> package_order(int n) {
     std::priority_queue<pr_task> q;
     for (int i = 0; i < n; ++i) q.push(pr_task{16383, i});
     q.push(pr_task{-16384, -1});
-    std::vector<int> order;
+    hvec<int> order;
     while (!q.empty()) { pr_task t = q.top(); q.pop(); if (t.id < 0) break; order.push_back(t.id); }
     return order;
 }
@@ -935,7 +935,7 @@ struct ReadState {
     u32 len, k;
     u64 pool_off[2];            // forward, reverse complement
     PexTree tree;
-    std::vector<u32> anchor_ids[2];
+    hvec<u32> anchor_ids[2];
 };
 
 struct AnchorState {
@@ -950,10 +950,10 @@ struct AnchorState {
 }  // namespace
 
 struct flx_run {
-    std::vector<flx_record> records;     // cigar_offset relative to this object's `cigars`
-    std::vector<u32> cigars;
-    std::vector<u8> skipped;
-    std::vector<flx_run> parts;          // a batch result is the in-order list of its slices (no concatenation on the host)
+    hvec<flx_record> records;     // cigar_offset relative to this object's `cigars`
+    hvec<u32> cigars;
+    hvec<u8> skipped;
+    hvec<flx_run> parts;          // a batch result is the in-order list of its slices (no concatenation on the host)
 };
 
 extern "C" void flx_params_default(flx_params* p) {
@@ -973,9 +973,9 @@ extern "C" void flx_params_default(flx_params* p) {
 struct flx_reads {
     flx_ctx* ctx = nullptr;
     uint64_t n_reads = 0;
-    std::vector<u64> lens;            // per read
-    std::vector<u64> pool_off;        // per read: offset of the forward sequence; reverse complement follows at +len
-    std::vector<u8> pool;             // host copy (forward + reverse complement per read)
+    hvec<u64> lens;            // per read
+    hvec<u64> pool_off;        // per read: offset of the forward sequence; reverse complement follows at +len
+    hvec<u8> pool;             // host copy (forward + reverse complement per read)
     flx::DeviceBuffer d_pool;         // HBM-resident copy
     // Peq planes of the whole pool (K0), built by the first flx_align_reads_resident call on these reads and shared by all
     // lanes and later calls (they depend on the pool only)
@@ -1046,14 +1046,14 @@ int align_slice(Lane* lane, const flx_params* P, const flx_reads* RD, u64 first_
     flx_ctx* ctx = lane->ctx;
     FLX_HIP(hipSetDevice(ctx->device));
     HostIndex const& H = *ctx->hidx;
-    std::vector<u8> const& pool = RD->pool;
+    hvec<u8> const& pool = RD->pool;
     PhaseTimer prof;
 
     // ---- reads -> PEX trees, seeds on the forward and reverse-complement sequence (parallelization.cpp:77-98)
-    std::vector<ReadState> reads;
-    std::vector<flx_seed> seeds;
+    hvec<ReadState> reads;
+    hvec<flx_seed> seeds;
     struct SeedOwner { u32 read; u8 orientation; };
-    std::vector<SeedOwner> seed_owner;
+    hvec<SeedOwner> seed_owner;
     for (u64 i = first_read; i < end_read; ++i) {
         u64 const len = RD->lens[i];
         if (len == 0 || len > 100000) { run->skipped[i] = 1; continue; }                       // input.cpp:95-110
@@ -1082,12 +1082,12 @@ int align_slice(Lane* lane, const flx_params* P, const flx_reads* RD, u64 first_
 
 
     // ---- seeding
-    std::vector<HostAnchor> anchors;
-    std::vector<SeedStats> sstats;
+    hvec<HostAnchor> anchors;
+    hvec<SeedStats> sstats;
     if ((rc = search_seeds_device(lane, d_pool, pool.data(), pool.size(), seeds.data(), seeds.size(), P->search, anchors, sstats, nullptr, 0))) return rc;
 
     prof.mark("search");
-    std::vector<AnchorState> A(anchors.size());
+    hvec<AnchorState> A(anchors.size());
     for (size_t a = 0; a < anchors.size(); ++a) {
         SeedOwner const so = seed_owner[anchors[a].seed_index];
         A[a].read = so.read;
@@ -1100,10 +1100,10 @@ int align_slice(Lane* lane, const flx_params* P, const flx_reads* RD, u64 first_
 
     // ---- verification order of each read: packages (forward then reverse complement, <= N anchors each) in the order one
     //      worker would run them (parallelization.cpp:14-43, 230)
-    std::vector<std::vector<u32>> exec_order(reads.size());
+    hvec<hvec<u32>> exec_order(reads.size());
     for (size_t r = 0; r < reads.size(); ++r) {
-        std::vector<std::pair<u32, u32>> pkgs;          // (first, count) into a concatenated list
-        std::vector<u32> concat;
+        hvec<std::pair<u32, u32>> pkgs;          // (first, count) into a concatenated list
+        hvec<u32> concat;
         for (int o = 0; o < 2; ++o) {
             auto const& ids = reads[r].anchor_ids[o];
             for (size_t i = 0; i < ids.size(); i += P->num_anchors_per_verification_task) {
@@ -1144,10 +1144,10 @@ int align_slice(Lane* lane, const flx_params* P, const flx_reads* RD, u64 first_
     // current node is in the smallest size class still pending (PEX trees are unbalanced: the same node is reached after a
     // different number of steps from different leaves). All tests of a node size then share one launch, and identical
     // (window, node) tests requested by anchors that started at different depths are found by the de-duplication.
-    std::vector<u32> climbing, selected, waiting;    // anchors that still have an inner node to test
+    hvec<u32> climbing, selected, waiting;    // anchors that still have an inner node to test
     for (u32 ai = 0; ai < A.size(); ++ai) if (A[ai].alive && !A[ai].at_root) climbing.push_back(ai);
-    std::vector<AlignRequest> reqs;
-    std::vector<DevAlignOut> outs;
+    hvec<AlignRequest> reqs;
+    hvec<DevAlignOut> outs;
     auto node_rows = [&](AnchorState const& a) { flx_pex_node const& nd = reads[a.read].tree.inner[a.node]; return nd.to - nd.from + 1; };
     while (!climbing.empty()) {
         u32 smallest = 0xFFFFFFFFu;
@@ -1171,11 +1171,11 @@ int align_slice(Lane* lane, const flx_params* P, const flx_reads* RD, u64 first_
 
     prof.mark("inner-levels");
     // ---- interval pass in verification order (verification.cpp:45, 106-109, 119-136): decides which anchors align the root
-    std::vector<AlignRequest> root_reqs;
-    std::vector<u32> root_anchor;
-    std::vector<Span> root_spans;
+    hvec<AlignRequest> root_reqs;
+    hvec<u32> root_anchor;
+    hvec<Span> root_spans;
     for (size_t r = 0; r < reads.size(); ++r) {
-        std::vector<VerifiedIntervals> cache[2];
+        hvec<VerifiedIntervals> cache[2];
         if (P->use_interval_optimization) { cache[0].resize(H.seq_len.size()); cache[1].resize(H.seq_len.size()); }
         for (u32 ai : exec_order[r]) {
             AnchorState& a = A[ai];
@@ -1198,23 +1198,23 @@ int align_slice(Lane* lane, const flx_params* P, const flx_reads* RD, u64 first_
     prof.mark("interval-pass");
     // ---- root alignments (alignment.cpp:115-180)
     struct RootAlignment { bool exists = false; u64 start = 0; u32 nm = 0; u64 cigar_off = 0; u32 cigar_len = 0; };
-    std::vector<RootAlignment> root_res(root_reqs.size());
-    std::vector<u32> cig;
+    hvec<RootAlignment> root_res(root_reqs.size());
+    hvec<u32> cig;
     if (P->without_cigar) {
         if ((rc = ensure_reversed_text(lane))) return rc;
-        std::vector<u8> qrev(pool.rbegin(), pool.rend());
+        hvec<u8> qrev(pool.rbegin(), pool.rend());
         if ((rc = h2d(lane, lane->seq_rev, qrev.data(), qrev.size(), 64))) return rc;
         if ((rc = build_peq(lane, lane->seq_rev.as<u8>(), qrev.size(), lane->peq_rev))) return rc;
-        std::vector<AlignRequest> rev(root_reqs.size());
+        hvec<AlignRequest> rev(root_reqs.size());
         for (size_t i = 0; i < rev.size(); ++i)
             rev[i] = AlignRequest{H.n - root_reqs[i].ref_off - root_reqs[i].n, pool.size() - root_reqs[i].q_off - root_reqs[i].m,
                                   root_reqs[i].n, root_reqs[i].m, root_reqs[i].k};
-        std::vector<DevAlignOut> outs;
+        hvec<DevAlignOut> outs;
         if ((rc = run_score_jobs(lane, ctx->text_rev.as<u8>() + TEXT_PAD, lane->peq_rev.as<u64>(), rev, outs, "ed_align_exists"))) return rc;
         for (size_t i = 0; i < outs.size(); ++i)
             if (outs[i].score != 0xFFFFFFFFu) { root_res[i].exists = true; root_res[i].nm = outs[i].score; root_res[i].start = root_spans[i].offset + (root_reqs[i].n - outs[i].end_col); }
     } else {
-        std::vector<TraceResult> tres;
+        hvec<TraceResult> tres;
         if ((rc = run_trace_jobs(lane, d_text, d_pool, d_peq, root_reqs, tres, cig))) return rc;
         for (size_t i = 0; i < tres.size(); ++i)
             if (tres[i].exists) root_res[i] = RootAlignment{true, root_spans[i].offset + tres[i].begin, tres[i].nm, tres[i].cigar_off, tres[i].cigar_len};
@@ -1222,7 +1222,7 @@ int align_slice(Lane* lane, const flx_params* P, const flx_reads* RD, u64 first_
 
     prof.mark("root-align");
     // ---- records (alignment.cpp:37-79, output.cpp:49-108): per reference in id order, alignments in verification order
-    std::vector<std::vector<u32>> roots_of_read(reads.size());
+    hvec<hvec<u32>> roots_of_read(reads.size());
     for (u32 i = 0; i < root_anchor.size(); ++i) roots_of_read[A[root_anchor[i]].read].push_back(i);   // already in verification order
     for (size_t r = 0; r < reads.size(); ++r) {
         bool have_best = false;
@@ -1270,8 +1270,8 @@ extern "C" int flx_align_reads_resident(flx_ctx* ctx, const flx_params* P, const
     if (n_lanes == 1) chunk_reads = std::max<u64>(n_reads, 1);
     size_t const n_chunks = std::max<size_t>(1, (n_reads + chunk_reads - 1) / chunk_reads);
     run->parts.resize(n_chunks);
-    std::vector<flx_run>& parts = run->parts;
-    std::vector<int> rcs(n_chunks, FLX_OK);
+    hvec<flx_run>& parts = run->parts;
+    hvec<int> rcs(n_chunks, FLX_OK);
     std::vector<std::string> errs(n_chunks);
     {
         std::lock_guard<std::mutex> g(RD->peq_mu);
@@ -1328,9 +1328,9 @@ extern "C" int flx_run_copy(const flx_run* run, flx_record* records, uint32_t* c
     if (!run) { set_error("null run"); return FLX_ERR_INVALID; }
     PhaseTimer cprof("run_copy");
     // the run itself plus its per-lane parts, each copied by its own thread (the CIGAR pools are tens of MB per part)
-    std::vector<const flx_run*> pieces{run};
+    hvec<const flx_run*> pieces{run};
     for (auto const& p : run->parts) pieces.push_back(&p);
-    std::vector<uint64_t> rec_base(pieces.size()), cig_base(pieces.size());
+    hvec<uint64_t> rec_base(pieces.size()), cig_base(pieces.size());
     uint64_t rb = 0, cb = 0;
     for (size_t i = 0; i < pieces.size(); ++i) { rec_base[i] = rb; cig_base[i] = cb; rb += pieces[i]->records.size(); cb += pieces[i]->cigars.size(); }
     auto emit = [&](size_t i) {
