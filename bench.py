@@ -32,12 +32,12 @@ HBM_PEAK_GBS = 8000.0      # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROA
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=6)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--reads-per-step", type=int, default=int(os.environ.get("FLX_BENCH_READS", 16384)), help="per GPU")
     ap.add_argument("--lanes", type=int, default=int(os.environ.get("FLX_LANES", 0)),
                     help="concurrent lanes (stream + host thread) per GPU; 0 = one per host core this rank can use, 4..16")
-    ap.add_argument("--inflight", type=int, default=int(os.environ.get("FLX_BENCH_INFLIGHT", 2)),
+    ap.add_argument("--inflight", type=int, default=int(os.environ.get("FLX_BENCH_INFLIGHT", 3)),
                     help="steps submitted to the context at a time (host threads calling align_reads); every step still runs in "
                          "full inside the timed region")
     ap.add_argument("--no-isolated-pass", action="store_true", help="skip the one-lane instrumented pass (timeline profiling)")

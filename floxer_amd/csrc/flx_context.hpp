@@ -52,7 +52,10 @@ struct Lane {
     std::vector<PendingTiming> pending;
     std::vector<hipEvent_t> event_pool;
     hipEvent_t sync_event = nullptr;
-    int sync();                      // stream synchronize + fold pending timings into the context's statistics
+    bool has_run = false;            // a chunk has run here (its workspaces have their working sizes)
+    int sync();
+    std::vector<DeviceBuffer*> workspaces();
+    int size_like(Lane& other);      // grow this lane's workspaces to the other lane's capacities                      // stream synchronize + fold pending timings into the context's statistics
     hipEvent_t get_event();
     void release_all();
 };
@@ -77,8 +80,9 @@ struct flx_ctx {
     std::mutex lane_mu;
     std::condition_variable lane_cv;
     std::vector<int> free_lanes;     // indices into `lanes`
-    flx::Lane* acquire_lane(int wanted = -1);   // blocks; wanted >= 0: that lane
+    flx::Lane* acquire_lane(int wanted = -1);   // blocks; wanted >= 0: that lane. Prefers the lane released last.
     void release_lane(flx::Lane* lane);
+    void warm_one_cold_lane(flx::Lane* like);   // gives one lane that never ran the workspace sizes of `like` (still held)
 
     flx::Lane* lane0() { return lanes[0].get(); }
     int sync_all();

@@ -76,10 +76,26 @@ hipEvent_t Lane::get_event() {
     (void)hipEventCreate(&e);
     return e;
 }
+hvec<DeviceBuffer*> lane_workspaces(Lane& l) {
+    return {&l.seq, &l.seq_rev, &l.peq, &l.peq_rev, &l.scheme, &l.seeds, &l.stack, &l.hits, &l.counters, &l.rows, &l.rows_out, &l.jobs,
+            &l.job_out, &l.trace, &l.tjobs, &l.tjob_out, &l.cigar, &l.user_text, &l.user_text_rev};
+}
+std::vector<DeviceBuffer*> Lane::workspaces() { auto v = lane_workspaces(*this); return std::vector<DeviceBuffer*>(v.begin(), v.end()); }
+int Lane::size_like(Lane& other) {
+    auto mine = workspaces(), theirs = other.workspaces();
+    for (size_t i = 0; i < mine.size(); ++i)
+        if (theirs[i]->cap > mine[i]->cap) {
+            // the other lane's capacity already holds the growth slack: take exactly that
+            void* p = nullptr;
+            if (hipMalloc(&p, theirs[i]->cap) != hipSuccess) { (void)hipGetLastError(); return FLX_OK; }     // best effort
+            mine[i]->release();
+            mine[i]->ptr = p;
+            mine[i]->cap = theirs[i]->cap;
+        }
+    return FLX_OK;
+}
 void Lane::release_all() {
-    for (DeviceBuffer* b : {&seq, &seq_rev, &peq, &peq_rev, &scheme, &seeds, &stack, &hits, &counters, &rows, &rows_out, &jobs, &job_out,
-                            &trace, &tjobs, &tjob_out, &cigar, &user_text, &user_text_rev})
-        b->release();
+    for (DeviceBuffer* b : workspaces()) b->release();
     for (auto& p : pending) { (void)hipEventDestroy(p.start); (void)hipEventDestroy(p.stop); }
     for (auto e : event_pool) (void)hipEventDestroy(e);
     pending.clear();
@@ -123,7 +139,7 @@ int Lane::sync() {
 flx::Lane* flx_ctx::acquire_lane(int wanted) {
     std::unique_lock<std::mutex> g(lane_mu);
     while (true) {
-        for (size_t i = 0; i < free_lanes.size(); ++i)
+        for (size_t i = free_lanes.size(); i-- > 0;)            // the lane released last first: its workspaces are warm
             if (wanted < 0 || free_lanes[i] == wanted) {
                 int const id = free_lanes[i];
                 free_lanes.erase(free_lanes.begin() + (long)i);
@@ -131,6 +147,25 @@ flx::Lane* flx_ctx::acquire_lane(int wanted) {
             }
         lane_cv.wait(g);
     }
+}
+void flx_ctx::warm_one_cold_lane(flx::Lane* like) {
+    // A lane allocates its workspaces (the trace arena alone is GBs) the first time a chunk runs on it. The thread that has
+    // just finished a chunk pays that for one lane that has not run yet, so that lanes first used later in a run, when more
+    // batches are in flight, start warm.
+    flx::Lane* cold = nullptr;
+    {
+        std::lock_guard<std::mutex> g(lane_mu);
+        for (size_t i = 0; i < free_lanes.size(); ++i)
+            if (!lanes[(size_t)free_lanes[i]]->has_run) {
+                cold = lanes[(size_t)free_lanes[i]].get();
+                free_lanes.erase(free_lanes.begin() + (long)i);
+                break;
+            }
+    }
+    if (!cold) return;
+    (void)cold->size_like(*like);
+    cold->has_run = true;
+    release_lane(cold);
 }
 void flx_ctx::release_lane(flx::Lane* lane) {
     { std::lock_guard<std::mutex> g(lane_mu); free_lanes.push_back(lane->id); }
@@ -1263,9 +1298,12 @@ extern "C" int flx_align_reads_resident(flx_ctx* ctx, const flx_params* P, const
     // thread with its own stream and workspaces) takes the next chunk when it is done with its last one.
     size_t n_lanes = ctx->external_stream ? 1 : ctx->lanes.size();
     n_lanes = std::max<size_t>(1, std::min<size_t>(n_lanes, (n_reads + 63) / 64));
-    // a chunk's kernels last as long as their longest job whatever the number of jobs, so chunks must not be small: one per
-    // lane up to 1024 reads, more than one per lane beyond that
-    u64 chunk_reads = std::max<u64>(64, std::min<u64>(1024, (n_reads + n_lanes - 1) / n_lanes));
+    // a chunk's kernels last as long as their longest job whatever the number of jobs, and a launch is the more efficient the
+    // more jobs it has, so chunks are large: one per lane up to 2048 reads, more than one per lane beyond that
+    // (a batch that gives every lane 1024 reads or more is cut into 2048-read chunks, batches overlap, see acquire_lane; with
+    // the interval optimisation a chunk has a tenth of the root alignments and is bound by its host work: 1024 reads)
+    u64 const big_chunk = P->use_interval_optimization ? 1024 : 2048;
+    u64 chunk_reads = n_reads >= 1024 * n_lanes ? big_chunk : std::max<u64>(64, (n_reads + n_lanes - 1) / n_lanes);
     if (const char* env = getenv("FLX_CHUNK_READS")) { u64 const v = strtoull(env, nullptr, 10); if (v >= 1) chunk_reads = v; }
     if (n_lanes == 1) chunk_reads = std::max<u64>(n_reads, 1);
     size_t const n_chunks = std::max<size_t>(1, (n_reads + chunk_reads - 1) / chunk_reads);
@@ -1293,6 +1331,7 @@ extern "C" int flx_align_reads_resident(flx_ctx* ctx, const flx_params* P, const
             LaneLease lease(ctx, ctx->external_stream ? 0 : -1);      // waits while other calls on this context hold all lanes
             rcs[c] = align_slice(lease.lane, P, RD, a, b, &parts[c]);
             if (rcs[c]) { errs[c] = flx_last_error(); failed.store(true); }
+            else { lease.lane->has_run = true; if (!ctx->external_stream) ctx->warm_one_cold_lane(lease.lane); }
         }
     };
     size_t const n_workers = std::min(n_lanes, n_chunks);
