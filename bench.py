@@ -124,12 +124,18 @@ def main():
     elapsed = 1.0
     stats = {}
     if not args.isolated_only:
-        for w in range(args.warmup):
-            exchange(al.align_reads(resident[w]))
+        # W untimed warm-up steps, run the way the timed steps run (--inflight at a time; with W < inflight the warm-up batches
+        # are aligned again until that many have been in flight together), so that workspaces and the host block pool reach
+        # their working sizes before the clock starts
+        from concurrent.futures import ThreadPoolExecutor
+        if args.warmup > 0:
+            with ThreadPoolExecutor(max_workers=max(1, args.inflight)) as wpool:
+                n_warm = max(args.warmup, args.inflight)
+                for f in [wpool.submit(al.align_reads, resident[w % args.warmup]) for w in range(n_warm)]:
+                    exchange(f.result())
         ctx.enable_kernel_timing(True)
         ctx.reset_kernel_stats()
 
-        from concurrent.futures import ThreadPoolExecutor
         pool = ThreadPoolExecutor(max_workers=max(1, args.inflight))
 
         barrier()
