@@ -47,7 +47,7 @@ struct Lane {
     int id = 0;
     hipStream_t own_stream = nullptr, stream = nullptr;
     DeviceBuffer seq, seq_rev, peq, peq_rev, scheme, seeds, stack, hits, counters, rows, rows_out;
-    DeviceBuffer jobs, job_out, trace, tjobs, tjob_out, cigar, user_text, user_text_rev;
+    DeviceBuffer jobs, job_out, trace, tjobs, tjob_out, cigar, user_text, user_text_rev, lastrow, row_windows, row_out;
     size_t trace_budget_bytes = 0;
     std::vector<PendingTiming> pending;
     std::vector<hipEvent_t> event_pool;

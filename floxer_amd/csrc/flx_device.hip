@@ -453,7 +453,7 @@ int DeviceApi::locate(void* stream, const DevIndex& idx, const u32* d_rows, u32 
 template <int W, bool TRACE>
 __global__ void __launch_bounds__(64) ed_align_kernel(const u8* __restrict__ text, const u64* __restrict__ peq,
                                                       const DevAlignJob* __restrict__ jobs, u32 n_jobs, u32 log2_g,
-                                                      u64* __restrict__ trace, DevAlignOut* __restrict__ out) {
+                                                      u64* __restrict__ trace, DevAlignOut* __restrict__ out, u16* __restrict__ lastrow) {
     extern __shared__ __attribute__((aligned(16))) u64 lds_eq[];     // [6 symbols][64 lanes][W words]
     u32 const lane = lane_id();
     u32 const G = 1u << log2_g;
@@ -589,7 +589,7 @@ __global__ void __launch_bounds__(64) ed_align_kernel(const u8* __restrict__ tex
 template <int W, bool TRACE>
 __global__ void __launch_bounds__(64) ed_band_kernel(const u8* __restrict__ text, const u64* __restrict__ peq,
                                                      const DevAlignJob* __restrict__ jobs, u32 n_jobs, u32 log2_r,
-                                                     u64* __restrict__ trace, DevAlignOut* __restrict__ out) {
+                                                     u64* __restrict__ trace, DevAlignOut* __restrict__ out, u16* __restrict__ lastrow) {
     // LDS: [6 symbols][64 lanes][W words] equality masks, then one 256-byte ring of reference symbols per job of the wave
     extern __shared__ __attribute__((aligned(16))) u64 lds_eq[];
     u8* const lds_sym = reinterpret_cast<u8*>(lds_eq + 6 * 64 * W);
@@ -750,6 +750,7 @@ __global__ void __launch_bounds__(64) ed_band_kernel(const u8* __restrict__ text
             else {
                 bot += (int)((hp_keep >> last_shift) & 1ull) - (int)((hn_keep >> last_shift) & 1ull);
                 if (bot <= best) { best = bot; best_col = c + 1; }
+                if (TRACE && lastrow) lastrow[job.lastrow_off + (u64)c] = (u16)min(bot, 0xFFFF);
             }
             cout = ((u32)c_hp << 1) | ((u32)c_hn << 2) | ((u32)bot << 3);
         } else {
@@ -827,14 +828,14 @@ u64 align_trace_slots(u32 n, u32 m, AlignShape sh) {
 
 template <int W>
 static int launch_align(hipStream_t s, const u8* d_text, const u64* d_peq, const DevAlignJob* d_jobs, u32 n_jobs, u32 log2_g, bool trace,
-                        bool banded, u64* d_trace, DevAlignOut* d_out) {
+                        bool banded, u64* d_trace, DevAlignOut* d_out, u16* d_lastrow) {
     u32 const jobs_per_wave = 64u >> log2_g;
     u32 const blocks = (n_jobs + jobs_per_wave - 1) / jobs_per_wave;
     size_t const lds = (size_t)6 * 64 * W * sizeof(u64) + (banded ? (size_t)jobs_per_wave * 256 : 0);
 #define FLX_LAUNCH(KERNEL)                                                                                                           \
     do {                                                                                                                             \
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&KERNEL), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);     \
-        hipLaunchKernelGGL((KERNEL), dim3(blocks), dim3(64), lds, s, d_text, d_peq, d_jobs, n_jobs, log2_g, d_trace, d_out);          \
+        hipLaunchKernelGGL((KERNEL), dim3(blocks), dim3(64), lds, s, d_text, d_peq, d_jobs, n_jobs, log2_g, d_trace, d_out, d_lastrow); \
     } while (0)
     if (banded) { if (trace) FLX_LAUNCH((ed_band_kernel<W, true>)); else FLX_LAUNCH((ed_band_kernel<W, false>)); }
     else { if (trace) FLX_LAUNCH((ed_align_kernel<W, true>)); else FLX_LAUNCH((ed_align_kernel<W, false>)); }
@@ -843,24 +844,61 @@ static int launch_align(hipStream_t s, const u8* d_text, const u64* d_peq, const
 }
 
 int DeviceApi::align(void* stream, const u8* d_text, const u64* d_peq, const DevAlignJob* d_jobs, u32 n_jobs, AlignShape shape, bool trace,
-                     u64* d_trace, DevAlignOut* d_out) {
+                     u64* d_trace, DevAlignOut* d_out, u16* d_lastrow) {
     if (n_jobs == 0) return 0;
     u32 log2_g = 0;
     while ((1u << log2_g) < shape.lanes_per_job) ++log2_g;
     hipStream_t s = (hipStream_t)stream;
     bool const b = shape.banded != 0;
     switch (shape.words_per_lane) {
-        case 1: return launch_align<1>(s, d_text, d_peq, d_jobs, n_jobs, log2_g, trace, b, d_trace, d_out);
-        case 2: return launch_align<2>(s, d_text, d_peq, d_jobs, n_jobs, log2_g, trace, b, d_trace, d_out);
-        case 3: return launch_align<3>(s, d_text, d_peq, d_jobs, n_jobs, log2_g, trace, b, d_trace, d_out);
-        case 4: return launch_align<4>(s, d_text, d_peq, d_jobs, n_jobs, log2_g, trace, b, d_trace, d_out);
-        case 5: return launch_align<5>(s, d_text, d_peq, d_jobs, n_jobs, log2_g, trace, b, d_trace, d_out);
-        case 6: return launch_align<6>(s, d_text, d_peq, d_jobs, n_jobs, log2_g, trace, b, d_trace, d_out);
-        case 8: return launch_align<8>(s, d_text, d_peq, d_jobs, n_jobs, log2_g, trace, b, d_trace, d_out);
-        case 13: return launch_align<13>(s, d_text, d_peq, d_jobs, n_jobs, log2_g, trace, b, d_trace, d_out);
-        case 25: return launch_align<25>(s, d_text, d_peq, d_jobs, n_jobs, log2_g, trace, b, d_trace, d_out);
+        case 1: return launch_align<1>(s, d_text, d_peq, d_jobs, n_jobs, log2_g, trace, b, d_trace, d_out, d_lastrow);
+        case 2: return launch_align<2>(s, d_text, d_peq, d_jobs, n_jobs, log2_g, trace, b, d_trace, d_out, d_lastrow);
+        case 3: return launch_align<3>(s, d_text, d_peq, d_jobs, n_jobs, log2_g, trace, b, d_trace, d_out, d_lastrow);
+        case 4: return launch_align<4>(s, d_text, d_peq, d_jobs, n_jobs, log2_g, trace, b, d_trace, d_out, d_lastrow);
+        case 5: return launch_align<5>(s, d_text, d_peq, d_jobs, n_jobs, log2_g, trace, b, d_trace, d_out, d_lastrow);
+        case 6: return launch_align<6>(s, d_text, d_peq, d_jobs, n_jobs, log2_g, trace, b, d_trace, d_out, d_lastrow);
+        case 8: return launch_align<8>(s, d_text, d_peq, d_jobs, n_jobs, log2_g, trace, b, d_trace, d_out, d_lastrow);
+        case 13: return launch_align<13>(s, d_text, d_peq, d_jobs, n_jobs, log2_g, trace, b, d_trace, d_out, d_lastrow);
+        case 25: return launch_align<25>(s, d_text, d_peq, d_jobs, n_jobs, log2_g, trace, b, d_trace, d_out, d_lastrow);
         default: return (int)hipErrorInvalidValue;
     }
+}
+
+// ------------------------------------------------------------------------------------------------ rightmost minimum of a last row
+// One wave per window: the best end column of a window inside a job's column range is the last column with the minimal
+// last-row value (alignment.cpp: seqan3 reports the rightmost best end), 1-based like ed_band_kernel's own result.
+__global__ void __launch_bounds__(64) lastrow_min_kernel(const u16* __restrict__ lastrow, const DevRowWindow* __restrict__ windows,
+                                                         u32 n_windows, DevAlignOut* __restrict__ out) {
+    u32 const id = blockIdx.x;
+    if (id >= n_windows) return;
+    DevRowWindow const w = windows[id];
+    u32 const lane = threadIdx.x & 63u;
+    const u16* __restrict__ row = lastrow + w.first;
+    u32 best = 0xFFFFu, col = 0;
+    for (u32 c = lane; c < w.n; c += 64u) {
+        u32 const v = row[c];
+        if (v <= best) { best = v; col = c + 1u; }
+    }
+    // wave reduction on (value ascending, column descending): key = value << 32 | ~column
+    u64 key = ((u64)best << 32) | (u64)(0xFFFFFFFFu - col);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        u64 const other = __shfl_xor(key, off);
+        key = other < key ? other : key;
+    }
+    if (lane == 0) {
+        u32 const v = (u32)(key >> 32), c = 0xFFFFFFFFu - (u32)key;
+        DevAlignOut o;
+        o.score = (v != 0xFFFFu && v <= w.k) ? v : 0xFFFFFFFFu;
+        o.end_col = c;
+        out[w.out_index] = o;
+    }
+}
+
+int DeviceApi::lastrow_min(void* stream, const u16* d_lastrow, const DevRowWindow* d_windows, u32 n_windows, DevAlignOut* d_out) {
+    if (n_windows == 0) return 0;
+    hipLaunchKernelGGL(lastrow_min_kernel, dim3(n_windows), dim3(64), 0, (hipStream_t)stream, d_lastrow, d_windows, n_windows, d_out);
+    return (int)hipGetLastError();
 }
 
 // ================================================================================================ K5: traceback + CIGAR

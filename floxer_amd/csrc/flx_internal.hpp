@@ -109,8 +109,12 @@ struct DevAlignJob {
     u64 trace_off;      // first 16-byte slot of this job's trace arena (TRACE launches)
     u32 n, m, k;
     u32 out_index;      // where the result goes
+    u64 lastrow_off;    // first entry of this job's last-row values (launches with a last-row buffer)
 };
 struct DevAlignOut { u32 score; u32 end_col; };    // score 0xFFFFFFFF: no alignment within k
+
+// one window inside a job's column range: its best end column is the rightmost minimum of the job's last row over [first, first+n)
+struct DevRowWindow { u64 first; u32 n, k; u32 out_index, pad; };
 
 struct DevTraceJob {
     u64 ref_off, q_off, trace_off, cigar_off;      // cigar_off: first word of this job's CIGAR slab
@@ -160,8 +164,10 @@ struct DeviceApi {
     static int search(void* stream, const DevIndex& idx, const u8* d_seq, const u32* d_scheme, const DevSeed* d_seeds,
                       u32 n_seeds, u32 max_hits_per_seed, DevFrame* d_stack, DevHit* d_hits, u32 hit_cap, u32* d_counters);
     static int locate(void* stream, const DevIndex& idx, const u32* d_rows, u32 n, u32* d_out);
+    // d_lastrow (banded TRACE launches only, may be null): D[m][c] of every computed column c, 0xFFFF elsewhere (pre-filled by the caller)
     static int align(void* stream, const u8* d_text, const u64* d_peq, const DevAlignJob* d_jobs, u32 n_jobs, AlignShape shape,
-                     bool trace, u64* d_trace, DevAlignOut* d_out);
+                     bool trace, u64* d_trace, DevAlignOut* d_out, u16* d_lastrow = nullptr);
+    static int lastrow_min(void* stream, const u16* d_lastrow, const DevRowWindow* d_windows, u32 n_windows, DevAlignOut* d_out);
     static int traceback(void* stream, const u8* d_text, const u8* d_query, const u64* d_peq, const u64* d_trace,
                          const DevTraceJob* d_jobs, u32 n_jobs, bool checkpointed, u32* d_cigar, DevTraceOut* d_out);
 };

@@ -78,7 +78,7 @@ hipEvent_t Lane::get_event() {
 }
 hvec<DeviceBuffer*> lane_workspaces(Lane& l) {
     return {&l.seq, &l.seq_rev, &l.peq, &l.peq_rev, &l.scheme, &l.seeds, &l.stack, &l.hits, &l.counters, &l.rows, &l.rows_out, &l.jobs,
-            &l.job_out, &l.trace, &l.tjobs, &l.tjob_out, &l.cigar, &l.user_text, &l.user_text_rev};
+            &l.job_out, &l.trace, &l.tjobs, &l.tjob_out, &l.cigar, &l.user_text, &l.user_text_rev, &l.lastrow, &l.row_windows, &l.row_out};
 }
 std::vector<DeviceBuffer*> Lane::workspaces() { auto v = lane_workspaces(*this); return std::vector<DeviceBuffer*>(v.begin(), v.end()); }
 int Lane::size_like(Lane& other) {
@@ -613,7 +613,7 @@ int run_score_jobs_unique(Lane* ctx, const u8* d_text, const u64* d_peq, hvec<Al
         Launch l{kv.first, (u32)jobs.size(), (u32)ids.size(), 0, 0};
         for (u32 id : ids) {
             AlignRequest const& r = reqs[id];
-            jobs.push_back(DevAlignJob{r.ref_off, r.q_off, 0, r.n, r.m, r.k, id});
+            jobs.push_back(DevAlignJob{r.ref_off, r.q_off, 0, r.n, r.m, r.k, id, 0});
             l.word_steps += job_word_steps(r.n, r.m, r.k, AlignShape{kv.first.w, kv.first.g, kv.first.banded});
             l.bytes += (u64)r.n + r.m;
         }
@@ -651,6 +651,7 @@ struct TraceResult { bool exists = false; u32 nm = 0; u32 begin = 0; u64 cigar_o
 
 int run_trace_jobs_unique(Lane* ctx, const u8* d_text, const u8* d_query, const u64* d_peq, hvec<AlignRequest> const& reqs,
                           hvec<TraceResult>& results, hvec<u32>& cigar_pool);
+int choose_shapes(hvec<AlignRequest> const& reqs, hvec<AlignShape>& shapes);
 
 // score, begin position and CIGAR for every request (alignment.cpp:147-180); CIGAR words land in cigar_pool (shared by duplicates)
 int run_trace_jobs(Lane* ctx, const u8* d_text, const u8* d_query, const u64* d_peq, hvec<AlignRequest> const& reqs,
@@ -661,6 +662,218 @@ int run_trace_jobs(Lane* ctx, const u8* d_text, const u8* d_query, const u64* d_
     hvec<TraceResult> ures;
     int rc = run_trace_jobs_unique(ctx, d_text, d_query, d_peq, uniq, ures, cigar_pool);
     if (rc) return rc;
+    results.resize(reqs.size());
+    for (size_t i = 0; i < reqs.size(); ++i) results[i] = ures[uniq_of[i]];
+    return FLX_OK;
+}
+
+// Root alignments of one locus. Anchors of the same read at the same locus ask for windows that differ by a few columns (their
+// indel drift), ten per read with floxer's defaults, and nearly always get the same alignment. One DP over the union U of such
+// windows serves them all, exactly:
+//   * a window w is a column range of U, and D_U <= D_w cell by cell (U only adds start columns), with equality on every cell of
+//     a D_U-optimal path that starts inside w;
+//   * let j be the rightmost column of w with the minimal D_U[m][.] = v over w. If the path traced back from (m, j) in D_U starts at
+//     a column of w, then D_w = D_U along it, so min D_w = v, j is also the rightmost minimum of D_w (right of j D_w >= D_U > v), and
+//     the trace decisions along the path agree (a move D_U rejects is rejected by D_w as well, a move D_U takes leads to a cell of
+//     the path): score, end, begin and CIGAR of w are those read off U;
+//   * v > k: no alignment in w either; the path starts left of w (rare): w is aligned on its own as before.
+// The band of U contains the band of every member, and a banded value is exact whenever it is <= k.
+constexpr u64 UNION_MAX_SHIFT = 256;      // members start within this many columns of the first member of their union
+
+int run_trace_jobs_union(Lane* ctx, const u8* d_text, const u8* d_query, const u64* d_peq, hvec<AlignRequest> const& reqs,
+                         hvec<TraceResult>& results, hvec<u32>& cigar_pool) {
+    hvec<AlignRequest> uniq;
+    hvec<u32> uniq_of;
+    dedup_requests(reqs, uniq, uniq_of);
+    hvec<TraceResult> ures(uniq.size());
+    bool usable = !uniq.empty() && choose_align_shape(uniq[0].n, uniq[0].m, uniq[0].k).banded != 0 && !getenv("FLX_NO_UNION");
+    for (auto const& r : uniq) usable = usable && r.k < 0xFFFFu;
+    // ---- unions: same query rows, starts within UNION_MAX_SHIFT of the first member
+    struct Union { AlignRequest req; u32 first_member, n_members; };
+    hvec<u32> order(uniq.size());
+    hvec<Union> unions;
+    hvec<u32> members;                       // indices into uniq, grouped by union
+    if (usable) {
+        std::iota(order.begin(), order.end(), 0u);
+        std::sort(order.begin(), order.end(), [&](u32 a, u32 b) {
+            AlignRequest const &x = uniq[a], &y = uniq[b];
+            if (x.q_off != y.q_off) return x.q_off < y.q_off;
+            if (x.m != y.m) return x.m < y.m;
+            if (x.k != y.k) return x.k < y.k;
+            return x.ref_off < y.ref_off;
+        });
+        for (u32 id : order) {
+            AlignRequest const& r = uniq[id];
+            if (!unions.empty()) {
+                Union& u = unions.back();
+                if (u.req.q_off == r.q_off && u.req.m == r.m && u.req.k == r.k && r.ref_off <= u.req.ref_off + UNION_MAX_SHIFT) {
+                    u64 const end = std::max<u64>(u.req.ref_off + u.req.n, r.ref_off + r.n);
+                    u.req.n = (u32)(end - u.req.ref_off);
+                    u.n_members++;
+                    members.push_back(id);
+                    continue;
+                }
+            }
+            unions.push_back(Union{r, (u32)members.size(), 1});
+            members.push_back(id);
+        }
+    }
+    if (!usable || unions.size() == uniq.size()) {          // nothing to share: the plain path
+        int const rc = run_trace_jobs_unique(ctx, d_text, d_query, d_peq, uniq, ures, cigar_pool);
+        if (rc) return rc;
+        results.resize(reqs.size());
+        for (size_t i = 0; i < reqs.size(); ++i) results[i] = ures[uniq_of[i]];
+        return FLX_OK;
+    }
+
+    hvec<AlignRequest> ureqs(unions.size());
+    for (size_t i = 0; i < unions.size(); ++i) ureqs[i] = unions[i].req;
+    hvec<AlignShape> shapes;
+    if (int const src = choose_shapes(ureqs, shapes)) return src;
+    hvec<u64> slots(ureqs.size());
+    u64 const budget_slots = std::max<u64>(ctx->trace_budget_bytes / 16, 1);
+    for (size_t i = 0; i < ureqs.size(); ++i) {
+        slots[i] = align_trace_slots(ureqs[i].n, ureqs[i].m, shapes[i]);
+        if (slots[i] > budget_slots) { set_error("one alignment needs more trace memory than the configured budget (FLX_TRACE_ARENA_MB)"); return FLX_ERR_CAPACITY; }
+    }
+    hvec<AlignRequest> fallback;
+    hvec<u32> fallback_of;                   // uniq index of each fallback request
+    int rc;
+    size_t next = 0;
+    while (next < ureqs.size()) {
+        size_t const begin = next;
+        u64 used = 0;
+        while (next < ureqs.size() && used + slots[next] <= budget_slots) { used += slots[next]; ++next; }
+        size_t const count = next - begin;
+        if ((rc = ctx->trace.ensure(std::max<size_t>(used * 16 + 64, ctx->trace.ptr ? 0 : std::min<size_t>(ctx->trace_budget_bytes, (size_t)budget_slots * 16) / 3 * 2)))) return rc;
+
+        // ---- K4 over the unions of this arena chunk, with their last rows
+        std::map<ShapeKey, hvec<u32>> by_shape;
+        for (size_t i = begin; i < next; ++i) by_shape[ShapeKey{shapes[i].words_per_lane, shapes[i].lanes_per_job, shapes[i].banded}].push_back((u32)i);
+        hvec<DevAlignJob> jobs;
+        hvec<u64> trace_off(count), row_off(count);
+        struct Launch { ShapeKey key; u32 first, count; u64 word_steps, bytes; };
+        hvec<Launch> launches;
+        u64 off = 0, rows = 0;
+        for (auto& kv : by_shape) {
+            auto& ids = kv.second;
+            std::stable_sort(ids.begin(), ids.end(), [&](u32 a, u32 b) { return ureqs[a].n > ureqs[b].n; });
+            Launch l{kv.first, (u32)jobs.size(), (u32)ids.size(), 0, 0};
+            for (u32 id : ids) {
+                AlignRequest const& r = ureqs[id];
+                trace_off[id - begin] = off;
+                row_off[id - begin] = rows;
+                jobs.push_back(DevAlignJob{r.ref_off, r.q_off, off, r.n, r.m, r.k, (u32)(id - begin), rows});
+                off += slots[id];
+                rows += r.n;
+                l.word_steps += job_word_steps(r.n, r.m, r.k, shapes[id]);
+                TraceLayout const tl = ckpt_trace_layout(r.n, r.m, shapes[id].words_per_lane, shapes[id].lanes_per_job);
+                l.bytes += (u64)r.n + r.m + (tl.carry_slots + tl.ckpt_slots) * 16 + 2ull * r.n;
+            }
+            launches.push_back(l);
+        }
+        if ((rc = h2d(ctx, ctx->jobs, jobs.data(), jobs.size() * sizeof(DevAlignJob)))) return rc;
+        if ((rc = ctx->job_out.ensure(count * sizeof(DevAlignOut)))) return rc;
+        if ((rc = ctx->lastrow.ensure(rows * 2 + 64))) return rc;
+        FLX_HIP(hipMemsetAsync(ctx->lastrow.ptr, 0xFF, rows * 2, ctx->stream));
+        for (auto const& l : launches) {
+            if (getenv("FLX_ALIGN_DEBUG")) fprintf(stderr, "[ed_align_trace] unions W %u R %u jobs %u word-steps %llu n0 %u m0 %u k0 %u\n", l.key.w, l.key.g, l.count, (unsigned long long)l.word_steps, jobs[l.first].n, jobs[l.first].m, jobs[l.first].k);
+            rc = timed_launch(ctx, "ed_align_trace", l.bytes, l.word_steps, [&] {
+                return DeviceApi::align(ctx->stream, d_text, d_peq, ctx->jobs.as<DevAlignJob>() + l.first, l.count,
+                                        AlignShape{l.key.w, l.key.g, l.key.banded}, true, ctx->trace.as<u64>(), ctx->job_out.as<DevAlignOut>(),
+                                        ctx->lastrow.as<u16>());
+            });
+            if (rc) return rc;
+        }
+        // ---- every member's rightmost minimum over its own columns
+        hvec<DevRowWindow> wins;
+        hvec<u32> win_member;                // uniq index per window
+        hvec<u32> win_union;                 // union index (absolute) per window
+        for (size_t ui = begin; ui < next; ++ui)
+            for (u32 j = 0; j < unions[ui].n_members; ++j) {
+                u32 const id = members[unions[ui].first_member + j];
+                AlignRequest const& r = uniq[id];
+                wins.push_back(DevRowWindow{row_off[ui - begin] + (r.ref_off - ureqs[ui].ref_off), r.n, r.k, (u32)wins.size(), 0});
+                win_member.push_back(id);
+                win_union.push_back((u32)ui);
+            }
+        if ((rc = h2d(ctx, ctx->row_windows, wins.data(), wins.size() * sizeof(DevRowWindow)))) return rc;
+        if ((rc = ctx->row_out.ensure(wins.size() * sizeof(DevAlignOut)))) return rc;
+        rc = timed_launch(ctx, "ed_lastrow_min", rows * 2, wins.size(), [&] {
+            return DeviceApi::lastrow_min(ctx->stream, ctx->lastrow.as<u16>(), ctx->row_windows.as<DevRowWindow>(), (u32)wins.size(), ctx->row_out.as<DevAlignOut>());
+        });
+        if (rc) return rc;
+        hvec<DevAlignOut> wouts(wins.size());
+        if ((rc = d2h(ctx, wouts.data(), ctx->row_out.ptr, wins.size() * sizeof(DevAlignOut)))) return rc;
+        if ((rc = ctx->sync())) return rc;
+
+        // ---- one traceback per distinct (union, end column)
+        hvec<DevTraceJob> tjobs;
+        hvec<u32> win_tjob(wins.size(), 0xFFFFFFFFu);
+        u64 cigar_words = 0, path_steps = 0;
+        {
+            size_t w0 = 0;
+            while (w0 < wins.size()) {                     // windows of one union are consecutive
+                size_t w1 = w0;
+                while (w1 < wins.size() && win_union[w1] == win_union[w0]) ++w1;
+                u32 const ui = win_union[w0];
+                AlignRequest const& ur = ureqs[ui];
+                AlignShape const sh = shapes[ui];
+                for (size_t w = w0; w < w1; ++w) {
+                    if (wouts[w].score == 0xFFFFFFFFu) continue;
+                    u32 const end_in_union = (u32)(uniq[win_member[w]].ref_off - ur.ref_off) + wouts[w].end_col;
+                    for (size_t v = w0; v < w; ++v)
+                        if (win_tjob[v] != 0xFFFFFFFFu && tjobs[win_tjob[v]].end_col == end_in_union) { win_tjob[w] = win_tjob[v]; break; }
+                    if (win_tjob[w] != 0xFFFFFFFFu) continue;
+                    u32 const cap = 2 * wouts[w].score + 2;
+                    win_tjob[w] = (u32)tjobs.size();
+                    tjobs.push_back(DevTraceJob{ur.ref_off, ur.q_off, trace_off[ui - begin], cigar_words, ur.n, ur.m, sh.lanes_per_job, sh.words_per_lane,
+                                                end_in_union, cap, (u32)tjobs.size(), ur.k});
+                    cigar_words += cap;
+                    path_steps += (u64)ur.m + wouts[w].score;
+                }
+                w0 = w1;
+            }
+        }
+        hvec<DevTraceOut> touts(tjobs.size());
+        size_t const pool_base = cigar_pool.size();
+        if (!tjobs.empty()) {
+            if ((rc = h2d(ctx, ctx->tjobs, tjobs.data(), tjobs.size() * sizeof(DevTraceJob)))) return rc;
+            if ((rc = ctx->tjob_out.ensure(tjobs.size() * sizeof(DevTraceOut)))) return rc;
+            if ((rc = ctx->cigar.ensure(cigar_words * 4 + 16))) return rc;
+            rc = timed_launch(ctx, "ed_traceback", path_steps * 18, path_steps, [&] {
+                return DeviceApi::traceback(ctx->stream, d_text, d_query, d_peq, ctx->trace.as<u64>(), ctx->tjobs.as<DevTraceJob>(),
+                                            (u32)tjobs.size(), true, ctx->cigar.as<u32>(), ctx->tjob_out.as<DevTraceOut>());
+            });
+            if (rc) return rc;
+            cigar_pool.resize(pool_base + cigar_words);
+            if ((rc = d2h(ctx, touts.data(), ctx->tjob_out.ptr, touts.size() * sizeof(DevTraceOut)))) return rc;
+            if ((rc = d2h(ctx, cigar_pool.data() + pool_base, ctx->cigar.ptr, cigar_words * 4))) return rc;
+            if ((rc = ctx->sync())) return rc;
+        }
+        // ---- members take the union's alignment when its path starts inside their window
+        for (size_t w = 0; w < wins.size(); ++w) {
+            u32 const id = win_member[w];
+            if (wouts[w].score == 0xFFFFFFFFu) continue;                       // no alignment within k in this window
+            DevTraceOut const& t = touts[win_tjob[w]];
+            if (t.cigar_len == 0xFFFFFFFFu) { set_error("ed_traceback: CIGAR slab overflow"); return FLX_ERR_INTERNAL; }
+            u64 const shift = uniq[id].ref_off - ureqs[win_union[w]].ref_off;
+            static int const force_own = getenv("FLX_UNION_ALIGN_OWN") ? 1 : 0;        // test hook: as if every path left its window
+            if (t.begin < shift || force_own) { fallback_of.push_back(id); fallback.push_back(uniq[id]); continue; }
+            TraceResult& res = ures[id];
+            res.exists = true;
+            res.nm = wouts[w].score;
+            res.begin = (u32)(t.begin - shift);
+            res.cigar_off = pool_base + tjobs[win_tjob[w]].cigar_off + t.cigar_start;
+            res.cigar_len = t.cigar_len;
+        }
+    }
+    if (!fallback.empty()) {
+        hvec<TraceResult> fres;
+        if ((rc = run_trace_jobs_unique(ctx, d_text, d_query, d_peq, fallback, fres, cigar_pool))) return rc;
+        for (size_t i = 0; i < fallback.size(); ++i) ures[fallback_of[i]] = fres[i];
+    }
+    if (getenv("FLX_ALIGN_DEBUG")) fprintf(stderr, "[root unions] requests %zu distinct %zu unions %zu aligned on their own %zu\n", reqs.size(), uniq.size(), unions.size(), fallback.size());
     results.resize(reqs.size());
     for (size_t i = 0; i < reqs.size(); ++i) results[i] = ures[uniq_of[i]];
     return FLX_OK;
@@ -704,7 +917,7 @@ int run_trace_jobs_unique(Lane* ctx, const u8* d_text, const u8* d_query, const 
             for (u32 id : ids) {
                 AlignRequest const& r = reqs[id];
                 trace_off[id - begin] = off;
-                jobs.push_back(DevAlignJob{r.ref_off, r.q_off, off, r.n, r.m, r.k, (u32)(id - begin)});
+                jobs.push_back(DevAlignJob{r.ref_off, r.q_off, off, r.n, r.m, r.k, (u32)(id - begin), 0});
                 off += slots[id];
                 u64 const ws = job_word_steps(r.n, r.m, r.k, shapes[id]);
                 l.word_steps += ws;
@@ -1250,7 +1463,7 @@ int align_slice(Lane* lane, const flx_params* P, const flx_reads* RD, u64 first_
             if (outs[i].score != 0xFFFFFFFFu) { root_res[i].exists = true; root_res[i].nm = outs[i].score; root_res[i].start = root_spans[i].offset + (root_reqs[i].n - outs[i].end_col); }
     } else {
         hvec<TraceResult> tres;
-        if ((rc = run_trace_jobs(lane, d_text, d_pool, d_peq, root_reqs, tres, cig))) return rc;
+        if ((rc = run_trace_jobs_union(lane, d_text, d_pool, d_peq, root_reqs, tres, cig))) return rc;
         for (size_t i = 0; i < tres.size(); ++i)
             if (tres[i].exists) root_res[i] = RootAlignment{true, root_spans[i].offset + tres[i].begin, tres[i].nm, tres[i].cigar_off, tres[i].cigar_len};
     }

@@ -469,6 +469,7 @@ def test_lanes_chunks_and_launch_forms_give_the_same_records(kw):
     assert sum(1 for r in base[1] if not r[1] & 4) >= 150
     assert _run_with_env(genome, reads, {"FLX_LANES": "4", "FLX_CHUNK_READS": "16"}, **kw) == base
     assert _run_with_env(genome, reads, {"FLX_LANES": "3", "FLX_CHUNK_READS": "70"}, **kw) == base
+    assert _run_with_env(genome, reads, {"FLX_LANES": "2", "FLX_NO_UNION": "1"}, **kw) == base          # every root window on its own
     assert _run_with_env(genome, reads, {"FLX_LANES": "2", "FLX_ALIGN_FEW_WAVES": "0"}, **kw) == base
     assert _run_with_env(genome, reads, {"FLX_LANES": "2", "FLX_ALIGN_FEW_WAVES": "1000000000"}, **kw) == base
     exp = O.Index(genome).run(reads[:40], O.params(error_probability=0.07, interval_opt=kw.get("interval_optimization", False)), threads=8)
@@ -524,3 +525,27 @@ def test_full_size_reads_both_launch_forms_match_oracle():
             os.environ.pop("FLX_ALIGN_FEW_WAVES", None)
         else:
             os.environ["FLX_ALIGN_FEW_WAVES"] = old
+
+
+def test_root_unions_and_their_fallback():
+    """root windows of one locus share one DP over their union; a member whose path leaves its window is aligned on its own (the
+    hook FLX_UNION_ALIGN_OWN sends every member that way): identical CIGAR slabs are shared, records equal the oracle's either way"""
+    import subprocess, sys, json
+    genome = S.make_genome(500000, 2, seed=61)
+    reads, _, _ = S.make_reads(genome, 40, 3000, 0.08, seed=62)
+    exp = O.Index(genome).run(reads, O.params(error_probability=0.08), threads=8)
+    ctx = F.context(F.fmindex(genome))
+    res = F.aligner(ctx, F.params(error_probability=0.08)).align_reads(reads)
+    assert res.records() == exp.records()
+    mapped = res.rows[(res.rows[:, 1] & 4) == 0]
+    assert len(mapped) > 3 * len(reads)                                    # several records per read ...
+    assert len(np.unique(mapped[:, 5])) < len(mapped) / 2                  # ... that share their CIGAR words
+    ctx.close()
+    # the hook is read once per process: run the forced variant in a child
+    code = ("import sys, json; sys.path.insert(0, %r); import numpy as np, floxer_amd as F; from floxer_amd import simulate as S;"
+            "g = S.make_genome(500000, 2, seed=61); r, _, _ = S.make_reads(g, 40, 3000, 0.08, seed=62);"
+            "c = F.context(F.fmindex(g)); print(json.dumps(F.aligner(c, F.params(error_probability=0.08)).align_reads(r).records()))"
+            % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, FLX_UNION_ALIGN_OWN="1"), capture_output=True, text=True, check=True)
+    forced = [tuple(r) for r in json.loads(out.stdout.strip().split("\n")[-1])]
+    assert forced == exp.records()
