@@ -53,7 +53,8 @@ struct Lane {
     std::vector<hipEvent_t> event_pool;
     hipEvent_t sync_event = nullptr;
     bool has_run = false;            // a chunk has run here (its workspaces have their working sizes)
-    int sync();
+    int wait_idle();                 // the stream has drained (the thread sleeps on a blocking event unless FLX_SPIN_SYNC is set)
+    int sync();                      // wait_idle + fold pending timings into the context's statistics
     std::vector<DeviceBuffer*> workspaces();
     int size_like(Lane& other);      // grow this lane's workspaces to the other lane's capacities                      // stream synchronize + fold pending timings into the context's statistics
     hipEvent_t get_event();

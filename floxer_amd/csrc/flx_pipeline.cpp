@@ -118,13 +118,23 @@ void flx_ctx::account(const char* name, u64 bytes, u64 units, hipEvent_t start, 
     it->second.algorithmic_bytes += bytes;
     it->second.work_units += units;
 }
+int Lane::wait_idle() {
+    // hipStreamSynchronize and hipEventSynchronize keep the calling core busy for as long as the GPU works (also with
+    // hipEventBlockingSync on this runtime); polling an event with short sleeps leaves the core to the other lanes' host work.
+    static int const spin = getenv("FLX_SPIN_SYNC") ? 1 : 0;
+    if (spin) { FLX_HIP(hipStreamSynchronize(stream)); return FLX_OK; }
+    if (!sync_event) FLX_HIP(hipEventCreateWithFlags(&sync_event, hipEventDisableTiming));
+    FLX_HIP(hipEventRecord(sync_event, stream));
+    for (unsigned waited = 0;; ++waited) {
+        hipError_t const e = hipEventQuery(sync_event);
+        if (e == hipSuccess) break;
+        if (e != hipErrorNotReady) { set_error(std::string("hipEventQuery: ") + hipGetErrorString(e)); return FLX_ERR_NO_DEVICE; }
+        std::this_thread::sleep_for(std::chrono::microseconds(waited < 4 ? 20 : 60));
+    }
+    return FLX_OK;
+}
 int Lane::sync() {
-    static int const blocking = getenv("FLX_BLOCKING_SYNC") ? 1 : 0;
-    if (blocking) {
-        if (!sync_event) FLX_HIP(hipEventCreateWithFlags(&sync_event, hipEventBlockingSync | hipEventDisableTiming));
-        FLX_HIP(hipEventRecord(sync_event, stream));
-        FLX_HIP(hipEventSynchronize(sync_event));
-    } else FLX_HIP(hipStreamSynchronize(stream));
+    if (int const rc = wait_idle()) return rc;
     if (!pending.empty()) {
         std::lock_guard<std::mutex> g(ctx->mu);
         for (auto& p : pending) {
@@ -186,7 +196,13 @@ static int h2d(Lane* ctx, DeviceBuffer& buf, const void* src, size_t bytes, size
     return FLX_OK;
 }
 static int d2h(Lane* ctx, void* dst, const void* src, size_t bytes) {
-    if (bytes) FLX_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    // A copy into pageable memory makes the calling thread wait, spinning, for everything queued before it. Waiting for the
+    // stream on a blocking event first lets the thread sleep while the kernels run, so its core serves another lane.
+    if (bytes) {
+        int const rc = ctx->wait_idle();
+        if (rc) return rc;
+        FLX_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    }
     return FLX_OK;
 }
 // upload a byte sequence with TEXT_PAD zero bytes in front and behind; returns pointer to element 0
