@@ -683,6 +683,113 @@ int run_trace_jobs(Lane* ctx, const u8* d_text, const u8* d_query, const u64* d_
     return FLX_OK;
 }
 
+// Existence tests of one locus. Anchors of the same read at the same locus test the same node in windows shifted by their indel
+// drift. Existence is monotone in the window: an alignment inside the intersection I of such windows lies inside every one of them,
+// and if their union U holds none then neither does any of them. So a cluster first tests I (one job instead of one per member);
+// only if that fails it tests U, and only if U holds an alignment that I does not are the members tested one by one.
+// outs[i].score is 0xFFFFFFFF for "no alignment within k" and some score <= k of a contained alignment otherwise (callers of
+// this function only look at that distinction); outs[i].end_col is not meaningful.
+int run_exists_jobs(Lane* ctx, const u8* d_text, const u64* d_peq, hvec<AlignRequest> const& reqs, hvec<DevAlignOut>& outs) {
+    hvec<AlignRequest> uniq;
+    hvec<u32> uniq_of;
+    dedup_requests(reqs, uniq, uniq_of);
+    hvec<DevAlignOut> uouts(uniq.size(), DevAlignOut{0xFFFFFFFFu, 0});
+    hvec<u32> order(uniq.size());
+    std::iota(order.begin(), order.end(), 0u);
+    static int const off = getenv("FLX_NO_UNION") ? 1 : 0;
+    if (!off)
+        std::sort(order.begin(), order.end(), [&](u32 a, u32 b) {
+            AlignRequest const &x = uniq[a], &y = uniq[b];
+            if (x.q_off != y.q_off) return x.q_off < y.q_off;
+            if (x.m != y.m) return x.m < y.m;
+            if (x.k != y.k) return x.k < y.k;
+            return x.ref_off < y.ref_off;
+        });
+    struct Cluster { u32 first, count; u64 lo_start, hi_start, lo_end, hi_end; };     // members = order[first .. first+count)
+    hvec<Cluster> clusters;
+    for (u32 pos = 0; pos < order.size(); ++pos) {
+        AlignRequest const& r = uniq[order[pos]];
+        if (!off && !clusters.empty()) {
+            Cluster& c = clusters.back();
+            AlignRequest const& f = uniq[order[c.first]];
+            if (f.q_off == r.q_off && f.m == r.m && f.k == r.k && r.ref_off <= f.ref_off + std::max<u64>(8, r.m / 8)) {
+                c.count++;
+                c.hi_start = std::max(c.hi_start, r.ref_off);
+                c.lo_end = std::min(c.lo_end, r.ref_off + r.n);
+                c.hi_end = std::max(c.hi_end, r.ref_off + r.n);
+                continue;
+            }
+        }
+        clusters.push_back(Cluster{pos, 1, r.ref_off, r.ref_off, r.ref_off + r.n, r.ref_off + r.n});
+    }
+    // ---- phase A: single windows on their own, clusters on their intersection
+    hvec<AlignRequest> jobs;
+    hvec<u32> job_cluster;
+    for (u32 ci = 0; ci < clusters.size(); ++ci) {
+        Cluster const& c = clusters[ci];
+        AlignRequest r = uniq[order[c.first]];
+        if (c.count > 1) {
+            if (c.lo_end <= c.hi_start) continue;            // no common column: straight to the members (phase C)
+            r.ref_off = c.hi_start;
+            r.n = (u32)(c.lo_end - c.hi_start);
+        }
+        jobs.push_back(r);
+        job_cluster.push_back(ci);
+    }
+    hvec<DevAlignOut> jouts;
+    int rc = run_score_jobs_unique(ctx, d_text, d_peq, jobs, jouts, "ed_align_exists");
+    if (rc) return rc;
+    hvec<u8> state(clusters.size(), 0);                      // 0 undecided, 1 all pass, 2 all fail
+    hvec<u32> pass_score(clusters.size(), 0);
+    for (size_t j = 0; j < jobs.size(); ++j) {
+        u32 const ci = job_cluster[j];
+        if (jouts[j].score != 0xFFFFFFFFu) { state[ci] = 1; pass_score[ci] = jouts[j].score; }
+        else if (clusters[ci].count == 1) state[ci] = 2;
+    }
+    // ---- phase B: the union of the clusters whose intersection holds no alignment
+    jobs.clear();
+    job_cluster.clear();
+    for (u32 ci = 0; ci < clusters.size(); ++ci) {
+        Cluster const& c = clusters[ci];
+        if (state[ci] != 0 || c.count == 1) continue;
+        AlignRequest r = uniq[order[c.first]];
+        r.ref_off = c.lo_start;
+        r.n = (u32)(c.hi_end - c.lo_start);
+        jobs.push_back(r);
+        job_cluster.push_back(ci);
+    }
+    if (!jobs.empty()) {
+        if ((rc = run_score_jobs_unique(ctx, d_text, d_peq, jobs, jouts, "ed_align_exists"))) return rc;
+        for (size_t j = 0; j < jobs.size(); ++j) if (jouts[j].score == 0xFFFFFFFFu) state[job_cluster[j]] = 2;
+    }
+    // ---- phase C: members of the clusters that are still undecided, one by one
+    jobs.clear();
+    hvec<u32> job_member;
+    for (u32 ci = 0; ci < clusters.size(); ++ci) {
+        Cluster const& c = clusters[ci];
+        if (state[ci] != 0) continue;
+        for (u32 j = 0; j < c.count; ++j) { jobs.push_back(uniq[order[c.first + j]]); job_member.push_back(order[c.first + j]); }
+    }
+    if (!jobs.empty()) {
+        if ((rc = run_score_jobs_unique(ctx, d_text, d_peq, jobs, jouts, "ed_align_exists"))) return rc;
+        for (size_t j = 0; j < jobs.size(); ++j) uouts[job_member[j]] = jouts[j];
+    }
+    for (u32 ci = 0; ci < clusters.size(); ++ci) {
+        if (state[ci] == 0) continue;
+        Cluster const& c = clusters[ci];
+        for (u32 j = 0; j < c.count; ++j) uouts[order[c.first + j]] = DevAlignOut{state[ci] == 1 ? pass_score[ci] : 0xFFFFFFFFu, 0};
+    }
+    if (getenv("FLX_ALIGN_DEBUG")) {
+        size_t multi = 0, decided_a = 0;
+        for (u32 ci = 0; ci < clusters.size(); ++ci) if (clusters[ci].count > 1) { ++multi; if (state[ci] == 1) ++decided_a; }
+        fprintf(stderr, "[exists clusters] requests %zu distinct %zu clusters %zu (of several windows %zu, passed on the intersection %zu) one by one %zu\n",
+                reqs.size(), uniq.size(), clusters.size(), multi, decided_a, jobs.size());
+    }
+    outs.resize(reqs.size());
+    for (size_t i = 0; i < reqs.size(); ++i) outs[i] = uouts[uniq_of[i]];
+    return FLX_OK;
+}
+
 // Root alignments of one locus. Anchors of the same read at the same locus ask for windows that differ by a few columns (their
 // indel drift), ten per read with floxer's defaults, and nearly always get the same alignment. One DP over the union U of such
 // windows serves them all, exactly:
@@ -1422,7 +1529,7 @@ int align_slice(Lane* lane, const flx_params* P, const flx_reads* RD, u64 first_
         for (u32 ai : climbing) (node_rows(A[ai]) <= limit ? selected : waiting).push_back(ai);
         reqs.clear();
         for (u32 ai : selected) reqs.push_back(window_request(A[ai], reads[A[ai].read].tree.inner[A[ai].node], 0.0, nullptr));
-        if ((rc = run_score_jobs(lane, d_text, d_peq, reqs, outs, "ed_align_exists"))) return rc;
+        if ((rc = run_exists_jobs(lane, d_text, d_peq, reqs, outs))) return rc;
         for (size_t i = 0; i < outs.size(); ++i) {
             AnchorState& a = A[selected[i]];
             if (outs[i].score == 0xFFFFFFFFu) { a.alive = false; continue; }
