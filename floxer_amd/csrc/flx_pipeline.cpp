@@ -689,22 +689,26 @@ int run_trace_jobs(Lane* ctx, const u8* d_text, const u8* d_query, const u64* d_
 // only if that fails it tests U, and only if U holds an alignment that I does not are the members tested one by one.
 // outs[i].score is 0xFFFFFFFF for "no alignment within k" and some score <= k of a contained alignment otherwise (callers of
 // this function only look at that distinction); outs[i].end_col is not meaningful.
+thread_local double g_exists_ms[4] = {0, 0, 0, 0};            // dedup, cluster, GPU round trip, scatter (FLX_HOST_PROFILE)
 int run_exists_jobs(Lane* ctx, const u8* d_text, const u64* d_peq, hvec<AlignRequest> const& reqs, hvec<DevAlignOut>& outs) {
+    auto t0 = std::chrono::steady_clock::now();
+    auto lap = [&](int slot) { auto const t1 = std::chrono::steady_clock::now(); g_exists_ms[slot] += std::chrono::duration<double, std::milli>(t1 - t0).count(); t0 = t1; };
     hvec<AlignRequest> uniq;
     hvec<u32> uniq_of;
     dedup_requests(reqs, uniq, uniq_of);
+    lap(0);
     hvec<DevAlignOut> uouts(uniq.size(), DevAlignOut{0xFFFFFFFFu, 0});
+    // windows of one (query rows, errors) next to each other by reference position: packed keys sorted in place (no indirection)
+    struct SortKey { u64 hi, lo; u32 idx; };                 // hi = q_off << 17 | m, lo = k << 32 | ref_off (text < 2^32, m, k < 2^17)
+    static int const off = (getenv("FLX_NO_UNION") || getenv("FLX_NO_EXISTS_CLUSTERS")) ? 1 : 0;
     hvec<u32> order(uniq.size());
-    std::iota(order.begin(), order.end(), 0u);
-    static int const off = getenv("FLX_NO_UNION") ? 1 : 0;
-    if (!off)
-        std::sort(order.begin(), order.end(), [&](u32 a, u32 b) {
-            AlignRequest const &x = uniq[a], &y = uniq[b];
-            if (x.q_off != y.q_off) return x.q_off < y.q_off;
-            if (x.m != y.m) return x.m < y.m;
-            if (x.k != y.k) return x.k < y.k;
-            return x.ref_off < y.ref_off;
-        });
+    if (off) std::iota(order.begin(), order.end(), 0u);
+    else {
+        hvec<SortKey> keys(uniq.size());
+        for (u32 i = 0; i < uniq.size(); ++i) keys[i] = SortKey{(uniq[i].q_off << 17) | uniq[i].m, ((u64)uniq[i].k << 32) | uniq[i].ref_off, i};
+        std::sort(keys.begin(), keys.end(), [](SortKey const& x, SortKey const& y) { return x.hi != y.hi ? x.hi < y.hi : x.lo < y.lo; });
+        for (u32 i = 0; i < keys.size(); ++i) order[i] = keys[i].idx;
+    }
     struct Cluster { u32 first, count; u64 lo_start, hi_start, lo_end, hi_end; };     // members = order[first .. first+count)
     hvec<Cluster> clusters;
     for (u32 pos = 0; pos < order.size(); ++pos) {
@@ -722,45 +726,41 @@ int run_exists_jobs(Lane* ctx, const u8* d_text, const u64* d_peq, hvec<AlignReq
         }
         clusters.push_back(Cluster{pos, 1, r.ref_off, r.ref_off, r.ref_off + r.n, r.ref_off + r.n});
     }
-    // ---- phase A: single windows on their own, clusters on their intersection
+    // ---- one launch: single windows on their own, clusters on their intersection and (speculatively: a separate round trip
+    //      to the GPU costs a chunk more than the extra jobs) on their union
     hvec<AlignRequest> jobs;
-    hvec<u32> job_cluster;
+    hvec<u32> job_cluster;                                   // cluster index, bit 31 set for the union job
     for (u32 ci = 0; ci < clusters.size(); ++ci) {
         Cluster const& c = clusters[ci];
         AlignRequest r = uniq[order[c.first]];
-        if (c.count > 1) {
-            if (c.lo_end <= c.hi_start) continue;            // no common column: straight to the members (phase C)
-            r.ref_off = c.hi_start;
-            r.n = (u32)(c.lo_end - c.hi_start);
+        if (c.count == 1) { jobs.push_back(r); job_cluster.push_back(ci); continue; }
+        if (c.lo_end > c.hi_start) {                         // the common columns (none: straight to the union and the members)
+            AlignRequest i = r;
+            i.ref_off = c.hi_start;
+            i.n = (u32)(c.lo_end - c.hi_start);
+            jobs.push_back(i);
+            job_cluster.push_back(ci);
         }
-        jobs.push_back(r);
-        job_cluster.push_back(ci);
-    }
-    hvec<DevAlignOut> jouts;
-    int rc = run_score_jobs_unique(ctx, d_text, d_peq, jobs, jouts, "ed_align_exists");
-    if (rc) return rc;
-    hvec<u8> state(clusters.size(), 0);                      // 0 undecided, 1 all pass, 2 all fail
-    hvec<u32> pass_score(clusters.size(), 0);
-    for (size_t j = 0; j < jobs.size(); ++j) {
-        u32 const ci = job_cluster[j];
-        if (jouts[j].score != 0xFFFFFFFFu) { state[ci] = 1; pass_score[ci] = jouts[j].score; }
-        else if (clusters[ci].count == 1) state[ci] = 2;
-    }
-    // ---- phase B: the union of the clusters whose intersection holds no alignment
-    jobs.clear();
-    job_cluster.clear();
-    for (u32 ci = 0; ci < clusters.size(); ++ci) {
-        Cluster const& c = clusters[ci];
-        if (state[ci] != 0 || c.count == 1) continue;
-        AlignRequest r = uniq[order[c.first]];
         r.ref_off = c.lo_start;
         r.n = (u32)(c.hi_end - c.lo_start);
         jobs.push_back(r);
-        job_cluster.push_back(ci);
+        job_cluster.push_back(ci | 0x80000000u);
     }
-    if (!jobs.empty()) {
-        if ((rc = run_score_jobs_unique(ctx, d_text, d_peq, jobs, jouts, "ed_align_exists"))) return rc;
-        for (size_t j = 0; j < jobs.size(); ++j) if (jouts[j].score == 0xFFFFFFFFu) state[job_cluster[j]] = 2;
+    hvec<DevAlignOut> jouts;
+    lap(1);
+    int rc = run_score_jobs_unique(ctx, d_text, d_peq, jobs, jouts, "ed_align_exists");
+    if (rc) return rc;
+    lap(2);
+    hvec<u8> state(clusters.size(), 0);                      // 0 undecided, 1 all pass, 2 all fail
+    hvec<u32> pass_score(clusters.size(), 0);
+    for (size_t j = 0; j < jobs.size(); ++j) {
+        u32 const ci = job_cluster[j] & 0x7FFFFFFFu;
+        bool const is_union = job_cluster[j] >> 31;
+        bool const found = jouts[j].score != 0xFFFFFFFFu;
+        if (!is_union) {
+            if (found) { state[ci] = 1; pass_score[ci] = jouts[j].score; }
+            else if (clusters[ci].count == 1) state[ci] = 2;
+        } else if (!found) state[ci] = 2;                   // (an intersection cannot hold an alignment the union does not)
     }
     // ---- phase C: members of the clusters that are still undecided, one by one
     jobs.clear();
@@ -787,6 +787,7 @@ int run_exists_jobs(Lane* ctx, const u8* d_text, const u64* d_peq, hvec<AlignReq
     }
     outs.resize(reqs.size());
     for (size_t i = 0; i < reqs.size(); ++i) outs[i] = uouts[uniq_of[i]];
+    lap(3);
     return FLX_OK;
 }
 
@@ -1516,6 +1517,7 @@ int align_slice(Lane* lane, const flx_params* P, const flx_reads* RD, u64 first_
     // different number of steps from different leaves). All tests of a node size then share one launch, and identical
     // (window, node) tests requested by anchors that started at different depths are found by the de-duplication.
     hvec<u32> climbing, selected, waiting;    // anchors that still have an inner node to test
+    double g_build_ms = 0;
     for (u32 ai = 0; ai < A.size(); ++ai) if (A[ai].alive && !A[ai].at_root) climbing.push_back(ai);
     hvec<AlignRequest> reqs;
     hvec<DevAlignOut> outs;
@@ -1527,8 +1529,10 @@ int align_slice(Lane* lane, const flx_params* P, const flx_reads* RD, u64 first_
         selected.clear();
         waiting.clear();
         for (u32 ai : climbing) (node_rows(A[ai]) <= limit ? selected : waiting).push_back(ai);
+        auto const tb0 = std::chrono::steady_clock::now();
         reqs.clear();
         for (u32 ai : selected) reqs.push_back(window_request(A[ai], reads[A[ai].read].tree.inner[A[ai].node], 0.0, nullptr));
+        g_build_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tb0).count();
         if ((rc = run_exists_jobs(lane, d_text, d_peq, reqs, outs))) return rc;
         for (size_t i = 0; i < outs.size(); ++i) {
             AnchorState& a = A[selected[i]];
@@ -1541,6 +1545,11 @@ int align_slice(Lane* lane, const flx_params* P, const flx_reads* RD, u64 first_
     }
 
     prof.mark("inner-levels");
+    if (prof.on) {
+        fprintf(stderr, "[flx host profile] exists rounds: dedup=%.2f cluster=%.2f gpu-round-trip=%.2f scatter=%.2f build-requests=%.2f ms\n",
+                g_exists_ms[0], g_exists_ms[1], g_exists_ms[2], g_exists_ms[3], g_build_ms);
+        g_exists_ms[0] = g_exists_ms[1] = g_exists_ms[2] = g_exists_ms[3] = 0;
+    }
     // ---- interval pass in verification order (verification.cpp:45, 106-109, 119-136): decides which anchors align the root
     hvec<AlignRequest> root_reqs;
     hvec<u32> root_anchor;
