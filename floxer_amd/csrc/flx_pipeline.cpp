@@ -298,7 +298,14 @@ int search_seeds_device(Lane* ctx, const u8* d_seq_pool_or_null, const u8* h_seq
     {
         std::map<u32, u32> first_of_class;                      // key -> number of seeds, then first launch position
         auto class_key = [&](u64 i) { return ((3u - seeds[i].num_errors) << 24) | std::min<u32>(seeds[i].length, 0xFFFFFFu); };
-        for (u64 i = 0; i < n_seeds; ++i) first_of_class[class_key(i)]++;
+        {
+            u32 last = 0xFFFFFFFFu, *slot = nullptr;                 // consecutive seeds are mostly of one class
+            for (u64 i = 0; i < n_seeds; ++i) {
+                u32 const key = class_key(i);
+                if (key != last) { slot = &first_of_class[key]; last = key; }
+                ++*slot;
+            }
+        }
         if (first_of_class.size() > 1) {
             u32 pos = 0;
             for (auto& kv : first_of_class) { u32 const n = kv.second; kv.second = pos; pos += n; }
@@ -700,7 +707,11 @@ int run_exists_jobs(Lane* ctx, const u8* d_text, const u64* d_peq, hvec<AlignReq
     hvec<DevAlignOut> uouts(uniq.size(), DevAlignOut{0xFFFFFFFFu, 0});
     // windows of one (query rows, errors) next to each other by reference position: packed keys sorted in place (no indirection)
     struct SortKey { u64 hi, lo; u32 idx; };                 // hi = q_off << 17 | m, lo = k << 32 | ref_off (text < 2^32, m, k < 2^17)
-    static int const off = (getenv("FLX_NO_UNION") || getenv("FLX_NO_EXISTS_CLUSTERS")) ? 1 : 0;
+    // (nodes below 256 rows: few windows of a locus per node yet, and their tests are cheap; sorting them costs more than it saves)
+    static int const disabled = (getenv("FLX_NO_UNION") || getenv("FLX_NO_EXISTS_CLUSTERS")) ? 1 : 0;
+    u32 largest = 0;
+    for (auto const& r : uniq) largest = std::max(largest, r.m);
+    bool const off = disabled || largest < 256;
     hvec<u32> order(uniq.size());
     if (off) std::iota(order.begin(), order.end(), 0u);
     else {
@@ -1284,7 +1295,7 @@ struct VerifiedIntervals {                                                      
 struct Span { u64 offset, length, extra; };
 Span compute_span(u64 anchor_pos, flx_pex_node const& node, u64 leaf_from, u64 reflen, double ratio) {   // verification.cpp:157-184
     u64 const base = (u64)(node.to - node.from + 1) + 2ull * node.num_errors + 1;
-    u64 const extra = fp_aware_ceil(base * ratio);
+    u64 const extra = ratio == 0.0 ? 0 : fp_aware_ceil(base * ratio);        // (inner nodes: no extension, fp_aware_ceil(0) = 0)
     i64 const start_signed = (i64)anchor_pos - (i64)(leaf_from - node.from) - (i64)node.num_errors - (i64)extra;
     u64 const start = start_signed >= 0 ? (u64)start_signed : 0;
     u64 const length = std::min(base + 2 * extra, reflen - start);
@@ -1316,6 +1327,7 @@ struct AnchorState {
     u32 leaf, ref_id;
     u64 pos;
     u32 node;                   // inner node under test
+    u32 node_rows = 0;          // its number of query rows (kept here: the rounds scan it)
     bool alive = true, at_root = false, wants_root = false;
 };
 
@@ -1521,14 +1533,15 @@ int align_slice(Lane* lane, const flx_params* P, const flx_reads* RD, u64 first_
     for (u32 ai = 0; ai < A.size(); ++ai) if (A[ai].alive && !A[ai].at_root) climbing.push_back(ai);
     hvec<AlignRequest> reqs;
     hvec<DevAlignOut> outs;
-    auto node_rows = [&](AnchorState const& a) { flx_pex_node const& nd = reads[a.read].tree.inner[a.node]; return nd.to - nd.from + 1; };
+    auto rows_of = [&](AnchorState const& a) { flx_pex_node const& nd = reads[a.read].tree.inner[a.node]; return nd.to - nd.from + 1; };
+    for (u32 ai : climbing) A[ai].node_rows = rows_of(A[ai]);
     while (!climbing.empty()) {
         u32 smallest = 0xFFFFFFFFu;
-        for (u32 ai : climbing) smallest = std::min(smallest, node_rows(A[ai]));
+        for (u32 ai : climbing) smallest = std::min(smallest, A[ai].node_rows);
         u64 const limit = (u64)smallest + smallest / 2;
         selected.clear();
         waiting.clear();
-        for (u32 ai : climbing) (node_rows(A[ai]) <= limit ? selected : waiting).push_back(ai);
+        for (u32 ai : climbing) (A[ai].node_rows <= limit ? selected : waiting).push_back(ai);
         auto const tb0 = std::chrono::steady_clock::now();
         reqs.clear();
         for (u32 ai : selected) reqs.push_back(window_request(A[ai], reads[A[ai].read].tree.inner[A[ai].node], 0.0, nullptr));
@@ -1539,7 +1552,7 @@ int align_slice(Lane* lane, const flx_params* P, const flx_reads* RD, u64 first_
             if (outs[i].score == 0xFFFFFFFFu) { a.alive = false; continue; }
             a.node = reads[a.read].tree.inner[a.node].parent_id;
             if (reads[a.read].tree.inner[a.node].parent_id == FLX_NULL_ID) a.at_root = true;
-            else waiting.push_back(selected[i]);
+            else { a.node_rows = rows_of(a); waiting.push_back(selected[i]); }
         }
         climbing.swap(waiting);
     }
