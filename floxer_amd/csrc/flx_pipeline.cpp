@@ -393,6 +393,12 @@ int search_seeds_device(Lane* ctx, const u8* d_seq_pool_or_null, const u8* h_seq
     hvec<u32> alive;
     for (u64 si = 0; si < n_seeds; ++si) {
         if (first[si] == first[si + 1]) continue;               // no hit at all: nothing to select
+        if (first[si] + 1 == first[si + 1] && by_seed[first[si]].len == 1 && cfg.max_num_anchors_hard >= 1 && cfg.max_num_anchors_soft >= 1) {
+            // one group of one row (most seeds of a read that has a single locus): every order and strategy keeps exactly it
+            total_raw[si] = 1;
+            reqs.push_back(RowReq{(u32)si, by_seed[first[si]].errors, by_seed[first[si]].lb});
+            continue;
+        }
         groups.clear();
         u64 total = 0;
         for (u32 h = first[si]; h < first[si + 1]; ++h) { groups.push_back(Group{by_seed[h].lb, by_seed[h].len, by_seed[h].errors}); total += by_seed[h].len; }
@@ -470,6 +476,16 @@ int search_seeds_device(Lane* ctx, const u8* d_seq_pool_or_null, const u8* h_seq
     for (u64 si = 0; si < n_seeds; ++si) {
         if (excluded[si]) { stats[si] = SeedStats{0, 0, 0, 1}; continue; }
         if (ri >= reqs.size() || reqs[ri].seed != si) continue;      // nothing kept: stats stay zero
+        if (ri + 1 == reqs.size() || reqs[ri + 1].seed != si) {
+            // a single anchor: its bucket holds nothing that could make it useless
+            u64 const p = textpos[ri];
+            if (p >= H.n) { set_error("fm_locate returned a position outside the text"); return FLX_ERR_INTERNAL; }
+            size_t const s = nref == 1 ? 0 : std::upper_bound(H.seq_start.begin(), H.seq_start.end(), p) - H.seq_start.begin() - 1;
+            stats[si] = SeedStats{1, 1, (u32)(total_raw[si] - 1), 0};
+            anchors.push_back(HostAnchor{(u32)si, seeds[si].pex_leaf_index, (u32)s, reqs[ri].errors, p - H.seq_start[s]});
+            ++ri;
+            continue;
+        }
         touched.clear();
         u32 raw = 0;
         while (ri < reqs.size() && reqs[ri].seed == si) {
