@@ -32,7 +32,7 @@ HBM_PEAK_GBS = 8000.0      # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROA
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=6)
+    ap.add_argument("--steps", type=int, default=12)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--reads-per-step", type=int, default=int(os.environ.get("FLX_BENCH_READS", 16384)), help="per GPU")
     ap.add_argument("--lanes", type=int, default=int(os.environ.get("FLX_LANES", 0)),
