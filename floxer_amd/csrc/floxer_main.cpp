@@ -11,6 +11,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <deque>
+#include <future>
+#include <memory>
 #include <string>
 #include <sys/stat.h>
 #include <vector>
@@ -300,50 +303,69 @@ int main(int argc, char** argv) {
     if (!qin.f) { log_line("error", "cannot open %s", o.queries.c_str()); return -1; }
     size_t batch_reads = 16384;      // 1024 reads per lane and chunk (see flx_align_reads_resident)
     if (const char* env = getenv("FLX_BATCH_READS")) { size_t const v = strtoull(env, nullptr, 10); if (v) batch_reads = v; }
-    ReadBatch batch;
+    // Batches are independent: up to three are in the context at a time (their chunks share its lanes), the next one is parsed
+    // while they run, and results are written in input order.
+    struct Finished { std::unique_ptr<ReadBatch> batch; std::vector<flx_record> recs; std::vector<uint32_t> cig; std::vector<uint8_t> skipped; int rc = FLX_OK; std::string err; };
+    auto align_batch = [&](std::unique_ptr<ReadBatch> b) {
+        Finished f;
+        flx_run* run = nullptr;
+        f.rc = flx_align_reads(ctx, &p, b->pool.data(), b->offsets.data(), b->ids.size(), &run);
+        if (f.rc != FLX_OK) { f.err = flx_last_error(); f.batch = std::move(b); return f; }
+        f.recs.resize(flx_run_num_records(run));
+        f.cig.resize(flx_run_num_cigar_words(run) + 1);
+        f.skipped.resize(b->ids.size());
+        flx_run_copy(run, f.recs.data(), f.cig.data(), f.skipped.data());
+        flx_run_free(run);
+        f.batch = std::move(b);
+        return f;
+    };
+    std::deque<std::future<Finished>> in_flight;
     std::string id, seq, qual;
     uint64_t total_reads = 0, total_records = 0;
     bool failed = false, eof = false, timed_out = false;
+    auto write_oldest = [&]() {
+        Finished f = in_flight.front().get();
+        in_flight.pop_front();
+        if (failed) return;
+        if (f.rc != FLX_OK) {
+            log_line("error", "An error occurred while aligning a batch of queries.\nShutting down. The output file is likely incomplete. Error message:\n%s", f.err.c_str());
+            failed = true;
+            return;
+        }
+        ReadBatch const& batch = *f.batch;
+        for (size_t i = 0; i < f.skipped.size(); ++i)
+            if (f.skipped[i]) log_line("warning", "skipping query: %s due to bad configuration regarding the number of errors.", batch.ids[i].c_str());
+        std::vector<const char*> idp, qp;
+        for (auto const& s : batch.ids) idp.push_back(s.c_str());
+        for (auto const& s : batch.quals) qp.push_back(s.c_str());
+        if (flx_sam_write(out, idp.data(), batch.pool.data(), batch.offsets.data(), qp.data(), f.recs.data(), f.recs.size(), f.cig.data()) != FLX_OK) { log_line("error", "%s", flx_last_error()); failed = true; }
+        total_reads += batch.ids.size();
+        total_records += f.recs.size();
+        log_line("debug", "finished a batch: %llu queries, %llu records so far", (unsigned long long)total_reads, (unsigned long long)total_records);
+    };
     while (!eof && !failed) {
         if (o.has_timeout && std::chrono::duration<double>(std::chrono::steady_clock::now() - t_align).count() > (double)o.timeout) {
             log_line("warning", "Timeout happened. Shutting down now. The output file might be incomplete.");
             timed_out = true;
             break;
         }
-        batch.clear();
-        while (batch.ids.size() < batch_reads) {
+        auto batch = std::make_unique<ReadBatch>();
+        while (batch->ids.size() < batch_reads) {
             if (!next_fastq(qin, id, seq, qual, err)) { eof = true; if (!err.empty()) { log_line("error", "%s", err.c_str()); failed = true; } break; }
             if (seq.empty()) { log_line("warning", "The record %s in the query file has an empty sequence and will be skipped.", id.c_str()); continue; }
             if (seq.size() > 100000) { log_line("warning", "skipping too large query: %s", id.c_str()); continue; }
-            batch.ids.push_back(id);
-            batch.quals.push_back(qual);
-            size_t const off = batch.pool.size();
-            batch.pool.resize(off + seq.size());
-            flx_chars_to_rank_sequence(seq.data(), seq.size(), batch.pool.data() + off);
-            batch.offsets.push_back(batch.pool.size());
+            batch->ids.push_back(id);
+            batch->quals.push_back(qual);
+            size_t const off = batch->pool.size();
+            batch->pool.resize(off + seq.size());
+            flx_chars_to_rank_sequence(seq.data(), seq.size(), batch->pool.data() + off);
+            batch->offsets.push_back(batch->pool.size());
         }
-        if (failed || batch.ids.empty()) break;
-        flx_run* run = nullptr;
-        if (flx_align_reads(ctx, &p, batch.pool.data(), batch.offsets.data(), batch.ids.size(), &run) != FLX_OK) {
-            log_line("error", "An error occurred while aligning a batch of queries.\nShutting down. The output file is likely incomplete. Error message:\n%s", flx_last_error());
-            failed = true;
-            break;
-        }
-        std::vector<flx_record> recs(flx_run_num_records(run));
-        std::vector<uint32_t> cig(flx_run_num_cigar_words(run) + 1);
-        std::vector<uint8_t> skipped(batch.ids.size());
-        flx_run_copy(run, recs.data(), cig.data(), skipped.data());
-        flx_run_free(run);
-        for (size_t i = 0; i < skipped.size(); ++i)
-            if (skipped[i]) log_line("warning", "skipping query: %s due to bad configuration regarding the number of errors.", batch.ids[i].c_str());
-        std::vector<const char*> idp, qp;
-        for (auto const& s : batch.ids) idp.push_back(s.c_str());
-        for (auto const& s : batch.quals) qp.push_back(s.c_str());
-        if (flx_sam_write(out, idp.data(), batch.pool.data(), batch.offsets.data(), qp.data(), recs.data(), recs.size(), cig.data()) != FLX_OK) { log_line("error", "%s", flx_last_error()); failed = true; }
-        total_reads += batch.ids.size();
-        total_records += recs.size();
-        log_line("debug", "finished a batch: %llu queries, %llu records so far", (unsigned long long)total_reads, (unsigned long long)total_records);
+        if (failed || batch->ids.empty()) break;
+        in_flight.push_back(std::async(std::launch::async, align_batch, std::move(batch)));
+        while (in_flight.size() >= 3) write_oldest();
     }
+    while (!in_flight.empty()) write_oldest();
     if (flx_sam_close(out) != FLX_OK) { log_line("error", "%s", flx_last_error()); failed = true; }
     flx_ctx_destroy(ctx);
     flx_index_free(index);
