@@ -549,3 +549,23 @@ def test_root_unions_and_their_fallback():
     out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, FLX_UNION_ALIGN_OWN="1"), capture_output=True, text=True, check=True)
     forced = [tuple(r) for r in json.loads(out.stdout.strip().split("\n")[-1])]
     assert forced == exp.records()
+
+
+def test_caller_owned_stream():
+    """flx_ctx_set_stream: every launch goes to the caller's HIP stream (one lane); results do not change"""
+    import torch
+    genome = S.make_genome(200000, 1, seed=71)
+    reads, _, _ = S.make_reads(genome, 60, 1500, 0.06, seed=72)
+    ctx = F.context(F.fmindex(genome))
+    al = F.aligner(ctx, F.params(error_probability=0.06))
+    base = al.align_reads(reads).records()
+    stream = torch.cuda.Stream()
+    ctx.set_stream(stream.cuda_stream)
+    rr = F.resident_reads(ctx, reads)
+    assert al.align_reads(rr).records() == base
+    assert al.align_reads(reads).records() == base
+    stream.synchronize()
+    ctx.set_stream(None)
+    assert al.align_reads(rr).records() == base
+    rr.close()
+    ctx.close()
