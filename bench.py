@@ -112,7 +112,7 @@ def main():
     def exchange(res):
         """the only exchange between ranks: the sizes of the ranks' parts (= where each part goes in the job's output, which is the
         parts in rank order); every rank keeps its own records. Returns the job's record count of this step."""
-        counts = D.exchange_counts(len(res.rows), len(res.cigars), rank, world, device=dev)
+        counts = D.exchange_counts(res.n_records, len(res.cigars), rank, world, device=dev)
         return int(counts[:, 0].sum())
 
     def barrier():

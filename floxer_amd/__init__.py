@@ -264,10 +264,27 @@ def params(error_probability=None, query_errors=None, seed_errors=2, max_anchors
 
 
 class RunResult:
-    def __init__(self, rows, cigars, skipped):
-        self.rows = rows            # (n,7) int64 {read_index, flag, ref_id, pos, nm, cigar_off, cigar_len}
+    """records of one flx_align_reads* call. `raw` is the flx_record array as the C ABI returns it; `rows` is the same as an (n,7)
+    int64 matrix {read_index, flag, ref_id, pos, nm, cigar_off, cigar_len}, made on first use."""
+
+    def __init__(self, raw, cigars, skipped):
+        self.raw = raw
         self.cigars = cigars
         self.skipped = skipped
+        self._rows = None
+
+    @property
+    def n_records(self):
+        return len(self.raw)
+
+    @property
+    def rows(self):
+        if self._rows is None:
+            raw = self.raw
+            self._rows = (np.stack([raw["read"].astype(np.int64), raw["flag"].astype(np.int64), raw["ref"].astype(np.int64),
+                                    raw["pos"].astype(np.int64), raw["nm"].astype(np.int64), raw["coff"].astype(np.int64),
+                                    raw["clen"].astype(np.int64)], axis=1) if len(raw) else np.zeros((0, 7), dtype=np.int64))
+        return self._rows
 
     def records(self):
         return [(int(r[0]), int(r[1]), int(r[2]), int(r[3]), int(r[4]), cigar_string(self.cigars[r[5]: r[5] + r[6]])) for r in self.rows]
@@ -317,12 +334,9 @@ def _collect_run(run, n):
         skipped = np.zeros(max(1, n), dtype=np.uint8)
         check(lib().flx_run_copy(run, raw.ctypes.data_as(C.POINTER(capi.Record)), ptr(cig, u32p), ptr(skipped, u8p)))
         raw = raw[:nr]
-        rows = np.stack([raw["read"].astype(np.int64), raw["flag"].astype(np.int64), raw["ref"].astype(np.int64),
-                         raw["pos"].astype(np.int64), raw["nm"].astype(np.int64), raw["coff"].astype(np.int64),
-                         raw["clen"].astype(np.int64)], axis=1) if nr else np.zeros((0, 7), dtype=np.int64)
     finally:
         lib().flx_run_free(run)
-    return RunResult(rows, cig[:nc], skipped[:n])
+    return RunResult(raw, cig[:nc], skipped[:n])
 
 
 class aligner:

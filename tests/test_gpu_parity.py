@@ -553,19 +553,22 @@ def test_root_unions_and_their_fallback():
 
 def test_caller_owned_stream():
     """flx_ctx_set_stream: every launch goes to the caller's HIP stream (one lane); results do not change"""
-    import torch
+    import ctypes
+    hip = ctypes.CDLL("libamdhip64.so")
     genome = S.make_genome(200000, 1, seed=71)
     reads, _, _ = S.make_reads(genome, 60, 1500, 0.06, seed=72)
     ctx = F.context(F.fmindex(genome))
     al = F.aligner(ctx, F.params(error_probability=0.06))
     base = al.align_reads(reads).records()
-    stream = torch.cuda.Stream()
-    ctx.set_stream(stream.cuda_stream)
+    stream = ctypes.c_void_p()
+    assert hip.hipStreamCreate(ctypes.byref(stream)) == 0
+    ctx.set_stream(stream)
     rr = F.resident_reads(ctx, reads)
     assert al.align_reads(rr).records() == base
     assert al.align_reads(reads).records() == base
-    stream.synchronize()
+    assert hip.hipStreamSynchronize(stream) == 0
     ctx.set_stream(None)
     assert al.align_reads(rr).records() == base
     rr.close()
     ctx.close()
+    assert hip.hipStreamDestroy(stream) == 0
