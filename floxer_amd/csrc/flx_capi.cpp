@@ -132,6 +132,7 @@ int flx_ctx_create(int hip_device, const flx_index* index, flx_ctx** out) {
     if ((rc = up(ctx->occ1, H.occ[1].data(), H.occ[1].size() * sizeof(OccBlock)))) return rc;
     if ((rc = up(ctx->sa, H.sa.data(), H.sa.size() * 4))) return rc;
     if ((rc = up(ctx->kmer, H.kmer_table.data(), H.kmer_table.size() * 4))) return rc;
+    if ((rc = up(ctx->seq_start, H.seq_start.data(), H.seq_start.size() * 8))) return rc;
     if ((rc = ctx->text.ensure(H.n + 2 * TEXT_PAD + 16))) return rc;
     FLX_HIP(hipMemsetAsync(ctx->text.ptr, 0, ctx->text.cap, s0));
     FLX_HIP(hipMemcpyAsync((char*)ctx->text.ptr + TEXT_PAD, H.text.data(), H.n, hipMemcpyHostToDevice, s0));
@@ -158,7 +159,7 @@ void flx_ctx_destroy(flx_ctx* ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     for (auto& lane : ctx->lanes) { (void)hipStreamSynchronize(lane->stream); lane->release_all(); }
-    for (DeviceBuffer* b : {&ctx->occ0, &ctx->occ1, &ctx->sa, &ctx->text, &ctx->text_rev, &ctx->kmer}) b->release();
+    for (DeviceBuffer* b : {&ctx->occ0, &ctx->occ1, &ctx->sa, &ctx->text, &ctx->text_rev, &ctx->kmer, &ctx->seq_start}) b->release();
     if (ctx->upload_stream) (void)hipStreamDestroy(ctx->upload_stream);
     delete ctx;
 }

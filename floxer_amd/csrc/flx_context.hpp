@@ -47,7 +47,8 @@ struct Lane {
     int id = 0;
     hipStream_t own_stream = nullptr, stream = nullptr;
     DeviceBuffer seq, seq_rev, peq, peq_rev, scheme, seeds, stack, hits, counters, rows, rows_out;
-    DeviceBuffer jobs, job_out, trace, tjobs, tjob_out, cigar, user_text, user_text_rev, lastrow, row_windows, row_out;
+    DeviceBuffer jobs, job_out, trace, tjobs, tjob_out, cigar, user_text, user_text_rev, lastrow, row_windows, row_out,
+        seed_cnt, hit_off, grouped, sel_stat, sel_n, sel_off, sel_out, sel_tmp;
     size_t trace_budget_bytes = 0;
     std::vector<PendingTiming> pending;
     std::vector<hipEvent_t> event_pool;
@@ -66,7 +67,7 @@ struct flx_ctx {
     int device = 0;
     const flx::HostIndex* hidx = nullptr;
     flx::DevIndex didx{};
-    flx::DeviceBuffer occ0, occ1, sa, text, text_rev, kmer;
+    flx::DeviceBuffer occ0, occ1, sa, text, text_rev, kmer, seq_start;
     bool text_rev_ready = false;
     std::mutex mu;                   // guards text_rev upload and the statistics
     std::vector<std::unique_ptr<flx::Lane>> lanes;

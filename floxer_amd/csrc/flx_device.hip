@@ -7,6 +7,7 @@
 //   K3/K4 ed_align    seqan3 edit-distance semi-global DP (alignment.cpp:89-125, 160): score + end column, optional trace
 //   K5 ed_traceback   trace walk + CIGAR (alignment.cpp:166-180)
 #include <hip/hip_runtime.h>
+#include <hipcub/hipcub.hpp>
 
 #include <cstdlib>
 
@@ -142,7 +143,7 @@ constexpr u32 FM_SEEDS_PER_WAVE = 256;      // a launch has at most n_seeds / th
 __global__ void __launch_bounds__(64) fm_search_kernel(DevIndex idx, const u8* __restrict__ seq, const u32* __restrict__ scheme,
                                                        const DevSeed* __restrict__ seeds, u32 n_seeds, u32 max_hits,
                                                        DevFrame* __restrict__ stack, DevHit* __restrict__ hits, u32 hit_cap,
-                                                       u32* __restrict__ counters) {
+                                                       u32* __restrict__ counters, u32* __restrict__ seed_cnt) {
     u32 q_next = 0, q_end = 0;                  // wave-uniform: the unserved rest of the last grabbed seed range
     bool queue_done = false;
     u32 h_next = 0, h_end = 0;                  // wave-uniform: the unwritten rest of the last reserved range of hit slots
@@ -169,6 +170,7 @@ __global__ void __launch_bounds__(64) fm_search_kernel(DevIndex idx, const u8* _
     bool have_frame = false, need_child = false;
     bool hit_pending = false;                   // a hit of this pair (sid, nlb, hit_rep, ne) waits for its slot
     u32 hit_rep = 0;
+    u32 hit_idx = 0;                            // hits of the current seed so far (the first SEED_HIT_SLOTS also go to its own slots)
 
     // child cursor of symbol `sym` out of per-lane slot arrays, from the lane that owns the symbol
     auto child_of = [&](const u32 abs_s[4], const u32 oth_s[4], const u32 len_s[4], u32 sym, u32& cabs, u32& coth, u32& clen) {
@@ -202,7 +204,11 @@ __global__ void __launch_bounds__(64) fm_search_kernel(DevIndex idx, const u8* _
             }
             if (hit_pending && h == 0u) {
                 u32 const slot = h_next + (u32)__popcll(emit & ((1ull << lane) - 1ull));
-                if (slot < hit_cap) hits[slot] = DevHit{sid, nlb, hit_rep, ne};
+                // the hit's ordinal within its seed rides in the upper bits of the error count (errors <= 3): the hits of a seed
+                // can be put back in emission order without a sort
+                if (slot < hit_cap) hits[slot] = DevHit{sid, nlb, hit_rep, seed_cnt ? ne | (min(hit_idx, 0xFFFFFFu) << 8) : ne};
+                if (seed_cnt) seed_cnt[sid] = hit_idx + 1u;
+                ++hit_idx;
             }
             h_next += n_emit;
             hit_pending = false;
@@ -247,6 +253,7 @@ __global__ void __launch_bounds__(64) fm_search_kernel(DevIndex idx, const u8* _
                     ex_base = scheme + seed.scheme_off;
                     srch = 0;
                     ct = 0;
+                    hit_idx = 0;
                     busy = true;
                     in_search = false;
                 } else exhausted = true;
@@ -422,10 +429,178 @@ __global__ void __launch_bounds__(64) fm_search_kernel(DevIndex idx, const u8* _
 }
 
 int DeviceApi::search(void* stream, const DevIndex& idx, const u8* d_seq, const u32* d_scheme, const DevSeed* d_seeds, u32 n_seeds,
-                      u32 max_hits_per_seed, DevFrame* d_stack, DevHit* d_hits, u32 hit_cap, u32* d_counters) {
+                      u32 max_hits_per_seed, DevFrame* d_stack, DevHit* d_hits, u32 hit_cap, u32* d_counters, u32* d_seed_cnt) {
     if (n_seeds == 0) return 0;
     hipLaunchKernelGGL(fm_search_kernel, dim3(std::min<u32>((n_seeds + FM_SEEDS_PER_WAVE - 1) / FM_SEEDS_PER_WAVE, FM_MAX_WAVES)), dim3(64), 0, (hipStream_t)stream, idx, d_seq, d_scheme, d_seeds,
-                       n_seeds, max_hits_per_seed, d_stack, d_hits, hit_cap, d_counters);
+                       n_seeds, max_hits_per_seed, d_stack, d_hits, hit_cap, d_counters, d_seed_cnt);
+    return (int)hipGetLastError();
+}
+
+// ================================================================================================ K1b: anchor selection
+// hits -> per-seed segments in emission order (a scan over the seeds' hit counts + a scatter by the ordinal each hit carries),
+// then one thread per seed does what search.cpp:190-318 does with the seed's groups: hard cap, group order, rows round robin,
+// locate through the suffix array, buckets per reference sorted by position, useless anchors erased (search.cpp:352-389).
+// Handled here: seeds with at most 16 groups whose rows all fit under the soft cap and SEL_MAX, and at most 16 anchors per
+// reference: libstdc++'s std::sort is a stable insertion sort up to 16 elements and not stable above, and the order of equal
+// elements shows in the result (groups tie on (count, errors); the same row reached through two groups gives two anchors of
+// equal position). Every seed not handled is flagged and goes through the host code.
+constexpr u32 SEL_MAX = 64;
+struct SelStat { u8 useful, raw, flag, excluded; };      // flag 1: the host selects this seed's anchors
+
+__global__ void __launch_bounds__(256) hit_scatter_kernel(const DevHit* __restrict__ hits, const u32* __restrict__ counters, u32 hit_cap,
+                                                          const u32* __restrict__ offset, DevHit* __restrict__ grouped) {
+    u32 const n_slots = min(counters[0], hit_cap);
+    for (u32 i = blockIdx.x * blockDim.x + threadIdx.x; i < n_slots; i += gridDim.x * blockDim.x) {
+        DevHit h = hits[i];
+        if (h.seed == 0xFFFFFFFFu) continue;
+        u32 const ordinal = h.errors >> 8;
+        h.errors &= 0xFFu;
+        grouped[offset[h.seed] + ordinal] = h;
+    }
+}
+
+// the selection of one seed whose groups (cnt <= CAP, cnt <= 16) hold `total` <= CAP rows; returns false when the seed has to go
+// to the host after all
+template <u32 CAP, bool WRITE>
+__device__ __forceinline__ bool select_seed(const DevHit* __restrict__ groups, u32 cnt, u32 total, const u32* __restrict__ sa, u32 n_text,
+                                            const u64* __restrict__ seq_start, u32 n_ref, u32 erase, u32 sid, SelStat& st, u32& produced,
+                                            DevOutAnchor* __restrict__ out, u32 at, u32 out_cap) {
+    u8 ord[CAP < 16 ? CAP : 16];                           // group order: stable insertion sort by (len, errors), which is what
+    for (u32 i = 0; i < cnt; ++i) ord[i] = (u8)i;          // std::sort does with up to 16 elements (search.cpp:200-212)
+    for (u32 i = 1; i < cnt; ++i) {
+        u8 const o = ord[i];
+        u32 const n = groups[o].len, e = groups[o].errors;
+        u32 j = i;
+        while (j > 0) {
+            DevHit const& p = groups[ord[j - 1]];
+            if (!(n != p.len ? n < p.len : e < p.errors)) break;
+            ord[j] = ord[j - 1];
+            --j;
+        }
+        ord[j] = o;
+    }
+    // rows round robin over the groups (search.cpp:239-272), located
+    u64 pos[CAP];
+    u32 ref[CAP];
+    u8 ae[CAP];
+    u32 kept = 0;
+    bool bad = false;
+    for (u32 round = 0; kept < total; ++round)
+        for (u32 gi = 0; gi < cnt; ++gi) {
+            DevHit const& g = groups[ord[gi]];
+            if (g.len <= round) continue;
+            u32 const row = g.lb + round;
+            u64 const p = row < n_text ? sa[row] : 0xFFFFFFFFull;
+            if (p >= n_text) bad = true;
+            u32 r = 0;
+            if (n_ref > 1) {                                   // last sequence that starts at or before p
+                u32 lo = 0, hi = n_ref;
+                while (hi - lo > 1) { u32 const mid = (lo + hi) >> 1; if (seq_start[mid] <= p) lo = mid; else hi = mid; }
+                r = lo;
+            }
+            pos[kept] = p - seq_start[r]; ref[kept] = r; ae[kept] = (u8)g.errors;
+            ++kept;
+        }
+    // a bucket is sorted by position with std::sort, which keeps anchors of equal position (the same row reached through two
+    // groups) in order only up to 16 elements
+    if (CAP > 16 && erase) {
+        u32 largest_bucket = 0;
+        for (u32 i = 0; i < kept; ++i) { u32 n = 0; for (u32 j = 0; j < kept; ++j) n += ref[j] == ref[i]; largest_bucket = max(largest_bucket, n); }
+        if (largest_bucket > 16) return false;
+    }
+    if (bad) return false;                                  // the host reports the error
+    // by reference id (stable), and by position when useless anchors are erased (erase_useless_anchors sorts its bucket); without
+    // erasing the buckets keep the order of selection
+    for (u32 i = 1; i < kept; ++i) {
+        u64 const p = pos[i]; u32 const r = ref[i]; u8 const e = ae[i];
+        u32 j = i;
+        while (j > 0 && (r != ref[j - 1] ? r < ref[j - 1] : (erase && p < pos[j - 1]))) { pos[j] = pos[j - 1]; ref[j] = ref[j - 1]; ae[j] = ae[j - 1]; --j; }
+        pos[j] = p; ref[j] = r; ae[j] = e;
+    }
+    u64 gone = 0;                                           // bit i: anchor i erased
+    if (erase) {
+        u32 b0 = 0;
+        while (b0 < kept) {                                 // one bucket = one reference
+            u32 b1 = b0;
+            while (b1 < kept && ref[b1] == ref[b0]) ++b1;
+            // search.cpp:352-389; an erased anchor compares with "infinitely many" errors
+            auto better = [&](u32 a, u32 b) {
+                u64 const ea = (gone >> a) & 1 ? ~0ull : (u64)ae[a], eb = (gone >> b) & 1 ? ~0ull : (u64)ae[b];
+                u64 const d = pos[a] < pos[b] ? pos[b] - pos[a] : pos[a] - pos[b];
+                return ea <= eb && d <= eb - ea;
+            };
+            for (u32 cur = b0; cur + 1 < b1;) {
+                u32 other = cur + 1;
+                while (other < b1 && better(cur, other)) { gone |= 1ull << other; ++other; }
+                if (other < b1 && better(other, cur)) gone |= 1ull << cur;
+                cur = other;
+            }
+            b0 = b1;
+        }
+    }
+    st.raw = (u8)kept;
+    for (u32 i = 0; i < kept; ++i)
+        if (!((gone >> i) & 1)) {
+            if (WRITE && at + produced < out_cap) out[at + produced] = DevOutAnchor{sid, 0u, ref[i], (u32)ae[i], pos[i]};
+            ++produced;
+        }
+    st.useful = (u8)produced;
+    return true;
+}
+
+template <bool WRITE>
+__global__ void __launch_bounds__(128) seed_select_kernel(const DevHit* __restrict__ grouped, const u32* __restrict__ hit_offset, u32 n_seeds,
+                                                          const u32* __restrict__ sa, u32 n_text, const u64* __restrict__ seq_start, u32 n_ref,
+                                                          u32 hard_cap, u32 soft_cap, u32 erase, SelStat* __restrict__ stat,
+                                                          u32* __restrict__ n_out, const u32* __restrict__ out_offset,
+                                                          DevOutAnchor* __restrict__ out, u32 out_cap) {
+    u32 const sid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (sid >= n_seeds) return;
+    u32 const g0 = hit_offset[sid], cnt = hit_offset[sid + 1] - g0;
+    SelStat st{0, 0, 0, 0};
+    u32 produced = 0;
+    if (WRITE) { st = stat[sid]; if (st.flag || st.useful == 0) return; }
+    if (cnt > 16) st.flag = 1;                              // a group order this kernel does not reproduce
+    else if (cnt > 0) {
+        u32 total = 0;
+        bool big = false;
+        for (u32 i = 0; i < cnt; ++i) { u32 const l = grouped[g0 + i].len; if (l > SEL_MAX) big = true; else total += l; }
+        if (big || total > SEL_MAX || total > soft_cap) st.flag = 1;           // a truncated selection
+        else if (total > hard_cap) st.excluded = 1;
+        else {
+            u32 const at = WRITE ? out_offset[sid] : 0;
+            bool ok;
+            if (cnt <= 8 && total <= 8) ok = select_seed<8, WRITE>(grouped + g0, cnt, total, sa, n_text, seq_start, n_ref, erase, sid, st, produced, out, at, out_cap);
+            else ok = select_seed<SEL_MAX, WRITE>(grouped + g0, cnt, total, sa, n_text, seq_start, n_ref, erase, sid, st, produced, out, at, out_cap);
+            if (!ok) { st = SelStat{0, 0, 1, 0}; produced = 0; }
+        }
+    }
+    if (!WRITE) { stat[sid] = st; n_out[sid] = st.flag ? 0u : produced; }
+}
+
+size_t DeviceApi::select_scan_bytes(u32 n_seeds) {
+    size_t bytes = 0;
+    (void)hipcub::DeviceScan::ExclusiveSum(nullptr, bytes, (const u32*)nullptr, (u32*)nullptr, (int)n_seeds + 1);
+    return bytes;
+}
+
+int DeviceApi::select(void* stream, const DevHit* d_hits, const u32* d_counters, u32 hit_cap, u32* d_seed_cnt, u32* d_hit_offset,
+                      DevHit* d_grouped, u32 n_seeds, const DevIndex& idx, const u64* d_seq_start, u32 n_ref, u32 hard_cap, u32 soft_cap,
+                      bool erase, void* d_stat, u32* d_n_out, u32* d_out_offset, DevOutAnchor* d_out, u32 out_cap, void* d_scan_tmp,
+                      size_t scan_bytes) {
+    if (n_seeds == 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    // d_seed_cnt and d_n_out have n_seeds + 1 entries, the last one zero: the scans end with the totals
+    hipError_t e = hipcub::DeviceScan::ExclusiveSum(d_scan_tmp, scan_bytes, d_seed_cnt, d_hit_offset, (int)n_seeds + 1, s);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(hit_scatter_kernel, dim3(2048), dim3(256), 0, s, d_hits, d_counters, hit_cap, d_hit_offset, d_grouped);
+    hipLaunchKernelGGL(seed_select_kernel<false>, dim3((n_seeds + 127) / 128), dim3(128), 0, s, d_grouped, d_hit_offset, n_seeds, idx.sa, idx.n,
+                       d_seq_start, n_ref, hard_cap, soft_cap, erase ? 1u : 0u, reinterpret_cast<SelStat*>(d_stat), d_n_out, nullptr, nullptr, 0u);
+    if ((e = hipGetLastError()) != hipSuccess) return (int)e;
+    e = hipcub::DeviceScan::ExclusiveSum(d_scan_tmp, scan_bytes, d_n_out, d_out_offset, (int)n_seeds + 1, s);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(seed_select_kernel<true>, dim3((n_seeds + 127) / 128), dim3(128), 0, s, d_grouped, d_hit_offset, n_seeds, idx.sa, idx.n,
+                       d_seq_start, n_ref, hard_cap, soft_cap, erase ? 1u : 0u, reinterpret_cast<SelStat*>(d_stat), d_n_out, d_out_offset, d_out, out_cap);
     return (int)hipGetLastError();
 }
 

@@ -101,6 +101,7 @@ struct DevFrame {       // 96 bytes: one branching node of the DFS, 48 bytes per
 static_assert(sizeof(DevFrame) == 96, "frame is six 16-byte slots");
 
 struct DevHit { u32 seed, lb, len, errors; };
+struct DevOutAnchor { u32 seed_index, leaf, ref_id, errors; u64 pos; };   // = HostAnchor (leaf is filled by the host)
 
 // ------------------------------------------------------------------------------------------------ K3/K4: alignment
 struct DevAlignJob {
@@ -161,8 +162,18 @@ struct KernelTimer;   // opaque, owned by the context
 struct DeviceApi {
     // all return 0 or a hipError_t (non-zero)
     static int build_peq(void* stream, const u8* d_seq, u64 len, u64* d_peq);
+    // d_seed_cnt (may be null): number of hits of every seed; each hit then carries its ordinal within its seed in errors >> 8
     static int search(void* stream, const DevIndex& idx, const u8* d_seq, const u32* d_scheme, const DevSeed* d_seeds,
-                      u32 n_seeds, u32 max_hits_per_seed, DevFrame* d_stack, DevHit* d_hits, u32 hit_cap, u32* d_counters);
+                      u32 n_seeds, u32 max_hits_per_seed, DevFrame* d_stack, DevHit* d_hits, u32 hit_cap, u32* d_counters,
+                      u32* d_seed_cnt = nullptr);
+    // anchor selection on the device (see seed_select_kernel). d_seed_cnt, d_hit_offset, d_n_out, d_out_offset: n_seeds + 1 entries
+    // (the caller zeroes the last entry of d_seed_cnt and d_n_out); d_stat: 4 bytes per seed {useful, raw, flag, excluded};
+    // d_grouped: as many entries as d_hits; d_out: one entry per selected anchor (at most the number of rows of the handled seeds)
+    static size_t select_scan_bytes(u32 n_seeds);
+    static int select(void* stream, const DevHit* d_hits, const u32* d_counters, u32 hit_cap, u32* d_seed_cnt, u32* d_hit_offset,
+                      DevHit* d_grouped, u32 n_seeds, const DevIndex& idx, const u64* d_seq_start, u32 n_ref, u32 hard_cap, u32 soft_cap,
+                      bool erase, void* d_stat, u32* d_n_out, u32* d_out_offset, DevOutAnchor* d_out, u32 out_cap, void* d_scan_tmp,
+                      size_t scan_bytes);
     static int locate(void* stream, const DevIndex& idx, const u32* d_rows, u32 n, u32* d_out);
     // d_lastrow (banded TRACE launches only, may be null): D[m][c] of every computed column c, 0xFFFF elsewhere (pre-filled by the caller)
     static int align(void* stream, const u8* d_text, const u64* d_peq, const DevAlignJob* d_jobs, u32 n_jobs, AlignShape shape,

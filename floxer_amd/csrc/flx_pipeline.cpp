@@ -78,7 +78,8 @@ hipEvent_t Lane::get_event() {
 }
 hvec<DeviceBuffer*> lane_workspaces(Lane& l) {
     return {&l.seq, &l.seq_rev, &l.peq, &l.peq_rev, &l.scheme, &l.seeds, &l.stack, &l.hits, &l.counters, &l.rows, &l.rows_out, &l.jobs,
-            &l.job_out, &l.trace, &l.tjobs, &l.tjob_out, &l.cigar, &l.user_text, &l.user_text_rev, &l.lastrow, &l.row_windows, &l.row_out};
+            &l.job_out, &l.trace, &l.tjobs, &l.tjob_out, &l.cigar, &l.user_text, &l.user_text_rev, &l.lastrow, &l.row_windows, &l.row_out,
+            &l.seed_cnt, &l.hit_off, &l.grouped, &l.sel_stat, &l.sel_n, &l.sel_off, &l.sel_out, &l.sel_tmp};
 }
 std::vector<DeviceBuffer*> Lane::workspaces() { auto v = lane_workspaces(*this); return std::vector<DeviceBuffer*>(v.begin(), v.end()); }
 int Lane::size_like(Lane& other) {
@@ -339,23 +340,65 @@ int search_seeds_device(Lane* ctx, const u8* d_seq_pool_or_null, const u8* h_seq
                                          : (u32)std::max(cfg.max_num_anchors_hard, cfg.max_num_anchors_hard + 1));
     u64 const hit_slack = 4096 * 64;            // unused ends of the per-wave slot ranges (FM_MAX_WAVES x FM_HIT_GRAB)
     u64 hit_cap = n_seeds * 6 + hit_slack;
+    // Anchor selection on the device (K1b) for the default group order and anchor choice; seeds it does not handle come back
+    // flagged and go through the host code below.
+    bool const device_select = !raw_hits && cfg.anchor_group_order == FLX_ORDER_COUNT_FIRST && cfg.anchor_choice_strategy == FLX_CHOICE_ROUND_ROBIN &&
+                               cfg.max_num_anchors_soft >= 1 && !getenv("FLX_HOST_SELECT");
+    size_t const scan_bytes = device_select ? DeviceApi::select_scan_bytes((u32)n_seeds) : 0;
+    hvec<u32> sel_stat;                       // per seed {useful, raw, flag, excluded} bytes
+    u32 sel_total = 0;
+    if (device_select) {
+        if ((rc = ctx->seed_cnt.ensure((n_seeds + 1) * 4))) return rc;
+        if ((rc = ctx->hit_off.ensure((n_seeds + 1) * 4))) return rc;
+        if ((rc = ctx->sel_stat.ensure(n_seeds * 4 + 16))) return rc;
+        if ((rc = ctx->sel_n.ensure((n_seeds + 1) * 4))) return rc;
+        if ((rc = ctx->sel_off.ensure((n_seeds + 1) * 4))) return rc;
+        if ((rc = ctx->sel_tmp.ensure(scan_bytes + 64))) return rc;
+        sel_stat.resize(n_seeds);
+    }
     u32 counters[16];
+    u64 sel_cap = 0;                          // entries of the selected-anchor list
     for (int attempt = 0;; ++attempt) {
+        sel_cap = std::max(sel_cap, hit_cap);
         if ((rc = ctx->hits.ensure(hit_cap * sizeof(DevHit)))) return rc;
         FLX_HIP(hipMemsetAsync(ctx->counters.ptr, 0, 64, ctx->stream));
+        if (device_select) {
+            // one selected anchor per hit row at most; rows <= hits * SEL_MAX would be the hard bound, the seeds the device
+            // handles have at most soft-cap rows each and nearly all hits have one row: hit_cap entries, checked after the run
+            if ((rc = ctx->grouped.ensure(hit_cap * sizeof(DevHit)))) return rc;
+            if ((rc = ctx->sel_out.ensure(sel_cap * sizeof(DevOutAnchor)))) return rc;
+            FLX_HIP(hipMemsetAsync(ctx->seed_cnt.ptr, 0, (n_seeds + 1) * 4, ctx->stream));
+            FLX_HIP(hipMemsetAsync((char*)ctx->sel_n.ptr + n_seeds * 4, 0, 4, ctx->stream));
+        }
         rc = timed_launch(ctx, "fm_search", 0, n_seeds, [&] {
             return DeviceApi::search(ctx->stream, ctx->ctx->didx, d_seq, ctx->scheme.as<u32>(), ctx->seeds.as<DevSeed>(), (u32)n_seeds,
                                      max_hits, ctx->stack.as<DevFrame>(), ctx->hits.as<DevHit>(), (u32)std::min<u64>(hit_cap, 0xFFFFFFFFu),
-                                     ctx->counters.as<u32>());
+                                     ctx->counters.as<u32>(), device_select ? ctx->seed_cnt.as<u32>() : nullptr);
         });
         if (rc) return rc;
+        if (device_select) {
+            rc = timed_launch(ctx, "fm_select", n_seeds * 5, n_seeds, [&] {
+                return DeviceApi::select(ctx->stream, ctx->hits.as<DevHit>(), ctx->counters.as<u32>(), (u32)std::min<u64>(hit_cap, 0xFFFFFFFFu),
+                                         ctx->seed_cnt.as<u32>(), ctx->hit_off.as<u32>(), ctx->grouped.as<DevHit>(), (u32)n_seeds, ctx->ctx->didx,
+                                         ctx->ctx->seq_start.as<u64>(), (u32)H.seq_start.size(), (u32)std::min<u64>(cfg.max_num_anchors_hard, 0xFFFFFFFFu),
+                                         (u32)std::min<u64>(cfg.max_num_anchors_soft, 0xFFFFFFFFu), cfg.erase_useless_anchors != 0, ctx->sel_stat.ptr,
+                                         ctx->sel_n.as<u32>(), ctx->sel_off.as<u32>(), ctx->sel_out.as<DevOutAnchor>(), (u32)std::min<u64>(sel_cap, 0xFFFFFFFFu),
+                                         ctx->sel_tmp.ptr, scan_bytes);
+            });
+            if (rc) return rc;
+        }
         if ((rc = d2h(ctx, counters, ctx->counters.ptr, 64))) return rc;
+        if (device_select) {
+            if ((rc = d2h(ctx, &sel_total, (char*)ctx->sel_off.ptr + n_seeds * 4, 4))) return rc;
+            if ((rc = d2h(ctx, sel_stat.data(), ctx->sel_stat.ptr, n_seeds * 4))) return rc;
+        }
         if ((rc = ctx->sync())) return rc;
         if (getenv("FLX_SEARCH_DEBUG")) fprintf(stderr, "[fm_search] seeds %llu ext %u wave-iterations %u (max per wave %u) busy pair-iterations %u, after the queue ran dry %u (max %u)\n", (unsigned long long)n_seeds, counters[2], counters[4], counters[5], counters[6], counters[8], counters[9]);
         if (counters[1]) { set_error("fm_search: DFS stack reservation exceeded"); return FLX_ERR_INTERNAL; }
-        if (counters[0] <= hit_cap) break;
+        if (counters[0] <= hit_cap && (!device_select || sel_total <= sel_cap)) break;
         if (attempt >= 2) { set_error("fm_search: hit buffer could not be sized"); return FLX_ERR_INTERNAL; }
-        hit_cap = (u64)counters[0] + hit_slack;      // the number of hits is known now; run again
+        if (counters[0] > hit_cap) hit_cap = (u64)counters[0] + hit_slack;      // the number of hits is known now; run again
+        else sel_cap = (u64)sel_total + 1024;
     }
     // fold the extension count into the kernel's accounting: 2 rank positions of one 128-byte block each
     if (ctx->ctx->timing) {
@@ -364,20 +407,55 @@ int search_seeds_device(Lane* ctx, const u8* d_seq_pool_or_null, const u8* h_seq
         if (it != ctx->ctx->stats.end()) { it->second.algorithmic_bytes += (u64)counters[2] * 2 * sizeof(OccBlock); it->second.work_units += counters[2]; }
     }
     sprof.mark("kernel");
-    u32 const n_slots = counters[0];          // reserved slots; unused ones carry seed 0xFFFFFFFF
-    hvec<DevHit> hits(n_slots);
-    if ((rc = d2h(ctx, hits.data(), ctx->hits.ptr, (size_t)n_slots * sizeof(DevHit)))) return rc;
-    if ((rc = ctx->sync())) return rc;
-
-    sprof.mark("d2h-hits");
-    // group by seed, keeping each seed's emission order (a seed stays on one wave, whose slot ranges and slots within a range
-    // are handed out in increasing order)
+    // ---- what the device selected; host_seed[si] != 0: this seed still goes through the host code
+    hvec<HostAnchor> dev_anchors;
+    hvec<u8> host_seed;
+    if (device_select) {
+        static_assert(sizeof(HostAnchor) == sizeof(DevOutAnchor), "the compact list is read as HostAnchor");
+        dev_anchors.resize(sel_total);
+        if (sel_total) {
+            if ((rc = d2h(ctx, dev_anchors.data(), ctx->sel_out.ptr, (size_t)sel_total * sizeof(HostAnchor)))) return rc;
+            if ((rc = ctx->sync())) return rc;
+        }
+        for (auto& a : dev_anchors) a.leaf = seeds[a.seed_index].pex_leaf_index;
+        host_seed.assign(n_seeds, 0);
+        bool any = false;
+        for (u64 si = 0; si < n_seeds; ++si) {
+            u32 const st = sel_stat[si];
+            u8 const useful = (u8)st, raw = (u8)(st >> 8), flag = (u8)(st >> 16), excl = (u8)(st >> 24);
+            if (flag) { host_seed[si] = 1; any = true; }
+            else stats[si] = SeedStats{useful, raw, 0, excl};
+        }
+        sprof.mark("device-select");
+        if (getenv("FLX_SEARCH_DEBUG")) {
+            u64 flagged = 0, with_anchors = 0, excl = 0;
+            for (u64 si = 0; si < n_seeds; ++si) { u32 const st = sel_stat[si]; flagged += (st >> 16) & 1; with_anchors += (st & 0xFF) != 0; excl += (st >> 24) & 1; }
+            fprintf(stderr, "[fm_select] seeds %llu: with anchors %llu, excluded %llu, left to the host %llu; anchors %u\n", (unsigned long long)n_seeds,
+                    (unsigned long long)with_anchors, (unsigned long long)excl, (unsigned long long)flagged, sel_total);
+        }
+        if (!any) { anchors.swap(dev_anchors); return FLX_OK; }
+    }
+    // ---- the hits per seed in emission order: `by_seed`, seed si owns [first[si], first[si+1]). With device-side selection the
+    //      device has grouped them already (only the seeds left to the host are looked at below); else the host groups them.
     hvec<u32> first(n_seeds + 1, 0);
-    for (auto const& h : hits) if (h.seed != 0xFFFFFFFFu) first[h.seed + 1]++;
-    for (u64 i = 0; i < n_seeds; ++i) first[i + 1] += first[i];
-    u32 const n_hits = first[n_seeds];
-    hvec<DevHit> by_seed(n_hits);
-    {
+    hvec<DevHit> by_seed;
+    if (device_select) {
+        if ((rc = d2h(ctx, first.data(), ctx->hit_off.ptr, (n_seeds + 1) * 4))) return rc;
+        if ((rc = ctx->sync())) return rc;
+        by_seed.resize(first[n_seeds]);
+        if ((rc = d2h(ctx, by_seed.data(), ctx->grouped.ptr, (size_t)first[n_seeds] * sizeof(DevHit)))) return rc;
+        if ((rc = ctx->sync())) return rc;
+        sprof.mark("d2h-hits");
+    } else {
+        u32 const n_slots = counters[0];      // reserved slots; unused ones carry seed 0xFFFFFFFF
+        hvec<DevHit> hits(n_slots);
+        if ((rc = d2h(ctx, hits.data(), ctx->hits.ptr, (size_t)n_slots * sizeof(DevHit)))) return rc;
+        if ((rc = ctx->sync())) return rc;
+        sprof.mark("d2h-hits");
+        // a seed stays on one wave, whose slot ranges and slots within a range are handed out in increasing order
+        for (auto const& h : hits) if (h.seed != 0xFFFFFFFFu) first[h.seed + 1]++;
+        for (u64 i = 0; i < n_seeds; ++i) first[i + 1] += first[i];
+        by_seed.resize(first[n_seeds]);
         hvec<u32> cursor(first.begin(), first.end() - 1);
         for (auto const& h : hits) if (h.seed != 0xFFFFFFFFu) by_seed[cursor[h.seed]++] = h;
     }
@@ -392,7 +470,7 @@ int search_seeds_device(Lane* ctx, const u8* d_seq_pool_or_null, const u8* h_seq
     hvec<Group> groups;
     hvec<u32> alive;
     for (u64 si = 0; si < n_seeds; ++si) {
-        if (first[si] == first[si + 1]) continue;               // no hit at all: nothing to select
+        if (first[si] == first[si + 1] || (!host_seed.empty() && !host_seed[si])) continue;   // no hit at all, or selected on the device
         if (first[si] + 1 == first[si + 1] && by_seed[first[si]].len == 1 && cfg.max_num_anchors_hard >= 1 && cfg.max_num_anchors_soft >= 1) {
             // one group of one row (most seeds of a read that has a single locus): every order and strategy keeps exactly it
             total_raw[si] = 1;
@@ -510,6 +588,12 @@ int search_seeds_device(Lane* ctx, const u8* d_seq_pool_or_null, const u8* h_seq
         }
     }
     sprof.mark("erase+flatten");
+    if (!dev_anchors.empty()) {               // both lists are in seed order
+        hvec<HostAnchor> merged(anchors.size() + dev_anchors.size());
+        std::merge(anchors.begin(), anchors.end(), dev_anchors.begin(), dev_anchors.end(), merged.begin(),
+                   [](HostAnchor const& a, HostAnchor const& b) { return a.seed_index < b.seed_index; });
+        anchors.swap(merged);
+    }
     return FLX_OK;
 }
 

@@ -77,15 +77,19 @@ def test_search_short_and_degenerate_seeds(small_genome):
 
 
 # ---------------------------------------------------------------- seam 1: search_seeds
-@pytest.mark.parametrize("order,choice,erase", [("count_first", "round_robin", True), ("errors_first", "full_groups", True),
-                                                 ("none", "first_reported", False), ("count_first", "full_groups", False)])
-def test_search_seeds_match_oracle(small_genome, order, choice, erase):
+@pytest.mark.parametrize("order,choice,erase,hard,soft", [
+    ("count_first", "round_robin", True, 60, 7), ("errors_first", "full_groups", True, 60, 7), ("none", "first_reported", False, 60, 7),
+    ("count_first", "full_groups", False, 60, 7),
+    # the combinations the device-side selection takes (default order and choice), with caps on either side of its eight slots
+    ("count_first", "round_robin", False, 60, 7), ("count_first", "round_robin", True, 500, 50), ("count_first", "round_robin", True, 5, 3),
+    ("count_first", "round_robin", True, 3, 3)])
+def test_search_seeds_match_oracle(small_genome, order, choice, erase, hard, soft):
     refs, idx, ctx, oidx = small_genome
     rng = np.random.default_rng(22)
     pool, seeds = _make_seeds(rng, refs, 300, kmax=2, lens=(12, 50))
-    cfg = F.search_config(60, 7, order, choice, erase)
+    cfg = F.search_config(hard, soft, order, choice, erase)
     anchors, stats = F.searcher(ctx, cfg).search_seeds(pool, seeds)
-    exp_a, exp_s = oidx.search_seeds(pool, [(o, l, k, leaf) for o, l, k, leaf in seeds], hard=60, soft=7, order=F.ORDER[order],
+    exp_a, exp_s = oidx.search_seeds(pool, [(o, l, k, leaf) for o, l, k, leaf in seeds], hard=hard, soft=soft, order=F.ORDER[order],
                                      choice=F.CHOICE[choice], erase=erase)
     assert stats.tolist() == exp_s.tolist()
     assert anchors.tolist() == exp_a.tolist()
