@@ -440,10 +440,10 @@ int DeviceApi::search(void* stream, const DevIndex& idx, const u8* d_seq, const 
 // hits -> per-seed segments in emission order (a scan over the seeds' hit counts + a scatter by the ordinal each hit carries),
 // then one thread per seed does what search.cpp:190-318 does with the seed's groups: hard cap, group order, rows round robin,
 // locate through the suffix array, buckets per reference sorted by position, useless anchors erased (search.cpp:352-389).
-// Handled here: seeds with at most 16 groups whose rows all fit under the soft cap and SEL_MAX, and at most 16 anchors per
-// reference: libstdc++'s std::sort is a stable insertion sort up to 16 elements and not stable above, and the order of equal
-// elements shows in the result (groups tie on (count, errors); the same row reached through two groups gives two anchors of
-// equal position). Every seed not handled is flagged and goes through the host code.
+// Handled here: seeds with at most SEL_MAX groups whose rows all fit under the soft cap and SEL_MAX. The two std::sort calls of
+// the reference (groups by (count, errors), a bucket's anchors by position) are reproduced step for step (std_sort_emulated):
+// their comparators tie (the same row reached through two groups gives two anchors of equal position) and the order of equal
+// elements shows in the result. Every seed not handled is flagged and goes through the host code.
 constexpr u32 SEL_MAX = 64;
 struct SelStat { u8 useful, raw, flag, excluded; };      // flag 1: the host selects this seed's anchors
 
@@ -459,37 +459,94 @@ __global__ void __launch_bounds__(256) hit_scatter_kernel(const DevHit* __restri
     }
 }
 
-// the selection of one seed whose groups (cnt <= CAP, cnt <= 16) hold `total` <= CAP rows; returns false when the seed has to go
-// to the host after all
+// libstdc++'s std::sort (bits/stl_algo.h: introsort with median-of-three pivots down to 16 elements, then insertion sort), step
+// for step: the reference orders hit groups and anchor buckets with it, its comparators tie often, and what it does with equal
+// elements shows in the output. Returns false if the depth limit is reached (the heap-sort fallback is left to the host).
+template <class T, class Less>
+__device__ bool std_sort_emulated(T* a, int n, Less less) {
+    auto swap_at = [&](int i, int j) { T const t = a[i]; a[i] = a[j]; a[j] = t; };
+    auto unguarded_linear_insert = [&](int last) {
+        T const val = a[last];
+        int next = last - 1;
+        while (less(val, a[next])) { a[last] = a[next]; last = next; --next; }
+        a[last] = val;
+    };
+    auto insertion_sort = [&](int first, int last) {
+        for (int i = first + 1; i < last; ++i) {
+            if (less(a[i], a[first])) { T const val = a[i]; for (int j = i; j > first; --j) a[j] = a[j - 1]; a[first] = val; }
+            else unguarded_linear_insert(i);
+        }
+    };
+    if (n <= 1) return true;
+    if (n > 16) {
+        // __introsort_loop: recursion on the right part, iteration on the left; at most 2*floor(log2 n) levels
+        int depth0 = 0;
+        for (int m = n; m > 1; m >>= 1) ++depth0;
+        depth0 *= 2;
+        int stack_first[16], stack_last[16], stack_depth[16], sp = 0;
+        int first = 0, last = n, depth = depth0;
+        while (true) {
+            while (last - first > 16) {
+                if (depth == 0) return false;
+                --depth;
+                int const mid = first + (last - first) / 2;
+                // __move_median_to_first(first, first + 1, mid, last - 1)
+                int const x = first + 1, y = mid, z = last - 1;
+                if (less(a[x], a[y])) {
+                    if (less(a[y], a[z])) swap_at(first, y);
+                    else if (less(a[x], a[z])) swap_at(first, z);
+                    else swap_at(first, x);
+                } else if (less(a[x], a[z])) swap_at(first, x);
+                else if (less(a[y], a[z])) swap_at(first, z);
+                else swap_at(first, y);
+                // __unguarded_partition(first + 1, last, pivot = first)
+                int lo = first + 1, hi = last;
+                while (true) {
+                    while (less(a[lo], a[first])) ++lo;
+                    --hi;
+                    while (less(a[first], a[hi])) --hi;
+                    if (!(lo < hi)) break;
+                    swap_at(lo, hi);
+                    ++lo;
+                }
+                int const cut = lo;
+                if (sp < 16) { stack_first[sp] = cut; stack_last[sp] = last; stack_depth[sp] = depth; ++sp; } else return false;
+                last = cut;
+            }
+            if (sp == 0) break;
+            --sp;
+            first = stack_first[sp]; last = stack_last[sp]; depth = stack_depth[sp];
+        }
+        // (the recursion of the original handles the right part before it continues with the left one; the parts are disjoint,
+        //  so the order in which they are partitioned does not change the result)
+        insertion_sort(0, 16);
+        for (int i = 16; i < n; ++i) unguarded_linear_insert(i);
+        return true;
+    }
+    insertion_sort(0, n);
+    return true;
+}
+
+struct SelGroup { u32 lb, len, errors; };
+struct SelAnchor { u64 pos; u32 ref; u32 errors; };
+
+// the selection of one seed whose groups (cnt <= CAP) hold `total` <= CAP rows; returns false when the seed has to go to the host
 template <u32 CAP, bool WRITE>
 __device__ __forceinline__ bool select_seed(const DevHit* __restrict__ groups, u32 cnt, u32 total, const u32* __restrict__ sa, u32 n_text,
                                             const u64* __restrict__ seq_start, u32 n_ref, u32 erase, u32 sid, SelStat& st, u32& produced,
                                             DevOutAnchor* __restrict__ out, u32 at, u32 out_cap) {
-    u8 ord[CAP < 16 ? CAP : 16];                           // group order: stable insertion sort by (len, errors), which is what
-    for (u32 i = 0; i < cnt; ++i) ord[i] = (u8)i;          // std::sort does with up to 16 elements (search.cpp:200-212)
-    for (u32 i = 1; i < cnt; ++i) {
-        u8 const o = ord[i];
-        u32 const n = groups[o].len, e = groups[o].errors;
-        u32 j = i;
-        while (j > 0) {
-            DevHit const& p = groups[ord[j - 1]];
-            if (!(n != p.len ? n < p.len : e < p.errors)) break;
-            ord[j] = ord[j - 1];
-            --j;
-        }
-        ord[j] = o;
-    }
+    // groups ordered by (count, errors) (search.cpp:200-212)
+    SelGroup g[CAP];
+    for (u32 i = 0; i < cnt; ++i) g[i] = SelGroup{groups[i].lb, groups[i].len, groups[i].errors};
+    if (!std_sort_emulated(g, (int)cnt, [](SelGroup const& x, SelGroup const& y) { return x.len != y.len ? x.len < y.len : x.errors < y.errors; })) return false;
     // rows round robin over the groups (search.cpp:239-272), located
-    u64 pos[CAP];
-    u32 ref[CAP];
-    u8 ae[CAP];
+    SelAnchor an[CAP];
     u32 kept = 0;
     bool bad = false;
     for (u32 round = 0; kept < total; ++round)
         for (u32 gi = 0; gi < cnt; ++gi) {
-            DevHit const& g = groups[ord[gi]];
-            if (g.len <= round) continue;
-            u32 const row = g.lb + round;
+            if (g[gi].len <= round) continue;
+            u32 const row = g[gi].lb + round;
             u64 const p = row < n_text ? sa[row] : 0xFFFFFFFFull;
             if (p >= n_text) bad = true;
             u32 r = 0;
@@ -498,35 +555,27 @@ __device__ __forceinline__ bool select_seed(const DevHit* __restrict__ groups, u
                 while (hi - lo > 1) { u32 const mid = (lo + hi) >> 1; if (seq_start[mid] <= p) lo = mid; else hi = mid; }
                 r = lo;
             }
-            pos[kept] = p - seq_start[r]; ref[kept] = r; ae[kept] = (u8)g.errors;
-            ++kept;
+            an[kept++] = SelAnchor{p - seq_start[r], r, g[gi].errors};
         }
-    // a bucket is sorted by position with std::sort, which keeps anchors of equal position (the same row reached through two
-    // groups) in order only up to 16 elements
-    if (CAP > 16 && erase) {
-        u32 largest_bucket = 0;
-        for (u32 i = 0; i < kept; ++i) { u32 n = 0; for (u32 j = 0; j < kept; ++j) n += ref[j] == ref[i]; largest_bucket = max(largest_bucket, n); }
-        if (largest_bucket > 16) return false;
-    }
     if (bad) return false;                                  // the host reports the error
-    // by reference id (stable), and by position when useless anchors are erased (erase_useless_anchors sorts its bucket); without
-    // erasing the buckets keep the order of selection
+    // buckets per reference in id order, each keeping the order of selection (search.cpp:78-100, 304-318)
     for (u32 i = 1; i < kept; ++i) {
-        u64 const p = pos[i]; u32 const r = ref[i]; u8 const e = ae[i];
+        SelAnchor const v = an[i];
         u32 j = i;
-        while (j > 0 && (r != ref[j - 1] ? r < ref[j - 1] : (erase && p < pos[j - 1]))) { pos[j] = pos[j - 1]; ref[j] = ref[j - 1]; ae[j] = ae[j - 1]; --j; }
-        pos[j] = p; ref[j] = r; ae[j] = e;
+        while (j > 0 && v.ref < an[j - 1].ref) { an[j] = an[j - 1]; --j; }
+        an[j] = v;
     }
     u64 gone = 0;                                           // bit i: anchor i erased
     if (erase) {
         u32 b0 = 0;
-        while (b0 < kept) {                                 // one bucket = one reference
+        while (b0 < kept) {                                 // one bucket = one reference (search.cpp:352-389)
             u32 b1 = b0;
-            while (b1 < kept && ref[b1] == ref[b0]) ++b1;
-            // search.cpp:352-389; an erased anchor compares with "infinitely many" errors
+            while (b1 < kept && an[b1].ref == an[b0].ref) ++b1;
+            if (!std_sort_emulated(an + b0, (int)(b1 - b0), [](SelAnchor const& x, SelAnchor const& y) { return x.pos < y.pos; })) return false;
+            // an erased anchor compares with "infinitely many" errors
             auto better = [&](u32 a, u32 b) {
-                u64 const ea = (gone >> a) & 1 ? ~0ull : (u64)ae[a], eb = (gone >> b) & 1 ? ~0ull : (u64)ae[b];
-                u64 const d = pos[a] < pos[b] ? pos[b] - pos[a] : pos[a] - pos[b];
+                u64 const ea = (gone >> a) & 1 ? ~0ull : (u64)an[a].errors, eb = (gone >> b) & 1 ? ~0ull : (u64)an[b].errors;
+                u64 const d = an[a].pos < an[b].pos ? an[b].pos - an[a].pos : an[a].pos - an[b].pos;
                 return ea <= eb && d <= eb - ea;
             };
             for (u32 cur = b0; cur + 1 < b1;) {
@@ -541,7 +590,7 @@ __device__ __forceinline__ bool select_seed(const DevHit* __restrict__ groups, u
     st.raw = (u8)kept;
     for (u32 i = 0; i < kept; ++i)
         if (!((gone >> i) & 1)) {
-            if (WRITE && at + produced < out_cap) out[at + produced] = DevOutAnchor{sid, 0u, ref[i], (u32)ae[i], pos[i]};
+            if (WRITE && at + produced < out_cap) out[at + produced] = DevOutAnchor{sid, 0u, an[i].ref, an[i].errors, an[i].pos};
             ++produced;
         }
     st.useful = (u8)produced;
@@ -560,12 +609,12 @@ __global__ void __launch_bounds__(128) seed_select_kernel(const DevHit* __restri
     SelStat st{0, 0, 0, 0};
     u32 produced = 0;
     if (WRITE) { st = stat[sid]; if (st.flag || st.useful == 0) return; }
-    if (cnt > 16) st.flag = 1;                              // a group order this kernel does not reproduce
+    if (cnt > SEL_MAX) st.flag = 1;
     else if (cnt > 0) {
         u32 total = 0;
         bool big = false;
         for (u32 i = 0; i < cnt; ++i) { u32 const l = grouped[g0 + i].len; if (l > SEL_MAX) big = true; else total += l; }
-        if (big || total > SEL_MAX || total > soft_cap) st.flag = 1;           // a truncated selection
+        if (big || total > SEL_MAX || total > soft_cap) st.flag = 1;           // a truncated selection: the host
         else if (total > hard_cap) st.excluded = 1;
         else {
             u32 const at = WRITE ? out_offset[sid] : 0;

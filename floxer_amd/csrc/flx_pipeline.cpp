@@ -460,6 +460,9 @@ int search_seeds_device(Lane* ctx, const u8* d_seq_pool_or_null, const u8* h_seq
         for (auto const& h : hits) if (h.seed != 0xFFFFFFFFu) by_seed[cursor[h.seed]++] = h;
     }
     if (raw_hits) { *raw_hits = std::move(by_seed); return FLX_OK; }
+    hvec<u32> todo;                           // the seeds the host selects for, ascending
+    if (host_seed.empty()) { todo.resize(n_seeds); std::iota(todo.begin(), todo.end(), 0u); }
+    else for (u64 si = 0; si < n_seeds; ++si) if (host_seed[si]) todo.push_back((u32)si);
 
     sprof.mark("group");
     // ---- hard cap, group order, anchor choice (search.cpp:190-302)
@@ -469,8 +472,8 @@ int search_seeds_device(Lane* ctx, const u8* d_seq_pool_or_null, const u8* h_seq
     hvec<u8> excluded(n_seeds, 0);
     hvec<Group> groups;
     hvec<u32> alive;
-    for (u64 si = 0; si < n_seeds; ++si) {
-        if (first[si] == first[si + 1] || (!host_seed.empty() && !host_seed[si])) continue;   // no hit at all, or selected on the device
+    for (u32 const si : todo) {
+        if (first[si] == first[si + 1]) continue;               // no hit at all: nothing to select
         if (first[si] + 1 == first[si + 1] && by_seed[first[si]].len == 1 && cfg.max_num_anchors_hard >= 1 && cfg.max_num_anchors_soft >= 1) {
             // one group of one row (most seeds of a read that has a single locus): every order and strategy keeps exactly it
             total_raw[si] = 1;
@@ -551,7 +554,7 @@ int search_seeds_device(Lane* ctx, const u8* d_seq_pool_or_null, const u8* h_seq
     hvec<hvec<RefAnchor>> by_ref(nref);
     hvec<u32> touched;                    // references that received an anchor of the current seed
     size_t ri = 0;
-    for (u64 si = 0; si < n_seeds; ++si) {
+    for (u32 const si : todo) {
         if (excluded[si]) { stats[si] = SeedStats{0, 0, 0, 1}; continue; }
         if (ri >= reqs.size() || reqs[ri].seed != si) continue;      // nothing kept: stats stay zero
         if (ri + 1 == reqs.size() || reqs[ri + 1].seed != si) {
