@@ -597,18 +597,29 @@ __device__ __forceinline__ bool select_seed(const DevHit* __restrict__ groups, u
     return true;
 }
 
-template <bool WRITE>
+// rows a seed would select if this kernel handles it (its slots in the sparse anchor list), 0 otherwise
+__global__ void __launch_bounds__(256) seed_rows_kernel(const DevHit* __restrict__ grouped, const u32* __restrict__ hit_offset, u32 n_seeds,
+                                                        u32 hard_cap, u32 soft_cap, u32* __restrict__ rows) {
+    u32 const sid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (sid >= n_seeds) return;
+    u32 const g0 = hit_offset[sid], cnt = hit_offset[sid + 1] - g0;
+    u32 total = 0;
+    bool handled = cnt > 0 && cnt <= SEL_MAX;
+    for (u32 i = 0; handled && i < cnt; ++i) { u32 const l = grouped[g0 + i].len; if (l > SEL_MAX) handled = false; else total += l; }
+    rows[sid] = handled && total <= SEL_MAX && total <= soft_cap && total <= hard_cap ? total : 0u;
+}
+
+// one pass: every handled seed writes its anchors to its slots of the sparse list (row_offset), n_out says how many
 __global__ void __launch_bounds__(128) seed_select_kernel(const DevHit* __restrict__ grouped, const u32* __restrict__ hit_offset, u32 n_seeds,
                                                           const u32* __restrict__ sa, u32 n_text, const u64* __restrict__ seq_start, u32 n_ref,
                                                           u32 hard_cap, u32 soft_cap, u32 erase, SelStat* __restrict__ stat,
-                                                          u32* __restrict__ n_out, const u32* __restrict__ out_offset,
-                                                          DevOutAnchor* __restrict__ out, u32 out_cap) {
+                                                          u32* __restrict__ n_out, const u32* __restrict__ row_offset,
+                                                          DevOutAnchor* __restrict__ sparse, u32 sparse_cap) {
     u32 const sid = blockIdx.x * blockDim.x + threadIdx.x;
     if (sid >= n_seeds) return;
     u32 const g0 = hit_offset[sid], cnt = hit_offset[sid + 1] - g0;
     SelStat st{0, 0, 0, 0};
     u32 produced = 0;
-    if (WRITE) { st = stat[sid]; if (st.flag || st.useful == 0) return; }
     if (cnt > SEL_MAX) st.flag = 1;
     else if (cnt > 0) {
         u32 total = 0;
@@ -617,14 +628,24 @@ __global__ void __launch_bounds__(128) seed_select_kernel(const DevHit* __restri
         if (big || total > SEL_MAX || total > soft_cap) st.flag = 1;           // a truncated selection: the host
         else if (total > hard_cap) st.excluded = 1;
         else {
-            u32 const at = WRITE ? out_offset[sid] : 0;
+            u32 const at = row_offset[sid];
             bool ok;
-            if (cnt <= 8 && total <= 8) ok = select_seed<8, WRITE>(grouped + g0, cnt, total, sa, n_text, seq_start, n_ref, erase, sid, st, produced, out, at, out_cap);
-            else ok = select_seed<SEL_MAX, WRITE>(grouped + g0, cnt, total, sa, n_text, seq_start, n_ref, erase, sid, st, produced, out, at, out_cap);
+            if (cnt <= 8 && total <= 8) ok = select_seed<8, true>(grouped + g0, cnt, total, sa, n_text, seq_start, n_ref, erase, sid, st, produced, sparse, at, sparse_cap);
+            else ok = select_seed<SEL_MAX, true>(grouped + g0, cnt, total, sa, n_text, seq_start, n_ref, erase, sid, st, produced, sparse, at, sparse_cap);
             if (!ok) { st = SelStat{0, 0, 1, 0}; produced = 0; }
         }
     }
-    if (!WRITE) { stat[sid] = st; n_out[sid] = st.flag ? 0u : produced; }
+    stat[sid] = st;
+    n_out[sid] = st.flag ? 0u : produced;
+}
+
+__global__ void __launch_bounds__(256) seed_compact_kernel(const DevOutAnchor* __restrict__ sparse, const u32* __restrict__ row_offset,
+                                                           const u32* __restrict__ n_out, const u32* __restrict__ out_offset, u32 n_seeds,
+                                                           DevOutAnchor* __restrict__ out, u32 out_cap) {
+    u32 const sid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (sid >= n_seeds) return;
+    u32 const n = n_out[sid], from = row_offset[sid], to = out_offset[sid];
+    for (u32 i = 0; i < n; ++i) if (to + i < out_cap) out[to + i] = sparse[from + i];
 }
 
 size_t DeviceApi::select_scan_bytes(u32 n_seeds) {
@@ -635,21 +656,26 @@ size_t DeviceApi::select_scan_bytes(u32 n_seeds) {
 
 int DeviceApi::select(void* stream, const DevHit* d_hits, const u32* d_counters, u32 hit_cap, u32* d_seed_cnt, u32* d_hit_offset,
                       DevHit* d_grouped, u32 n_seeds, const DevIndex& idx, const u64* d_seq_start, u32 n_ref, u32 hard_cap, u32 soft_cap,
-                      bool erase, void* d_stat, u32* d_n_out, u32* d_out_offset, DevOutAnchor* d_out, u32 out_cap, void* d_scan_tmp,
-                      size_t scan_bytes) {
+                      bool erase, void* d_stat, u32* d_n_out, u32* d_out_offset, DevOutAnchor* d_out, u32 out_cap, u32* d_rows,
+                      u32* d_row_offset, DevOutAnchor* d_sparse, u32 sparse_cap, void* d_scan_tmp, size_t scan_bytes) {
     if (n_seeds == 0) return 0;
     hipStream_t s = (hipStream_t)stream;
-    // d_seed_cnt and d_n_out have n_seeds + 1 entries, the last one zero: the scans end with the totals
+    // d_seed_cnt, d_rows and d_n_out have n_seeds + 1 entries, the last one zero: the scans end with the totals
     hipError_t e = hipcub::DeviceScan::ExclusiveSum(d_scan_tmp, scan_bytes, d_seed_cnt, d_hit_offset, (int)n_seeds + 1, s);
     if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL(hit_scatter_kernel, dim3(2048), dim3(256), 0, s, d_hits, d_counters, hit_cap, d_hit_offset, d_grouped);
-    hipLaunchKernelGGL(seed_select_kernel<false>, dim3((n_seeds + 127) / 128), dim3(128), 0, s, d_grouped, d_hit_offset, n_seeds, idx.sa, idx.n,
-                       d_seq_start, n_ref, hard_cap, soft_cap, erase ? 1u : 0u, reinterpret_cast<SelStat*>(d_stat), d_n_out, nullptr, nullptr, 0u);
+    hipLaunchKernelGGL(seed_rows_kernel, dim3((n_seeds + 255) / 256), dim3(256), 0, s, d_grouped, d_hit_offset, n_seeds, hard_cap, soft_cap, d_rows);
+    if ((e = hipGetLastError()) != hipSuccess) return (int)e;
+    e = hipcub::DeviceScan::ExclusiveSum(d_scan_tmp, scan_bytes, d_rows, d_row_offset, (int)n_seeds + 1, s);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(seed_select_kernel, dim3((n_seeds + 127) / 128), dim3(128), 0, s, d_grouped, d_hit_offset, n_seeds, idx.sa, idx.n,
+                       d_seq_start, n_ref, hard_cap, soft_cap, erase ? 1u : 0u, reinterpret_cast<SelStat*>(d_stat), d_n_out, d_row_offset,
+                       d_sparse, sparse_cap);
     if ((e = hipGetLastError()) != hipSuccess) return (int)e;
     e = hipcub::DeviceScan::ExclusiveSum(d_scan_tmp, scan_bytes, d_n_out, d_out_offset, (int)n_seeds + 1, s);
     if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(seed_select_kernel<true>, dim3((n_seeds + 127) / 128), dim3(128), 0, s, d_grouped, d_hit_offset, n_seeds, idx.sa, idx.n,
-                       d_seq_start, n_ref, hard_cap, soft_cap, erase ? 1u : 0u, reinterpret_cast<SelStat*>(d_stat), d_n_out, d_out_offset, d_out, out_cap);
+    hipLaunchKernelGGL(seed_compact_kernel, dim3((n_seeds + 255) / 256), dim3(256), 0, s, d_sparse, d_row_offset, d_n_out, d_out_offset, n_seeds,
+                       d_out, out_cap);
     return (int)hipGetLastError();
 }
 

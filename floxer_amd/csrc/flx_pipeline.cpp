@@ -79,7 +79,7 @@ hipEvent_t Lane::get_event() {
 hvec<DeviceBuffer*> lane_workspaces(Lane& l) {
     return {&l.seq, &l.seq_rev, &l.peq, &l.peq_rev, &l.scheme, &l.seeds, &l.stack, &l.hits, &l.counters, &l.rows, &l.rows_out, &l.jobs,
             &l.job_out, &l.trace, &l.tjobs, &l.tjob_out, &l.cigar, &l.user_text, &l.user_text_rev, &l.lastrow, &l.row_windows, &l.row_out,
-            &l.seed_cnt, &l.hit_off, &l.grouped, &l.sel_stat, &l.sel_n, &l.sel_off, &l.sel_out, &l.sel_tmp};
+            &l.seed_cnt, &l.hit_off, &l.grouped, &l.sel_stat, &l.sel_n, &l.sel_off, &l.sel_out, &l.sel_tmp, &l.sel_rows, &l.sel_row_off, &l.sel_sparse};
 }
 std::vector<DeviceBuffer*> Lane::workspaces() { auto v = lane_workspaces(*this); return std::vector<DeviceBuffer*>(v.begin(), v.end()); }
 int Lane::size_like(Lane& other) {
@@ -346,13 +346,15 @@ int search_seeds_device(Lane* ctx, const u8* d_seq_pool_or_null, const u8* h_seq
                                cfg.max_num_anchors_soft >= 1 && !getenv("FLX_HOST_SELECT");
     size_t const scan_bytes = device_select ? DeviceApi::select_scan_bytes((u32)n_seeds) : 0;
     hvec<u32> sel_stat;                       // per seed {useful, raw, flag, excluded} bytes
-    u32 sel_total = 0;
+    u32 sel_total = 0, sel_rows_total = 0;
     if (device_select) {
         if ((rc = ctx->seed_cnt.ensure((n_seeds + 1) * 4))) return rc;
         if ((rc = ctx->hit_off.ensure((n_seeds + 1) * 4))) return rc;
         if ((rc = ctx->sel_stat.ensure(n_seeds * 4 + 16))) return rc;
         if ((rc = ctx->sel_n.ensure((n_seeds + 1) * 4))) return rc;
         if ((rc = ctx->sel_off.ensure((n_seeds + 1) * 4))) return rc;
+        if ((rc = ctx->sel_rows.ensure((n_seeds + 1) * 4))) return rc;
+        if ((rc = ctx->sel_row_off.ensure((n_seeds + 1) * 4))) return rc;
         if ((rc = ctx->sel_tmp.ensure(scan_bytes + 64))) return rc;
         sel_stat.resize(n_seeds);
     }
@@ -367,6 +369,8 @@ int search_seeds_device(Lane* ctx, const u8* d_seq_pool_or_null, const u8* h_seq
             // handles have at most soft-cap rows each and nearly all hits have one row: hit_cap entries, checked after the run
             if ((rc = ctx->grouped.ensure(hit_cap * sizeof(DevHit)))) return rc;
             if ((rc = ctx->sel_out.ensure(sel_cap * sizeof(DevOutAnchor)))) return rc;
+            if ((rc = ctx->sel_sparse.ensure(sel_cap * sizeof(DevOutAnchor)))) return rc;
+            FLX_HIP(hipMemsetAsync((char*)ctx->sel_rows.ptr + n_seeds * 4, 0, 4, ctx->stream));
             FLX_HIP(hipMemsetAsync(ctx->seed_cnt.ptr, 0, (n_seeds + 1) * 4, ctx->stream));
             FLX_HIP(hipMemsetAsync((char*)ctx->sel_n.ptr + n_seeds * 4, 0, 4, ctx->stream));
         }
@@ -383,22 +387,24 @@ int search_seeds_device(Lane* ctx, const u8* d_seq_pool_or_null, const u8* h_seq
                                          ctx->ctx->seq_start.as<u64>(), (u32)H.seq_start.size(), (u32)std::min<u64>(cfg.max_num_anchors_hard, 0xFFFFFFFFu),
                                          (u32)std::min<u64>(cfg.max_num_anchors_soft, 0xFFFFFFFFu), cfg.erase_useless_anchors != 0, ctx->sel_stat.ptr,
                                          ctx->sel_n.as<u32>(), ctx->sel_off.as<u32>(), ctx->sel_out.as<DevOutAnchor>(), (u32)std::min<u64>(sel_cap, 0xFFFFFFFFu),
-                                         ctx->sel_tmp.ptr, scan_bytes);
+                                         ctx->sel_rows.as<u32>(), ctx->sel_row_off.as<u32>(), ctx->sel_sparse.as<DevOutAnchor>(),
+                                         (u32)std::min<u64>(sel_cap, 0xFFFFFFFFu), ctx->sel_tmp.ptr, scan_bytes);
             });
             if (rc) return rc;
         }
         if ((rc = d2h(ctx, counters, ctx->counters.ptr, 64))) return rc;
         if (device_select) {
             if ((rc = d2h(ctx, &sel_total, (char*)ctx->sel_off.ptr + n_seeds * 4, 4))) return rc;
+            if ((rc = d2h(ctx, &sel_rows_total, (char*)ctx->sel_row_off.ptr + n_seeds * 4, 4))) return rc;
             if ((rc = d2h(ctx, sel_stat.data(), ctx->sel_stat.ptr, n_seeds * 4))) return rc;
         }
         if ((rc = ctx->sync())) return rc;
         if (getenv("FLX_SEARCH_DEBUG")) fprintf(stderr, "[fm_search] seeds %llu ext %u wave-iterations %u (max per wave %u) busy pair-iterations %u, after the queue ran dry %u (max %u)\n", (unsigned long long)n_seeds, counters[2], counters[4], counters[5], counters[6], counters[8], counters[9]);
         if (counters[1]) { set_error("fm_search: DFS stack reservation exceeded"); return FLX_ERR_INTERNAL; }
-        if (counters[0] <= hit_cap && (!device_select || sel_total <= sel_cap)) break;
+        if (counters[0] <= hit_cap && (!device_select || sel_rows_total <= sel_cap)) break;      // (selected anchors <= rows)
         if (attempt >= 2) { set_error("fm_search: hit buffer could not be sized"); return FLX_ERR_INTERNAL; }
         if (counters[0] > hit_cap) hit_cap = (u64)counters[0] + hit_slack;      // the number of hits is known now; run again
-        else sel_cap = (u64)sel_total + 1024;
+        else sel_cap = (u64)sel_rows_total + 1024;
     }
     // fold the extension count into the kernel's accounting: 2 rank positions of one 128-byte block each
     if (ctx->ctx->timing) {
