@@ -809,43 +809,51 @@ thread_local double g_exists_ms[4] = {0, 0, 0, 0};            // dedup, cluster,
 int run_exists_jobs(Lane* ctx, const u8* d_text, const u64* d_peq, hvec<AlignRequest> const& reqs, hvec<DevAlignOut>& outs) {
     auto t0 = std::chrono::steady_clock::now();
     auto lap = [&](int slot) { auto const t1 = std::chrono::steady_clock::now(); g_exists_ms[slot] += std::chrono::duration<double, std::milli>(t1 - t0).count(); t0 = t1; };
+    // The requests come in anchor order, and the anchors of a read and orientation are in leaf order: all requests for one node
+    // (the leaves below it are a contiguous range) form one run of equal (query rows, errors). Sorting a run by reference
+    // position puts equal windows and the windows of one locus next to each other: no hash table, no sort of the whole round.
+    // (Requests for one node that are not adjacent would only be tested more than once.)
+    static int const disabled = (getenv("FLX_NO_UNION") || getenv("FLX_NO_EXISTS_CLUSTERS")) ? 1 : 0;
     hvec<AlignRequest> uniq;
-    hvec<u32> uniq_of;
-    dedup_requests(reqs, uniq, uniq_of);
+    hvec<u32> uniq_of(reqs.size());
+    hvec<u32> order;                                          // position in `uniq` (identity: kept for the code below)
+    struct Cluster { u32 first, count; u64 lo_start, hi_start, lo_end, hi_end; };     // members = uniq[first .. first+count)
+    hvec<Cluster> clusters;
+    uniq.reserve(reqs.size());
+    hvec<u32> run;
+    for (size_t i0 = 0; i0 < reqs.size();) {
+        size_t i1 = i0 + 1;
+        while (i1 < reqs.size() && reqs[i1].q_off == reqs[i0].q_off && reqs[i1].m == reqs[i0].m && reqs[i1].k == reqs[i0].k) ++i1;
+        run.resize(i1 - i0);
+        for (size_t j = 0; j < run.size(); ++j) run[j] = (u32)(i0 + j);
+        if (run.size() > 1)
+            std::sort(run.begin(), run.end(), [&](u32 x, u32 y) { return reqs[x].ref_off != reqs[y].ref_off ? reqs[x].ref_off < reqs[y].ref_off : reqs[x].n < reqs[y].n; });
+        bool first_of_run = true;
+        for (u32 idx : run) {
+            AlignRequest const& r = reqs[idx];
+            if (!first_of_run && uniq.back().ref_off == r.ref_off && uniq.back().n == r.n) { uniq_of[idx] = (u32)uniq.size() - 1; continue; }
+            uniq_of[idx] = (u32)uniq.size();
+            if (!first_of_run && !disabled) {
+                Cluster& c = clusters.back();
+                if (r.ref_off <= uniq[c.first].ref_off + std::max<u64>(8, r.m / 8)) {
+                    c.count++;
+                    c.hi_start = std::max(c.hi_start, r.ref_off);
+                    c.lo_end = std::min(c.lo_end, r.ref_off + r.n);
+                    c.hi_end = std::max(c.hi_end, r.ref_off + r.n);
+                    uniq.push_back(r);
+                    continue;
+                }
+            }
+            clusters.push_back(Cluster{(u32)uniq.size(), 1, r.ref_off, r.ref_off, r.ref_off + r.n, r.ref_off + r.n});
+            uniq.push_back(r);
+            first_of_run = false;
+        }
+        i0 = i1;
+    }
+    order.resize(uniq.size());
+    std::iota(order.begin(), order.end(), 0u);
     lap(0);
     hvec<DevAlignOut> uouts(uniq.size(), DevAlignOut{0xFFFFFFFFu, 0});
-    // windows of one (query rows, errors) next to each other by reference position: packed keys sorted in place (no indirection)
-    struct SortKey { u64 hi, lo; u32 idx; };                 // hi = q_off << 17 | m, lo = k << 32 | ref_off (text < 2^32, m, k < 2^17)
-    // (nodes below 256 rows: few windows of a locus per node yet, and their tests are cheap; sorting them costs more than it saves)
-    static int const disabled = (getenv("FLX_NO_UNION") || getenv("FLX_NO_EXISTS_CLUSTERS")) ? 1 : 0;
-    u32 largest = 0;
-    for (auto const& r : uniq) largest = std::max(largest, r.m);
-    bool const off = disabled || largest < 256;
-    hvec<u32> order(uniq.size());
-    if (off) std::iota(order.begin(), order.end(), 0u);
-    else {
-        hvec<SortKey> keys(uniq.size());
-        for (u32 i = 0; i < uniq.size(); ++i) keys[i] = SortKey{(uniq[i].q_off << 17) | uniq[i].m, ((u64)uniq[i].k << 32) | uniq[i].ref_off, i};
-        std::sort(keys.begin(), keys.end(), [](SortKey const& x, SortKey const& y) { return x.hi != y.hi ? x.hi < y.hi : x.lo < y.lo; });
-        for (u32 i = 0; i < keys.size(); ++i) order[i] = keys[i].idx;
-    }
-    struct Cluster { u32 first, count; u64 lo_start, hi_start, lo_end, hi_end; };     // members = order[first .. first+count)
-    hvec<Cluster> clusters;
-    for (u32 pos = 0; pos < order.size(); ++pos) {
-        AlignRequest const& r = uniq[order[pos]];
-        if (!off && !clusters.empty()) {
-            Cluster& c = clusters.back();
-            AlignRequest const& f = uniq[order[c.first]];
-            if (f.q_off == r.q_off && f.m == r.m && f.k == r.k && r.ref_off <= f.ref_off + std::max<u64>(8, r.m / 8)) {
-                c.count++;
-                c.hi_start = std::max(c.hi_start, r.ref_off);
-                c.lo_end = std::min(c.lo_end, r.ref_off + r.n);
-                c.hi_end = std::max(c.hi_end, r.ref_off + r.n);
-                continue;
-            }
-        }
-        clusters.push_back(Cluster{pos, 1, r.ref_off, r.ref_off, r.ref_off + r.n, r.ref_off + r.n});
-    }
     // ---- one launch: single windows on their own, clusters on their intersection and (speculatively: a separate round trip
     //      to the GPU costs a chunk more than the extra jobs) on their union
     hvec<AlignRequest> jobs;
@@ -1637,7 +1645,7 @@ int align_slice(Lane* lane, const flx_params* P, const flx_reads* RD, u64 first_
     // current node is in the smallest size class still pending (PEX trees are unbalanced: the same node is reached after a
     // different number of steps from different leaves). All tests of a node size then share one launch, and identical
     // (window, node) tests requested by anchors that started at different depths are found by the de-duplication.
-    hvec<u32> climbing, selected, waiting;    // anchors that still have an inner node to test
+    hvec<u32> climbing, selected, waiting, survivors;    // anchors that still have an inner node to test (in anchor order)
     double g_build_ms = 0;
     for (u32 ai = 0; ai < A.size(); ++ai) if (A[ai].alive && !A[ai].at_root) climbing.push_back(ai);
     hvec<AlignRequest> reqs;
@@ -1650,7 +1658,8 @@ int align_slice(Lane* lane, const flx_params* P, const flx_reads* RD, u64 first_
         u64 const limit = (u64)smallest + smallest / 2;
         selected.clear();
         waiting.clear();
-        for (u32 ai : climbing) (A[ai].node_rows <= limit ? selected : waiting).push_back(ai);
+        survivors.clear();
+        for (u32 ai : climbing) (A[ai].node_rows <= limit ? selected : waiting).push_back(ai);     // both stay in anchor order
         auto const tb0 = std::chrono::steady_clock::now();
         reqs.clear();
         for (u32 ai : selected) reqs.push_back(window_request(A[ai], reads[A[ai].read].tree.inner[A[ai].node], 0.0, nullptr));
@@ -1661,9 +1670,10 @@ int align_slice(Lane* lane, const flx_params* P, const flx_reads* RD, u64 first_
             if (outs[i].score == 0xFFFFFFFFu) { a.alive = false; continue; }
             a.node = reads[a.read].tree.inner[a.node].parent_id;
             if (reads[a.read].tree.inner[a.node].parent_id == FLX_NULL_ID) a.at_root = true;
-            else { a.node_rows = rows_of(a); waiting.push_back(selected[i]); }
+            else { a.node_rows = rows_of(a); survivors.push_back(selected[i]); }
         }
-        climbing.swap(waiting);
+        climbing.resize(waiting.size() + survivors.size());
+        std::merge(waiting.begin(), waiting.end(), survivors.begin(), survivors.end(), climbing.begin());
     }
 
     prof.mark("inner-levels");
