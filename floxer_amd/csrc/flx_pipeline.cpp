@@ -1651,29 +1651,38 @@ int align_slice(Lane* lane, const flx_params* P, const flx_reads* RD, u64 first_
     hvec<AlignRequest> reqs;
     hvec<DevAlignOut> outs;
     auto rows_of = [&](AnchorState const& a) { flx_pex_node const& nd = reads[a.read].tree.inner[a.node]; return nd.to - nd.from + 1; };
-    for (u32 ai : climbing) A[ai].node_rows = rows_of(A[ai]);
-    while (!climbing.empty()) {
-        u32 smallest = 0xFFFFFFFFu;
-        for (u32 ai : climbing) smallest = std::min(smallest, A[ai].node_rows);
+    // `climbing` carries each anchor's node size next to its index (the rounds scan it): {anchor, rows}
+    struct Climber { u32 anchor, rows; };
+    hvec<Climber> climbers, sel, wait, surv;
+    u32 smallest = 0xFFFFFFFFu;
+    climbers.reserve(climbing.size());
+    for (u32 ai : climbing) { u32 const r = rows_of(A[ai]); climbers.push_back(Climber{ai, r}); smallest = std::min(smallest, r); }
+    while (!climbers.empty()) {
         u64 const limit = (u64)smallest + smallest / 2;
-        selected.clear();
-        waiting.clear();
-        survivors.clear();
-        for (u32 ai : climbing) (A[ai].node_rows <= limit ? selected : waiting).push_back(ai);     // both stay in anchor order
         auto const tb0 = std::chrono::steady_clock::now();
+        sel.clear();
+        wait.clear();
+        surv.clear();
         reqs.clear();
-        for (u32 ai : selected) reqs.push_back(window_request(A[ai], reads[A[ai].read].tree.inner[A[ai].node], 0.0, nullptr));
+        u32 next_smallest = 0xFFFFFFFFu;
+        for (Climber const& c : climbers) {                  // both parts stay in anchor order
+            if (c.rows <= limit) {
+                sel.push_back(c);
+                reqs.push_back(window_request(A[c.anchor], reads[A[c.anchor].read].tree.inner[A[c.anchor].node], 0.0, nullptr));
+            } else { wait.push_back(c); next_smallest = std::min(next_smallest, c.rows); }
+        }
         g_build_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tb0).count();
         if ((rc = run_exists_jobs(lane, d_text, d_peq, reqs, outs))) return rc;
         for (size_t i = 0; i < outs.size(); ++i) {
-            AnchorState& a = A[selected[i]];
+            AnchorState& a = A[sel[i].anchor];
             if (outs[i].score == 0xFFFFFFFFu) { a.alive = false; continue; }
             a.node = reads[a.read].tree.inner[a.node].parent_id;
             if (reads[a.read].tree.inner[a.node].parent_id == FLX_NULL_ID) a.at_root = true;
-            else { a.node_rows = rows_of(a); survivors.push_back(selected[i]); }
+            else { u32 const r = rows_of(a); surv.push_back(Climber{sel[i].anchor, r}); next_smallest = std::min(next_smallest, r); }
         }
-        climbing.resize(waiting.size() + survivors.size());
-        std::merge(waiting.begin(), waiting.end(), survivors.begin(), survivors.end(), climbing.begin());
+        climbers.resize(wait.size() + surv.size());
+        std::merge(wait.begin(), wait.end(), surv.begin(), surv.end(), climbers.begin(), [](Climber const& x, Climber const& y) { return x.anchor < y.anchor; });
+        smallest = next_smallest;
     }
 
     prof.mark("inner-levels");
