@@ -12,6 +12,7 @@
 #include <cstdlib>
 
 #include "flx_internal.hpp"
+#include "flx_stdsort.hpp"
 
 namespace flx {
 
@@ -457,74 +458,6 @@ __global__ void __launch_bounds__(256) hit_scatter_kernel(const DevHit* __restri
         h.errors &= 0xFFu;
         grouped[offset[h.seed] + ordinal] = h;
     }
-}
-
-// libstdc++'s std::sort (bits/stl_algo.h: introsort with median-of-three pivots down to 16 elements, then insertion sort), step
-// for step: the reference orders hit groups and anchor buckets with it, its comparators tie often, and what it does with equal
-// elements shows in the output. Returns false if the depth limit is reached (the heap-sort fallback is left to the host).
-template <class T, class Less>
-__device__ bool std_sort_emulated(T* a, int n, Less less) {
-    auto swap_at = [&](int i, int j) { T const t = a[i]; a[i] = a[j]; a[j] = t; };
-    auto unguarded_linear_insert = [&](int last) {
-        T const val = a[last];
-        int next = last - 1;
-        while (less(val, a[next])) { a[last] = a[next]; last = next; --next; }
-        a[last] = val;
-    };
-    auto insertion_sort = [&](int first, int last) {
-        for (int i = first + 1; i < last; ++i) {
-            if (less(a[i], a[first])) { T const val = a[i]; for (int j = i; j > first; --j) a[j] = a[j - 1]; a[first] = val; }
-            else unguarded_linear_insert(i);
-        }
-    };
-    if (n <= 1) return true;
-    if (n > 16) {
-        // __introsort_loop: recursion on the right part, iteration on the left; at most 2*floor(log2 n) levels
-        int depth0 = 0;
-        for (int m = n; m > 1; m >>= 1) ++depth0;
-        depth0 *= 2;
-        int stack_first[16], stack_last[16], stack_depth[16], sp = 0;
-        int first = 0, last = n, depth = depth0;
-        while (true) {
-            while (last - first > 16) {
-                if (depth == 0) return false;
-                --depth;
-                int const mid = first + (last - first) / 2;
-                // __move_median_to_first(first, first + 1, mid, last - 1)
-                int const x = first + 1, y = mid, z = last - 1;
-                if (less(a[x], a[y])) {
-                    if (less(a[y], a[z])) swap_at(first, y);
-                    else if (less(a[x], a[z])) swap_at(first, z);
-                    else swap_at(first, x);
-                } else if (less(a[x], a[z])) swap_at(first, x);
-                else if (less(a[y], a[z])) swap_at(first, z);
-                else swap_at(first, y);
-                // __unguarded_partition(first + 1, last, pivot = first)
-                int lo = first + 1, hi = last;
-                while (true) {
-                    while (less(a[lo], a[first])) ++lo;
-                    --hi;
-                    while (less(a[first], a[hi])) --hi;
-                    if (!(lo < hi)) break;
-                    swap_at(lo, hi);
-                    ++lo;
-                }
-                int const cut = lo;
-                if (sp < 16) { stack_first[sp] = cut; stack_last[sp] = last; stack_depth[sp] = depth; ++sp; } else return false;
-                last = cut;
-            }
-            if (sp == 0) break;
-            --sp;
-            first = stack_first[sp]; last = stack_last[sp]; depth = stack_depth[sp];
-        }
-        // (the recursion of the original handles the right part before it continues with the left one; the parts are disjoint,
-        //  so the order in which they are partitioned does not change the result)
-        insertion_sort(0, 16);
-        for (int i = 16; i < n; ++i) unguarded_linear_insert(i);
-        return true;
-    }
-    insertion_sort(0, n);
-    return true;
 }
 
 struct SelGroup { u32 lb, len, errors; };

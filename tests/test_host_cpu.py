@@ -168,3 +168,14 @@ def test_cli_rejects_bad_invocations(tmp_path):
     for cmd in cases:
         r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
         assert r.returncode == 255 and r.stdout == b"" and b"CLI PARSER ERROR" in r.stderr, cmd
+
+
+def test_std_sort_emulation_matches_std_sort(tmp_path):
+    """the device-side anchor selection reproduces libstdc++'s std::sort (order of equal elements included); the same template
+    compiled for the host is compared with the real std::sort on 195 000 arrays full of ties"""
+    import subprocess
+    exe = str(tmp_path / "stdsort_check")
+    src = os.path.join(os.path.dirname(os.path.abspath(__file__)), "stdsort_check.cpp")
+    subprocess.run(["g++", "-O2", "-std=c++17", "-o", exe, src], check=True)
+    out = subprocess.run([exe], capture_output=True, text=True)
+    assert out.returncode == 0 and out.stdout.startswith("ok "), out.stdout + out.stderr
