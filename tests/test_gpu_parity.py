@@ -576,3 +576,24 @@ def test_caller_owned_stream():
     rr.close()
     ctx.close()
     assert hip.hipStreamDestroy(stream) == 0
+
+
+@pytest.mark.parametrize("kw,okw", [(dict(), dict()), (dict(interval_optimization=True), dict(interval_opt=True))])
+def test_repeats_and_several_references_match_oracle(kw, okw):
+    """five references with copied segments: seeds with many hits (hard and soft cap, the device-side selection and its host
+    remainder, std::sort on more than 16 equal keys), loci that share windows, anchors on several references"""
+    genome = S.make_genome(1_000_000, 5, seed=101)
+    rng = np.random.default_rng(7)
+    for g in genome:
+        for _ in range(6):
+            a, b, ln = rng.integers(0, len(g) - 5000), rng.integers(0, len(g) - 5000), int(rng.integers(500, 4000))
+            g[b:b + ln] = g[a:a + ln]
+    ctx = F.context(F.fmindex(genome))
+    oidx = O.Index(genome)
+    for length, rate, seed in [(1500, 0.05, 1), (3000, 0.08, 2), (600, 0.10, 3)]:
+        reads, _, _ = S.make_reads(genome, 250, length, rate, seed=300 + seed)
+        got = F.aligner(ctx, F.params(error_probability=rate, **kw)).align_reads(reads)
+        exp = oidx.run(reads, O.params(error_probability=rate, **okw), threads=8)
+        assert got.skipped.tolist() == exp.skipped.tolist()
+        assert got.records() == exp.records(), (length, rate)
+    ctx.close()
