@@ -99,7 +99,7 @@ def main():
 
     os.environ["FLX_LANES"] = str(args.lanes)
     t0 = time.time()
-    index = F.fmindex(genome)                       # built on the host, not timed (floxer's stopwatch excludes it too, floxer.cpp:154)
+    index = F.fmindex(genome, device=local_rank)    # suffix arrays on the GPU; not timed (floxer's stopwatch excludes it too, floxer.cpp:154)
     index_s = time.time() - t0
     ctx = F.context(index, device=local_rank)
     p = F.params(error_probability=args.error_rate, interval_optimization=args.interval_optimization)

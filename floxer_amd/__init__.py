@@ -84,7 +84,8 @@ class pex_tree:
 
 # ------------------------------------------------------------------------------------------------ index + context
 class fmindex:
-    def __init__(self, references=None, path=None):
+    def __init__(self, references=None, path=None, device=None):
+        """device: HIP device ordinal to build the suffix arrays on (None: on the host, as flx_index_build)"""
         self.h = C.c_void_p()
         if path is not None and references is None:
             check(lib().flx_index_load(path.encode(), C.byref(self.h)))
@@ -92,7 +93,10 @@ class fmindex:
             refs = [as_u8(r) for r in references]
             pool = np.concatenate(refs) if refs else np.zeros(0, np.uint8)
             lens = np.array([len(r) for r in refs], dtype=np.uint64)
-            check(lib().flx_index_build(ptr(pool, u8p), ptr(lens, u64p), len(refs), C.byref(self.h)))
+            if device is None:
+                check(lib().flx_index_build(ptr(pool, u8p), ptr(lens, u64p), len(refs), C.byref(self.h)))
+            else:
+                check(lib().flx_index_build_on_device(int(device), ptr(pool, u8p), ptr(lens, u64p), len(refs), C.byref(self.h)))
 
     def save(self, path):
         check(lib().flx_index_save(self.h, path.encode()))

@@ -77,7 +77,7 @@ class KernelStat(C.Structure):
 # every symbol include/floxer_amd.h declares (tests check that the library exports all of them)
 EXPORTED = [
     "flx_last_error", "flx_version", "flx_ceil_div", "flx_floating_point_error_aware_ceil", "flx_saturate_value_to_int32_max",
-    "flx_chars_to_rank_sequence", "flx_reverse_complement_rank", "flx_pex_tree_build", "flx_index_build", "flx_index_save",
+    "flx_chars_to_rank_sequence", "flx_reverse_complement_rank", "flx_pex_tree_build", "flx_index_build", "flx_index_build_on_device", "flx_index_save",
     "flx_index_load", "flx_index_free", "flx_index_text_length", "flx_index_num_references", "flx_index_device_bytes",
     "flx_index_copy_sa", "flx_index_copy_bwt", "flx_ctx_create", "flx_ctx_destroy", "flx_ctx_set_stream", "flx_search_seeds",
     "flx_search_groups", "flx_align_batch", "flx_params_default", "flx_align_reads", "flx_reads_upload", "flx_reads_free",
@@ -109,6 +109,7 @@ def lib():
     L.flx_reverse_complement_rank.argtypes = [u8p, C.c_uint64, u8p]
     L.flx_pex_tree_build.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64, C.c_int, C.POINTER(PexNode), C.c_uint64, u64p, u64p]
     L.flx_index_build.argtypes = [u8p, u64p, C.c_uint32, C.POINTER(C.c_void_p)]
+    L.flx_index_build_on_device.argtypes = [C.c_int, u8p, u64p, C.c_uint32, C.POINTER(C.c_void_p)]
     L.flx_index_save.argtypes = [C.c_void_p, C.c_char_p]
     L.flx_index_load.argtypes = [C.c_char_p, C.POINTER(C.c_void_p)]
     L.flx_index_free.argtypes = [C.c_void_p]

@@ -261,7 +261,10 @@ int main(int argc, char** argv) {
     } else {
         log_line("info", "building index with %llu thread%s", (unsigned long long)o.threads, o.threads == 1 ? "" : "s");
         auto const t0 = std::chrono::steady_clock::now();
-        if (flx_index_build(ref.pool.data(), ref.lens.data(), (uint32_t)ref.ids.size(), &index) != FLX_OK) { log_line("error", "index construction failed: %s", flx_last_error()); return -1; }
+        // suffix arrays on the GPU (FLX_INDEX_ON_HOST=1: the host's SA-IS; the index is the same either way)
+        int const brc = getenv("FLX_INDEX_ON_HOST") ? flx_index_build(ref.pool.data(), ref.lens.data(), (uint32_t)ref.ids.size(), &index)
+                                                    : flx_index_build_on_device(0, ref.pool.data(), ref.lens.data(), (uint32_t)ref.ids.size(), &index);
+        if (brc != FLX_OK) { log_line("error", "index construction failed: %s", flx_last_error()); return -1; }
         log_line("info", "building index took %.3f seconds", std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
         if (!o.index.empty() && flx_index_save(index, o.index.c_str()) != FLX_OK)
             log_line("warning", "An error occured while trying to write the index to the file %s.\nContinuing without saving the index.\n%s", o.index.c_str(), flx_last_error());

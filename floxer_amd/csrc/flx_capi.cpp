@@ -45,6 +45,16 @@ int flx_index_build(const uint8_t* concat, const uint64_t* lens, uint32_t n_refs
     *out = new flx_index{h};
     return FLX_OK;
 }
+int flx_index_build_on_device(int hip_device, const uint8_t* concat, const uint64_t* lens, uint32_t n_refs, flx_index** out) {
+    if (!concat || !lens || !out || n_refs == 0) { set_error("flx_index_build_on_device: null argument or no reference"); return FLX_ERR_INVALID; }
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) { (void)hipGetLastError(); set_error("flx_index_build_on_device: no HIP device"); return FLX_ERR_NO_DEVICE; }
+    if (hip_device < 0 || hip_device >= count) { set_error("flx_index_build_on_device: device ordinal out of range"); return FLX_ERR_INVALID; }
+    HostIndex* h = build_host_index(concat, lens, n_refs, hip_device);
+    if (!h) return FLX_ERR_INVALID;
+    *out = new flx_index{h};
+    return FLX_OK;
+}
 int flx_index_save(const flx_index* index, const char* path) {
     if (!index || !path) { set_error("flx_index_save: null argument"); return FLX_ERR_INVALID; }
     return save_host_index(*index->host, path);

@@ -8,6 +8,7 @@
 //   K5 ed_traceback   trace walk + CIGAR (alignment.cpp:166-180)
 #include <hip/hip_runtime.h>
 #include <hipcub/hipcub.hpp>
+#include <rocprim/rocprim.hpp>
 
 #include <cstdlib>
 
@@ -53,6 +54,84 @@ int DeviceApi::build_peq(void* stream, const u8* d_seq, u64 len, u64* d_peq) {
     hipLaunchKernelGGL(peq_build_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, (hipStream_t)stream, d_seq, len,
                        d_peq, n_words);
     return (int)hipGetLastError();
+}
+
+// ================================================================================================ suffix array (index construction)
+// Prefix doubling with radix sorts: ranks of the first 10 symbols, then h = 10, 20, 40, ...: suffixes sorted by (rank[i], rank[i+h])
+// until all ranks differ. A suffix that is a prefix of another sorts first (positions past the end rank 0), as the host's SA-IS
+// orders them. 36 bytes of HBM per text symbol while it runs.
+__global__ void __launch_bounds__(256) sa_init_kernel(const u8* __restrict__ text, u64 n, u64* __restrict__ keys, u32* __restrict__ sa) {
+    u64 const i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    u64 key = 0;
+    for (u32 j = 0; j < 10; ++j) key = (key << 3) | (i + j < n ? (u64)text[i + j] + 1u : 0u);
+    keys[i] = key;
+    sa[i] = (u32)i;
+}
+__global__ void __launch_bounds__(256) sa_flag_kernel(const u64* __restrict__ keys, u64 n, u32* __restrict__ flags) {
+    u64 const j = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    flags[j] = (j == 0 || keys[j] != keys[j - 1]) ? 1u : 0u;
+}
+__global__ void __launch_bounds__(256) sa_rank_kernel(const u32* __restrict__ sa, const u32* __restrict__ r, u64 n, u32* __restrict__ rank) {
+    u64 const j = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    rank[sa[j]] = r[j];
+}
+__global__ void __launch_bounds__(256) sa_key_kernel(const u32* __restrict__ sa, const u32* __restrict__ rank, u64 n, u64 h, u64* __restrict__ keys) {
+    u64 const j = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    u64 const i = sa[j];
+    keys[j] = ((u64)rank[i] << 32) | (i + h < n ? (u64)rank[i + h] : 0ull);
+}
+
+int DeviceApi::suffix_array(int hip_device, const u8* text, u64 n, u32* out) {
+    if (n == 0) return 0;
+    hipError_t e;
+#define SA_HIP(x) do { e = (x); if (e != hipSuccess) goto done; } while (0)
+    u8* d_text = nullptr;
+    u64 *d_keys = nullptr, *d_keys2 = nullptr;
+    u32 *d_sa = nullptr, *d_sa2 = nullptr, *d_rank = nullptr, *d_flags = nullptr;
+    void* d_tmp = nullptr;
+    size_t sort_bytes = 0, scan_bytes = 0, tmp_bytes = 0;
+    hipStream_t s = nullptr;
+    unsigned const blocks = (unsigned)((n + 255) / 256);
+    u32 top = 0;
+    SA_HIP(hipSetDevice(hip_device));
+    SA_HIP(hipStreamCreate(&s));
+    SA_HIP(hipMalloc(&d_text, n));
+    SA_HIP(hipMalloc(&d_keys, n * 8));
+    SA_HIP(hipMalloc(&d_keys2, n * 8));
+    SA_HIP(hipMalloc(&d_sa, n * 4));
+    SA_HIP(hipMalloc(&d_sa2, n * 4));
+    SA_HIP(hipMalloc(&d_rank, n * 4));
+    SA_HIP(hipMalloc(&d_flags, n * 4));
+    SA_HIP(rocprim::radix_sort_pairs(nullptr, sort_bytes, d_keys, d_keys2, d_sa, d_sa2, (size_t)n, 0u, 64u, s));
+    SA_HIP(rocprim::inclusive_scan(nullptr, scan_bytes, d_flags, d_flags, (size_t)n, rocprim::plus<u32>(), s));
+    tmp_bytes = std::max(sort_bytes, scan_bytes);
+    SA_HIP(hipMalloc(&d_tmp, tmp_bytes));
+    SA_HIP(hipMemcpyAsync(d_text, text, n, hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(sa_init_kernel, dim3(blocks), dim3(256), 0, s, d_text, n, d_keys, d_sa);
+    for (u64 h = 10;; h *= 2) {
+        // sort the suffixes by their keys; ranks = number of distinct keys up to and including each position
+        SA_HIP(rocprim::radix_sort_pairs(d_tmp, tmp_bytes, d_keys, d_keys2, d_sa, d_sa2, (size_t)n, 0u, 64u, s));
+        hipLaunchKernelGGL(sa_flag_kernel, dim3(blocks), dim3(256), 0, s, d_keys2, n, d_flags);
+        SA_HIP(rocprim::inclusive_scan(d_tmp, tmp_bytes, d_flags, d_flags, (size_t)n, rocprim::plus<u32>(), s));
+        hipLaunchKernelGGL(sa_rank_kernel, dim3(blocks), dim3(256), 0, s, d_sa2, d_flags, n, d_rank);
+        SA_HIP(hipMemcpyAsync(&top, d_flags + (n - 1), 4, hipMemcpyDeviceToHost, s));
+        SA_HIP(hipStreamSynchronize(s));
+        std::swap(d_sa, d_sa2);
+        if ((u64)top == n || h >= n) break;                    // all suffixes distinct
+        hipLaunchKernelGGL(sa_key_kernel, dim3(blocks), dim3(256), 0, s, d_sa, d_rank, n, h, d_keys);
+    }
+    SA_HIP(hipMemcpyAsync(out, d_sa, n * 4, hipMemcpyDeviceToHost, s));
+    SA_HIP(hipStreamSynchronize(s));
+    e = hipGetLastError();
+done:
+#undef SA_HIP
+    for (void* p : {(void*)d_text, (void*)d_keys, (void*)d_keys2, (void*)d_sa, (void*)d_sa2, (void*)d_rank, (void*)d_flags, d_tmp}) if (p) (void)hipFree(p);
+    if (s) (void)hipStreamDestroy(s);
+    return (int)e;
 }
 
 // ================================================================================================ K1: FM search

@@ -200,7 +200,7 @@ void build_kmer_table(HostIndex& idx) {
 
 }  // namespace
 
-HostIndex* build_host_index(const u8* concat, const u64* lens, u32 n_refs) {
+HostIndex* build_host_index(const u8* concat, const u64* lens, u32 n_refs, int hip_device) {
     auto idx = std::make_unique<HostIndex>();
     constexpr u64 sampling = 4;    // floxer.cpp:92: padding keeps every sequence a multiple of the reference's sampling rate
     u64 off = 0;
@@ -219,12 +219,20 @@ HostIndex* build_host_index(const u8* concat, const u64* lens, u32 n_refs) {
     if (idx->n == 0) { set_error("empty reference"); return nullptr; }
     if (idx->n >= ((u64)1 << 32) - 512) { set_error("text of 2^32 symbols or more is not supported by this build"); return nullptr; }
     u64 const n = idx->n;
-    idx->sa = suffix_array(idx->text);
+    auto sa_of = [&](const std::vector<u8>& t, std::vector<u32>& out) {
+        if (hip_device < 0) { out = suffix_array(t); return true; }
+        out.resize(t.size());
+        int const e = DeviceApi::suffix_array(hip_device, t.data(), t.size(), out.data());
+        if (e) { set_error("suffix array construction on the device failed (HIP error " + std::to_string(e) + ")"); return false; }
+        return true;
+    };
+    if (!sa_of(idx->text, idx->sa)) return nullptr;
     idx->bwt[0].resize(n);
     for (u64 i = 0; i < n; ++i) idx->bwt[0][i] = idx->text[(idx->sa[i] + n - 1) % n];
     {
         std::vector<u8> rev(idx->text.rbegin(), idx->text.rend());
-        std::vector<u32> sa_rev = suffix_array(rev);
+        std::vector<u32> sa_rev;
+        if (!sa_of(rev, sa_rev)) return nullptr;
         idx->bwt[1].resize(n);
         for (u64 i = 0; i < n; ++i) idx->bwt[1][i] = rev[(sa_rev[i] + n - 1) % n];
     }

@@ -161,6 +161,8 @@ struct KernelTimer;   // opaque, owned by the context
 
 struct DeviceApi {
     // all return 0 or a hipError_t (non-zero)
+    // suffix array of text[0, n) on the device (a suffix that is a prefix of another sorts first); out: n entries on the host
+    static int suffix_array(int hip_device, const u8* text, u64 n, u32* out);
     static int build_peq(void* stream, const u8* d_seq, u64 len, u64* d_peq);
     // d_seed_cnt (may be null): number of hits of every seed; each hit then carries its ordinal within its seed in errors >> 8
     static int search(void* stream, const DevIndex& idx, const u8* d_seq, const u32* d_scheme, const DevSeed* d_seeds,
@@ -203,7 +205,8 @@ const std::vector<SearchDef>& optimum_scheme(u32 k);
 // the scheme cannot be expanded (len < number of parts)
 std::vector<u32> expanded_scheme(u32 k, u32 len);
 
-HostIndex* build_host_index(const u8* concat, const u64* lens, u32 n_refs);
+// hip_device >= 0: the two suffix arrays are built on that device (prefix doubling), else on the host (SA-IS)
+HostIndex* build_host_index(const u8* concat, const u64* lens, u32 n_refs, int hip_device = -1);
 int save_host_index(const HostIndex& idx, const char* path);
 HostIndex* load_host_index(const char* path);
 

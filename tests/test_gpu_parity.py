@@ -6,6 +6,7 @@ import numpy as np
 import pytest
 
 import floxer_amd as F
+from floxer_amd import capi
 from floxer_amd import simulate as S
 import oracle_lib as O
 
@@ -597,3 +598,34 @@ def test_repeats_and_several_references_match_oracle(kw, okw):
         assert got.skipped.tolist() == exp.skipped.tolist()
         assert got.records() == exp.records(), (length, rate)
     ctx.close()
+
+
+def test_index_built_on_the_device_is_the_host_index(tmp_path):
+    """flx_index_build_on_device: suffix arrays by prefix doubling on the GPU; the index (SA, both BWTs) equals the host-built one,
+    for references with repeats, N runs, several sequences and a sequence that is a prefix of another"""
+    rng = np.random.default_rng(81)
+    base = rng.integers(1, 5, size=30000, dtype=np.uint8)
+    refs = [base.copy(), base[:12000].copy(), np.concatenate([base[5000:9000], base[5000:9000], base[5000:9000]]),
+            np.concatenate([np.full(700, 5, np.uint8), rng.integers(1, 5, size=4001, dtype=np.uint8), np.full(300, 1, np.uint8)]),
+            np.array([3], np.uint8)]
+    host = F.fmindex(refs)
+    dev = F.fmindex(refs, device=0)
+    n = capi.lib().flx_index_text_length(host.h)
+    assert capi.lib().flx_index_text_length(dev.h) == n
+
+    def arrays(ix):
+        sa = np.zeros(n, dtype=np.uint64)
+        capi.check(capi.lib().flx_index_copy_sa(ix.h, capi.ptr(sa, capi.u64p)))
+        bwts = []
+        for rev in (0, 1):
+            b = np.zeros(n, dtype=np.uint8)
+            capi.check(capi.lib().flx_index_copy_bwt(ix.h, rev, capi.ptr(b, capi.u8p)))
+            bwts.append(b)
+        return sa, bwts
+    sa_h, bwt_h = arrays(host)
+    sa_d, bwt_d = arrays(dev)
+    assert (sa_h == sa_d).all()
+    assert (bwt_h[0] == bwt_d[0]).all() and (bwt_h[1] == bwt_d[1]).all()
+    p1, p2 = str(tmp_path / "h.idx"), str(tmp_path / "d.idx")
+    host.save(p1); dev.save(p2)
+    assert open(p1, "rb").read() == open(p2, "rb").read()
