@@ -8,7 +8,7 @@ from floxer_amd import simulate as S
 G = int(sys.argv[1]); NR = int(sys.argv[2]); L = int(sys.argv[3]); rate = float(sys.argv[4])
 t = time.time(); genome = S.make_genome(G, 1, seed=S.DEFAULT_SEED); print("genome", round(time.time() - t, 1), "s", flush=True)
 t = time.time(); reads, names, truth = S.make_reads(genome, NR, L, rate, seed=11); print("reads", round(time.time() - t, 1), "s", flush=True)
-t = time.time(); idx = F.fmindex(genome); print("index build", round(time.time() - t, 1), "s, device bytes", idx.device_bytes, flush=True)
+t = time.time(); idx = F.fmindex(genome, device=0); print("index build (suffix arrays on the device)", round(time.time() - t, 1), "s, device bytes", idx.device_bytes, flush=True)
 ctx = F.context(idx)
 al = F.aligner(ctx, F.params(error_probability=rate))
 rr = F.resident_reads(ctx, reads)
