@@ -5,7 +5,7 @@ import floxer_amd as F
 from floxer_amd import simulate as S
 G, NR, L = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
 genome = S.make_genome(G, 1, seed=S.DEFAULT_SEED)
-t = time.time(); idx = F.fmindex(genome); print("index build", round(time.time() - t, 1), "s", flush=True)
+t = time.time(); idx = F.fmindex(genome, device=0); print("index build", round(time.time() - t, 1), "s", flush=True)
 os.environ["FLX_LANES"] = "1"
 ctx = F.context(idx)
 al = F.aligner(ctx, F.params(error_probability=0.08, interval_optimization=True))
