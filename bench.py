@@ -1,12 +1,13 @@
 #!/usr/bin/env python3
-"""bench.py — reads/s of the seed-and-verify hot path on MI355X.
+"""bench.py — reads/s of the seed-and-verify hot path on MI355X, on the configuration BASELINE.json's metric is quoted on:
+10 kb reads @ 8 % error against a GRCh38-size reference (3.1 Gb in 25 sequences; synthetic, uniform over ACGT: hg38 itself is not
+available offline), floxer's default flags.
 
-One "step" = one pass of the whole path (PEX seeding -> FM search -> hierarchical verification -> root alignment with
-CIGAR -> records) over one batch of synthetic long reads that is already resident in HBM. Reads shard across ranks with
-no data-path collective (FM index replicated per GPU); every rank keeps its part of the output (the job's output is the parts
-in rank order), the ranks exchange the sizes of their parts (RCCL all-gather) at the end of every step and the fixed-size
-alignment records of the whole job are gathered to rank 0 once at the end (RCCL gather, inside the timed region). Prints ONE
-JSON line on rank 0.
+One "step" = one pass of the whole path (PEX seeding -> FM search -> hierarchical verification -> root alignment with CIGAR ->
+records) over one batch of synthetic long reads that is already resident in HBM. Reads shard across ranks with no data-path
+collective (FM index replicated per GPU); every rank keeps its part of the output (the job's output is the parts in rank order),
+the ranks exchange the sizes of their parts (RCCL all-gather) at the end of every step and the fixed-size alignment records of the
+whole job are gathered to rank 0 once at the end (RCCL gatherv over xGMI, inside the timed region). Prints ONE JSON line on rank 0.
 
   python bench.py --gpus 1 --steps K --warmup W
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
@@ -27,14 +28,15 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
+PROFILE_TAG = "r02"        # profiles/<tag>_pmc_traffic_<kernel>.json: committed FETCH_SIZE / WRITE_SIZE passes over this workload
 
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=12)
-    ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--reads-per-step", type=int, default=int(os.environ.get("FLX_BENCH_READS", 16384)), help="per GPU")
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--reads-per-step", type=int, default=int(os.environ.get("FLX_BENCH_READS", 8192)), help="per GPU")
     ap.add_argument("--lanes", type=int, default=int(os.environ.get("FLX_LANES", 0)),
                     help="concurrent lanes (stream + host thread) per GPU; 0 = one per host core this rank can use, 4..16")
     ap.add_argument("--inflight", type=int, default=int(os.environ.get("FLX_BENCH_INFLIGHT", 3)),
@@ -42,12 +44,13 @@ def parse():
                          "full inside the timed region")
     ap.add_argument("--no-isolated-pass", action="store_true", help="skip the one-lane instrumented pass (timeline profiling)")
     ap.add_argument("--isolated-only", action="store_true",
-                    help="only the one-lane instrumented pass (used under rocprofv3 so that its per-kernel averages are those of roofline_isolated)")
-    ap.add_argument("--genome", type=int, default=4_600_000, help="synthetic reference length (E. coli K-12 size)")
-    ap.add_argument("--read-length", type=int, default=5000)
+                    help="only the one-lane instrumented pass (used under rocprofv3 so that its per-kernel averages are those of roofline)")
+    ap.add_argument("--genome", type=int, default=3_100_000_000, help="synthetic reference length in total (GRCh38 size)")
+    ap.add_argument("--chromosomes", type=int, default=25, help="sequences the reference is cut into (hg38: 22 + X + Y + M)")
+    ap.add_argument("--read-length", type=int, default=10000)
     ap.add_argument("--error-rate", type=float, default=0.08)
     ap.add_argument("--interval-optimization", action="store_true")
-    ap.add_argument("--cpu-sample", type=int, default=int(os.environ.get("FLX_BENCH_CPU_SAMPLE", 256)))
+    ap.add_argument("--cpu-sample", type=int, default=int(os.environ.get("FLX_BENCH_CPU_SAMPLE", 768)))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     return ap.parse_args()
 
@@ -64,6 +67,11 @@ def usable_cores():
     return n
 
 
+def log(msg):
+    if os.environ.get("FLX_BENCH_VERBOSE"):
+        print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
+
+
 def main():
     args = parse()
     rank = int(os.environ.get("RANK", 0))
@@ -72,46 +80,55 @@ def main():
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
 
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", world))
+    cores = max(1, usable_cores() // max(1, local_world))
+    os.environ.setdefault("FLX_SIM_THREADS", str(cores))
     if args.lanes <= 0:
-        local_world = int(os.environ.get("LOCAL_WORLD_SIZE", world))
-        args.lanes = max(4, min(16, usable_cores() // max(1, local_world)))
+        args.lanes = max(4, min(16, cores))
 
     import torch
     import torch.distributed as dist
     import floxer_amd as F
     from floxer_amd import simulate as S
+    from floxer_amd import distributed as D
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the product has no CPU path")
     torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
-    # ---- workload: BASELINE.json configs[1] shape (4.6 Mb reference, 5 kb reads @ 8 %), synthetic (no network for E. coli)
-    genome = S.make_genome(args.genome, 1, seed=S.DEFAULT_SEED)
+    # ---- workload: BASELINE.json's metric configuration (configs[3] per GPU): GRCh38-size reference, 10 kb reads @ 8 %
+    t0 = time.time()
+    chrom_len = args.genome // args.chromosomes
+    pool, genome = S.make_genome_fast(chrom_len, args.chromosomes, seed=S.DEFAULT_SEED)
+    chrom_lens = [chrom_len] * args.chromosomes
+    log(f"genome {time.time() - t0:.1f} s")
     n_batches = args.steps + args.warmup
     B = args.reads_per_step
-    batches = []
-    for b in range(n_batches):
-        # every rank and every step gets its own reads (weak scaling: per-GPU work is fixed)
-        reads, _, _ = S.make_reads(genome, B, args.read_length, args.error_rate, seed=S.DEFAULT_SEED + 1 + rank * 1000 + b)
-        batches.append(reads)
+    t0 = time.time()
+    # every rank and every step gets its own reads (weak scaling: per-GPU work is fixed)
+    batches = [S.make_reads_fast(pool, chrom_lens, B, args.read_length, args.error_rate, seed=S.DEFAULT_SEED + 1 + rank * 1000 + b)[0]
+               for b in range(n_batches)]
+    log(f"reads {time.time() - t0:.1f} s")
 
     os.environ["FLX_LANES"] = str(args.lanes)
     t0 = time.time()
-    index = F.fmindex(genome, device=local_rank)    # suffix arrays on the GPU; not timed (floxer's stopwatch excludes it too, floxer.cpp:154)
+    # the index is built once per job on rank 0's GPU and handed to the other ranks as a file in shared memory; not timed
+    # (floxer's stopwatch excludes it too, floxer.cpp:154)
+    index = D.build_index_once(genome, rank, world, device=local_rank)
     index_s = time.time() - t0
+    log(f"index {index_s:.1f} s")
     ctx = F.context(index, device=local_rank)
     p = F.params(error_probability=args.error_rate, interval_optimization=args.interval_optimization)
     al = F.aligner(ctx, p)
     resident = [F.resident_reads(ctx, r) for r in batches]       # inputs resident in HBM before the timed region
-
-    from floxer_amd import distributed as D
-    dev = torch.device("cuda", local_rank)
+    log("reads resident")
 
     def exchange(res):
-        """the only exchange between ranks: the sizes of the ranks' parts (= where each part goes in the job's output, which is the
-        parts in rank order); every rank keeps its own records. Returns the job's record count of this step."""
+        """the only exchange between ranks per step: the sizes of the ranks' parts (= where each part goes in the job's output,
+        which is the parts in rank order); every rank keeps its own records. Returns the job's record count of this step."""
         counts = D.exchange_counts(res.n_records, len(res.cigars), rank, world, device=dev)
         return int(counts[:, 0].sum())
 
@@ -133,22 +150,19 @@ def main():
                 n_warm = max(args.warmup, args.inflight)
                 for f in [wpool.submit(al.align_reads, resident[w % args.warmup]) for w in range(n_warm)]:
                     exchange(f.result())
+        log("warm")
         ctx.enable_kernel_timing(True)
         ctx.reset_kernel_stats()
 
-        pool = ThreadPoolExecutor(max_workers=max(1, args.inflight))
+        tpool = ThreadPoolExecutor(max_workers=max(1, args.inflight))
 
         barrier()
-        import resource
-        ru0 = resource.getrusage(resource.RUSAGE_SELF)
-        if os.environ.get("FLX_ALLOC_DEBUG"):
-            print(f"[bench] {time.time():.3f} timed region starts", file=sys.stderr, flush=True)
         t_start = time.perf_counter()
         # a step = the whole hot path over one batch. Batches are independent (floxer itself streams reads through a thread
         # pool without a barrier between them), so up to --inflight steps are in the context at once: while one batch's lanes
         # are in a host phase another batch's kernels keep the GPU busy. All K steps start and finish inside the timed region.
-        futures = [pool.submit(al.align_reads, resident[args.warmup + s]) for s in range(args.steps)]
-        kept_rows, my_rows = [], 0
+        futures = [tpool.submit(al.align_reads, resident[args.warmup + s]) for s in range(args.steps)]
+        kept_rows = []
         for si, f in enumerate(futures):
             res = f.result()
             n_records += exchange(res)
@@ -156,32 +170,28 @@ def main():
                 rows = res.rows.copy()
                 rows[:, 0] += (si * world + rank) * B          # global read index of this step's shard
                 kept_rows.append(rows)
-                my_rows += len(rows)
         if world > 1:
             # the job's one gather (RCCL over xGMI): the fixed-size alignment records of all K steps go to rank 0 and stay in its
             # HBM; CIGAR words stay in the owners' parts (see floxer_amd/distributed.py)
-            totals = D.exchange_counts(my_rows, 0, rank, world, device=dev)
-            table = D.gather_rows(np.concatenate(kept_rows, axis=0) if kept_rows else np.zeros((0, 7), np.int64), totals, rank, world, device=dev)
+            mine = np.concatenate(kept_rows, axis=0) if kept_rows else np.zeros((0, 7), np.int64)
+            totals = D.exchange_counts(len(mine), 0, rank, world, device=dev)
+            table = D.gather_rows(mine, totals, rank, world, device=dev)
             if rank == 0:
-                assert sum(int(t.shape[0]) for t in table) == n_records
+                assert int(table.shape[0]) == n_records
         barrier()
         elapsed = time.perf_counter() - t_start
-        ru1 = resource.getrusage(resource.RUSAGE_SELF)
-        if os.environ.get("FLX_ALLOC_DEBUG"):
-            print(f"[bench] {time.time():.3f} timed region ends", file=sys.stderr, flush=True)
-            print(f"[bench] timed region: minor page faults {ru1.ru_minflt - ru0.ru_minflt}, user {ru1.ru_utime - ru0.ru_utime:.3f} s, "
-                  f"system {ru1.ru_stime - ru0.ru_stime:.3f} s, wall {elapsed:.3f} s", file=sys.stderr, flush=True)
-        pool.shutdown()
+        tpool.shutdown()
         if world > 1:
-            t = torch.tensor([elapsed], device=torch.device("cuda", local_rank), dtype=torch.float64)
+            t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed = float(t.item())
+        log(f"timed region {elapsed:.2f} s")
 
         stats = ctx.kernel_stats()
         ctx.enable_kernel_timing(False)
 
-    # ---- isolated pass (rank 0): the first timed batch once more on ONE lane, so that no two kernels overlap and a kernel's
-    #      HIP-event time is its own duration. Outside the timed region; feeds "roofline_isolated".
+    # ---- isolated pass (rank 0): the first timed batch once more on ONE lane, so that no two kernels overlap and a launch's
+    #      HIP-event time (on the launch stream) is its own duration. Outside the timed region; feeds "roofline".
     iso_stats = {}
     if rank == 0 and not args.no_isolated_pass:
         os.environ["FLX_LANES"] = "1"
@@ -195,93 +205,90 @@ def main():
         iso_stats = ctx1.kernel_stats()
         rr1.close()
         ctx1.close()
+        log("isolated pass")
 
     if rank == 0:
         total_reads = B * args.steps * world
-        mean_len = float(np.mean([len(r) for r in batches[args.warmup]]))
+        offs = batches[args.warmup][1]
+        mean_len = float(offs[-1]) / max(1, len(offs) - 1)
         value = total_reads / elapsed
-        # ---- roofline of the dominant kernel (largest summed device time in the timed region, HIP events on the launch stream)
-        # the dominant kernel is chosen on the isolated pass (un-overlapped durations); summed event times of the timed region
-        # count the time a launch shares the chip with the other lanes' kernels
-        if iso_stats:
-            dom_name = max(iso_stats.items(), key=lambda kv: kv[1]["device_ms"])[0]
-            dom = (dom_name, stats[dom_name]) if dom_name in stats else None
-        else:
-            dom = max(stats.items(), key=lambda kv: kv[1]["device_ms"]) if stats else None
-        roofline = None
-        kernels = {}
-        for name, st in stats.items():
-            ms = st["device_ms"]
-            kernels[name] = {"launches": st["launches"], "device_ms": round(ms, 3),
-                             "algorithmic_GB": round(st["algorithmic_bytes"] / 1e9, 4), "work_units": st["work_units"],
-                             "GBps": round(st["algorithmic_bytes"] / 1e6 / ms, 2) if ms > 0 else None}
+
+        def load_traffic(name, st):
+            """HBM bytes per launch = algorithmic bytes per launch x (PMC bytes / algorithmic bytes) of the committed FETCH_SIZE /
+            WRITE_SIZE passes over this workload (profiles/<tag>_pmc_traffic_<kernel>.json; launches per pass vary with the
+            chunking, the ratio does not); null when no pass over this workload is committed"""
+            try:
+                t = json.load(open(os.path.join(ROOT, "profiles", f"{PROFILE_TAG}_pmc_traffic_{name}.json")))
+                if t.get("kernel") == name and t.get("read_length") == args.read_length and t.get("genome") == args.genome:
+                    return int(st["algorithmic_bytes"] / st["launches"] * t["traffic_over_algorithmic"])
+            except (OSError, ValueError, KeyError):
+                pass
+            return None
+
         def roof(name, st, note):
             achieved = st["algorithmic_bytes"] / 1e9 / (st["device_ms"] / 1e3)
             return {"kernel": name, "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": load_traffic(name, st),
                     "avg_launch_ms": round(st["device_ms"] / st["launches"], 4),
                     "algorithmic_bytes_per_launch": int(st["algorithmic_bytes"] / st["launches"]), "launches": st["launches"],
-                    # the path is integer bit-vector work: what binds these kernels is VALU issue, not HBM and not MFMA. The
-                    # fraction of VALU issue slots in use comes from the committed SQ counter pass over this workload.
-                    "valu_busy_frac": load_valu(name), "note": note}
+                    "work_units_per_launch": int(st["work_units"] / st["launches"]), "note": note}
 
-        def load_valu(name):
-            try:
-                t = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_valu.json")))
-                return t["kernels"][name]["valu_busy_frac"]
-            except (OSError, ValueError, KeyError):
-                return None
+        def table(sts):
+            return {k: {"launches": v["launches"], "device_ms": round(v["device_ms"], 3),
+                        "algorithmic_GB": round(v["algorithmic_bytes"] / 1e9, 4), "work_units": v["work_units"],
+                        "GBps": round(v["algorithmic_bytes"] / 1e6 / v["device_ms"], 2) if v["device_ms"] > 0 else None}
+                    for k, v in sts.items()}
 
-        def load_traffic(name, st):
-            """HBM bytes per launch = algorithmic bytes per launch x (PMC bytes / algorithmic bytes) of the committed FETCH_SIZE /
-            WRITE_SIZE passes over this workload (profiles/r01_pmc_traffic_<kernel>.json; launches per pass vary with the trace
-            arena, the ratio does not)"""
-            try:
-                t = json.load(open(os.path.join(ROOT, "profiles", f"r01_pmc_traffic_{name}.json")))
-                if t.get("kernel") == name and t.get("read_length") == args.read_length:
-                    return int(st["algorithmic_bytes"] / st["launches"] * t["traffic_over_algorithmic"])
-            except (OSError, ValueError, KeyError):
-                pass
-            return None
-
-        roofline_iso = None
+        # the dominant kernel = largest device time when nothing overlaps (the one-lane pass); its roofline is that pass's:
+        # summed event times of the timed region count the time a launch shares the chip with the other lanes' kernels
+        roofline = roofline_timed = None
+        dom = None
         if iso_stats:
-            iname = max(iso_stats.items(), key=lambda kv: kv[1]["device_ms"])[0]
-            roofline_iso = roof(iname, iso_stats[iname], "one-lane pass of the first timed batch outside the timed region: kernels do not overlap")
-            if not dom:
-                dom = (iname, iso_stats[iname])
-        if dom and stats:
-            roofline = roof(dom[0], dom[1], f"timed region, {args.lanes} lanes: kernels of different lanes overlap on the GPU, so a launch's "
-                                             "HIP-event time includes the time it shares the chip")
-        else:
-            roofline = roofline_iso
+            dom = max(iso_stats.items(), key=lambda kv: kv[1]["device_ms"])[0]
+            roofline = roof(dom, iso_stats[dom], "one-lane pass over the first timed batch, outside the timed region: launches do not overlap, "
+                            "HIP events on the launch stream; fm_search bytes = 2 x 64 B per cursor extension (SURVEY.md 8d), "
+                            "extensions counted by the kernel")
+        if stats:
+            name = dom if dom in stats else max(stats.items(), key=lambda kv: kv[1]["device_ms"])[0]
+            roofline_timed = roof(name, stats[name], f"timed region, {args.lanes} lanes: kernels of different lanes overlap on the GPU, so a "
+                                  "launch's HIP-event time includes the time it shares the chip (not a duration of its own)")
+        if roofline is None:
+            roofline = roofline_timed
 
         cpu = None
         if not args.no_cpu_baseline:
             sys.path.insert(0, os.path.join(ROOT, "tests"))
             import oracle_lib as O                      # the checker, timed as the reported CPU baseline only
-            cores = usable_cores()
-            sample = batches[args.warmup][: args.cpu_sample]
-            oidx = O.Index(genome)
-            ores = oidx.run(sample, O.params(error_probability=args.error_rate, interval_opt=args.interval_optimization), threads=cores)
-            cpu = {"value": round(len(sample) / ores.seconds, 3), "unit": "reads/s", "cores": cores, "kind": "port",
-                   "sample": f"first {len(sample)} reads of the first timed batch, oracle (CPU restatement of floxer's path), "
-                             f"{cores} threads, index build excluded"}
+            ncores = usable_cores()
+            offs0 = batches[args.warmup][1]
+            n_s = min(args.cpu_sample, B)
+            sample = [batches[args.warmup][0][int(offs0[i]):int(offs0[i + 1])] for i in range(n_s)]
+            t0 = time.time()
+            # the oracle takes the suffix array and the BWTs of the reference as data (a text has one suffix array; sorting 3.1 G
+            # suffixes on the CPU would take the better part of an hour) and lays out its own index around them
+            oidx = O.Index(genome, imported=(index.suffix_array_u32(), index.bwt(False), index.bwt(True)), pool=pool)
+            log(f"oracle index import {time.time() - t0:.1f} s")
+            ores = oidx.run(sample, O.params(error_probability=args.error_rate, interval_opt=args.interval_optimization), threads=ncores)
+            log(f"oracle run {ores.seconds:.1f} s")
+            cpu = {"value": round(len(sample) / ores.seconds, 3), "unit": "reads/s", "cores": ncores, "kind": "port",
+                   "sample": f"first {len(sample)} reads of the first timed batch against the same {args.genome / 1e9:.1f} Gb reference, oracle "
+                             f"(CPU restatement of floxer's path) on {ncores} threads; index build excluded on both sides (the oracle's "
+                             "index is laid out around the suffix array and BWTs imported from the product's index)"}
         line = {
-            "metric": "aligned reads/sec, simulated long reads vs synthetic reference (seed-and-verify path, CIGAR)",
+            "metric": "aligned reads/sec, 10 kb ONT-like reads @ 8 % error vs a GRCh38-size reference (seed-and-verify path, CIGAR)",
             "value": round(value, 2), "unit": "reads/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u64", "data": "synthetic",
-            "config": {"workload": f"{args.genome / 1e6:.1f} Mb uniform random reference + {B} reads/GPU/step of {args.read_length} bp "
-                                   f"@ {args.error_rate:.0%} error (BASELINE.json configs[1] shape; E. coli itself is not available offline)",
+            "config": {"workload": f"{args.genome / 1e9:.1f} Gb uniform random reference in {args.chromosomes} sequences (GRCh38 size; hg38 itself is "
+                                   f"not available offline) + {B} reads/GPU/step of {args.read_length} bp @ {args.error_rate:.0%} error "
+                                   "(BASELINE.json configs[3] shape per GPU, the metric's configuration)",
                        "reads_per_step_per_gpu": B, "mean_read_length": round(mean_len, 1), "cli_flags": "defaults (-s 2 -M 500 -m 50 "
                        "-g count_first -y round_robin -v 0.05)" + (" -I" if args.interval_optimization else ""),
                        "lanes_per_gpu": args.lanes, "steps_in_flight": args.inflight, "parallelism": f"read-sharded x{world}, index replicated"},
             "gbases_per_s": round(value * mean_len / 1e9, 5), "records": n_records, "index_build_s": round(index_s, 2),
-            "roofline": roofline, "roofline_isolated": roofline_iso, "cpu_baseline": cpu, "kernels": kernels,
-            "kernels_isolated": {k: {"launches": v["launches"], "device_ms": round(v["device_ms"], 3),
-                                     "GBps": round(v["algorithmic_bytes"] / 1e6 / v["device_ms"], 2) if v["device_ms"] > 0 else None}
-                                 for k, v in iso_stats.items()},
+            "index_device_bytes": int(index.device_bytes),
+            "roofline": roofline, "roofline_timed_region": roofline_timed, "cpu_baseline": cpu,
+            "kernels": table(stats), "kernels_isolated": table(iso_stats),
         }
         print(json.dumps(line), flush=True)
     if world > 1:

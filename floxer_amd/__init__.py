@@ -123,6 +123,11 @@ class fmindex:
         check(lib().flx_index_copy_sa(self.h, ptr(out, u64p)))
         return out
 
+    def suffix_array_u32(self):
+        out = np.empty(self.text_length, dtype=np.uint32)
+        check(lib().flx_index_copy_sa_u32(self.h, ptr(out, u32p)))
+        return out
+
     def bwt(self, reversed_text=False):
         out = np.zeros(self.text_length, dtype=np.uint8)
         check(lib().flx_index_copy_bwt(self.h, int(reversed_text), ptr(out, u8p)))

@@ -79,11 +79,11 @@ EXPORTED = [
     "flx_last_error", "flx_version", "flx_ceil_div", "flx_floating_point_error_aware_ceil", "flx_saturate_value_to_int32_max",
     "flx_chars_to_rank_sequence", "flx_reverse_complement_rank", "flx_pex_tree_build", "flx_index_build", "flx_index_build_on_device", "flx_index_save",
     "flx_index_load", "flx_index_free", "flx_index_text_length", "flx_index_num_references", "flx_index_device_bytes",
-    "flx_index_copy_sa", "flx_index_copy_bwt", "flx_ctx_create", "flx_ctx_destroy", "flx_ctx_set_stream", "flx_search_seeds",
+    "flx_index_copy_sa", "flx_index_copy_sa_u32", "flx_index_copy_bwt", "flx_ctx_create", "flx_ctx_destroy", "flx_ctx_set_stream", "flx_search_seeds",
     "flx_search_groups", "flx_align_batch", "flx_params_default", "flx_align_reads", "flx_reads_upload", "flx_reads_free",
     "flx_align_reads_resident", "flx_run_num_records",
     "flx_run_num_cigar_words", "flx_run_copy", "flx_run_free", "flx_ctx_enable_kernel_timing", "flx_ctx_reset_kernel_stats",
-    "flx_ctx_get_kernel_stats", "flx_sam_open", "flx_sam_write", "flx_sam_close",
+    "flx_ctx_get_kernel_stats", "flx_sam_open", "flx_sam_write", "flx_sam_close", "flx_sim_genome", "flx_sim_reads",
 ]
 
 _lib = None
@@ -120,6 +120,7 @@ def lib():
     L.flx_index_device_bytes.restype = C.c_uint64
     L.flx_index_device_bytes.argtypes = [C.c_void_p]
     L.flx_index_copy_sa.argtypes = [C.c_void_p, u64p]
+    L.flx_index_copy_sa_u32.argtypes = [C.c_void_p, u32p]
     L.flx_index_copy_bwt.argtypes = [C.c_void_p, C.c_int, u8p]
     L.flx_ctx_create.argtypes = [C.c_int, C.c_void_p, C.POINTER(C.c_void_p)]
     L.flx_ctx_destroy.argtypes = [C.c_void_p]
@@ -146,6 +147,9 @@ def lib():
     L.flx_sam_open.argtypes = [C.c_char_p, C.POINTER(C.c_char_p), u64p, C.c_uint32, C.POINTER(C.c_void_p)]
     L.flx_sam_write.argtypes = [C.c_void_p, C.POINTER(C.c_char_p), u8p, u64p, C.POINTER(C.c_char_p), C.POINTER(Record), C.c_uint64, u32p]
     L.flx_sam_close.argtypes = [C.c_void_p]
+    L.flx_sim_genome.argtypes = [C.c_uint64, C.c_uint64, u8p]
+    L.flx_sim_reads.argtypes = [u8p, u64p, C.c_uint32, C.c_uint64, C.c_uint32, C.c_double, C.c_double, C.c_uint64, u8p, C.c_uint64,
+                                u64p, u32p, u64p, u8p]
     _lib = L
     return L
 

@@ -83,6 +83,11 @@ int flx_index_copy_sa(const flx_index* index, uint64_t* out) {
     for (size_t i = 0; i < index->host->sa.size(); ++i) out[i] = index->host->sa[i];
     return FLX_OK;
 }
+int flx_index_copy_sa_u32(const flx_index* index, uint32_t* out) {
+    if (!index || !out) { set_error("null argument"); return FLX_ERR_INVALID; }
+    memcpy(out, index->host->sa.data(), index->host->sa.size() * 4);
+    return FLX_OK;
+}
 int flx_index_copy_bwt(const flx_index* index, int reversed, uint8_t* out) {
     if (!index || !out) { set_error("null argument"); return FLX_ERR_INVALID; }
     auto const& b = index->host->bwt[reversed ? 1 : 0];

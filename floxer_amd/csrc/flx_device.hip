@@ -85,68 +85,172 @@ __global__ void __launch_bounds__(256) sa_key_kernel(const u32* __restrict__ sa,
     keys[j] = ((u64)rank[i] << 32) | (i + h < n ? (u64)rank[i + h] : 0ull);
 }
 
+namespace {
+// workspaces of one suffix-array construction (36 bytes per text symbol)
+struct SaWork {
+    u64 *keys = nullptr, *keys2 = nullptr;
+    u32 *sa = nullptr, *sa2 = nullptr, *rank = nullptr, *flags = nullptr;
+    void* tmp = nullptr;
+    size_t tmp_bytes = 0;
+    hipError_t alloc(u64 n, hipStream_t s) {
+        hipError_t e;
+        if ((e = hipMalloc(&keys, n * 8)) != hipSuccess) return e;
+        if ((e = hipMalloc(&keys2, n * 8)) != hipSuccess) return e;
+        if ((e = hipMalloc(&sa, n * 4)) != hipSuccess) return e;
+        if ((e = hipMalloc(&sa2, n * 4)) != hipSuccess) return e;
+        if ((e = hipMalloc(&rank, n * 4)) != hipSuccess) return e;
+        if ((e = hipMalloc(&flags, n * 4)) != hipSuccess) return e;
+        size_t sort_bytes = 0, scan_bytes = 0;
+        if ((e = rocprim::radix_sort_pairs(nullptr, sort_bytes, keys, keys2, sa, sa2, (size_t)n, 0u, 64u, s)) != hipSuccess) return e;
+        if ((e = rocprim::inclusive_scan(nullptr, scan_bytes, flags, flags, (size_t)n, rocprim::plus<u32>(), s)) != hipSuccess) return e;
+        tmp_bytes = std::max(sort_bytes, scan_bytes);
+        return hipMalloc(&tmp, tmp_bytes);
+    }
+    void release() {
+        for (void* p : {(void*)keys, (void*)keys2, (void*)sa, (void*)sa2, (void*)rank, (void*)flags, tmp}) if (p) (void)hipFree(p);
+        keys = keys2 = nullptr; sa = sa2 = rank = flags = nullptr; tmp = nullptr;
+    }
+};
+
+// suffix array of d_text[0, n) into w.sa (device)
+hipError_t sa_on_device(hipStream_t s, const u8* d_text, u64 n, SaWork& w) {
+    hipError_t e;
+    unsigned const blocks = (unsigned)((n + 255) / 256);
+    u32 top = 0;
+    hipLaunchKernelGGL(sa_init_kernel, dim3(blocks), dim3(256), 0, s, d_text, n, w.keys, w.sa);
+    for (u64 h = 10;; h *= 2) {
+        // sort the suffixes by their keys; ranks = number of distinct keys up to and including each position
+        if ((e = rocprim::radix_sort_pairs(w.tmp, w.tmp_bytes, w.keys, w.keys2, w.sa, w.sa2, (size_t)n, 0u, 64u, s)) != hipSuccess) return e;
+        hipLaunchKernelGGL(sa_flag_kernel, dim3(blocks), dim3(256), 0, s, w.keys2, n, w.flags);
+        if ((e = rocprim::inclusive_scan(w.tmp, w.tmp_bytes, w.flags, w.flags, (size_t)n, rocprim::plus<u32>(), s)) != hipSuccess) return e;
+        hipLaunchKernelGGL(sa_rank_kernel, dim3(blocks), dim3(256), 0, s, w.sa2, w.flags, n, w.rank);
+        if ((e = hipMemcpyAsync(&top, w.flags + (n - 1), 4, hipMemcpyDeviceToHost, s)) != hipSuccess) return e;
+        if ((e = hipStreamSynchronize(s)) != hipSuccess) return e;
+        std::swap(w.sa, w.sa2);
+        if ((u64)top == n || h >= n) break;                    // all suffixes distinct
+        hipLaunchKernelGGL(sa_key_kernel, dim3(blocks), dim3(256), 0, s, w.sa, w.rank, n, h, w.keys);
+    }
+    return hipGetLastError();
+}
+}  // namespace
+
 int DeviceApi::suffix_array(int hip_device, const u8* text, u64 n, u32* out) {
     if (n == 0) return 0;
     hipError_t e;
-#define SA_HIP(x) do { e = (x); if (e != hipSuccess) goto done; } while (0)
     u8* d_text = nullptr;
-    u64 *d_keys = nullptr, *d_keys2 = nullptr;
-    u32 *d_sa = nullptr, *d_sa2 = nullptr, *d_rank = nullptr, *d_flags = nullptr;
-    void* d_tmp = nullptr;
-    size_t sort_bytes = 0, scan_bytes = 0, tmp_bytes = 0;
     hipStream_t s = nullptr;
-    unsigned const blocks = (unsigned)((n + 255) / 256);
-    u32 top = 0;
+    SaWork w;
+#define SA_HIP(x) do { e = (x); if (e != hipSuccess) goto done; } while (0)
     SA_HIP(hipSetDevice(hip_device));
     SA_HIP(hipStreamCreate(&s));
     SA_HIP(hipMalloc(&d_text, n));
-    SA_HIP(hipMalloc(&d_keys, n * 8));
-    SA_HIP(hipMalloc(&d_keys2, n * 8));
-    SA_HIP(hipMalloc(&d_sa, n * 4));
-    SA_HIP(hipMalloc(&d_sa2, n * 4));
-    SA_HIP(hipMalloc(&d_rank, n * 4));
-    SA_HIP(hipMalloc(&d_flags, n * 4));
-    SA_HIP(rocprim::radix_sort_pairs(nullptr, sort_bytes, d_keys, d_keys2, d_sa, d_sa2, (size_t)n, 0u, 64u, s));
-    SA_HIP(rocprim::inclusive_scan(nullptr, scan_bytes, d_flags, d_flags, (size_t)n, rocprim::plus<u32>(), s));
-    tmp_bytes = std::max(sort_bytes, scan_bytes);
-    SA_HIP(hipMalloc(&d_tmp, tmp_bytes));
+    SA_HIP(w.alloc(n, s));
     SA_HIP(hipMemcpyAsync(d_text, text, n, hipMemcpyHostToDevice, s));
-    hipLaunchKernelGGL(sa_init_kernel, dim3(blocks), dim3(256), 0, s, d_text, n, d_keys, d_sa);
-    for (u64 h = 10;; h *= 2) {
-        // sort the suffixes by their keys; ranks = number of distinct keys up to and including each position
-        SA_HIP(rocprim::radix_sort_pairs(d_tmp, tmp_bytes, d_keys, d_keys2, d_sa, d_sa2, (size_t)n, 0u, 64u, s));
-        hipLaunchKernelGGL(sa_flag_kernel, dim3(blocks), dim3(256), 0, s, d_keys2, n, d_flags);
-        SA_HIP(rocprim::inclusive_scan(d_tmp, tmp_bytes, d_flags, d_flags, (size_t)n, rocprim::plus<u32>(), s));
-        hipLaunchKernelGGL(sa_rank_kernel, dim3(blocks), dim3(256), 0, s, d_sa2, d_flags, n, d_rank);
-        SA_HIP(hipMemcpyAsync(&top, d_flags + (n - 1), 4, hipMemcpyDeviceToHost, s));
-        SA_HIP(hipStreamSynchronize(s));
-        std::swap(d_sa, d_sa2);
-        if ((u64)top == n || h >= n) break;                    // all suffixes distinct
-        hipLaunchKernelGGL(sa_key_kernel, dim3(blocks), dim3(256), 0, s, d_sa, d_rank, n, h, d_keys);
-    }
-    SA_HIP(hipMemcpyAsync(out, d_sa, n * 4, hipMemcpyDeviceToHost, s));
+    SA_HIP(sa_on_device(s, d_text, n, w));
+    SA_HIP(hipMemcpyAsync(out, w.sa, n * 4, hipMemcpyDeviceToHost, s));
     SA_HIP(hipStreamSynchronize(s));
     e = hipGetLastError();
 done:
+    w.release();
+    if (d_text) (void)hipFree(d_text);
+    if (s) (void)hipStreamDestroy(s);
+    return (int)e;
+}
+
+// ------------------------------------------------------------------------------------------------ BWT + occurrence blocks on the device
+__global__ void __launch_bounds__(256) bwt_kernel(const u8* __restrict__ text, const u32* __restrict__ sa, u64 n, u8* __restrict__ bwt) {
+    u64 const i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    u32 const p = sa[i];
+    bwt[i] = text[p ? p - 1 : n - 1];
+}
+__global__ void __launch_bounds__(256) reverse_kernel(const u8* __restrict__ text, u64 n, u8* __restrict__ rev) {
+    u64 const i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) rev[i] = text[n - 1 - i];
+}
+// one wave per 64-position block: the three bit-planes by ballot, the block's own symbol counts into cnt[c * nb + b]
+__global__ void __launch_bounds__(256) occ_planes_kernel(const u8* __restrict__ bwt, u64 n, u64 nb, OccBlock* __restrict__ blocks, u32* __restrict__ cnt) {
+    u64 const b = ((u64)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (b >= nb) return;
+    u32 const lane = lane_id();
+    u64 const pos = b * 64 + lane;
+    u32 const sym = pos < n ? bwt[pos] : 7u;
+    u64 const p0 = __ballot(sym & 1u), p1 = __ballot(sym & 2u), p2 = __ballot(sym & 4u);
+    u32 v = 0;
+    if (lane < 6) {
+        u64 const m = (lane & 1u ? p0 : ~p0) & (lane & 2u ? p1 : ~p1) & (lane & 4u ? p2 : ~p2);
+        cnt[(u64)lane * nb + b] = (u32)__popcll(m);
+    } else if (lane < 12) {
+        u64 const pl = lane < 8 ? p0 : lane < 10 ? p1 : p2;
+        v = (u32)(lane & 1u ? pl >> 32 : pl);
+    }
+    if (lane >= 6 && lane < 16) blocks[b].w[lane] = v;
+}
+__global__ void __launch_bounds__(256) occ_counts_kernel(const u32* __restrict__ cnt, u64 nb, OccBlock* __restrict__ blocks) {
+    u64 const i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nb * 6) return;
+    u64 const c = i / nb, b = i - c * nb;
+    blocks[b].w[c] = cnt[i];
+}
+
+// Suffix array, both BWTs and both occurrence tables of text[0, n) on the device; results land in host memory. The counts of the
+// six symbols per block are made absolute by six exclusive scans over the blocks.
+int DeviceApi::index_arrays(int hip_device, const u8* text, u64 n, u32* out_sa, u8* out_bwt0, u8* out_bwt1, OccBlock* out_occ0, OccBlock* out_occ1) {
+    if (n == 0) return 0;
+    hipError_t e;
+    u8 *d_text = nullptr, *d_rev = nullptr, *d_bwt = nullptr;
+    OccBlock* d_occ = nullptr;
+    u32* d_cnt = nullptr;
+    hipStream_t s = nullptr;
+    SaWork w;
+    u64 const nb = n / OCC_BLOCK_POS + 1;
+    unsigned const blocks_n = (unsigned)((n + 255) / 256);
+    SA_HIP(hipSetDevice(hip_device));
+    SA_HIP(hipStreamCreate(&s));
+    SA_HIP(hipMalloc(&d_text, n));
+    SA_HIP(hipMalloc(&d_rev, n));
+    SA_HIP(hipMalloc(&d_bwt, n));
+    SA_HIP(hipMalloc(&d_occ, nb * sizeof(OccBlock)));
+    SA_HIP(hipMalloc(&d_cnt, nb * 6 * 4));
+    SA_HIP(w.alloc(std::max<u64>(n, nb), s));
+    {
+        size_t need = 0;
+        SA_HIP(rocprim::exclusive_scan(nullptr, need, d_cnt, d_cnt, 0u, (size_t)nb, rocprim::plus<u32>(), s));
+        if (need > w.tmp_bytes) { (void)hipFree(w.tmp); w.tmp = nullptr; w.tmp_bytes = need; SA_HIP(hipMalloc(&w.tmp, need)); }
+    }
+    SA_HIP(hipMemcpyAsync(d_text, text, n, hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(reverse_kernel, dim3(blocks_n), dim3(256), 0, s, d_text, n, d_rev);
+    for (int dir = 0; dir < 2; ++dir) {
+        const u8* t = dir ? d_rev : d_text;
+        SA_HIP(sa_on_device(s, t, n, w));
+        if (dir == 0) SA_HIP(hipMemcpyAsync(out_sa, w.sa, n * 4, hipMemcpyDeviceToHost, s));
+        hipLaunchKernelGGL(bwt_kernel, dim3(blocks_n), dim3(256), 0, s, t, w.sa, n, d_bwt);
+        SA_HIP(hipMemcpyAsync(dir ? out_bwt1 : out_bwt0, d_bwt, n, hipMemcpyDeviceToHost, s));
+        hipLaunchKernelGGL(occ_planes_kernel, dim3((unsigned)((nb * 64 + 255) / 256)), dim3(256), 0, s, d_bwt, n, nb, d_occ, d_cnt);
+        for (u32 c = 0; c < 6; ++c)
+            SA_HIP(rocprim::exclusive_scan(w.tmp, w.tmp_bytes, d_cnt + (u64)c * nb, d_cnt + (u64)c * nb, 0u, (size_t)nb, rocprim::plus<u32>(), s));
+        hipLaunchKernelGGL(occ_counts_kernel, dim3((unsigned)((nb * 6 + 255) / 256)), dim3(256), 0, s, d_cnt, nb, d_occ);
+        SA_HIP(hipMemcpyAsync(dir ? out_occ1 : out_occ0, d_occ, nb * sizeof(OccBlock), hipMemcpyDeviceToHost, s));
+        SA_HIP(hipStreamSynchronize(s));
+    }
+    e = hipGetLastError();
+done:
 #undef SA_HIP
-    for (void* p : {(void*)d_text, (void*)d_keys, (void*)d_keys2, (void*)d_sa, (void*)d_sa2, (void*)d_rank, (void*)d_flags, d_tmp}) if (p) (void)hipFree(p);
+    w.release();
+    for (void* p : {(void*)d_text, (void*)d_rev, (void*)d_bwt, (void*)d_occ, (void*)d_cnt}) if (p) (void)hipFree(p);
     if (s) (void)hipStreamDestroy(s);
     return (int)e;
 }
 
 // ================================================================================================ K1: FM search
-// Two lanes (a DPP pair) serve one seed. A rank query reads one 128-byte block as 2 x 64 bytes (lane h reads quarters 2h, 2h+1:
-// four 32-position chunks of the three bit-planes plus four of the eight counter slots), every lane pop-counts its 128 positions
-// for all six symbols, one quad_perm DPP add gives both lanes the six totals; lane 0 then owns the ranks of symbols 0..3, lane 1
-// those of symbols 4, 5. The DFS frame is spread the same way (32 bytes per lane, 64 contiguous bytes per push/pop). Control
-// state is replicated in the pair, so a pair never diverges; different pairs of a wave do. (One lane per seed made every load
-// touch 64 different lines and was bound by the L1; four lanes per seed replicated the control flow four times and was bound by
-// instruction issue: two lanes balance the two.)
-
-__device__ __forceinline__ u32 pair_even(u32 v) { return (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0xA0 /* quad_perm:[0,0,2,2] */, 0xf, 0xf, false); }
-__device__ __forceinline__ u32 pair_odd(u32 v) { return (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0xF5 /* quad_perm:[1,1,3,3] */, 0xf, 0xf, false); }
-__device__ __forceinline__ u32 pair_sum(u32 v) { return v + (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1 /* quad_perm:[1,0,3,2] */, 0xf, 0xf, false); }
-__device__ __forceinline__ u32 pair_from(u32 v, u32 owner) { u32 const e = pair_even(v), o = pair_odd(v); return owner ? o : e; }
+// One lane serves one seed. A rank query reads the 48 used bytes of one 64-byte block (64 BWT positions: six absolute counters +
+// three bit-planes) with three 16-byte loads and pop-counts the positions below the offset for all six symbols (v_bcnt
+// accumulates onto the counters): 2 x 64 B per cursor extension, the unit SURVEY.md section 8(d) prices it at. The DFS is
+// explicit: the node under inspection lives in registers, the children of the top frame (the last branching node) in LDS
+// ([symbol][lane] x 16 B, conflict-free for ds_read_b128: the child to descend into is picked by a run-time symbol), every frame
+// is written to the seed's stack in HBM when it is made (64 B = four 16-byte stores) and read back when the DFS returns to it.
+// (Round 1 served a seed with a DPP pair of lanes on 128-byte blocks: every control instruction was issued twice per seed and
+// the kernel was bound by VALU issue at the same extensions/s for a 4.6 Mb and a 3.1 Gb index.)
 
 // symbol counts of the positions selected by `mask` in one 32-position chunk, added to six accumulators (v_bcnt accumulates)
 __device__ __forceinline__ void count_chunk(u32 p0, u32 p1, u32 p2, u32 mask, u32 acc[6]) {
@@ -164,34 +268,14 @@ __device__ __forceinline__ u32 below_mask32(u32 off, u32 chunk) {       // posit
     return (u32)(0xFFFFFFFFull >> (32 - w));                            // w = 0 -> 0, w = 32 -> all ones
 }
 
-// symbol counts of bwt[256*block, pos) restricted to this lane's half of the block, pair-summed, plus this lane's four absolute
-// counter slots: r[j] = rank of symbol 4h+j at `pos` (slots of lane 1 beyond symbol 5 are dummies)
-__device__ __forceinline__ void pair_rank(const OccBlock* __restrict__ tab, u32 pos, u32 h, u32 r[4]) {
-    const uint4* __restrict__ qa = reinterpret_cast<const uint4*>(tab + (pos >> 8)) + 4u * h;
-    uint4 const x0 = qa[0], x1 = qa[1], x2 = qa[2], x3 = qa[3];
-    u32 const off = pos & 255u, c0 = 4u * h;
-    u32 acc[6] = {0, 0, 0, 0, 0, 0};
-    count_chunk(x0.x, x0.y, x0.z, below_mask32(off, c0), acc);
-    count_chunk(x1.x, x1.y, x1.z, below_mask32(off, c0 + 1), acc);
-    count_chunk(x2.x, x2.y, x2.z, below_mask32(off, c0 + 2), acc);
-    count_chunk(x3.x, x3.y, x3.z, below_mask32(off, c0 + 3), acc);
-#pragma unroll
-    for (u32 c = 0; c < 6; ++c) acc[c] = pair_sum(acc[c]);
-    r[0] = x0.w + (h ? acc[4] : acc[0]);
-    r[1] = x1.w + (h ? acc[5] : acc[1]);
-    r[2] = x2.w + acc[2];
-    r[3] = x3.w + acc[3];
-}
-
-// ranks at the two ends [lo, hi) of an SA interval for the four counter slots this lane owns (slot j = symbol 4*h + j).
-// a[j] = rank at lo, d[j] = number of that symbol inside [lo, hi). Both ends take the same path also when they fall into one
-// block (the second read then hits the L1): in a divergent wave the union of the paths is what costs.
-__device__ __forceinline__ void pair_rank_pair(const OccBlock* __restrict__ tab, u32 lo, u32 hi, u32 h, u32 a[4], u32 d[4]) {
-    u32 b[4];
-    pair_rank(tab, lo, h, a);
-    pair_rank(tab, hi, h, b);
-#pragma unroll
-    for (u32 j = 0; j < 4; ++j) d[j] = b[j] - a[j];
+// r[c] = number of symbol c in bwt[0, pos)
+__device__ __forceinline__ void rank6(const OccBlock* __restrict__ tab, u32 pos, u32 r[6]) {
+    const uint4* __restrict__ q = reinterpret_cast<const uint4*>(tab + (pos >> 6));
+    uint4 const a = q[0], b = q[1], c = q[2];
+    u32 const off = pos & 63u;
+    r[0] = a.x; r[1] = a.y; r[2] = a.z; r[3] = a.w; r[4] = b.x; r[5] = b.y;
+    count_chunk(b.z, c.x, c.z, below_mask32(off, 0), r);
+    count_chunk(b.w, c.y, c.w, below_mask32(off, 1), r);
 }
 
 // frame state word: x:20 | e:3 | linfo:2 | rinfo:2 | next_sym:3 | right:1
@@ -206,16 +290,21 @@ __device__ __forceinline__ u32 st_pack(u32 x, u32 e, u32 li, u32 ri, u32 sym, u3
 #define ST_SYM(s) (((s) >> 27) & 7u)
 #define ST_RIGHT(s) (((s) >> 30) & 1u)
 
+__device__ __forceinline__ u32 wave_sum_u32(u32 v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += (u32)__shfl_xor((int)v, off);
+    return v;
+}
+
 // counters: [0] hit slots reserved, [1] stack overflow flag, [2] cursor extensions (rank pairs), [3] unused,
-//           [4] wave-iterations, [5] max iterations of a wave, [6] busy pair-iterations, [7] seed queue head,
+//           [4] wave-iterations, [5] max iterations of a wave, [6] busy lane-iterations, [7] seed queue head,
 //           [8] wave-iterations after the seed queue ran dry, [9] their maximum over the waves
 //
-// DFS sizes differ by orders of magnitude between seeds, so neither pairs nor waves are bound to seeds: the launch is a fixed
-// number of waves, a wave takes FM_GRAB consecutive seeds at a time from a global counter (counters[7]) and hands them to its pairs
-// as they finish (wave-uniform bookkeeping in scalar registers). One loop iteration = one DFS step of every busy pair (at most one
-// rank pair), which keeps the divergent part of the loop short. (Per-wave chunks of seeds left half of the pairs idle behind
-// the heaviest seed of their chunk.)
-constexpr u32 FM_GRAB = 32;
+// DFS sizes differ by orders of magnitude between seeds, so neither lanes nor waves are bound to seeds: the launch is a fixed
+// number of waves, a wave takes FM_GRAB consecutive seeds at a time from a global counter (counters[7]) and hands them to its lanes
+// as they finish (wave-uniform bookkeeping in scalar registers). One loop iteration = one DFS step of every busy lane (at most one
+// rank pair), which keeps the divergent part of the loop short.
+constexpr u32 FM_GRAB = 64;
 constexpr u32 FM_HIT_GRAB = 64;
 constexpr u32 FM_MAX_WAVES = 4096;
 constexpr u32 FM_SEEDS_PER_WAVE = 256;      // a launch has at most n_seeds / this many waves, so that every wave gets several ranges
@@ -224,15 +313,15 @@ __global__ void __launch_bounds__(64) fm_search_kernel(DevIndex idx, const u8* _
                                                        const DevSeed* __restrict__ seeds, u32 n_seeds, u32 max_hits,
                                                        DevFrame* __restrict__ stack, DevHit* __restrict__ hits, u32 hit_cap,
                                                        u32* __restrict__ counters, u32* __restrict__ seed_cnt) {
+    __shared__ uint4 child[5][64];              // top frame: {abs, oth, len, -} of the child cursor of symbol s+1, per lane
     u32 q_next = 0, q_end = 0;                  // wave-uniform: the unserved rest of the last grabbed seed range
     bool queue_done = false;
     u32 h_next = 0, h_end = 0;                  // wave-uniform: the unwritten rest of the last reserved range of hit slots
     u32 const lane = threadIdx.x & 63u;
-    u32 const h = lane & 1u;                    // lane within the pair
-    u32 const sym0 = 4u * h;                    // first counter slot / symbol owned by this lane
+    u64 const lanes_below = (1ull << lane) - 1ull;
 
     u32 n_ext = 0, n_iter = 0, n_busy_iter = 0, n_tail_iter = 0;
-    // ---- per-seed state (replicated in the pair)
+    // ---- per-seed state
     bool busy = false, exhausted = false;
     u32 sid = 0, srch = 0, num_searches = 0, len = 0, ct = 0, stack_frames = 0;
     const u8* __restrict__ q = seq;
@@ -243,26 +332,13 @@ __global__ void __launch_bounds__(64) fm_search_kernel(DevIndex idx, const u8* _
     const u32* __restrict__ ex = scheme;
     u32 l_last = 0, u_last = 0;
     u32 nlb = 0, nlbr = 0, nlen = 0, nx = 0, ne = 0, nli = INFO_M, nri = INFO_M;
-    // top frame: replicated node part + this lane's four child-cursor slots (extended side, other side, length)
+    // top frame (frame depth-1 of the stack): its node and the mask of children not taken yet; the child cursors are in LDS
     u32 f_lb = 0, f_lbr = 0, f_len = 0, f_state = 0, f_mask = 0;
-    u32 f_abs[4] = {0, 0, 0, 0}, f_oth[4] = {0, 0, 0, 0}, f_cl[4] = {0, 0, 0, 0};
-    u32 depth = 0;
-    bool have_frame = false, need_child = false;
-    bool hit_pending = false;                   // a hit of this pair (sid, nlb, hit_rep, ne) waits for its slot
+    u32 depth = 0;                              // frames on the stack, the top one included
+    bool need_child = false;
+    bool hit_pending = false;                   // a hit of this lane (sid, nlb, hit_rep, ne) waits for its slot
     u32 hit_rep = 0;
-    u32 hit_idx = 0;                            // hits of the current seed so far (the first SEED_HIT_SLOTS also go to its own slots)
-
-    // child cursor of symbol `sym` out of per-lane slot arrays, from the lane that owns the symbol
-    auto child_of = [&](const u32 abs_s[4], const u32 oth_s[4], const u32 len_s[4], u32 sym, u32& cabs, u32& coth, u32& clen) {
-        u32 const j = sym & 3u;
-        u32 const my_abs = j == 0 ? abs_s[0] : j == 1 ? abs_s[1] : j == 2 ? abs_s[2] : abs_s[3];
-        u32 const my_oth = j == 0 ? oth_s[0] : j == 1 ? oth_s[1] : j == 2 ? oth_s[2] : oth_s[3];
-        u32 const my_len = j == 0 ? len_s[0] : j == 1 ? len_s[1] : j == 2 ? len_s[2] : len_s[3];
-        u32 const owner = sym >> 2;
-        cabs = pair_from(my_abs, owner);
-        coth = pair_from(my_oth, owner);
-        clen = pair_from(my_len, owner);
-    };
+    u32 hit_idx = 0;                            // hits of the current seed so far
 
     // hit slots are reserved FM_HIT_GRAB at a time per wave (one global atomic per range instead of one per hit, all on one
     // address); the unused rest of a range is filled with entries of seed FLX_NO_SEED, which the host skips
@@ -272,7 +348,7 @@ __global__ void __launch_bounds__(64) fm_search_kernel(DevIndex idx, const u8* _
     };
 
     while (true) {
-        u64 const emit = __ballot(hit_pending && h == 0u);
+        u64 const emit = __ballot(hit_pending);
         if (emit) {                                                     // wave-uniform
             u32 const n_emit = (u32)__popcll(emit);
             if (h_end - h_next < n_emit) {
@@ -282,8 +358,8 @@ __global__ void __launch_bounds__(64) fm_search_kernel(DevIndex idx, const u8* _
                 h_next = (u32)__builtin_amdgcn_readfirstlane((int)b);
                 h_end = h_next + FM_HIT_GRAB;
             }
-            if (hit_pending && h == 0u) {
-                u32 const slot = h_next + (u32)__popcll(emit & ((1ull << lane) - 1ull));
+            if (hit_pending) {
+                u32 const slot = h_next + (u32)__popcll(emit & lanes_below);
                 // the hit's ordinal within its seed rides in the upper bits of the error count (errors <= 3): the hits of a seed
                 // can be put back in emission order without a sort
                 if (slot < hit_cap) hits[slot] = DevHit{sid, nlb, hit_rep, seed_cnt ? ne | (min(hit_idx, 0xFFFFFFu) << 8) : ne};
@@ -294,7 +370,7 @@ __global__ void __launch_bounds__(64) fm_search_kernel(DevIndex idx, const u8* _
             hit_pending = false;
         }
         bool const want = !busy && !exhausted;
-        u64 const idle = __ballot(want && h == 0u);
+        u64 const idle = __ballot(want);
         if (idle) {                                                     // wave-uniform
             u32 const n_idle = (u32)__popcll(idle);
             u32 const avail = q_end - q_next;
@@ -306,13 +382,12 @@ __global__ void __launch_bounds__(64) fm_search_kernel(DevIndex idx, const u8* _
                 new_base = (u32)__builtin_amdgcn_readfirstlane((int)b);
                 grabbed = true;
             }
-            u32 const r = (u32)__popcll(idle & ((1ull << lane) - 1ull));   // rank of this pair among the idle ones
+            u32 const r = (u32)__popcll(idle & lanes_below);           // rank of this lane among the idle ones
             u32 k = 0xFFFFFFFFu;
-            if (want && h == 0u) {
+            if (want) {
                 if (r < avail) k = q_next + r;
                 else if (grabbed && new_base + (r - avail) < n_seeds) k = new_base + (r - avail);
             }
-            k = pair_even(k);
             if (grabbed) {
                 if (new_base >= n_seeds) { q_next = 0; q_end = 0; queue_done = true; }
                 else {
@@ -354,7 +429,6 @@ __global__ void __launch_bounds__(64) fm_search_kernel(DevIndex idx, const u8* _
             nlb = 0; nlbr = 0; nlen = idx.n; nx = 0; ne = 0; nli = INFO_M; nri = INFO_M;
             f_mask = 0;
             depth = 0;
-            have_frame = false;
             need_child = false;
             in_search = true;
             // the exact, rightward first part of the search starts from the KMER_Q-mer table when it is long enough and free of N
@@ -376,18 +450,22 @@ __global__ void __launch_bounds__(64) fm_search_kernel(DevIndex idx, const u8* _
 
         // ---- one DFS step
         if (need_child) {
-            if (!have_frame || f_mask == 0) {
-                if (depth == 0) { in_search = false; ++srch; continue; }    // search exhausted
+            if (f_mask == 0u) {
+                // the top frame has no child left (or there is no frame): back to the frame below it
+                if (depth <= 1u) { in_search = false; ++srch; continue; }    // search exhausted
                 --depth;
-                const uint4* __restrict__ fr = stk + depth * 6u + 3u * h;
-                uint4 const v0 = fr[0], v1 = fr[1], v2 = fr[2];
-                f_abs[0] = v0.x; f_oth[0] = v0.y; f_cl[0] = v0.z; f_abs[1] = v0.w;
-                f_oth[1] = v1.x; f_cl[1] = v1.y;
-                if (h == 0) { f_abs[2] = v1.z; f_oth[2] = v1.w; f_cl[2] = v2.x; f_abs[3] = v2.y; f_oth[3] = v2.z; f_cl[3] = v2.w; }
-                else { f_abs[2] = 0; f_oth[2] = 0; f_cl[2] = 0; f_abs[3] = 0; f_oth[3] = 0; f_cl[3] = 0; }
-                f_lb = pair_odd(v1.z); f_lbr = pair_odd(v1.w); f_len = pair_odd(v2.x); f_state = pair_odd(v2.y);
-                f_mask = pair_even(v0.x);                                  // never empty: exhausted frames are not pushed
-                have_frame = true;
+                const uint4* __restrict__ fr = stk + (depth - 1u) * 4u;
+                uint4 const v0 = fr[0], v1 = fr[1], v2 = fr[2], v3 = fr[3];
+                f_lb = v2.w; f_lbr = v3.x; f_len = v3.y; f_state = v3.z;
+                f_mask = v3.w;                                             // never empty: see where frames are made
+                // bounds of the children on the other side: prefix sums of their lengths, symbol 0 first
+                u32 const o1 = (ST_RIGHT(f_state) ? f_lb : f_lbr) + v1.y;
+                u32 const o2 = o1 + v1.z, o3 = o2 + v1.w, o4 = o3 + v2.x, o5 = o4 + v2.y;
+                child[0][lane] = uint4{v0.x, o1, v1.z, 0u};
+                child[1][lane] = uint4{v0.y, o2, v1.w, 0u};
+                child[2][lane] = uint4{v0.z, o3, v2.x, 0u};
+                child[3][lane] = uint4{v0.w, o4, v2.y, 0u};
+                child[4][lane] = uint4{v1.x, o5, v2.z, 0u};
             }
             u32 const ci = (u32)__ffs((int)f_mask) - 1u;
             f_mask &= f_mask - 1u;
@@ -396,7 +474,7 @@ __global__ void __launch_bounds__(64) fm_search_kernel(DevIndex idx, const u8* _
             u32 const px = ST_X(st), pe = ST_E(st);
             u32 info, sym;
             if (ci == 0) { sym = ST_SYM(st); nx = px + 1; ne = pe; info = INFO_M; }
-            else if (ci == 11) { sym = 0; nx = px + 1; ne = pe + 1; info = INFO_I; }
+            else if (ci == 11) { sym = 1; nx = px + 1; ne = pe + 1; info = INFO_I; }
             else {
                 sym = (ci + 1) >> 1;
                 bool const del = ci & 1u;
@@ -404,10 +482,9 @@ __global__ void __launch_bounds__(64) fm_search_kernel(DevIndex idx, const u8* _
                 ne = pe + 1;
                 info = del ? INFO_D : INFO_S;
             }
-            u32 cabs, coth, clen;
-            child_of(f_abs, f_oth, f_cl, sym, cabs, coth, clen);
+            uint4 const c = child[sym - 1u][lane];                         // sym is 1..5 for every child (a match of 0 or N > 5 is never a child)
             if (ci == 11) { nlb = f_lb; nlbr = f_lbr; nlen = f_len; }
-            else { nlen = clen; nlb = right ? coth : cabs; nlbr = right ? cabs : coth; }
+            else { nlen = c.z; nlb = right ? c.y : c.x; nlbr = right ? c.x : c.y; }
             nli = right ? ST_LI(st) : info;
             nri = right ? info : ST_RI(st);
             need_child = false;
@@ -437,64 +514,64 @@ __global__ void __launch_bounds__(64) fm_search_kernel(DevIndex idx, const u8* _
         u32 const next_sym = q[sch & SCH_POS_MASK];
         const OccBlock* __restrict__ tab = idx.occ[right];
         u32 const lo = right ? nlbr : nlb, other = right ? nlb : nlbr;
-        u32 ra[4], cl[4], s_abs[4], s_oth[4];
-        pair_rank_pair(tab, lo, lo + nlen, h, ra, cl);
+        u32 ra[6], cl[6];
+        rank6(tab, lo, ra);
+        rank6(tab, lo + nlen, cl);
         ++n_ext;
-        if (h) { cl[2] = 0; cl[3] = 0; }                     // dummy slots of lane 1
-        // other-side bounds: the lengths of all smaller symbols come first (exclusive prefix over the six symbols)
-        u32 const e1 = cl[0], e2 = e1 + cl[1], e3 = e2 + cl[2], tot = e3 + cl[3];
-        u32 const tot0 = pair_even(tot);                     // all lanes execute the DPP move (not under a lane-dependent select)
-        u32 const base = other + (tot0 & (0u - h));
-        s_oth[0] = base; s_oth[1] = base + e1; s_oth[2] = base + e2; s_oth[3] = base + e3;
 #pragma unroll
-        for (u32 j = 0; j < 4; ++j) {
-            u32 const c = sym0 + j;
-            s_abs[j] = idx.C[c < 6u ? c : 5u] + ra[j];
-        }
+        for (u32 c = 0; c < 6; ++c) cl[c] -= ra[c];                   // rows of the child of symbol c
+#pragma unroll
+        for (u32 c = 1; c < 6; ++c) ra[c] += idx.C[c];                // its bound on the extended side
 
         if (mismatch_allowed) {
-            // this node branches: it becomes the top frame, the previous top goes to memory (48 bytes per lane) unless all
-            // of its children have been taken already
-            if (have_frame && f_mask != 0u) {
-                if (depth >= stack_frames) { if (h == 0) atomicOr(&counters[1], 1u); busy = false; continue; }
-                uint4 v0, v1, v2;
-                v0.x = h ? f_abs[0] : f_mask; v0.y = f_oth[0]; v0.z = f_cl[0]; v0.w = f_abs[1];
-                v1.x = f_oth[1]; v1.y = f_cl[1];
-                if (h == 0) { v1.z = f_abs[2]; v1.w = f_oth[2]; v2.x = f_cl[2]; v2.y = f_abs[3]; v2.z = f_oth[3]; v2.w = f_cl[3]; }
-                else { v1.z = f_lb; v1.w = f_lbr; v2.x = f_len; v2.y = f_state; v2.z = 0; v2.w = 0; }
-                uint4* __restrict__ fr = stk + depth * 6u + 3u * h;
-                fr[0] = v0; fr[1] = v1; fr[2] = v2;
-                ++depth;
+            // this node branches: it becomes the top frame. The frame below keeps its place on the stack if it still has children
+            // (its mask is brought up to date), else its place is taken.
+            if (depth > 0u) {
+                if (f_mask != 0u) reinterpret_cast<u32*>(stk + (depth - 1u) * 4u)[15] = f_mask;
+                else --depth;
             }
-            have_frame = true;
+            if (depth >= stack_frames) { atomicOr(&counters[1], 1u); busy = false; continue; }
             u32 const tinfo = right ? nri : nli;
             bool const deletion = tinfo == INFO_M || tinfo == INFO_D;
             bool const insertion = tinfo == INFO_M || tinfo == INFO_I;
             f_lb = nlb; f_lbr = nlbr; f_len = nlen;
             f_state = st_pack(nx, ne, nli, nri, next_sym, right);
-            // children of symbols 1..5 that are not empty: this lane contributes the bits of its symbols, pair-OR via sum
-            u32 mine = 0;
+            // children of symbols 1..5 that are not empty
+            u32 mask = 0;
 #pragma unroll
-            for (u32 j = 0; j < 4; ++j) {
-                u32 const c = sym0 + j;
-                f_abs[j] = s_abs[j];
-                f_oth[j] = s_oth[j];
-                f_cl[j] = cl[j];
-                if (c >= 1u && c < 6u && cl[j] > 0u) {
-                    if (deletion) mine |= 1u << (2u * c - 1u);
-                    if (c != next_sym) mine |= 1u << (2u * c);
-                    else if (match_allowed) mine |= 1u;
+            for (u32 c = 1; c < 6; ++c) {
+                if (cl[c] > 0u) {
+                    if (deletion) mask |= 1u << (2u * c - 1u);
+                    if (c != next_sym) mask |= 1u << (2u * c);
+                    else if (match_allowed) mask |= 1u;
                 }
             }
-            u32 mask = pair_sum(mine);              // the two contributions have disjoint bits
             if (insertion) mask |= 1u << 11;
             f_mask = mask;
+            uint4* __restrict__ fr = stk + depth * 4u;
+            fr[0] = uint4{ra[1], ra[2], ra[3], ra[4]};
+            fr[1] = uint4{ra[5], cl[0], cl[1], cl[2]};
+            fr[2] = uint4{cl[3], cl[4], cl[5], nlb};
+            fr[3] = uint4{nlbr, nlen, f_state, mask};
+            ++depth;
+            u32 const o1 = other + cl[0], o2 = o1 + cl[1], o3 = o2 + cl[2], o4 = o3 + cl[3], o5 = o4 + cl[4];
+            child[0][lane] = uint4{ra[1], o1, cl[1], 0u};
+            child[1][lane] = uint4{ra[2], o2, cl[2], 0u};
+            child[2][lane] = uint4{ra[3], o3, cl[3], 0u};
+            child[3][lane] = uint4{ra[4], o4, cl[4], 0u};
+            child[4][lane] = uint4{ra[5], o5, cl[5], 0u};
             need_child = true;
         } else {
             // only an exact extension is possible: continue in place (no frame)
             if (next_sym == 0u || next_sym > 5u) { need_child = true; continue; }       // the sentinel never matches
-            u32 cabs, coth, clen;
-            child_of(s_abs, s_oth, cl, next_sym, cabs, coth, clen);
+            u32 clen = cl[1], cabs = ra[1], coth = other + cl[0];
+#pragma unroll
+            for (u32 c = 2; c < 6; ++c) {
+                coth += c <= next_sym ? cl[c - 1u] : 0u;
+                bool const take = c == next_sym;
+                clen = take ? cl[c] : clen;
+                cabs = take ? ra[c] : cabs;
+            }
             if (clen == 0) { need_child = true; continue; }
             nlb = right ? coth : cabs;
             nlbr = right ? cabs : coth;
@@ -504,14 +581,24 @@ __global__ void __launch_bounds__(64) fm_search_kernel(DevIndex idx, const u8* _
         }
     }
     fill_rest();
-    if (h == 0) { atomicAdd(&counters[2], n_ext); atomicAdd(&counters[6], n_busy_iter); }
-    if (threadIdx.x == 0) { atomicAdd(&counters[4], n_iter); atomicMax(&counters[5], n_iter); atomicAdd(&counters[8], n_tail_iter); atomicMax(&counters[9], n_tail_iter); }
+    n_ext = wave_sum_u32(n_ext);
+    n_busy_iter = wave_sum_u32(n_busy_iter);
+    if (lane == 0) {
+        atomicAdd(&counters[2], n_ext); atomicAdd(&counters[6], n_busy_iter);
+        atomicAdd(&counters[4], n_iter); atomicMax(&counters[5], n_iter); atomicAdd(&counters[8], n_tail_iter); atomicMax(&counters[9], n_tail_iter);
+    }
+}
+
+static u32 fm_seeds_per_wave() {
+    static u32 const v = [] { const char* e = getenv("FLX_FM_SEEDS_PER_WAVE"); u32 const x = e ? (u32)strtoul(e, nullptr, 10) : 0u; return x ? x : FM_SEEDS_PER_WAVE; }();
+    return v;
 }
 
 int DeviceApi::search(void* stream, const DevIndex& idx, const u8* d_seq, const u32* d_scheme, const DevSeed* d_seeds, u32 n_seeds,
                       u32 max_hits_per_seed, DevFrame* d_stack, DevHit* d_hits, u32 hit_cap, u32* d_counters, u32* d_seed_cnt) {
     if (n_seeds == 0) return 0;
-    hipLaunchKernelGGL(fm_search_kernel, dim3(std::min<u32>((n_seeds + FM_SEEDS_PER_WAVE - 1) / FM_SEEDS_PER_WAVE, FM_MAX_WAVES)), dim3(64), 0, (hipStream_t)stream, idx, d_seq, d_scheme, d_seeds,
+    u32 const spw = fm_seeds_per_wave();
+    hipLaunchKernelGGL(fm_search_kernel, dim3(std::min<u32>((n_seeds + spw - 1) / spw, FM_MAX_WAVES)), dim3(64), 0, (hipStream_t)stream, idx, d_seq, d_scheme, d_seeds,
                        n_seeds, max_hits_per_seed, d_stack, d_hits, hit_cap, d_counters, d_seed_cnt);
     return (int)hipGetLastError();
 }

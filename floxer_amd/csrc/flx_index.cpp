@@ -2,8 +2,8 @@
 // Replaces fmindex(refs, sampling_rate, threads) (floxer.cpp:93-97; fmindex.hpp:7-10 = BiFMIndex<EprV2_16<6>>).
 //
 // Layout decisions (MI355X-first, not the reference's EPR layout):
-//  * occurrence tables as 128-byte blocks over 256 BWT positions (absolute u32 counts + 3 bit-planes): a rank query is one
-//    128-byte line, 0.5 B per text symbol and direction (hg38: 1.6 GB per direction instead of the reference's ~5 GB);
+//  * occurrence tables as 64-byte blocks over 64 BWT positions (absolute u32 counts + 3 bit-planes): a rank query is one
+//    64-byte block, 1 B per text symbol and direction (hg38: 3.1 GB per direction);
 //  * the FULL suffix array as u32 (4 B per symbol, 12.4 GB for hg38 out of 288 GB HBM) instead of a sampled one:
 //    locate() becomes one 4-byte gather with no LF walk. The result is identical to BiFMIndex::locate because both return
 //    SA[row] split into (sequence, offset).
@@ -12,6 +12,7 @@
 #include <cstring>
 #include <memory>
 #include <stdexcept>
+#include <type_traits>
 
 #include "flx_internal.hpp"
 
@@ -131,43 +132,36 @@ std::vector<u32> suffix_array(const std::vector<u8>& text) {
 
 void build_occ_blocks(const std::vector<u8>& bwt, std::vector<OccBlock>& blocks) {
     u64 const n = bwt.size();
-    u64 const nb = n / 256 + 1;
+    u64 const nb = n / OCC_BLOCK_POS + 1;
     blocks.assign(nb, OccBlock{});
     u32 cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     for (u64 b = 0; b < nb; ++b) {
         OccBlock& blk = blocks[b];
-        for (int c = 0; c < 6; ++c) blk.w[(c >> 1) * 8 + (c & 1) * 4 + 3] = cnt[c];
-        for (int j = 0; j < 8; ++j) {                   // 32-position chunk j lives in quarter j/2, half j%2
+        for (int c = 0; c < 6; ++c) blk.w[c] = cnt[c];
+        for (int j = 0; j < 2; ++j) {                   // 32-position half j of the three planes
             u32 p0 = 0, p1 = 0, p2 = 0;
             for (int k = 0; k < 32; ++k) {
-                u64 const pos = b * 256 + (u64)j * 32 + k;
+                u64 const pos = b * OCC_BLOCK_POS + (u64)j * 32 + k;
                 u8 const sym = pos < n ? bwt[pos] : 7;
                 p0 |= (u32)(sym & 1) << k;
                 p1 |= (u32)((sym >> 1) & 1) << k;
                 p2 |= (u32)((sym >> 2) & 1) << k;
                 if (pos < n) cnt[sym]++;
             }
-            u32* q = &blk.w[(j >> 1) * 8 + (j & 1) * 4];
-            q[0] = p0; q[1] = p1; q[2] = p2;
+            blk.w[6 + j] = p0; blk.w[8 + j] = p1; blk.w[10 + j] = p2;
         }
     }
 }
 
 // rank of all symbols at position i on the host (same block layout the device reads)
 void host_rank_all(const std::vector<OccBlock>& tab, u64 i, u64 out[6]) {
-    OccBlock const& b = tab[i >> 8];
-    u32 const off = (u32)(i & 255);
-    for (int c = 0; c < 6; ++c) out[c] = b.w[(c >> 1) * 8 + (c & 1) * 4 + 3];
-    for (u32 j = 0; j < 8; ++j) {
-        if (off <= j * 32) break;
-        u32 const take = std::min<u32>(32, off - j * 32);
-        u32 const mask = take == 32 ? ~0u : ((1u << take) - 1u);
-        const u32* q = &b.w[(j >> 1) * 8 + (j & 1) * 4];
-        for (u32 k = 0; k < 32; ++k) {
-            if (!((mask >> k) & 1)) continue;
-            u32 const sym = ((q[0] >> k) & 1) | (((q[1] >> k) & 1) << 1) | (((q[2] >> k) & 1) << 2);
-            if (sym < 6) out[sym]++;
-        }
+    OccBlock const& b = tab[i / OCC_BLOCK_POS];
+    u32 const off = (u32)(i % OCC_BLOCK_POS);
+    for (int c = 0; c < 6; ++c) out[c] = b.w[c];
+    for (u32 k = 0; k < off; ++k) {
+        u32 const j = k >> 5, bit = k & 31;
+        u32 const sym = ((b.w[6 + j] >> bit) & 1) | (((b.w[8 + j] >> bit) & 1) << 1) | (((b.w[10 + j] >> bit) & 1) << 2);
+        if (sym < 6) out[sym]++;
     }
 }
 
@@ -203,51 +197,57 @@ void build_kmer_table(HostIndex& idx) {
 HostIndex* build_host_index(const u8* concat, const u64* lens, u32 n_refs, int hip_device) {
     auto idx = std::make_unique<HostIndex>();
     constexpr u64 sampling = 4;    // floxer.cpp:92: padding keeps every sequence a multiple of the reference's sampling rate
-    u64 off = 0;
+    u64 total = 0;
+    for (u32 r = 0; r < n_refs; ++r) total += lens[r] + (sampling - lens[r] % sampling);
+    if (total == 0) { set_error("empty reference"); return nullptr; }
+    if (total >= ((u64)1 << 32) - 512) { set_error("text of 2^32 symbols or more is not supported by this build"); return nullptr; }
+    idx->text.assign(total, 0);
+    u64 off = 0, at = 0;
     for (u32 r = 0; r < n_refs; ++r) {
-        idx->seq_start.push_back(idx->text.size());
+        idx->seq_start.push_back(at);
         idx->seq_len.push_back(lens[r]);
-        for (u64 i = 0; i < lens[r]; ++i) {
-            u8 const c = concat[off + i];
-            if (c > 5) { set_error("reference rank > 5"); return nullptr; }
-            idx->text.push_back(c);
-        }
+        memcpy(idx->text.data() + at, concat + off, lens[r]);
         off += lens[r];
-        idx->text.resize(idx->text.size() + (sampling - lens[r] % sampling), 0);
+        at += lens[r] + (sampling - lens[r] % sampling);
     }
-    idx->n = idx->text.size();
-    if (idx->n == 0) { set_error("empty reference"); return nullptr; }
-    if (idx->n >= ((u64)1 << 32) - 512) { set_error("text of 2^32 symbols or more is not supported by this build"); return nullptr; }
+    idx->n = total;
     u64 const n = idx->n;
-    auto sa_of = [&](const std::vector<u8>& t, std::vector<u32>& out) {
-        if (hip_device < 0) { out = suffix_array(t); return true; }
-        out.resize(t.size());
-        int const e = DeviceApi::suffix_array(hip_device, t.data(), t.size(), out.data());
-        if (e) { set_error("suffix array construction on the device failed (HIP error " + std::to_string(e) + ")"); return false; }
-        return true;
-    };
-    if (!sa_of(idx->text, idx->sa)) return nullptr;
-    idx->bwt[0].resize(n);
-    for (u64 i = 0; i < n; ++i) idx->bwt[0][i] = idx->text[(idx->sa[i] + n - 1) % n];
-    {
-        std::vector<u8> rev(idx->text.rbegin(), idx->text.rend());
-        std::vector<u32> sa_rev;
-        if (!sa_of(rev, sa_rev)) return nullptr;
-        idx->bwt[1].resize(n);
-        for (u64 i = 0; i < n; ++i) idx->bwt[1][i] = rev[(sa_rev[i] + n - 1) % n];
-    }
-    u64 cnt[6] = {0, 0, 0, 0, 0, 0};
-    for (u8 c : idx->text) cnt[c]++;
+    u64 cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    u8 seen = 0;
+    for (u8 c : idx->text) { cnt[c & 7]++; seen |= c; }
+    if ((seen & 0xF8) || cnt[6] || cnt[7]) { set_error("reference rank > 5"); return nullptr; }
     for (int c = 0; c < 6; ++c) idx->C[c + 1] = idx->C[c] + cnt[c];
-    build_occ_blocks(idx->bwt[0], idx->occ[0]);
-    build_occ_blocks(idx->bwt[1], idx->occ[1]);
+    if (hip_device >= 0) {
+        // suffix arrays (prefix doubling with radix sorts), BWTs and occurrence tables on the device
+        idx->sa.resize(n);
+        idx->bwt[0].resize(n);
+        idx->bwt[1].resize(n);
+        u64 const nb = n / OCC_BLOCK_POS + 1;
+        idx->occ[0].resize(nb);
+        idx->occ[1].resize(nb);
+        int const e = DeviceApi::index_arrays(hip_device, idx->text.data(), n, idx->sa.data(), idx->bwt[0].data(), idx->bwt[1].data(),
+                                              idx->occ[0].data(), idx->occ[1].data());
+        if (e) { set_error("index construction on the device failed (HIP error " + std::to_string(e) + ")"); return nullptr; }
+    } else {
+        idx->sa = suffix_array(idx->text);
+        idx->bwt[0].resize(n);
+        for (u64 i = 0; i < n; ++i) idx->bwt[0][i] = idx->text[(idx->sa[i] + n - 1) % n];
+        {
+            std::vector<u8> rev(idx->text.rbegin(), idx->text.rend());
+            std::vector<u32> sa_rev = suffix_array(rev);
+            idx->bwt[1].resize(n);
+            for (u64 i = 0; i < n; ++i) idx->bwt[1][i] = rev[(sa_rev[i] + n - 1) % n];
+        }
+        build_occ_blocks(idx->bwt[0], idx->occ[0]);
+        build_occ_blocks(idx->bwt[1], idx->occ[1]);
+    }
     build_kmer_table(*idx);
     return idx.release();
 }
 
 // ---------------------------------------------------------------- own index file format (replaces the cereal archive)
 namespace {
-constexpr char MAGIC[8] = {'F', 'L', 'X', 'I', 'D', 'X', '0', '3'};
+constexpr char MAGIC[8] = {'F', 'L', 'X', 'I', 'D', 'X', '0', '4'};
 template <class T> bool wr(FILE* f, const std::vector<T>& v) {
     u64 const n = v.size();
     return fwrite(&n, 8, 1, f) == 1 && (n == 0 || fwrite(v.data(), sizeof(T), n, f) == n);
@@ -274,13 +274,42 @@ int save_host_index(const HostIndex& idx, const char* path) {
 HostIndex* load_host_index(const char* path) {
     FILE* f = fopen(path, "rb");
     if (!f) { set_error(std::string("cannot open index file: ") + path); return nullptr; }
+    // the length words of the file are not trusted: a bogus one must not make resize() throw across the C ABI
+    struct Closer { FILE* f; ~Closer() { fclose(f); } } closer{f};
+    u64 file_bytes = 0;
+    if (fseek(f, 0, SEEK_END) == 0) { long const e = ftell(f); if (e > 0) file_bytes = (u64)e; rewind(f); }
     auto idx = std::make_unique<HostIndex>();
+    auto rd_checked = [&](auto& v, u64 expected) {
+        using T = typename std::remove_reference<decltype(v)>::type::value_type;
+        u64 n = 0;
+        if (fread(&n, 8, 1, f) != 1 || n != expected || n * sizeof(T) > file_bytes) return false;
+        try { v.resize(n); } catch (std::exception const&) { return false; }
+        return n == 0 || fread(v.data(), sizeof(T), n, f) == n;
+    };
     char magic[8];
-    bool ok = fread(magic, 8, 1, f) == 1 && memcmp(magic, MAGIC, 8) == 0 && fread(&idx->n, 8, 1, f) == 1 &&
-              fread(idx->C, 8, 7, f) == 7 && rd(f, idx->text) && rd(f, idx->seq_start) && rd(f, idx->seq_len) && rd(f, idx->sa) &&
-              rd(f, idx->occ[0]) && rd(f, idx->occ[1]) && rd(f, idx->bwt[0]) && rd(f, idx->bwt[1]) && rd(f, idx->kmer_table);
-    fclose(f);
-    if (!ok || idx->text.size() != idx->n || idx->sa.size() != idx->n) { set_error("index file is corrupt or of another version"); return nullptr; }
+    bool ok = fread(magic, 8, 1, f) == 1 && memcmp(magic, MAGIC, 8) == 0 && fread(&idx->n, 8, 1, f) == 1 && fread(idx->C, 8, 7, f) == 7;
+    u64 const n = idx->n;
+    ok = ok && n > 0 && n < ((u64)1 << 32) && n <= file_bytes && rd_checked(idx->text, n);
+    if (ok) {
+        u64 n_refs = 0;                                   // seq_start: its own length word says how many references there are
+        long const at = ftell(f);
+        ok = fread(&n_refs, 8, 1, f) == 1 && n_refs >= 1 && n_refs <= n && fseek(f, at, SEEK_SET) == 0 &&
+             rd_checked(idx->seq_start, n_refs) && rd_checked(idx->seq_len, n_refs);
+    }
+    u64 const nb = n / OCC_BLOCK_POS + 1;
+    ok = ok && rd_checked(idx->sa, n) && rd_checked(idx->occ[0], nb) && rd_checked(idx->occ[1], nb) && rd_checked(idx->bwt[0], n) &&
+         rd_checked(idx->bwt[1], n) && rd_checked(idx->kmer_table, ((u64)1 << (2 * KMER_Q)) * 3);
+    if (ok) {
+        // sequences lie inside the text, in order, with their sentinel padding; C is a prefix sum that ends at n
+        u64 prev_end = 0;
+        for (size_t r = 0; ok && r < idx->seq_start.size(); ++r) {
+            ok = idx->seq_start[r] >= prev_end && idx->seq_len[r] <= n && idx->seq_start[r] + idx->seq_len[r] < n + 1;
+            prev_end = idx->seq_start[r] + idx->seq_len[r];
+        }
+        ok = ok && idx->C[0] == 0 && idx->C[6] == n;
+        for (int c = 0; ok && c < 6; ++c) ok = idx->C[c] <= idx->C[c + 1];
+    }
+    if (!ok) { set_error("index file is corrupt, truncated or of another version"); return nullptr; }
     return idx.release();
 }
 

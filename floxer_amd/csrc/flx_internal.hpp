@@ -39,14 +39,17 @@ struct PoolAlloc {
 template <class T> using hvec = std::vector<T, PoolAlloc<T>>;
 
 // ------------------------------------------------------------------------------------------------ HBM data layout
-// Occurrence table block: 256 BWT positions in one 128-byte line (one L2 line / one HBM request on gfx950), cut into four
-// 32-byte quarters so that the two lanes that serve one seed each read two quarters with four 16-byte loads (coalesced 128 B):
-//   quarter q = { p0[2q], p1[2q], p2[2q], cnt[2q],  p0[2q+1], p1[2q+1], p2[2q+1], cnt[2q+1] }        (8 x u32)
-//   pk[j]  = bit-plane k (symbol bit k) of the 32 positions bwt[256*b + 32*j ..+31]   (symbols 0..5; tail filled with 7)
-//   cnt[c] = number of symbol c in bwt[0, 256*b) for c < 6 (absolute; text < 2^32 symbols); cnt[6], cnt[7] unused
-struct alignas(128) OccBlock {
-    u32 w[32];
+// Occurrence table block: 64 BWT positions in one 64-byte block = the unit SURVEY.md section 8(d) prices a rank query at (one
+// 64-symbol block incl. its counters per position), 1 byte of HBM per text symbol and direction (hg38: 3.1 GB per direction out
+// of 288 GB). One lane serves one seed and reads the 48 used bytes of a block with three 16-byte loads:
+//   w[0..5]   cnt[c] = number of symbol c in bwt[0, 64*b), absolute (text < 2^32 symbols)
+//   w[6..11]  bit-planes of the 64 positions: p0.lo, p0.hi, p1.lo, p1.hi, p2.lo, p2.hi (plane k = bit k of the symbol, lo = positions
+//             0..31; symbols 0..5, positions past the end of the text filled with 7)
+//   w[12..15] unused
+struct alignas(64) OccBlock {
+    u32 w[16];
 };
+constexpr u32 OCC_BLOCK_POS = 64;
 constexpr u32 TEXT_PAD = 128;     // bytes of padding in front of and behind the device copy of a reference text
 
 struct HostIndex {
@@ -91,14 +94,14 @@ struct DevSeed {
     u32 id;             // index of the seed in the caller's list (the launch order is by expected cost, see search_seeds_device)
 };
 
-struct DevFrame {       // 96 bytes: one branching node of the DFS, 48 bytes per lane of the seed's pair
-    // lane 0: { abs, oth, len } of the child cursors for symbols 0..3 (abs = C[c] + occ on the extended side, oth = bound on the
-    //         other side; symbol 0 is never a child and its abs carries the mask of remaining children instead)
-    // lane 1: { abs, oth, len } for symbols 4, 5, then { lb, lb_rev, len, state } of the node itself and 8 unused bytes;
-    //         state = x:20 | e:3 | linfo:2 | rinfo:2 | next_sym:3 | right:1
-    u32 v[24];
+struct DevFrame {       // 64 bytes: one branching node of the DFS, written when the node is made (four 16-byte stores of one lane)
+    // v[0..4]   abs of the child cursors of symbols 1..5 on the extended side (C[c] + occ)
+    // v[5..10]  number of rows of the children of symbols 0..5 (their bounds on the other side are prefix sums of these)
+    // v[11..14] { lb, lb_rev, len, state } of the node itself; state = x:20 | e:3 | linfo:2 | rinfo:2 | next_sym:3 | right:1
+    // v[15]     mask of the children not taken yet (rewritten when a frame is put on top of this one)
+    u32 v[16];
 };
-static_assert(sizeof(DevFrame) == 96, "frame is six 16-byte slots");
+static_assert(sizeof(DevFrame) == 64, "frame is four 16-byte slots");
 
 struct DevHit { u32 seed, lb, len, errors; };
 struct DevOutAnchor { u32 seed_index, leaf, ref_id, errors; u64 pos; };   // = HostAnchor (leaf is filled by the host)
@@ -163,6 +166,9 @@ struct DeviceApi {
     // all return 0 or a hipError_t (non-zero)
     // suffix array of text[0, n) on the device (a suffix that is a prefix of another sorts first); out: n entries on the host
     static int suffix_array(int hip_device, const u8* text, u64 n, u32* out);
+    // suffix array, BWT of the text and of the reversed text and both occurrence tables (n / 64 + 1 blocks each), built on the
+    // device; all outputs on the host
+    static int index_arrays(int hip_device, const u8* text, u64 n, u32* out_sa, u8* out_bwt0, u8* out_bwt1, OccBlock* out_occ0, OccBlock* out_occ1);
     static int build_peq(void* stream, const u8* d_seq, u64 len, u64* d_peq);
     // d_seed_cnt (may be null): number of hits of every seed; each hit then carries its ordinal within its seed in errors >> 8
     static int search(void* stream, const DevIndex& idx, const u8* d_seq, const u32* d_scheme, const DevSeed* d_seeds,

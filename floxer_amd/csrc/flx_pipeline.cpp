@@ -288,10 +288,10 @@ int search_seeds_device(Lane* ctx, const u8* d_seq_pool_or_null, const u8* h_seq
         d.seq_off = s.seq_offset;
         d.length = s.length;
         d.scheme_off = it->second.first;
-        d.frames_searches = (s.length + s.num_errors + 2) | (it->second.second << 24);
+        d.frames_searches = (s.length + s.num_errors + 3) | (it->second.second << 24);
         d.stack_off = frames;
         d.id = (u32)i;
-        frames += s.length + s.num_errors + 2;
+        frames += s.length + s.num_errors + 3;
     }
     // Launch order = expected cost, heaviest class first (more errors, then shorter): the work of a seed grows steeply with its
     // errors (k = 2 leaves of a 5-kb read cost 4x the k = 1 leaves), and what a wave still holds when the seed queue runs dry
@@ -1792,7 +1792,23 @@ extern "C" int flx_align_reads_resident(flx_ctx* ctx, const flx_params* P, const
     u64 chunk_reads = n_reads >= 1024 * n_lanes ? big_chunk : std::max<u64>(64, (n_reads + n_lanes - 1) / n_lanes);
     if (const char* env = getenv("FLX_CHUNK_READS")) { u64 const v = strtoull(env, nullptr, 10); if (v >= 1) chunk_reads = v; }
     if (n_lanes == 1) chunk_reads = std::max<u64>(n_reads, 1);
-    size_t const n_chunks = std::max<size_t>(1, (n_reads + chunk_reads - 1) / chunk_reads);
+    // A chunk's workspaces grow with its bases, not its reads (the DFS stacks of K1 alone are ~150 bytes per read base): chunks are
+    // also cut at FLX_CHUNK_BASES read bases (default 12 M: ~1.8 GB of stacks per lane), so a batch of 100-kb reads gets more,
+    // smaller chunks instead of workspaces of tens of GB per lane.
+    u64 chunk_bases = 12ull << 20;
+    if (const char* env = getenv("FLX_CHUNK_BASES")) { u64 const v = strtoull(env, nullptr, 10); if (v >= 1) chunk_bases = v; }
+    hvec<u64> chunk_first{0};                                // chunk c = reads [chunk_first[c], chunk_first[c + 1])
+    {
+        u64 reads_in = 0, bases_in = 0;
+        for (u64 i = 0; i < n_reads; ++i) {
+            u64 const len = RD->lens[i];
+            if (reads_in > 0 && (reads_in >= chunk_reads || bases_in + len > chunk_bases)) { chunk_first.push_back(i); reads_in = 0; bases_in = 0; }
+            ++reads_in;
+            bases_in += len;
+        }
+        chunk_first.push_back(n_reads);
+    }
+    size_t const n_chunks = chunk_first.size() - 1;
     run->parts.resize(n_chunks);
     hvec<flx_run>& parts = run->parts;
     hvec<int> rcs(n_chunks, FLX_OK);
@@ -1812,7 +1828,7 @@ extern "C" int flx_align_reads_resident(flx_ctx* ctx, const flx_params* P, const
     std::atomic<bool> failed{false};
     auto work = [&]() {
         for (size_t c; (c = next_chunk.fetch_add(1)) < n_chunks && !failed.load();) {
-            u64 const a = c * chunk_reads, b = std::min<u64>(n_reads, a + chunk_reads);
+            u64 const a = chunk_first[c], b = chunk_first[c + 1];
             parts[c].skipped.assign(n_reads, 0);
             LaneLease lease(ctx, ctx->external_stream ? 0 : -1);      // waits while other calls on this context hold all lanes
             rcs[c] = align_slice(lease.lane, P, RD, a, b, &parts[c]);

@@ -7,7 +7,8 @@ Output is in input order, so the job's output is the concatenation of the ranks'
     funnelling all parts through one rank would make that rank's host the bottleneck of the whole job.
   * `gather_records`: one variable-length gather of all records to rank 0 (RCCL over xGMI when the backend is "nccl"; gloo on
     CPU in tests) for callers that want a single stream; rank 0 re-emits the records in global read order, so the result is
-    identical for any number of ranks."""
+    identical for any number of ranks.
+Both gathers are true gathervs (all-gather of the counts, then grouped send/recv of exactly the counted rows)."""
 import numpy as np
 
 
@@ -32,26 +33,44 @@ def exchange_counts(n_records, n_cigar_words, rank, world, device=None):
     return torch.stack(parts).cpu().numpy()
 
 
+def _gatherv(mine, counts, rank, world):
+    """variable-length gather to rank 0 of one tensor per rank whose first dimension is counts[r] on rank r: the receiver posts one
+    receive of exactly counts[r] rows per sender straight into its slice of the result, the senders one send each, all in one
+    group (RCCL: ncclGroupStart / ncclSend / ncclRecv / ncclGroupEnd over xGMI; gloo: its send/recv pairs). Nothing is padded to
+    the largest part and nothing is copied after it has arrived. Returns the concatenation on rank 0, None elsewhere."""
+    import torch
+    import torch.distributed as dist
+    counts = [int(c) for c in counts]
+    if rank == 0:
+        out = torch.empty((sum(counts),) + tuple(mine.shape[1:]), device=mine.device, dtype=mine.dtype)
+        out[: counts[0]] = mine
+        ops, at = [], counts[0]
+        for r in range(1, world):
+            if counts[r]:
+                ops.append(dist.P2POp(dist.irecv, out[at: at + counts[r]], r))
+            at += counts[r]
+        if ops:
+            for w in dist.batch_isend_irecv(ops):
+                w.wait()
+        return out
+    if counts[rank]:
+        for w in dist.batch_isend_irecv([dist.P2POp(dist.isend, mine, 0)]):
+            w.wait()
+    return None
+
+
 def gather_rows(rows, counts, rank, world, device=None):
     """Final gather of the fixed-size alignment records (read, flag, reference, position, NM, CIGAR offset/length in the owner's
     part) to rank 0 — the job's mapping table; the CIGAR words stay in the owners' parts. rows: (n,7) int64 of this rank (read
     index already global); counts: exchange_counts-style (world, >=1) array whose column 0 is every rank's number of rows.
-    Returns on rank 0 a list of `world` tensors (left on `device`: over RCCL nothing passes through a host), None elsewhere."""
+    Returns on rank 0 one (sum of counts, 7) tensor in rank order (left on `device`: over RCCL nothing passes through a host),
+    None elsewhere."""
     import torch
     rows = np.ascontiguousarray(rows, dtype=np.int64).reshape(-1, 7)
     if world == 1:
-        return [torch.from_numpy(rows)]
-    import torch.distributed as dist
+        return torch.from_numpy(rows)
     dev = device if device is not None else torch.device("cpu")
-    n_max = max(1, int(np.max(np.asarray(counts)[:, 0])))
-    mine = torch.zeros((n_max, 7), device=dev, dtype=torch.int64)
-    mine[: rows.shape[0]] = torch.from_numpy(rows).to(dev)
-    if rank == 0:
-        parts = [torch.zeros_like(mine) for _ in range(world)]
-        dist.gather(mine, parts, dst=0)
-        return [parts[r][: int(counts[r][0])] for r in range(world)]
-    dist.gather(mine, None, dst=0)
-    return None
+    return _gatherv(torch.from_numpy(rows).to(dev), np.asarray(counts)[:, 0], rank, world)
 
 
 def gather_records(rows, cigars, read_offset, rank, world, device=None):
@@ -63,34 +82,38 @@ def gather_records(rows, cigars, read_offset, rank, world, device=None):
     if world == 1:
         return rows, cigars
     import torch
-    import torch.distributed as dist
     dev = device if device is not None else torch.device("cpu")
-    t_rows = torch.from_numpy(rows).to(dev)
-    t_cig = torch.from_numpy(cigars.view(np.int32)).to(dev)          # the same 32 bits; torch has no uint32 collectives
-    counts = torch.tensor([t_rows.shape[0], t_cig.shape[0]], device=dev, dtype=torch.int64)
-    all_counts = [torch.zeros_like(counts) for _ in range(world)]
-    dist.all_gather(all_counts, counts)
-    all_counts = [(int(c[0].item()), int(c[1].item())) for c in all_counts]
-    max_r = max(1, max(c[0] for c in all_counts))
-    max_c = max(1, max(c[1] for c in all_counts))
-    pad_r = torch.zeros((max_r, 7), device=dev, dtype=torch.int64)
-    pad_r[: t_rows.shape[0]] = t_rows
-    pad_c = torch.zeros((max_c,), device=dev, dtype=torch.int32)
-    pad_c[: t_cig.shape[0]] = t_cig
+    counts = exchange_counts(len(rows), len(cigars), rank, world, device=device)
+    # a part's CIGAR offsets are rebased by the words of the parts in front of it before it leaves its owner
+    rows[:, 5] += int(counts[:rank, 1].sum())
+    t_rows = _gatherv(torch.from_numpy(rows).to(dev), counts[:, 0], rank, world)
+    t_cig = _gatherv(torch.from_numpy(cigars.view(np.int32)).to(dev), counts[:, 1], rank, world)   # the same 32 bits; no uint32 collectives
     if rank == 0:
-        gr = [torch.zeros_like(pad_r) for _ in range(world)]
-        gc = [torch.zeros_like(pad_c) for _ in range(world)]
-        dist.gather(pad_r, gr, dst=0)
-        dist.gather(pad_c, gc, dst=0)
-        out_rows, out_cig, base = [], [], 0
-        for r in range(world):
-            nr, nc = all_counts[r]
-            rr = gr[r][:nr].cpu().numpy().copy()
-            rr[:, 5] += base
-            out_rows.append(rr)
-            out_cig.append(gc[r][:nc].cpu().numpy().view(np.uint32))
-            base += nc
-        return np.concatenate(out_rows, axis=0), np.concatenate(out_cig)
-    dist.gather(pad_r, None, dst=0)
-    dist.gather(pad_c, None, dst=0)
+        return t_rows.cpu().numpy(), t_cig.cpu().numpy().view(np.uint32)
     return None
+
+
+def build_index_once(references, rank, world, device=None, tag=None):
+    """The FM index of a multi-rank job: built once (rank 0; suffix arrays / BWTs / occurrence tables on HIP device `device`, on the
+    host when it is None), written to a file in shared memory, loaded by the other ranks, removed again. world == 1: just built.
+    Every rank then uploads its replica to its own GPU (flx_ctx_create)."""
+    import os
+    import floxer_amd as F
+    if world == 1:
+        return F.fmindex(references, device=device)
+    import torch.distributed as dist
+    base = "/dev/shm" if os.path.isdir("/dev/shm") else "/tmp"
+    path = os.path.join(base, f"flx_index_{tag or os.environ.get('MASTER_PORT', 'job')}_{os.getuid()}.bin")
+    index = None
+    try:
+        if rank == 0:
+            index = F.fmindex(references, device=device)
+            index.save(path)
+        dist.barrier()
+        if rank != 0:
+            index = F.fmindex(path=path)
+        dist.barrier()
+    finally:
+        if rank == 0 and os.path.exists(path):
+            os.remove(path)
+    return index

@@ -77,3 +77,33 @@ def write_fastq(path, reads, names):
     with open(path, "w") as f:
         for r, n in zip(reads, names):
             f.write(f"@{n}\n{ranks_to_str(r)}\n+\n{'I' * len(r)}\n")
+
+
+# ------------------------------------------------------------------------------------------------ the same, at benchmark scale
+# flx_sim_genome / flx_sim_reads (floxer_amd/csrc/flx_simulate.cpp): same semantics, multi-threaded, own portable generator
+# (a different stream of random numbers than make_genome / make_reads above).
+def make_genome_fast(chromosome_length, num_chromosomes=1, seed=DEFAULT_SEED):
+    """one contiguous uint8 rank array of num_chromosomes * chromosome_length symbols + the list of per-chromosome views"""
+    import ctypes as C
+    from . import capi
+    pool = np.empty(chromosome_length * num_chromosomes, dtype=np.uint8)
+    capi.check(capi.lib().flx_sim_genome(len(pool), seed, capi.ptr(pool, capi.u8p)))
+    return pool, [pool[i * chromosome_length:(i + 1) * chromosome_length] for i in range(num_chromosomes)]
+
+
+def make_reads_fast(genome_pool, chrom_lens, num_reads, base_len, error_rate, seed=DEFAULT_SEED + 1, revcomp_fraction=0.5):
+    """Returns ((pool, offsets), truth) with truth = (chrom u32[n], pos u64[n], reverse u8[n]); the (pool, offsets) pair is what
+    resident_reads / aligner.align_reads take."""
+    from . import capi
+    lens = np.ascontiguousarray(chrom_lens, dtype=np.uint64)
+    cap = num_reads * (base_len + int(error_rate * base_len))
+    pool = np.empty(max(cap, 1), dtype=np.uint8)
+    offs = np.zeros(num_reads + 1, dtype=np.uint64)
+    chrom = np.zeros(max(num_reads, 1), dtype=np.uint32)
+    pos = np.zeros(max(num_reads, 1), dtype=np.uint64)
+    rev = np.zeros(max(num_reads, 1), dtype=np.uint8)
+    capi.check(capi.lib().flx_sim_reads(capi.ptr(genome_pool, capi.u8p), capi.ptr(lens, capi.u64p), len(lens), num_reads, base_len,
+                                        float(error_rate), float(revcomp_fraction), seed, capi.ptr(pool, capi.u8p), len(pool),
+                                        capi.ptr(offs, capi.u64p), capi.ptr(chrom, capi.u32p), capi.ptr(pos, capi.u64p),
+                                        capi.ptr(rev, capi.u8p)))
+    return (pool[: int(offs[-1])], offs), (chrom[:num_reads], pos[:num_reads], rev[:num_reads])

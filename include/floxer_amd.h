@@ -75,6 +75,7 @@ uint32_t flx_index_num_references(const flx_index* index);
 uint64_t flx_index_device_bytes(const flx_index* index);    /* HBM footprint once uploaded */
 /* test hooks: suffix array / BWT as built (text_length entries) */
 int flx_index_copy_sa(const flx_index* index, uint64_t* out);
+int flx_index_copy_sa_u32(const flx_index* index, uint32_t* out);   /* the same as stored (text < 2^32 symbols) */
 int flx_index_copy_bwt(const flx_index* index, int reversed, uint8_t* out);
 
 /* ------------------------------------------------------------------------------------------------ device context */
@@ -221,6 +222,16 @@ int flx_sam_open(const char* path /* .sam or .bam */, const char* const* ref_ids
 int flx_sam_write(flx_sam_writer* w, const char* const* read_ids, const uint8_t* read_pool, const uint64_t* read_offsets,
                   const char* const* quals, const flx_record* records, uint64_t n_records, const uint32_t* cigar_words);
 int flx_sam_close(flx_sam_writer* w);
+
+/* ------------------------------------------------------------------------------------------------ synthetic inputs
+ * The reference's simulator (src/main/simulated_dataset.cpp:30-49, 81-223), multi-threaded and with a portable generator:
+ * uniform genome over ACGT; reads = substrings of base_len with exactly floor(error_rate * base_len) distinct positions mutated
+ * (mismatch / insertion / deletion uniformly), reverse-complemented with probability revcomp_fraction. Read r depends on
+ * (seed, r) only. out_offsets has n_reads + 1 entries; out_chrom / out_pos / out_reverse (may be NULL) receive the truth. */
+int flx_sim_genome(uint64_t length, uint64_t seed, uint8_t* out_ranks);
+int flx_sim_reads(const uint8_t* genome_concat, const uint64_t* chrom_lens, uint32_t n_chrom, uint64_t n_reads, uint32_t base_len,
+                  double error_rate, double revcomp_fraction, uint64_t seed, uint8_t* out_pool, uint64_t pool_capacity,
+                  uint64_t* out_offsets, uint32_t* out_chrom, uint64_t* out_pos, uint8_t* out_reverse);
 
 #ifdef __cplusplus
 }

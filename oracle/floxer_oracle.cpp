@@ -188,19 +188,38 @@ static void build_occ(const std::vector<uint8_t>& bwt, std::vector<uint32_t>& cp
     if (n % 64 == 0) for (int c = 0; c < 6; ++c) cp[(n / 64) * 6 + c] = cnt[c];
 }
 
-fm_index build_index(const std::vector<std::vector<uint8_t>>& refs, uint32_t sampling) {
-    fm_index idx;
+static void lay_out_text(fm_index& idx, const std::vector<std::vector<uint8_t>>& refs, uint32_t sampling) {
     idx.sampling = sampling;
+    uint64_t total = 0;
+    for (auto const& r : refs) total += r.size() + (sampling - (r.size() % sampling));
+    idx.text.assign(total, 0);
+    uint64_t at = 0;
     for (auto const& r : refs) {
-        idx.seq_start.push_back(idx.text.size());
+        idx.seq_start.push_back(at);
         idx.seq_len.push_back(r.size());
-        idx.text.insert(idx.text.end(), r.begin(), r.end());
-        uint64_t const delim = sampling - (r.size() % sampling);
-        idx.text.resize(idx.text.size() + delim, 0);
+        std::copy(r.begin(), r.end(), idx.text.begin() + at);
+        at += r.size() + (sampling - (r.size() % sampling));         // delimiters: zero sentinels up to the next multiple (>= 1)
     }
     idx.n = idx.text.size();
     if (idx.n >= (uint64_t)1 << 32) throw std::runtime_error("oracle index limited to < 2^32 symbols");
-    idx.sa = build_suffix_array(idx.text);
+}
+
+static void finish_index(fm_index& idx) {
+    uint64_t cnt[6] = {0, 0, 0, 0, 0, 0};
+    for (auto c : idx.text) cnt[c]++;
+    idx.C[0] = 0;
+    for (int c = 0; c < 6; ++c) idx.C[c + 1] = idx.C[c] + cnt[c];
+    build_occ(idx.bwt, idx.occ_cp);
+    build_occ(idx.bwt_rev, idx.occ_rev_cp);
+}
+
+fm_index build_index(const std::vector<std::vector<uint8_t>>& refs, uint32_t sampling) {
+    fm_index idx;
+    lay_out_text(idx, refs, sampling);
+    {
+        auto const sa = build_suffix_array(idx.text);
+        idx.sa.assign(sa.begin(), sa.end());
+    }
     idx.bwt.resize(idx.n);
     for (uint64_t i = 0; i < idx.n; ++i) idx.bwt[i] = idx.text[(idx.sa[i] + idx.n - 1) % idx.n];
     {
@@ -209,12 +228,38 @@ fm_index build_index(const std::vector<std::vector<uint8_t>>& refs, uint32_t sam
         idx.bwt_rev.resize(idx.n);
         for (uint64_t i = 0; i < idx.n; ++i) idx.bwt_rev[i] = rev[(sa_rev[i] + idx.n - 1) % idx.n];
     }
-    uint64_t cnt[6] = {0, 0, 0, 0, 0, 0};
-    for (auto c : idx.text) cnt[c]++;
-    idx.C[0] = 0;
-    for (int c = 0; c < 6; ++c) idx.C[c + 1] = idx.C[c] + cnt[c];
-    build_occ(idx.bwt, idx.occ_cp);
-    build_occ(idx.bwt_rev, idx.occ_rev_cp);
+    finish_index(idx);
+    return idx;
+}
+
+fm_index import_index(const std::vector<std::vector<uint8_t>>& refs, uint32_t sampling, const uint32_t* sa, const uint8_t* bwt,
+                      const uint8_t* bwt_rev) {
+    fm_index idx;
+    lay_out_text(idx, refs, sampling);
+    uint64_t const n = idx.n;
+    idx.sa.assign(sa, sa + n);
+    idx.bwt.assign(bwt, bwt + n);
+    idx.bwt_rev.assign(bwt_rev, bwt_rev + n);
+    // consistency on a sample of rows: neighbouring suffixes in order, BWT = symbol in front of the suffix, and the two BWTs are
+    // permutations of the same text
+    auto suffix_less_eq = [&](uint64_t a, uint64_t b) {
+        for (uint64_t d = 0; d < 4096; ++d) {
+            if (a + d >= n) return true;
+            if (b + d >= n) return false;
+            if (idx.text[a + d] != idx.text[b + d]) return idx.text[a + d] < idx.text[b + d];
+        }
+        return true;
+    };
+    uint64_t const step = std::max<uint64_t>(1, n / 100000);
+    for (uint64_t i = 0; i < n; i += step) {
+        if (idx.sa[i] >= n) throw std::runtime_error("imported suffix array: entry outside the text");
+        if (i + 1 < n && !suffix_less_eq(idx.sa[i], idx.sa[i + 1])) throw std::runtime_error("imported suffix array: rows out of order");
+        if (idx.bwt[i] != idx.text[(idx.sa[i] + n - 1) % n]) throw std::runtime_error("imported BWT does not match the suffix array");
+    }
+    uint64_t c0[8] = {0}, c1[8] = {0}, c2[8] = {0};
+    for (uint64_t i = 0; i < n; ++i) { c0[idx.text[i] & 7]++; c1[idx.bwt[i] & 7]++; c2[idx.bwt_rev[i] & 7]++; }
+    for (int c = 0; c < 8; ++c) if (c0[c] != c1[c] || c0[c] != c2[c]) throw std::runtime_error("imported BWT is not a permutation of the text");
+    finish_index(idx);
     return idx;
 }
 

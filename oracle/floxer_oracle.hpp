@@ -74,7 +74,7 @@ struct fm_index {
     std::vector<uint8_t> text;              // concatenated ranks + zero padding
     std::vector<uint64_t> seq_start;        // start of each sequence in text
     std::vector<uint64_t> seq_len;
-    std::vector<int64_t> sa;                // full suffix array of text (only sampled rows are *used* by locate)
+    std::vector<uint32_t> sa;               // full suffix array of text, n < 2^32 (only sampled rows are *used* by locate)
     std::vector<uint8_t> bwt, bwt_rev;
     uint64_t C[7];                          // C[c] = #symbols < c
     // occ checkpoints every 64 positions
@@ -87,6 +87,11 @@ struct fm_index {
 };
 
 fm_index build_index(const std::vector<std::vector<uint8_t>>& refs, uint32_t sampling);
+// The same index with its suffix array and the two BWTs taken as data instead of being sorted here (the suffix array of a text is
+// unique, so this is the index build_index() would make; used where sorting 3 G suffixes on the CPU is out of reach: the
+// benchmark's cpu_baseline leg and the scale tests). The arrays are checked for consistency on a sample of rows.
+fm_index import_index(const std::vector<std::vector<uint8_t>>& refs, uint32_t sampling, const uint32_t* sa, const uint8_t* bwt,
+                      const uint8_t* bwt_rev);
 
 struct cursor { uint64_t lb, lb_rev, len; };
 

@@ -81,9 +81,18 @@ void* orc_index_build(const uint8_t* pool, const uint64_t* lens, uint32_t n_refs
     try { h->idx = build_index(h->refs, sampling); } catch (...) { return nullptr; }
     return h.release();
 }
+// the same with the suffix array (u32) and the two BWTs given as data (see import_index)
+void* orc_index_import(const uint8_t* pool, const uint64_t* lens, uint32_t n_refs, uint32_t sampling, const uint32_t* sa,
+                       const uint8_t* bwt, const uint8_t* bwt_rev) {
+    auto h = std::make_unique<index_handle>();
+    uint64_t off = 0;
+    for (uint32_t i = 0; i < n_refs; ++i) { h->refs.emplace_back(pool + off, pool + off + lens[i]); off += lens[i]; }
+    try { h->idx = import_index(h->refs, sampling, sa, bwt, bwt_rev); } catch (...) { return nullptr; }
+    return h.release();
+}
 void orc_index_free(void* h) { delete (index_handle*)h; }
 uint64_t orc_index_size(void* h) { return ((index_handle*)h)->idx.n; }
-void orc_index_sa(void* h, int64_t* out) { auto& i = ((index_handle*)h)->idx; memcpy(out, i.sa.data(), i.n * 8); }
+void orc_index_sa(void* h, int64_t* out) { auto& i = ((index_handle*)h)->idx; for (uint64_t r = 0; r < i.n; ++r) out[r] = (int64_t)i.sa[r]; }
 void orc_index_bwt(void* h, int rev, uint8_t* out) {
     auto& i = ((index_handle*)h)->idx;
     memcpy(out, (rev ? i.bwt_rev : i.bwt).data(), i.n);

@@ -46,6 +46,8 @@ def lib():
         L.orc_pex_build.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64, C.c_int, u64p, C.c_uint64, u64p, u64p]
         L.orc_index_build.restype = C.c_void_p
         L.orc_index_build.argtypes = [u8p, u64p, C.c_uint32, C.c_uint32]
+        L.orc_index_import.restype = C.c_void_p
+        L.orc_index_import.argtypes = [u8p, u64p, C.c_uint32, C.c_uint32, u32p, u8p, u8p]
         L.orc_index_free.argtypes = [C.c_void_p]
         L.orc_index_size.restype = C.c_uint64
         L.orc_index_size.argtypes = [C.c_void_p]
@@ -139,11 +141,20 @@ def params(error_probability=-1.0, query_errors=0, seed_errors=2, hard=500, soft
 
 
 class Index:
-    def __init__(self, refs, sampling=4):
+    def __init__(self, refs, sampling=4, imported=None, pool=None):
+        """imported = (suffix array u32, BWT, BWT of the reversed text) of the padded text: the index is then laid out around
+        these arrays instead of sorting the suffixes here (a text has one suffix array; the arrays are spot-checked)."""
         self.refs = [as_u8(r) for r in refs]
-        pool = np.concatenate(self.refs) if self.refs else np.zeros(0, np.uint8)
+        if pool is None:
+            pool = np.concatenate(self.refs) if self.refs else np.zeros(0, np.uint8)
         lens = np.array([len(r) for r in self.refs], dtype=np.uint64)
-        self.h = lib().orc_index_build(_p(pool, u8p), _p(lens, u64p), len(self.refs), sampling)
+        if imported is None:
+            self.h = lib().orc_index_build(_p(pool, u8p), _p(lens, u64p), len(self.refs), sampling)
+        else:
+            sa, bwt, bwt_rev = imported
+            sa = np.ascontiguousarray(sa, dtype=np.uint32)
+            bwt, bwt_rev = as_u8(bwt), as_u8(bwt_rev)
+            self.h = lib().orc_index_import(_p(pool, u8p), _p(lens, u64p), len(self.refs), sampling, _p(sa, u32p), _p(bwt, u8p), _p(bwt_rev, u8p))
         assert self.h
 
     def __del__(self):
