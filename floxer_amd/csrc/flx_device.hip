@@ -168,33 +168,32 @@ __global__ void __launch_bounds__(256) reverse_kernel(const u8* __restrict__ tex
     u64 const i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) rev[i] = text[n - 1 - i];
 }
-// one wave per 64-position block: the three bit-planes by ballot, the block's own symbol counts into cnt[c * nb + b]
+// one wave per two 32-position blocks: the three bit-planes by ballot, every block's own symbol counts into cnt[c * nb + b]
 __global__ void __launch_bounds__(256) occ_planes_kernel(const u8* __restrict__ bwt, u64 n, u64 nb, OccBlock* __restrict__ blocks, u32* __restrict__ cnt) {
-    u64 const b = ((u64)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    if (b >= nb) return;
+    u64 const pair = ((u64)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (pair * 2 >= nb) return;
     u32 const lane = lane_id();
-    u64 const pos = b * 64 + lane;
+    u64 const pos = pair * 64 + lane;
     u32 const sym = pos < n ? bwt[pos] : 7u;
     u64 const p0 = __ballot(sym & 1u), p1 = __ballot(sym & 2u), p2 = __ballot(sym & 4u);
-    u32 v = 0;
-    if (lane < 6) {
-        u64 const m = (lane & 1u ? p0 : ~p0) & (lane & 2u ? p1 : ~p1) & (lane & 4u ? p2 : ~p2);
-        cnt[(u64)lane * nb + b] = (u32)__popcll(m);
-    } else if (lane < 12) {
-        u64 const pl = lane < 8 ? p0 : lane < 10 ? p1 : p2;
-        v = (u32)(lane & 1u ? pl >> 32 : pl);
-    }
-    if (lane >= 6 && lane < 16) blocks[b].w[lane] = v;
+    u32 const half = lane >> 5, l = lane & 31u;                 // lanes 0..31 write block 2*pair, lanes 32..63 block 2*pair + 1
+    u64 const b = pair * 2 + half;
+    if (b >= nb) return;
+    u32 const q0 = (u32)(half ? p0 >> 32 : p0), q1 = (u32)(half ? p1 >> 32 : p1), q2 = (u32)(half ? p2 >> 32 : p2);
+    if (l < 5) {
+        u32 const m = (l & 1u ? q0 : ~q0) & (l & 2u ? q1 : ~q1) & (l & 4u ? q2 : ~q2);
+        cnt[(u64)l * nb + b] = (u32)__popc(m);
+    } else if (l < 8) blocks[b].w[l] = l == 5 ? q0 : l == 6 ? q1 : q2;
 }
 __global__ void __launch_bounds__(256) occ_counts_kernel(const u32* __restrict__ cnt, u64 nb, OccBlock* __restrict__ blocks) {
     u64 const i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= nb * 6) return;
+    if (i >= nb * 5) return;
     u64 const c = i / nb, b = i - c * nb;
     blocks[b].w[c] = cnt[i];
 }
 
 // Suffix array, both BWTs and both occurrence tables of text[0, n) on the device; results land in host memory. The counts of the
-// six symbols per block are made absolute by six exclusive scans over the blocks.
+// symbols 0..4 per block are made absolute by five exclusive scans over the blocks.
 int DeviceApi::index_arrays(int hip_device, const u8* text, u64 n, u32* out_sa, u8* out_bwt0, u8* out_bwt1, OccBlock* out_occ0, OccBlock* out_occ1) {
     if (n == 0) return 0;
     hipError_t e;
@@ -211,7 +210,7 @@ int DeviceApi::index_arrays(int hip_device, const u8* text, u64 n, u32* out_sa, 
     SA_HIP(hipMalloc(&d_rev, n));
     SA_HIP(hipMalloc(&d_bwt, n));
     SA_HIP(hipMalloc(&d_occ, nb * sizeof(OccBlock)));
-    SA_HIP(hipMalloc(&d_cnt, nb * 6 * 4));
+    SA_HIP(hipMalloc(&d_cnt, nb * 5 * 4));
     SA_HIP(w.alloc(std::max<u64>(n, nb), s));
     {
         size_t need = 0;
@@ -226,10 +225,10 @@ int DeviceApi::index_arrays(int hip_device, const u8* text, u64 n, u32* out_sa, 
         if (dir == 0) SA_HIP(hipMemcpyAsync(out_sa, w.sa, n * 4, hipMemcpyDeviceToHost, s));
         hipLaunchKernelGGL(bwt_kernel, dim3(blocks_n), dim3(256), 0, s, t, w.sa, n, d_bwt);
         SA_HIP(hipMemcpyAsync(dir ? out_bwt1 : out_bwt0, d_bwt, n, hipMemcpyDeviceToHost, s));
-        hipLaunchKernelGGL(occ_planes_kernel, dim3((unsigned)((nb * 64 + 255) / 256)), dim3(256), 0, s, d_bwt, n, nb, d_occ, d_cnt);
-        for (u32 c = 0; c < 6; ++c)
+        hipLaunchKernelGGL(occ_planes_kernel, dim3((unsigned)(((nb + 1) / 2 * 64 + 255) / 256)), dim3(256), 0, s, d_bwt, n, nb, d_occ, d_cnt);
+        for (u32 c = 0; c < 5; ++c)
             SA_HIP(rocprim::exclusive_scan(w.tmp, w.tmp_bytes, d_cnt + (u64)c * nb, d_cnt + (u64)c * nb, 0u, (size_t)nb, rocprim::plus<u32>(), s));
-        hipLaunchKernelGGL(occ_counts_kernel, dim3((unsigned)((nb * 6 + 255) / 256)), dim3(256), 0, s, d_cnt, nb, d_occ);
+        hipLaunchKernelGGL(occ_counts_kernel, dim3((unsigned)((nb * 5 + 255) / 256)), dim3(256), 0, s, d_cnt, nb, d_occ);
         SA_HIP(hipMemcpyAsync(dir ? out_occ1 : out_occ0, d_occ, nb * sizeof(OccBlock), hipMemcpyDeviceToHost, s));
         SA_HIP(hipStreamSynchronize(s));
     }
@@ -243,39 +242,56 @@ done:
 }
 
 // ================================================================================================ K1: FM search
-// One lane serves one seed. A rank query reads the 48 used bytes of one 64-byte block (64 BWT positions: six absolute counters +
-// three bit-planes) with three 16-byte loads and pop-counts the positions below the offset for all six symbols (v_bcnt
-// accumulates onto the counters): 2 x 64 B per cursor extension, the unit SURVEY.md section 8(d) prices it at. The DFS is
-// explicit: the node under inspection lives in registers, the children of the top frame (the last branching node) in LDS
-// ([symbol][lane] x 16 B, conflict-free for ds_read_b128: the child to descend into is picked by a run-time symbol), every frame
-// is written to the seed's stack in HBM when it is made (64 B = four 16-byte stores) and read back when the DFS returns to it.
-// (Round 1 served a seed with a DPP pair of lanes on 128-byte blocks: every control instruction was issued twice per seed and
-// the kernel was bound by VALU issue at the same extensions/s for a 4.6 Mb and a 3.1 Gb index.)
+// One lane serves one seed. A rank query reads one 32-byte block (32 BWT positions: five absolute counters + three bit-planes)
+// with two 16-byte loads and pop-counts the positions below the offset (v_bcnt accumulates onto the counters); the count of
+// symbol 5 is what is left of the interval. A cursor extension is two rank queries (both ends of the interval, usually in the same
+// 128-byte line). The roofline accounting stays the one of SURVEY.md section 8(d): 2 x 64 B per extension.
+//
+// fm_search_kernel (the default path) walks the DFS of search_ng21 in a different order than the reference: at a branching node
+// the children that cost an error are visited first and the match child last, as a tail call. A frame (the node and its child
+// cursors) is then only alive while one of its error children is explored, so at most `errors` frames exist at a time: the whole
+// stack lives in LDS ([level][word][lane], conflict-free b32 accesses), nothing of the DFS is written to HBM and no stack has to be
+// reserved per seed. Every hit carries a key that puts the hits of a seed back into the reference's emission order (which decides
+// ties of the unstable sorts downstream): the DFS order is the lexicographic order of the child indices taken along the path,
+// match = 0 first; a path is determined by its <= 3 error edges, so key = search << 54 | three 18-bit components, one per
+// error edge in path order: (MAX_X - x of the node the edge leaves) << 4 | child index, 0 when there is no such edge (between two
+// error edges the depth grows with x, so comparing x is comparing depths). This only works when all hits of a seed are wanted
+// (round_robin / full_groups: a seed with more rows than the hard cap is excluded whatever the rows are).
+// fm_search_ordered_kernel walks the DFS in the reference's order with an explicit stack in HBM: for first_reported (the first n
+// rows in emission order) and the raw-emission test hook.
+//
+// (Round 1 served a seed with a DPP pair of lanes on 128-byte blocks and was bound by VALU issue, every control instruction being
+// issued twice per seed; one lane per seed on 64-byte blocks with the stack in HBM was bound by the vector memory path: 18 vector
+// memory instructions per DFS step, three loads per block, TA busy 82 %, profiles/r02_k1_pmc_1gb_64B_blocks.txt.)
 
-// symbol counts of the positions selected by `mask` in one 32-position chunk, added to six accumulators (v_bcnt accumulates)
-__device__ __forceinline__ void count_chunk(u32 p0, u32 p1, u32 p2, u32 mask, u32 acc[6]) {
-    u32 const n2 = ~p2 & mask, q2 = p2 & mask;
-    u32 const a00 = ~(p1 | p0), a01 = ~p1 & p0, a10 = p1 & ~p0, a11 = p1 & p0;
-    acc[0] += (u32)__popc(n2 & a00);
-    acc[1] += (u32)__popc(n2 & a01);
-    acc[2] += (u32)__popc(n2 & a10);
-    acc[3] += (u32)__popc(n2 & a11);
-    acc[4] += (u32)__popc(q2 & a00);
-    acc[5] += (u32)__popc(q2 & a01);
-}
-__device__ __forceinline__ u32 below_mask32(u32 off, u32 chunk) {       // positions of chunk (32*chunk ..) below `off`
-    int const w = min(max((int)off - (int)(chunk * 32u), 0), 32);       // v_med3_i32
-    return (u32)(0xFFFFFFFFull >> (32 - w));                            // w = 0 -> 0, w = 32 -> all ones
+// r[c] = number of symbol c in bwt[0, pos) for c = 0..4
+__device__ __forceinline__ void rank5(const OccBlock* __restrict__ tab, u32 pos, u32 r[5]) {
+    const uint4* __restrict__ q = reinterpret_cast<const uint4*>(tab + (pos >> 5));
+    uint4 const a = q[0], b = q[1];
+    u32 const mask = (1u << (pos & 31u)) - 1u;
+    u32 const p0 = b.y, p1 = b.z, p2 = b.w;
+    u32 const n2 = ~p2 & mask;
+    r[0] = a.x + (u32)__popc(n2 & ~(p1 | p0));
+    r[1] = a.y + (u32)__popc(n2 & ~p1 & p0);
+    r[2] = a.z + (u32)__popc(n2 & p1 & ~p0);
+    r[3] = a.w + (u32)__popc(n2 & p1 & p0);
+    r[4] = b.x + (u32)__popc(p2 & mask & ~(p1 | p0));
 }
 
-// r[c] = number of symbol c in bwt[0, pos)
-__device__ __forceinline__ void rank6(const OccBlock* __restrict__ tab, u32 pos, u32 r[6]) {
-    const uint4* __restrict__ q = reinterpret_cast<const uint4*>(tab + (pos >> 6));
-    uint4 const a = q[0], b = q[1], c = q[2];
-    u32 const off = pos & 63u;
-    r[0] = a.x; r[1] = a.y; r[2] = a.z; r[3] = a.w; r[4] = b.x; r[5] = b.y;
-    count_chunk(b.z, c.x, c.z, below_mask32(off, 0), r);
-    count_chunk(b.w, c.y, c.w, below_mask32(off, 1), r);
+// both ends of the interval [lo, lo + nlen): cl[c] = rows of the child of symbol c (c = 0..5), ab[c] = its lower bound on the
+// extended side (c = 1..5; ab[0] is not used)
+__device__ __forceinline__ void extend_all(const DevIndex& idx, const OccBlock* __restrict__ tab, u32 lo, u32 nlen, u32 ab[6], u32 cl[6]) {
+    u32 ra[5], rb[5];
+    rank5(tab, lo, ra);
+    rank5(tab, lo + nlen, rb);
+    u32 sum_a = 0, sum_l = 0;
+#pragma unroll
+    for (u32 c = 0; c < 5; ++c) { cl[c] = rb[c] - ra[c]; sum_a += ra[c]; sum_l += cl[c]; }
+    cl[5] = nlen - sum_l;
+    ab[0] = 0;
+#pragma unroll
+    for (u32 c = 1; c < 5; ++c) ab[c] = idx.C[c] + ra[c];
+    ab[5] = idx.C[5] + (lo - sum_a);
 }
 
 // frame state word: x:20 | e:3 | linfo:2 | rinfo:2 | next_sym:3 | right:1
@@ -308,107 +324,146 @@ constexpr u32 FM_GRAB = 64;
 constexpr u32 FM_HIT_GRAB = 64;
 constexpr u32 FM_MAX_WAVES = 4096;
 constexpr u32 FM_SEEDS_PER_WAVE = 256;      // a launch has at most n_seeds / this many waves, so that every wave gets several ranges
+constexpr u32 FM_FRAME_WORDS = 17;          // LDS frame: oth[1..5], end, abs[1..5], lb, lb_rev, state, mask, key lo, key hi
+constexpr u32 FM_KEY_BITS = 18;             // per error edge: (0x3FFF - x) << 4 | child index
+constexpr u32 FM_KEY_MAX_X = 0x3FFFu;
+
+// hit slots for the hits the lanes found in the last iteration. Slots are reserved FM_HIT_GRAB at a time per wave (one global
+// atomic per range instead of one per hit, all on one address); the unused rest of a range is filled with entries of seed
+// 0xFFFFFFFF, which the consumers skip. The hit's ordinal within its seed (the order the kernel found them in) rides in the upper
+// bits of the error count (errors <= 3): the hits of a seed are put into one segment without a sort.
+#define FM_EMIT_HITS()                                                                                                              \
+    do {                                                                                                                            \
+        u64 const emit = __ballot(hit_pending);                                                                                     \
+        if (emit) {                                                                                                                 \
+            u32 const n_emit = (u32)__popcll(emit);                                                                                 \
+            if (h_end - h_next < n_emit) {                                                                                          \
+                { u32 const at = h_next + lane; if (at < h_end && at < hit_cap) hits[at] = DevHit{0xFFFFFFFFu, 0u, 0u, 0u, 0ull}; } \
+                u32 b = 0;                                                                                                          \
+                if (lane == 0) b = atomicAdd(&counters[0], FM_HIT_GRAB);                                                            \
+                h_next = (u32)__builtin_amdgcn_readfirstlane((int)b);                                                               \
+                h_end = h_next + FM_HIT_GRAB;                                                                                       \
+            }                                                                                                                       \
+            if (hit_pending) {                                                                                                      \
+                u32 const slot = h_next + (u32)__popcll(emit & lanes_below);                                                        \
+                if (slot < hit_cap) hits[slot] = DevHit{sid, nlb, hit_rep, seed_cnt ? ne | (min(hit_idx, 0xFFFFFFu) << 8) : ne, hit_key}; \
+                if (seed_cnt) seed_cnt[sid] = hit_idx + 1u;                                                                         \
+                ++hit_idx;                                                                                                          \
+            }                                                                                                                       \
+            h_next += n_emit;                                                                                                       \
+            hit_pending = false;                                                                                                    \
+        }                                                                                                                           \
+    } while (0)
+
+// seeds for the idle lanes: k = index of this lane's new seed or 0xFFFFFFFF (wave-uniform bookkeeping of the grabbed range)
+#define FM_ASSIGN_SEEDS(k)                                                                                                          \
+    do {                                                                                                                            \
+        u32 const n_idle = (u32)__popcll(idle);                                                                                     \
+        u32 const avail = q_end - q_next;                                                                                           \
+        u32 new_base = 0;                                                                                                           \
+        bool grabbed = false;                                                                                                       \
+        if (avail < n_idle && !queue_done) {                                                                                        \
+            u32 b = 0;                                                                                                              \
+            if (lane == 0) b = atomicAdd(&counters[7], FM_GRAB);                                                                    \
+            new_base = (u32)__builtin_amdgcn_readfirstlane((int)b);                                                                 \
+            grabbed = true;                                                                                                         \
+        }                                                                                                                           \
+        u32 const r = (u32)__popcll(idle & lanes_below);                                                                            \
+        if (want) {                                                                                                                 \
+            if (r < avail) k = q_next + r;                                                                                          \
+            else if (grabbed && new_base + (r - avail) < n_seeds) k = new_base + (r - avail);                                       \
+        }                                                                                                                           \
+        if (grabbed) {                                                                                                              \
+            if (new_base >= n_seeds) { q_next = 0; q_end = 0; queue_done = true; }                                                  \
+            else {                                                                                                                  \
+                q_end = min(new_base + FM_GRAB, n_seeds);                                                                           \
+                q_next = min(new_base + (n_idle - avail), q_end);                                                                   \
+                queue_done = new_base + FM_GRAB >= n_seeds;                                                                         \
+            }                                                                                                                       \
+        } else q_next += min(n_idle, avail);                                                                                        \
+    } while (0)
+
+// start of search `srch` of the seed: the root cursor, or the cursor of the seed's first KMER_Q characters when the search begins
+// with an exact, rightward part that long and free of N. false: the search finds nothing.
+__device__ __forceinline__ bool fm_begin_search(DevIndex const& idx, const u32* __restrict__ ex, const u8* __restrict__ q, u32 len,
+                                                u32& nlb, u32& nlbr, u32& nlen, u32& nx) {
+    nlb = 0; nlbr = 0; nlen = idx.n; nx = 0;
+    if (len >= KMER_Q && ((ex[KMER_Q - 1] >> 27) & 1u)) {
+        u32 const p0 = ex[0] & SCH_POS_MASK;
+        u32 w[2];
+        __builtin_memcpy(w, q + p0, 8);                                  // eight ranks, first character in the low byte
+        u32 const t0 = w[0] - 0x01010101u, t1 = w[1] - 0x01010101u;      // A,C,G,T -> 0..3; anything else leaves bits 2..7 set
+        if (((t0 | t1) & 0xFCFCFCFCu) == 0u) {
+            // gather the four 2-bit fields of a word, first character most significant: b0<<6 | b1<<4 | b2<<2 | b3
+            u32 const code = (((t0 * 0x40100401u) >> 24) << 8) | ((t1 * 0x40100401u) >> 24);
+            const u32* __restrict__ e = idx.kmer + 3u * code;
+            nlb = e[0]; nlbr = e[1]; nlen = e[2];
+            nx = KMER_Q;
+            if (nlen == 0) return false;
+        }
+    }
+    return true;
+}
+
+// the children of a branching node that exist: bit 0 match, bits 2c-1 / 2c deletion / substitution of symbol c, bit 11 insertion
+__device__ __forceinline__ u32 fm_child_mask(const u32 cl[6], u32 next_sym, bool match_allowed, bool deletion, bool insertion) {
+    u32 mask = 0;
+#pragma unroll
+    for (u32 c = 1; c < 6; ++c) {
+        if (cl[c] > 0u) {
+            if (deletion) mask |= 1u << (2u * c - 1u);
+            if (c != next_sym) mask |= 1u << (2u * c);
+            else if (match_allowed) mask |= 1u;
+        }
+    }
+    if (insertion) mask |= 1u << 11;
+    return mask;
+}
 
 __global__ void __launch_bounds__(64) fm_search_kernel(DevIndex idx, const u8* __restrict__ seq, const u32* __restrict__ scheme,
-                                                       const DevSeed* __restrict__ seeds, u32 n_seeds, u32 max_hits,
-                                                       DevFrame* __restrict__ stack, DevHit* __restrict__ hits, u32 hit_cap,
-                                                       u32* __restrict__ counters, u32* __restrict__ seed_cnt) {
-    __shared__ uint4 child[5][64];              // top frame: {abs, oth, len, -} of the child cursor of symbol s+1, per lane
+                                                       const DevSeed* __restrict__ seeds, u32 n_seeds, u32 max_hits, u32 levels,
+                                                       DevHit* __restrict__ hits, u32 hit_cap, u32* __restrict__ counters,
+                                                       u32* __restrict__ seed_cnt) {
+    extern __shared__ u32 lds[];                // frames: [level][FM_FRAME_WORDS][64 lanes]
     u32 q_next = 0, q_end = 0;                  // wave-uniform: the unserved rest of the last grabbed seed range
     bool queue_done = false;
     u32 h_next = 0, h_end = 0;                  // wave-uniform: the unwritten rest of the last reserved range of hit slots
     u32 const lane = threadIdx.x & 63u;
     u64 const lanes_below = (1ull << lane) - 1ull;
+    auto fr = [&](u32 level, u32 word) -> u32& { return lds[(level * FM_FRAME_WORDS + word) * 64u + lane]; };
 
     u32 n_ext = 0, n_iter = 0, n_busy_iter = 0, n_tail_iter = 0;
-    // ---- per-seed state
     bool busy = false, exhausted = false;
-    u32 sid = 0, srch = 0, num_searches = 0, len = 0, ct = 0, stack_frames = 0;
+    u32 sid = 0, srch = 0, num_searches = 0, len = 0, ct = 0;
     const u8* __restrict__ q = seq;
-    uint4* __restrict__ stk = reinterpret_cast<uint4*>(stack);
     const u32* __restrict__ ex_base = scheme;
-    // ---- per-search state
     bool in_search = false;
     const u32* __restrict__ ex = scheme;
     u32 l_last = 0, u_last = 0;
     u32 nlb = 0, nlbr = 0, nlen = 0, nx = 0, ne = 0, nli = INFO_M, nri = INFO_M;
-    // top frame (frame depth-1 of the stack): its node and the mask of children not taken yet; the child cursors are in LDS
-    u32 f_lb = 0, f_lbr = 0, f_len = 0, f_state = 0, f_mask = 0;
-    u32 depth = 0;                              // frames on the stack, the top one included
+    u64 nkey = 0;                               // key of the node under inspection
+    u32 depth = 0;                              // frames alive
     bool need_child = false;
-    bool hit_pending = false;                   // a hit of this lane (sid, nlb, hit_rep, ne) waits for its slot
-    u32 hit_rep = 0;
-    u32 hit_idx = 0;                            // hits of the current seed so far
-
-    // hit slots are reserved FM_HIT_GRAB at a time per wave (one global atomic per range instead of one per hit, all on one
-    // address); the unused rest of a range is filled with entries of seed FLX_NO_SEED, which the host skips
-    auto fill_rest = [&]() {
-        u32 const at = h_next + lane;
-        if (at < h_end && at < hit_cap) hits[at] = DevHit{0xFFFFFFFFu, 0u, 0u, 0u};
-    };
+    bool hit_pending = false;                   // a hit of this lane (sid, nlb, hit_rep, ne, hit_key) waits for its slot
+    u32 hit_rep = 0, hit_idx = 0;
+    u64 hit_key = 0;
 
     while (true) {
-        u64 const emit = __ballot(hit_pending);
-        if (emit) {                                                     // wave-uniform
-            u32 const n_emit = (u32)__popcll(emit);
-            if (h_end - h_next < n_emit) {
-                fill_rest();
-                u32 b = 0;
-                if (lane == 0) b = atomicAdd(&counters[0], FM_HIT_GRAB);
-                h_next = (u32)__builtin_amdgcn_readfirstlane((int)b);
-                h_end = h_next + FM_HIT_GRAB;
-            }
-            if (hit_pending) {
-                u32 const slot = h_next + (u32)__popcll(emit & lanes_below);
-                // the hit's ordinal within its seed rides in the upper bits of the error count (errors <= 3): the hits of a seed
-                // can be put back in emission order without a sort
-                if (slot < hit_cap) hits[slot] = DevHit{sid, nlb, hit_rep, seed_cnt ? ne | (min(hit_idx, 0xFFFFFFu) << 8) : ne};
-                if (seed_cnt) seed_cnt[sid] = hit_idx + 1u;
-                ++hit_idx;
-            }
-            h_next += n_emit;
-            hit_pending = false;
-        }
+        FM_EMIT_HITS();
         bool const want = !busy && !exhausted;
         u64 const idle = __ballot(want);
         if (idle) {                                                     // wave-uniform
-            u32 const n_idle = (u32)__popcll(idle);
-            u32 const avail = q_end - q_next;
-            u32 new_base = 0;
-            bool grabbed = false;
-            if (avail < n_idle && !queue_done) {
-                u32 b = 0;
-                if (lane == 0) b = atomicAdd(&counters[7], FM_GRAB);
-                new_base = (u32)__builtin_amdgcn_readfirstlane((int)b);
-                grabbed = true;
-            }
-            u32 const r = (u32)__popcll(idle & lanes_below);           // rank of this lane among the idle ones
             u32 k = 0xFFFFFFFFu;
-            if (want) {
-                if (r < avail) k = q_next + r;
-                else if (grabbed && new_base + (r - avail) < n_seeds) k = new_base + (r - avail);
-            }
-            if (grabbed) {
-                if (new_base >= n_seeds) { q_next = 0; q_end = 0; queue_done = true; }
-                else {
-                    q_end = min(new_base + FM_GRAB, n_seeds);
-                    q_next = min(new_base + (n_idle - avail), q_end);
-                    queue_done = new_base + FM_GRAB >= n_seeds;
-                }
-            } else q_next += min(n_idle, avail);
+            FM_ASSIGN_SEEDS(k);
             if (want) {
                 if (k != 0xFFFFFFFFu) {
                     DevSeed const seed = seeds[k];
                     sid = seed.id;
                     q = seq + seed.seq_off;
-                    stk = reinterpret_cast<uint4*>(stack + seed.stack_off);
                     len = seed.length;
                     num_searches = seed.frames_searches >> 24;
-                    stack_frames = seed.frames_searches & 0xFFFFFFu;
                     ex_base = scheme + seed.scheme_off;
-                    srch = 0;
-                    ct = 0;
-                    hit_idx = 0;
+                    srch = 0; ct = 0; hit_idx = 0;
                     busy = true;
                     in_search = false;
                 } else exhausted = true;
@@ -426,26 +481,193 @@ __global__ void __launch_bounds__(64) fm_search_kernel(DevIndex idx, const u8* _
             u32 const last_entry = ex[len - 1];
             l_last = (last_entry >> 20) & 7u;
             u_last = (last_entry >> 23) & 7u;
-            nlb = 0; nlbr = 0; nlen = idx.n; nx = 0; ne = 0; nli = INFO_M; nri = INFO_M;
+            ne = 0; nli = INFO_M; nri = INFO_M;
+            nkey = (u64)srch << (3u * FM_KEY_BITS);
+            depth = 0;
+            need_child = false;
+            in_search = true;
+            if (!fm_begin_search(idx, ex, q, len, nlb, nlbr, nlen, nx)) { in_search = false; ++srch; continue; }
+        }
+
+        // ---- the next child of the top frame becomes the node: children that cost an error first, the match child last
+        if (need_child) {
+            if (depth == 0u) { in_search = false; ++srch; continue; }        // search exhausted
+            u32 const lv = depth - 1u;
+            u32 const mask = fr(lv, 14);
+            u32 const st = fr(lv, 13);
+            u32 const costly = mask & ~1u;
+            u32 const ci = costly ? (u32)__ffs((int)costly) - 1u : 0u;
+            u32 const rest = mask & ~(1u << ci);
+            if (rest) fr(lv, 14) = rest;
+            else --depth;                                                   // the last child of a frame is a tail call: the frame is gone
+            u32 const right = ST_RIGHT(st);
+            u32 const px = ST_X(st), pe = ST_E(st);
+            u32 info, sym;
+            if (ci == 0) { sym = ST_SYM(st); nx = px + 1; ne = pe; info = INFO_M; }
+            else if (ci == 11) { sym = 1; nx = px + 1; ne = pe + 1; info = INFO_I; }
+            else {
+                sym = (ci + 1) >> 1;
+                bool const del = ci & 1u;
+                nx = del ? px : px + 1;
+                ne = pe + 1;
+                info = del ? INFO_D : INFO_S;
+            }
+            // sym is 1..5 for every child (a match of 0 or of a symbol > 5 is never a child)
+            u32 const c_oth = fr(lv, sym - 1u), c_end = fr(lv, sym), c_abs = fr(lv, 5u + sym);
+            u32 const p_lb = fr(lv, 11), p_lbr = fr(lv, 12);
+            u64 const pkey = (u64)fr(lv, 15) | ((u64)fr(lv, 16) << 32);
+            if (ci == 11) { nlb = p_lb; nlbr = p_lbr; nlen = fr(lv, 5) - (right ? p_lb : p_lbr); }
+            else { nlen = c_end - c_oth; nlb = right ? c_oth : c_abs; nlbr = right ? c_abs : c_oth; }
+            nli = right ? ST_LI(st) : info;
+            nri = right ? info : ST_RI(st);
+            nkey = ci ? pkey | ((u64)(((FM_KEY_MAX_X - px) << 4) | ci) << (FM_KEY_BITS * (2u - pe))) : pkey;
+            need_child = false;
+        }
+
+        // ---- inspect node (nlb, nlbr, nlen, nx, ne, nli, nri); nlen > 0 by construction
+        if (nx == len) {
+            bool const ok_l = nli == INFO_M || nli == INFO_I, ok_r = nri == INFO_M || nri == INFO_I;
+            if (ok_l && ok_r && l_last <= ne && ne <= u_last) {
+                u32 rep = nlen;
+                if (ct + rep > max_hits) rep = max_hits - ct;        // more rows than the caller wants to know of
+                ct += rep;
+                hit_pending = true;                                  // written at the top of the next iteration
+                hit_rep = rep;
+                hit_key = nkey;
+                if (ct == max_hits) { busy = false; continue; }      // the seed has too many rows: its other hits do not matter
+            }
+            need_child = true;
+            continue;
+        }
+        u32 const sch = ex[nx];
+        u32 const lower = (sch >> 20) & 7u, upper = (sch >> 23) & 7u, right = (sch >> 26) & 1u;
+        if (ne > upper) { need_child = true; continue; }
+        bool const mismatch_allowed = lower <= ne + 1 && ne + 1 <= upper;
+        bool const match_allowed = lower <= ne && ne <= upper;
+        if (!mismatch_allowed && !match_allowed) { need_child = true; continue; }
+
+        u32 const next_sym = q[sch & SCH_POS_MASK];
+        u32 const lo = right ? nlbr : nlb, other = right ? nlb : nlbr;
+        u32 ab[6], cl[6];
+        extend_all(idx, idx.occ[right], lo, nlen, ab, cl);
+        ++n_ext;
+
+        if (mismatch_allowed) {
+            // this node branches: its frame goes on top of the frames of the error edges taken so far (at most `ne` of them)
+            u32 const tinfo = right ? nri : nli;
+            u32 const mask = fm_child_mask(cl, next_sym, match_allowed, tinfo == INFO_M || tinfo == INFO_D, tinfo == INFO_M || tinfo == INFO_I);
+            if (mask == 0u) { need_child = true; continue; }
+            if (depth >= levels) { atomicOr(&counters[1], 1u); busy = false; continue; }
+            u32 const lv = depth;
+            u32 const o1 = other + cl[0], o2 = o1 + cl[1], o3 = o2 + cl[2], o4 = o3 + cl[3], o5 = o4 + cl[4];
+            fr(lv, 0) = o1; fr(lv, 1) = o2; fr(lv, 2) = o3; fr(lv, 3) = o4; fr(lv, 4) = o5; fr(lv, 5) = o5 + cl[5];
+            fr(lv, 6) = ab[1]; fr(lv, 7) = ab[2]; fr(lv, 8) = ab[3]; fr(lv, 9) = ab[4]; fr(lv, 10) = ab[5];
+            fr(lv, 11) = nlb; fr(lv, 12) = nlbr;
+            fr(lv, 13) = st_pack(nx, ne, nli, nri, next_sym, right);
+            fr(lv, 14) = mask;
+            fr(lv, 15) = (u32)nkey; fr(lv, 16) = (u32)(nkey >> 32);
+            ++depth;
+            need_child = true;
+        } else {
+            // only an exact extension is possible: continue in place (no frame)
+            if (next_sym == 0u || next_sym > 5u) { need_child = true; continue; }       // the sentinel never matches
+            u32 clen = cl[1], cabs = ab[1], coth = other + cl[0];
+#pragma unroll
+            for (u32 c = 2; c < 6; ++c) {
+                coth += c <= next_sym ? cl[c - 1u] : 0u;
+                bool const take = c == next_sym;
+                clen = take ? cl[c] : clen;
+                cabs = take ? ab[c] : cabs;
+            }
+            if (clen == 0) { need_child = true; continue; }
+            nlb = right ? coth : cabs;
+            nlbr = right ? cabs : coth;
+            if (right) nri = INFO_M; else nli = INFO_M;
+            nlen = clen;
+            nx = nx + 1;
+        }
+    }
+    { u32 const at = h_next + lane; if (at < h_end && at < hit_cap) hits[at] = DevHit{0xFFFFFFFFu, 0u, 0u, 0u, 0ull}; }
+    n_ext = wave_sum_u32(n_ext);
+    n_busy_iter = wave_sum_u32(n_busy_iter);
+    if (lane == 0) {
+        atomicAdd(&counters[2], n_ext); atomicAdd(&counters[6], n_busy_iter);
+        atomicAdd(&counters[4], n_iter); atomicMax(&counters[5], n_iter); atomicAdd(&counters[8], n_tail_iter); atomicMax(&counters[9], n_tail_iter);
+    }
+}
+
+// The DFS in the reference's own order (match child first): frames are written to the seed's stack in HBM when they are made
+// (64 B = four 16-byte stores) and read back when the DFS returns to them; the children of the top frame are in LDS.
+__global__ void __launch_bounds__(64) fm_search_ordered_kernel(DevIndex idx, const u8* __restrict__ seq, const u32* __restrict__ scheme,
+                                                               const DevSeed* __restrict__ seeds, u32 n_seeds, u32 max_hits,
+                                                               DevFrame* __restrict__ stack, DevHit* __restrict__ hits, u32 hit_cap,
+                                                               u32* __restrict__ counters, u32* __restrict__ seed_cnt) {
+    __shared__ uint4 child[5][64];              // top frame: {abs, oth, len, -} of the child cursor of symbol s+1, per lane
+    u32 q_next = 0, q_end = 0;
+    bool queue_done = false;
+    u32 h_next = 0, h_end = 0;
+    u32 const lane = threadIdx.x & 63u;
+    u64 const lanes_below = (1ull << lane) - 1ull;
+
+    u32 n_ext = 0, n_iter = 0, n_busy_iter = 0, n_tail_iter = 0;
+    bool busy = false, exhausted = false;
+    u32 sid = 0, srch = 0, num_searches = 0, len = 0, ct = 0, stack_frames = 0;
+    const u8* __restrict__ q = seq;
+    uint4* __restrict__ stk = reinterpret_cast<uint4*>(stack);
+    const u32* __restrict__ ex_base = scheme;
+    bool in_search = false;
+    const u32* __restrict__ ex = scheme;
+    u32 l_last = 0, u_last = 0;
+    u32 nlb = 0, nlbr = 0, nlen = 0, nx = 0, ne = 0, nli = INFO_M, nri = INFO_M;
+    // top frame (frame depth-1 of the stack): its node and the mask of children not taken yet
+    u32 f_lb = 0, f_lbr = 0, f_len = 0, f_state = 0, f_mask = 0;
+    u32 depth = 0;                              // frames on the stack, the top one included
+    bool need_child = false;
+    bool hit_pending = false;
+    u32 hit_rep = 0, hit_idx = 0;
+    u64 const hit_key = 0;                      // the ordinals of this kernel's hits are the emission order
+
+    while (true) {
+        FM_EMIT_HITS();
+        bool const want = !busy && !exhausted;
+        u64 const idle = __ballot(want);
+        if (idle) {                                                     // wave-uniform
+            u32 k = 0xFFFFFFFFu;
+            FM_ASSIGN_SEEDS(k);
+            if (want) {
+                if (k != 0xFFFFFFFFu) {
+                    DevSeed const seed = seeds[k];
+                    sid = seed.id;
+                    q = seq + seed.seq_off;
+                    stk = reinterpret_cast<uint4*>(stack + seed.stack_off);
+                    len = seed.length;
+                    num_searches = seed.frames_searches >> 24;
+                    stack_frames = seed.frames_searches & 0xFFFFFFu;
+                    ex_base = scheme + seed.scheme_off;
+                    srch = 0; ct = 0; hit_idx = 0;
+                    busy = true;
+                    in_search = false;
+                } else exhausted = true;
+            }
+        }
+        if (__all(exhausted && !busy)) break;
+        ++n_iter;
+        if (queue_done && q_next == q_end) ++n_tail_iter;
+        if (!busy) continue;
+        ++n_busy_iter;
+
+        if (!in_search) {
+            if (srch >= num_searches) { busy = false; continue; }
+            ex = ex_base + (u64)srch * len;
+            u32 const last_entry = ex[len - 1];
+            l_last = (last_entry >> 20) & 7u;
+            u_last = (last_entry >> 23) & 7u;
+            ne = 0; nli = INFO_M; nri = INFO_M;
             f_mask = 0;
             depth = 0;
             need_child = false;
             in_search = true;
-            // the exact, rightward first part of the search starts from the KMER_Q-mer table when it is long enough and free of N
-            if (len >= KMER_Q && ((ex[KMER_Q - 1] >> 27) & 1u)) {
-                u32 const p0 = ex[0] & SCH_POS_MASK;
-                u32 w[2];
-                __builtin_memcpy(w, q + p0, 8);                                  // eight ranks, first character in the low byte
-                u32 const t0 = w[0] - 0x01010101u, t1 = w[1] - 0x01010101u;      // A,C,G,T -> 0..3; anything else leaves bits 2..7 set
-                if (((t0 | t1) & 0xFCFCFCFCu) == 0u) {
-                    // gather the four 2-bit fields of a word, first character most significant: b0<<6 | b1<<4 | b2<<2 | b3
-                    u32 const code = (((t0 * 0x40100401u) >> 24) << 8) | ((t1 * 0x40100401u) >> 24);
-                    const u32* __restrict__ e = idx.kmer + 3u * code;
-                    nlb = e[0]; nlbr = e[1]; nlen = e[2];
-                    nx = KMER_Q;
-                    if (nlen == 0) { in_search = false; ++srch; continue; }     // the k-mer does not occur: this search finds nothing
-                }
-            }
+            if (!fm_begin_search(idx, ex, q, len, nlb, nlbr, nlen, nx)) { in_search = false; ++srch; continue; }
         }
 
         // ---- one DFS step
@@ -454,8 +676,8 @@ __global__ void __launch_bounds__(64) fm_search_kernel(DevIndex idx, const u8* _
                 // the top frame has no child left (or there is no frame): back to the frame below it
                 if (depth <= 1u) { in_search = false; ++srch; continue; }    // search exhausted
                 --depth;
-                const uint4* __restrict__ fr = stk + (depth - 1u) * 4u;
-                uint4 const v0 = fr[0], v1 = fr[1], v2 = fr[2], v3 = fr[3];
+                const uint4* __restrict__ g = stk + (depth - 1u) * 4u;
+                uint4 const v0 = g[0], v1 = g[1], v2 = g[2], v3 = g[3];
                 f_lb = v2.w; f_lbr = v3.x; f_len = v3.y; f_state = v3.z;
                 f_mask = v3.w;                                             // never empty: see where frames are made
                 // bounds of the children on the other side: prefix sums of their lengths, symbol 0 first
@@ -482,7 +704,7 @@ __global__ void __launch_bounds__(64) fm_search_kernel(DevIndex idx, const u8* _
                 ne = pe + 1;
                 info = del ? INFO_D : INFO_S;
             }
-            uint4 const c = child[sym - 1u][lane];                         // sym is 1..5 for every child (a match of 0 or N > 5 is never a child)
+            uint4 const c = child[sym - 1u][lane];                         // sym is 1..5 for every child
             if (ci == 11) { nlb = f_lb; nlbr = f_lbr; nlen = f_len; }
             else { nlen = c.z; nlb = right ? c.y : c.x; nlbr = right ? c.x : c.y; }
             nli = right ? ST_LI(st) : info;
@@ -512,16 +734,10 @@ __global__ void __launch_bounds__(64) fm_search_kernel(DevIndex idx, const u8* _
         if (!mismatch_allowed && !match_allowed) { need_child = true; continue; }
 
         u32 const next_sym = q[sch & SCH_POS_MASK];
-        const OccBlock* __restrict__ tab = idx.occ[right];
         u32 const lo = right ? nlbr : nlb, other = right ? nlb : nlbr;
-        u32 ra[6], cl[6];
-        rank6(tab, lo, ra);
-        rank6(tab, lo + nlen, cl);
+        u32 ab[6], cl[6];
+        extend_all(idx, idx.occ[right], lo, nlen, ab, cl);
         ++n_ext;
-#pragma unroll
-        for (u32 c = 0; c < 6; ++c) cl[c] -= ra[c];                   // rows of the child of symbol c
-#pragma unroll
-        for (u32 c = 1; c < 6; ++c) ra[c] += idx.C[c];                // its bound on the extended side
 
         if (mismatch_allowed) {
             // this node branches: it becomes the top frame. The frame below keeps its place on the stack if it still has children
@@ -532,45 +748,32 @@ __global__ void __launch_bounds__(64) fm_search_kernel(DevIndex idx, const u8* _
             }
             if (depth >= stack_frames) { atomicOr(&counters[1], 1u); busy = false; continue; }
             u32 const tinfo = right ? nri : nli;
-            bool const deletion = tinfo == INFO_M || tinfo == INFO_D;
-            bool const insertion = tinfo == INFO_M || tinfo == INFO_I;
             f_lb = nlb; f_lbr = nlbr; f_len = nlen;
             f_state = st_pack(nx, ne, nli, nri, next_sym, right);
-            // children of symbols 1..5 that are not empty
-            u32 mask = 0;
-#pragma unroll
-            for (u32 c = 1; c < 6; ++c) {
-                if (cl[c] > 0u) {
-                    if (deletion) mask |= 1u << (2u * c - 1u);
-                    if (c != next_sym) mask |= 1u << (2u * c);
-                    else if (match_allowed) mask |= 1u;
-                }
-            }
-            if (insertion) mask |= 1u << 11;
-            f_mask = mask;
-            uint4* __restrict__ fr = stk + depth * 4u;
-            fr[0] = uint4{ra[1], ra[2], ra[3], ra[4]};
-            fr[1] = uint4{ra[5], cl[0], cl[1], cl[2]};
-            fr[2] = uint4{cl[3], cl[4], cl[5], nlb};
-            fr[3] = uint4{nlbr, nlen, f_state, mask};
+            f_mask = fm_child_mask(cl, next_sym, match_allowed, tinfo == INFO_M || tinfo == INFO_D, tinfo == INFO_M || tinfo == INFO_I);
+            uint4* __restrict__ g = stk + depth * 4u;
+            g[0] = uint4{ab[1], ab[2], ab[3], ab[4]};
+            g[1] = uint4{ab[5], cl[0], cl[1], cl[2]};
+            g[2] = uint4{cl[3], cl[4], cl[5], nlb};
+            g[3] = uint4{nlbr, nlen, f_state, f_mask};
             ++depth;
             u32 const o1 = other + cl[0], o2 = o1 + cl[1], o3 = o2 + cl[2], o4 = o3 + cl[3], o5 = o4 + cl[4];
-            child[0][lane] = uint4{ra[1], o1, cl[1], 0u};
-            child[1][lane] = uint4{ra[2], o2, cl[2], 0u};
-            child[2][lane] = uint4{ra[3], o3, cl[3], 0u};
-            child[3][lane] = uint4{ra[4], o4, cl[4], 0u};
-            child[4][lane] = uint4{ra[5], o5, cl[5], 0u};
+            child[0][lane] = uint4{ab[1], o1, cl[1], 0u};
+            child[1][lane] = uint4{ab[2], o2, cl[2], 0u};
+            child[2][lane] = uint4{ab[3], o3, cl[3], 0u};
+            child[3][lane] = uint4{ab[4], o4, cl[4], 0u};
+            child[4][lane] = uint4{ab[5], o5, cl[5], 0u};
             need_child = true;
         } else {
             // only an exact extension is possible: continue in place (no frame)
             if (next_sym == 0u || next_sym > 5u) { need_child = true; continue; }       // the sentinel never matches
-            u32 clen = cl[1], cabs = ra[1], coth = other + cl[0];
+            u32 clen = cl[1], cabs = ab[1], coth = other + cl[0];
 #pragma unroll
             for (u32 c = 2; c < 6; ++c) {
                 coth += c <= next_sym ? cl[c - 1u] : 0u;
                 bool const take = c == next_sym;
                 clen = take ? cl[c] : clen;
-                cabs = take ? ra[c] : cabs;
+                cabs = take ? ab[c] : cabs;
             }
             if (clen == 0) { need_child = true; continue; }
             nlb = right ? coth : cabs;
@@ -580,7 +783,7 @@ __global__ void __launch_bounds__(64) fm_search_kernel(DevIndex idx, const u8* _
             nx = nx + 1;
         }
     }
-    fill_rest();
+    { u32 const at = h_next + lane; if (at < h_end && at < hit_cap) hits[at] = DevHit{0xFFFFFFFFu, 0u, 0u, 0u, 0ull}; }
     n_ext = wave_sum_u32(n_ext);
     n_busy_iter = wave_sum_u32(n_busy_iter);
     if (lane == 0) {
@@ -588,18 +791,35 @@ __global__ void __launch_bounds__(64) fm_search_kernel(DevIndex idx, const u8* _
         atomicAdd(&counters[4], n_iter); atomicMax(&counters[5], n_iter); atomicAdd(&counters[8], n_tail_iter); atomicMax(&counters[9], n_tail_iter);
     }
 }
+#undef FM_EMIT_HITS
+#undef FM_ASSIGN_SEEDS
 
 static u32 fm_seeds_per_wave() {
     static u32 const v = [] { const char* e = getenv("FLX_FM_SEEDS_PER_WAVE"); u32 const x = e ? (u32)strtoul(e, nullptr, 10) : 0u; return x ? x : FM_SEEDS_PER_WAVE; }();
     return v;
 }
 
+static u32 fm_max_waves() {
+    static u32 const v = [] { const char* e = getenv("FLX_FM_MAX_WAVES"); u32 const x = e ? (u32)strtoul(e, nullptr, 10) : 0u; return x ? x : FM_MAX_WAVES; }();
+    return v;
+}
+
+u32 fm_search_max_keyed_length() { return FM_KEY_MAX_X; }
+
 int DeviceApi::search(void* stream, const DevIndex& idx, const u8* d_seq, const u32* d_scheme, const DevSeed* d_seeds, u32 n_seeds,
-                      u32 max_hits_per_seed, DevFrame* d_stack, DevHit* d_hits, u32 hit_cap, u32* d_counters, u32* d_seed_cnt) {
+                      u32 max_hits_per_seed, u32 frame_levels, DevFrame* d_stack, DevHit* d_hits, u32 hit_cap, u32* d_counters, u32* d_seed_cnt) {
     if (n_seeds == 0) return 0;
     u32 const spw = fm_seeds_per_wave();
-    hipLaunchKernelGGL(fm_search_kernel, dim3(std::min<u32>((n_seeds + spw - 1) / spw, FM_MAX_WAVES)), dim3(64), 0, (hipStream_t)stream, idx, d_seq, d_scheme, d_seeds,
-                       n_seeds, max_hits_per_seed, d_stack, d_hits, hit_cap, d_counters, d_seed_cnt);
+    dim3 const grid(std::min<u32>((n_seeds + spw - 1) / spw, fm_max_waves()));
+    if (d_stack)      // the reference's DFS order, stack in HBM
+        hipLaunchKernelGGL(fm_search_ordered_kernel, grid, dim3(64), 0, (hipStream_t)stream, idx, d_seq, d_scheme, d_seeds, n_seeds,
+                           max_hits_per_seed, d_stack, d_hits, hit_cap, d_counters, d_seed_cnt);
+    else {
+        u32 const levels = std::max(1u, frame_levels);
+        size_t const lds = (size_t)levels * FM_FRAME_WORDS * 64 * sizeof(u32);
+        hipLaunchKernelGGL(fm_search_kernel, grid, dim3(64), lds, (hipStream_t)stream, idx, d_seq, d_scheme, d_seeds, n_seeds,
+                           max_hits_per_seed, levels, d_hits, hit_cap, d_counters, d_seed_cnt);
+    }
     return (int)hipGetLastError();
 }
 
@@ -623,6 +843,22 @@ __global__ void __launch_bounds__(256) hit_scatter_kernel(const DevHit* __restri
         u32 const ordinal = h.errors >> 8;
         h.errors &= 0xFFu;
         grouped[offset[h.seed] + ordinal] = h;
+    }
+}
+
+// the hits of every seed the device selects for (at most SEL_MAX hits) into the reference's emission order (keys of
+// fm_search_kernel); one thread per seed, stable. Longer segments are left as they are: the host sorts the ones it looks at.
+__global__ void __launch_bounds__(256) seed_sort_kernel(DevHit* __restrict__ grouped, const u32* __restrict__ hit_offset, u32 n_seeds) {
+    u32 const sid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (sid >= n_seeds) return;
+    u32 const g0 = hit_offset[sid], cnt = hit_offset[sid + 1] - g0;
+    if (cnt < 2u || cnt > 64u) return;
+    DevHit* __restrict__ g = grouped + g0;
+    for (u32 i = 1; i < cnt; ++i) {
+        DevHit const v = g[i];
+        u32 j = i;
+        while (j > 0 && v.key < g[j - 1].key) { g[j] = g[j - 1]; --j; }
+        if (j != i) g[j] = v;
     }
 }
 
@@ -756,13 +992,14 @@ size_t DeviceApi::select_scan_bytes(u32 n_seeds) {
 int DeviceApi::select(void* stream, const DevHit* d_hits, const u32* d_counters, u32 hit_cap, u32* d_seed_cnt, u32* d_hit_offset,
                       DevHit* d_grouped, u32 n_seeds, const DevIndex& idx, const u64* d_seq_start, u32 n_ref, u32 hard_cap, u32 soft_cap,
                       bool erase, void* d_stat, u32* d_n_out, u32* d_out_offset, DevOutAnchor* d_out, u32 out_cap, u32* d_rows,
-                      u32* d_row_offset, DevOutAnchor* d_sparse, u32 sparse_cap, void* d_scan_tmp, size_t scan_bytes) {
+                      u32* d_row_offset, DevOutAnchor* d_sparse, u32 sparse_cap, void* d_scan_tmp, size_t scan_bytes, bool sort_by_key) {
     if (n_seeds == 0) return 0;
     hipStream_t s = (hipStream_t)stream;
     // d_seed_cnt, d_rows and d_n_out have n_seeds + 1 entries, the last one zero: the scans end with the totals
     hipError_t e = hipcub::DeviceScan::ExclusiveSum(d_scan_tmp, scan_bytes, d_seed_cnt, d_hit_offset, (int)n_seeds + 1, s);
     if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL(hit_scatter_kernel, dim3(2048), dim3(256), 0, s, d_hits, d_counters, hit_cap, d_hit_offset, d_grouped);
+    if (sort_by_key) hipLaunchKernelGGL(seed_sort_kernel, dim3((n_seeds + 255) / 256), dim3(256), 0, s, d_grouped, d_hit_offset, n_seeds);
     hipLaunchKernelGGL(seed_rows_kernel, dim3((n_seeds + 255) / 256), dim3(256), 0, s, d_grouped, d_hit_offset, n_seeds, hard_cap, soft_cap, d_rows);
     if ((e = hipGetLastError()) != hipSuccess) return (int)e;
     e = hipcub::DeviceScan::ExclusiveSum(d_scan_tmp, scan_bytes, d_rows, d_row_offset, (int)n_seeds + 1, s);
@@ -1507,10 +1744,219 @@ __global__ void __launch_bounds__(64) ed_traceback_ckpt_kernel(const u8* __restr
     }
 }
 
+// ------------------------------------------------------------------------------------------------ K5: traceback over a checkpointed trace, one wave per job
+// The walk is serial, the recomputation of the trace is not: a path moves up its diagonal and drifts from it by one column per
+// indel only, so the (word, 16-step block) windows it is going to cross are known in advance. A round therefore recomputes 64
+// windows at once, one per lane: for each of the 8 words at and above the walker the 8 blocks around the steps the path's
+// current diagonal crosses in that word (exactly one checkpoint + one carry word + 16 steps each; the old form recomputed up to
+// 31 steps per window with one lane per job and all lanes of a wave waiting for each other). Then the wave walks: lane l looks at
+// cell (i - l, j - l), ballots give the stretch of diagonal moves up to the first indel, and the walk goes on until it needs a
+// window the round does not hold (the path drifted further than foreseen, or left the 8 words), which starts the next round from
+// where the walker stands. ~20 rounds for a 10-kb path instead of ~700 dependent window recomputations.
+constexpr u32 TBW_WORDS = 8, TBW_BLOCKS = 8;     // windows of a round: words x blocks = 64 lanes
+constexpr u32 TBW_REF = 1024;                    // reference symbols cached per round (columns)
+
+__global__ void __launch_bounds__(64) ed_traceback_wave_kernel(const u8* __restrict__ text, const u64* __restrict__ peq,
+                                                               const u64* __restrict__ trace, const DevTraceJob* __restrict__ jobs,
+                                                               u32 n_jobs, u32* __restrict__ cigar, DevTraceOut* __restrict__ out) {
+    static_assert(TRACE_CKPT == 16 && TRACE_CARRY_STEPS == 16, "a window is one checkpoint block");
+    __shared__ ulonglong2 win[64 * 17];              // [window * 17 + step % 16] = {hp, vp} of the window's word after that step (17: no bank conflicts)
+    __shared__ u32 win_valid[64];                    // bit s: step s of the window was computed
+    __shared__ u64 eqm[TBW_WORDS][6];                // equality masks of the round's words
+    __shared__ u8 refs[TBW_REF];                     // reference symbols of columns [ref_base, ref_base + TBW_REF)
+    u32 const id = blockIdx.x;
+    if (id >= n_jobs) return;
+    u32 const lane = threadIdx.x & 63u;
+    DevTraceJob const job = jobs[id];
+    const u8* __restrict__ r = text + job.ref_off;
+    u32* __restrict__ slab = cigar + job.cigar_off;
+    int const W = (int)job.words_per_lane, R = (int)job.lanes;
+    int const n = (int)job.n, m = (int)job.m, k = (int)job.k;
+    int const band_hi = n - m + k;
+    TraceLayout const tl = ckpt_trace_layout(job.n, job.m ? job.m : 1u, (u32)W, (u32)R);
+    const u32* __restrict__ carry = reinterpret_cast<const u32*>(reinterpret_cast<const ulonglong2*>(trace) + job.trace_off);
+    const ulonglong2* __restrict__ ckpt = reinterpret_cast<const ulonglong2*>(trace) + job.trace_off + tl.carry_slots;
+
+    u32 wpos = job.cigar_cap;
+    int i = m, j = (int)job.end_col;                 // wave-uniform walker position
+    u32 cur_op = 0xFFu, cur_len = 0;
+    bool overflow = false;
+    auto emit = [&](u32 op, u32 len) {               // wave-uniform run-length merge; lane 0 stores
+        if (len == 0) return;
+        if (op == cur_op) { cur_len += len; return; }
+        if (cur_len) {
+            if (wpos == 0) overflow = true;
+            else { --wpos; if (lane == 0) slab[wpos] = (cur_len << 4) | cur_op; }
+        }
+        cur_op = op;
+        cur_len = len;
+    };
+    // first block of word w's windows in a round that started on diagonal `diag` (column - row): the path crosses the word's rows
+    // 64w+1 .. 64w+64 at columns row + diag, i.e. steps 64w + diag + g .. 64w + 63 + diag + g
+    auto first_block = [&](int w, int diag) {
+        int const g = w / W;
+        int const t_lo = 64 * w + diag + g;
+        return (t_lo >= 0 ? t_lo / 16 : -((-t_lo + 15) / 16)) - 1;
+    };
+
+    while (i > 0 && !overflow) {
+        if (j == 0) { emit(1u, (u32)i); i = 0; break; }                 // only insertions remain
+        // ---- a round: windows of words gw_top, gw_top-1, ... around the walker's diagonal
+        int const gw_top = (i - 1) >> 6;
+        int const diag = j - i;
+        // columns the round can touch: from 64 * TBW_WORDS + 32 below the walker's to 16 * TBW_BLOCKS above it
+        int const ref_base = max(0, j - 640);
+        __syncthreads();                                                // (one wave: orders this round's LDS writes after the last round's reads)
+        for (u32 x = lane; x < TBW_REF; x += 64u) { int const c = ref_base + (int)x; refs[x] = c < n ? r[c] : (u8)7; }
+        __syncthreads();
+        {
+            int const w = gw_top - (int)(lane / TBW_BLOCKS);
+            u32 valid = 0;
+            if (w >= 0) {
+                int const g = w / W, ww = w - g * W, p = g % R;
+                int const B = first_block(w, diag) + (int)(lane % TBW_BLOCKS);
+                int const r0 = 64 * W * g, r1 = min(m, r0 + 64 * W);
+                int const c_lo = max(0, r0 - k), c_hi = min(n - 1, r1 - 1 + band_hi);
+                int const t_first = c_lo + g, t_last = c_hi + g;
+                // equality masks of the word (the lane of the word's first window also keeps them for the walk)
+                u64 eq[6];
+                {
+                    u64 const a = job.q_off >> 6;
+                    u32 const sh = (u32)(job.q_off & 63u);
+                    int const rows_left = m - w * 64;
+#pragma unroll
+                    for (u32 sy = 0; sy < 6; ++sy) {
+                        u64 const lo = peq[(a + (u64)w) * 6 + sy];
+                        u64 const hi = peq[(a + (u64)w + 1) * 6 + sy];
+                        u64 v = sh ? (lo >> sh) | (hi << (64 - sh)) : lo;
+                        if (rows_left < 64) v &= (1ull << rows_left) - 1ull;
+                        eq[sy] = v;
+                    }
+                    if (lane % TBW_BLOCKS == 0) {
+#pragma unroll
+                        for (u32 sy = 0; sy < 6; ++sy) eqm[lane / TBW_BLOCKS][sy] = eq[sy];
+                    }
+                }
+                // the steps of the block the group is active in; all of their columns must be in the symbol cache (a step left
+                // out in the middle would spoil the ones after it)
+                int const s_lo = max(16 * B, t_first), s_hi = min(16 * B + 15, t_last);
+                if (B >= 0 && s_lo <= s_hi && (u64)B * 16 < tl.steps && s_lo - g >= ref_base && s_hi - g < ref_base + (int)TBW_REF) {
+                    u64 pv = ~0ull, mv = 0ull;
+                    if (t_first <= 16 * B) {                            // the group was running before the block: its checkpoint
+                        ulonglong2 const v = ckpt[((u64)B * R + p) * W + ww];
+                        pv = v.x;
+                        mv = v.y;
+                    }
+                    u32 const cw = carry[((u64)B * R + p) * W + ww];
+                    for (int t = s_lo; t <= s_hi; ++t) {
+                        u32 const sidx = (u32)t & 15u;
+                        u32 const cb = (cw >> (2u * sidx)) & 3u;
+                        u64 const c_hp = cb & 1u, c_hn = cb >> 1;
+                        u32 const rsym = refs[t - g - ref_base] & 7u;
+                        u64 const e = rsym == 0 ? eq[0] : rsym == 1 ? eq[1] : rsym == 2 ? eq[2] : rsym == 3 ? eq[3] : rsym == 4 ? eq[4] : rsym == 5 ? eq[5] : 0ull;
+                        u64 const x_ = e | mv;
+                        u64 const sum = pv + (x_ & pv) + c_hn;
+                        u64 const d0 = (sum ^ pv) | x_;
+                        u64 const hn = pv & d0;
+                        u64 const hp = mv | ~(pv | d0);
+                        u64 const xh = (hp << 1) | c_hp;
+                        mv = xh & d0;
+                        pv = (hn << 1) | ~(xh | d0) | c_hn;
+                        ulonglong2 o;
+                        o.x = hp;
+                        o.y = pv;
+                        win[lane * 17u + sidx] = o;
+                        valid |= 1u << sidx;
+                    }
+                }
+            }
+            win_valid[lane] = valid;
+        }
+        __syncthreads();
+        // ---- walk while the round's windows cover the walker
+        bool progressed = false;
+        while (i > 0 && !overflow) {
+            if (j == 0) break;
+            // lane l looks at cell (i - l, j - l)
+            bool const in_range = (int)lane < i && (int)lane < j;
+            bool have = false, up = false, left = false, same = false;
+            if (in_range) {
+                int const ci = i - (int)lane, cj = j - (int)lane;
+                int const w = (ci - 1) >> 6;
+                u32 const bit = (u32)(ci - 1) & 63u;
+                int const g = w / W;
+                int const t = (cj - 1) + g;
+                int const wslot = gw_top - w;
+                int const bslot = (t >> 4) - first_block(w, diag);
+                int const col = cj - 1 - ref_base;
+                if (wslot < (int)TBW_WORDS && bslot >= 0 && bslot < (int)TBW_BLOCKS && col >= 0) {
+                    u32 const slot = (u32)wslot * TBW_BLOCKS + (u32)bslot;
+                    if ((win_valid[slot] >> ((u32)t & 15u)) & 1u) {
+                        have = true;
+                        ulonglong2 const v = win[slot * 17u + ((u32)t & 15u)];
+                        up = (v.y >> bit) & 1ull;
+                        left = (v.x >> bit) & 1ull;
+                        u32 const rsym = refs[col] & 7u;
+                        same = rsym < 6u && ((eqm[wslot][rsym] >> bit) & 1ull);
+                    }
+                }
+            }
+            u64 const m_range = __ballot(in_range);
+            u64 const m_have = __ballot(have);
+            u64 const m_miss = m_range & ~m_have;
+            u32 const n_range = (u32)__popcll(m_range);                     // cells on this diagonal (contiguous from lane 0)
+            u32 const n_have = m_miss ? (u32)__builtin_ctzll(m_miss) : n_range;   // cells from lane 0 up to the first one without a window
+            if (n_have == 0) break;                                         // the walker's own cell is not covered: next round
+            u64 const m_indel = __ballot(up || left) & m_have;
+            u64 const m_eq = __ballot(same);
+            u32 n_diag = m_indel ? (u32)__builtin_ctzll(m_indel) : 64u;     // diagonal cells before the first indel
+            bool const take_indel = n_diag < n_have;
+            if (n_diag > n_have) n_diag = n_have;
+            // run-length encode the diagonal stretch [0, n_diag)
+            u32 pos = 0;
+            while (pos < n_diag) {
+                bool const is_eq = (m_eq >> pos) & 1ull;
+                u64 const sm = is_eq ? m_eq : ~m_eq;
+                u64 const rest = ~(sm >> pos);                              // first position (relative) where the kind changes
+                u32 run = rest ? (u32)__builtin_ctzll(rest) : 64u - pos;
+                if (run > n_diag - pos) run = n_diag - pos;
+                emit(is_eq ? 7u : 8u, run);
+                pos += run;
+            }
+            i -= (int)n_diag;
+            j -= (int)n_diag;
+            if (take_indel) {
+                // the cell at lane n_diag takes an indel: up (I) has priority over left (D)
+                bool const is_up = __shfl((int)up, (int)n_diag) != 0;
+                if (is_up) { emit(1u, 1u); --i; }
+                else { emit(2u, 1u); --j; }
+            }
+            progressed = true;
+        }
+        if (!progressed && i > 0 && j > 0 && !overflow) { overflow = true; }   // (cannot happen: the walker's window is always in its own round)
+    }
+    if (!overflow && cur_len) {
+        if (wpos == 0) overflow = true;
+        else { --wpos; if (lane == 0) slab[wpos] = (cur_len << 4) | cur_op; }
+    }
+    if (lane == 0) {
+        DevTraceOut o;
+        o.begin = (u32)j;
+        o.cigar_start = wpos;
+        o.cigar_len = overflow ? 0xFFFFFFFFu : job.cigar_cap - wpos;
+        o.pad = 0;
+        out[job.out_index] = o;
+    }
+}
+
 int DeviceApi::traceback(void* stream, const u8* d_text, const u8* d_query, const u64* d_peq, const u64* d_trace, const DevTraceJob* d_jobs,
                          u32 n_jobs, bool checkpointed, u32* d_cigar, DevTraceOut* d_out) {
     if (n_jobs == 0) return 0;
-    if (checkpointed)
+    static int const lane_per_job = getenv("FLX_TB_LANE_PER_JOB") ? 1 : 0;      // A/B: the round-1 form
+    if (checkpointed && !lane_per_job)
+        hipLaunchKernelGGL(ed_traceback_wave_kernel, dim3(n_jobs), dim3(64), 0, (hipStream_t)stream, d_text, d_peq, d_trace, d_jobs, n_jobs,
+                           d_cigar, d_out);
+    else if (checkpointed)
         hipLaunchKernelGGL(ed_traceback_ckpt_kernel, dim3((n_jobs + 63) / 64), dim3(64), 0, (hipStream_t)stream, d_text, d_query, d_peq,
                            d_trace, d_jobs, n_jobs, d_cigar, d_out);
     else

@@ -2,8 +2,8 @@
 // Replaces fmindex(refs, sampling_rate, threads) (floxer.cpp:93-97; fmindex.hpp:7-10 = BiFMIndex<EprV2_16<6>>).
 //
 // Layout decisions (MI355X-first, not the reference's EPR layout):
-//  * occurrence tables as 64-byte blocks over 64 BWT positions (absolute u32 counts + 3 bit-planes): a rank query is one
-//    64-byte block, 1 B per text symbol and direction (hg38: 3.1 GB per direction);
+//  * occurrence tables as 32-byte blocks over 32 BWT positions (absolute u32 counts + 3 bit-planes): a rank query is one
+//    32-byte block, 2 B per text symbol and direction (hg38: 6.2 GB per direction);
 //  * the FULL suffix array as u32 (4 B per symbol, 12.4 GB for hg38 out of 288 GB HBM) instead of a sampled one:
 //    locate() becomes one 4-byte gather with no LF walk. The result is identical to BiFMIndex::locate because both return
 //    SA[row] split into (sequence, offset).
@@ -137,19 +137,17 @@ void build_occ_blocks(const std::vector<u8>& bwt, std::vector<OccBlock>& blocks)
     u32 cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     for (u64 b = 0; b < nb; ++b) {
         OccBlock& blk = blocks[b];
-        for (int c = 0; c < 6; ++c) blk.w[c] = cnt[c];
-        for (int j = 0; j < 2; ++j) {                   // 32-position half j of the three planes
-            u32 p0 = 0, p1 = 0, p2 = 0;
-            for (int k = 0; k < 32; ++k) {
-                u64 const pos = b * OCC_BLOCK_POS + (u64)j * 32 + k;
-                u8 const sym = pos < n ? bwt[pos] : 7;
-                p0 |= (u32)(sym & 1) << k;
-                p1 |= (u32)((sym >> 1) & 1) << k;
-                p2 |= (u32)((sym >> 2) & 1) << k;
-                if (pos < n) cnt[sym]++;
-            }
-            blk.w[6 + j] = p0; blk.w[8 + j] = p1; blk.w[10 + j] = p2;
+        for (int c = 0; c < 5; ++c) blk.w[c] = cnt[c];
+        u32 p0 = 0, p1 = 0, p2 = 0;
+        for (u32 k = 0; k < OCC_BLOCK_POS; ++k) {
+            u64 const pos = b * OCC_BLOCK_POS + k;
+            u8 const sym = pos < n ? bwt[pos] : 7;
+            p0 |= (u32)(sym & 1) << k;
+            p1 |= (u32)((sym >> 1) & 1) << k;
+            p2 |= (u32)((sym >> 2) & 1) << k;
+            if (pos < n) cnt[sym]++;
         }
+        blk.w[5] = p0; blk.w[6] = p1; blk.w[7] = p2;
     }
 }
 
@@ -157,12 +155,12 @@ void build_occ_blocks(const std::vector<u8>& bwt, std::vector<OccBlock>& blocks)
 void host_rank_all(const std::vector<OccBlock>& tab, u64 i, u64 out[6]) {
     OccBlock const& b = tab[i / OCC_BLOCK_POS];
     u32 const off = (u32)(i % OCC_BLOCK_POS);
-    for (int c = 0; c < 6; ++c) out[c] = b.w[c];
+    for (int c = 0; c < 5; ++c) out[c] = b.w[c];
     for (u32 k = 0; k < off; ++k) {
-        u32 const j = k >> 5, bit = k & 31;
-        u32 const sym = ((b.w[6 + j] >> bit) & 1) | (((b.w[8 + j] >> bit) & 1) << 1) | (((b.w[10 + j] >> bit) & 1) << 2);
-        if (sym < 6) out[sym]++;
+        u32 const sym = ((b.w[5] >> k) & 1) | (((b.w[6] >> k) & 1) << 1) | (((b.w[7] >> k) & 1) << 2);
+        if (sym < 5) out[sym]++;
     }
+    out[5] = i - (out[0] + out[1] + out[2] + out[3] + out[4]);
 }
 
 // cursor of every KMER_Q-mer, built level by level with BiFMIndexCursor::extendRight semantics
@@ -247,7 +245,7 @@ HostIndex* build_host_index(const u8* concat, const u64* lens, u32 n_refs, int h
 
 // ---------------------------------------------------------------- own index file format (replaces the cereal archive)
 namespace {
-constexpr char MAGIC[8] = {'F', 'L', 'X', 'I', 'D', 'X', '0', '4'};
+constexpr char MAGIC[8] = {'F', 'L', 'X', 'I', 'D', 'X', '0', '5'};
 template <class T> bool wr(FILE* f, const std::vector<T>& v) {
     u64 const n = v.size();
     return fwrite(&n, 8, 1, f) == 1 && (n == 0 || fwrite(v.data(), sizeof(T), n, f) == n);

@@ -39,17 +39,17 @@ struct PoolAlloc {
 template <class T> using hvec = std::vector<T, PoolAlloc<T>>;
 
 // ------------------------------------------------------------------------------------------------ HBM data layout
-// Occurrence table block: 64 BWT positions in one 64-byte block = the unit SURVEY.md section 8(d) prices a rank query at (one
-// 64-symbol block incl. its counters per position), 1 byte of HBM per text symbol and direction (hg38: 3.1 GB per direction out
-// of 288 GB). One lane serves one seed and reads the 48 used bytes of a block with three 16-byte loads:
-//   w[0..5]   cnt[c] = number of symbol c in bwt[0, 64*b), absolute (text < 2^32 symbols)
-//   w[6..11]  bit-planes of the 64 positions: p0.lo, p0.hi, p1.lo, p1.hi, p2.lo, p2.hi (plane k = bit k of the symbol, lo = positions
-//             0..31; symbols 0..5, positions past the end of the text filled with 7)
-//   w[12..15] unused
-struct alignas(64) OccBlock {
-    u32 w[16];
+// Occurrence table block: 32 BWT positions in 32 bytes, 2 bytes of HBM per text symbol and direction (hg38: 6.2 GB per direction
+// out of 288 GB). One lane serves one seed and reads a block with two 16-byte loads (a third load per block was what bound the
+// kernel: the L1's miss handling, not HBM; scripts/micro/gather_cost.hip), four blocks share a 128-byte line:
+//   w[0..4]  cnt[c] = number of symbol c in bwt[0, 32*b) for c = 0..4, absolute (text < 2^32 symbols); the count of symbol 5 (N)
+//            is the position minus the other five
+//   w[5..7]  bit-planes of the 32 positions: p0, p1, p2 (plane k = bit k of the symbol; symbols 0..5, positions past the end of
+//            the text filled with 7)
+struct alignas(32) OccBlock {
+    u32 w[8];
 };
-constexpr u32 OCC_BLOCK_POS = 64;
+constexpr u32 OCC_BLOCK_POS = 32;
 constexpr u32 TEXT_PAD = 128;     // bytes of padding in front of and behind the device copy of a reference text
 
 struct HostIndex {
@@ -103,7 +103,10 @@ struct DevFrame {       // 64 bytes: one branching node of the DFS, written when
 };
 static_assert(sizeof(DevFrame) == 64, "frame is four 16-byte slots");
 
-struct DevHit { u32 seed, lb, len, errors; };
+// errors: bits 0..7 the hit's error count, bits 8.. its ordinal among the hits of its seed in the order the kernel found them.
+// key: position of the hit in search_n's emission order among the hits of its seed (see fm_search_kernel; 0 from the ordered kernel,
+// whose ordinals are the emission order already)
+struct DevHit { u32 seed, lb, len, errors; u64 key; };
 struct DevOutAnchor { u32 seed_index, leaf, ref_id, errors; u64 pos; };   // = HostAnchor (leaf is filled by the host)
 
 // ------------------------------------------------------------------------------------------------ K3/K4: alignment
@@ -158,6 +161,7 @@ FLX_HD inline TraceLayout ckpt_trace_layout(u32 n, u32 m, u32 W, u32 R) {
 AlignShape choose_align_shape(u32 n, u32 m, u32 k, bool parallel = false);
 u64 align_trace_slots(u32 n, u32 m, AlignShape sh);     // 16-byte trace slots a TRACE launch of this shape needs for one job
 u32 align_supported_max_query();
+u32 fm_search_max_keyed_length();
 
 // ------------------------------------------------------------------------------------------------ device launchers (flx_device.hip)
 struct KernelTimer;   // opaque, owned by the context
@@ -170,10 +174,13 @@ struct DeviceApi {
     // device; all outputs on the host
     static int index_arrays(int hip_device, const u8* text, u64 n, u32* out_sa, u8* out_bwt0, u8* out_bwt1, OccBlock* out_occ0, OccBlock* out_occ1);
     static int build_peq(void* stream, const u8* d_seq, u64 len, u64* d_peq);
-    // d_seed_cnt (may be null): number of hits of every seed; each hit then carries its ordinal within its seed in errors >> 8
+    // d_seed_cnt (may be null): number of hits of every seed; each hit then carries its ordinal within its seed in errors >> 8.
+    // d_stack == nullptr: the DFS with error children first and its frames in LDS (frame_levels = largest error count of a seed;
+    // hits carry keys that restore the emission order; every seed shorter than fm_search_max_keyed_length()); else the DFS in the
+    // reference's order with DevSeed::stack_off / frames into d_stack.
     static int search(void* stream, const DevIndex& idx, const u8* d_seq, const u32* d_scheme, const DevSeed* d_seeds,
-                      u32 n_seeds, u32 max_hits_per_seed, DevFrame* d_stack, DevHit* d_hits, u32 hit_cap, u32* d_counters,
-                      u32* d_seed_cnt = nullptr);
+                      u32 n_seeds, u32 max_hits_per_seed, u32 frame_levels, DevFrame* d_stack, DevHit* d_hits, u32 hit_cap,
+                      u32* d_counters, u32* d_seed_cnt = nullptr);
     // anchor selection on the device (see seed_select_kernel). d_seed_cnt, d_hit_offset, d_n_out, d_out_offset: n_seeds + 1 entries
     // (the caller zeroes the last entry of d_seed_cnt and d_n_out); d_stat: 4 bytes per seed {useful, raw, flag, excluded};
     // d_grouped: as many entries as d_hits; d_out: one entry per selected anchor (at most the number of rows of the handled seeds)
@@ -181,7 +188,7 @@ struct DeviceApi {
     static int select(void* stream, const DevHit* d_hits, const u32* d_counters, u32 hit_cap, u32* d_seed_cnt, u32* d_hit_offset,
                       DevHit* d_grouped, u32 n_seeds, const DevIndex& idx, const u64* d_seq_start, u32 n_ref, u32 hard_cap, u32 soft_cap,
                       bool erase, void* d_stat, u32* d_n_out, u32* d_out_offset, DevOutAnchor* d_out, u32 out_cap, u32* d_rows,
-                      u32* d_row_offset, DevOutAnchor* d_sparse, u32 sparse_cap, void* d_scan_tmp, size_t scan_bytes);
+                      u32* d_row_offset, DevOutAnchor* d_sparse, u32 sparse_cap, void* d_scan_tmp, size_t scan_bytes, bool sort_by_key);
     static int locate(void* stream, const DevIndex& idx, const u32* d_rows, u32 n, u32* d_out);
     // d_lastrow (banded TRACE launches only, may be null): D[m][c] of every computed column c, 0xFFFF elsewhere (pre-filled by the caller)
     static int align(void* stream, const u8* d_text, const u64* d_peq, const DevAlignJob* d_jobs, u32 n_jobs, AlignShape shape,

@@ -263,8 +263,11 @@ int search_seeds_device(Lane* ctx, const u8* d_seq_pool_or_null, const u8* h_seq
     hvec<u32> scheme_table;
     hvec<DevSeed> dseeds(n_seeds);
     u64 frames = 0;
+    u32 max_errors = 0, max_length = 0;
     for (u64 i = 0; i < n_seeds; ++i) {
         flx_seed const& s = seeds[i];
+        max_errors = std::max(max_errors, s.num_errors);
+        max_length = std::max(max_length, s.length);
         if (s.num_errors > 3) { set_error("seed errors must be in [0,3] (floxer_cli.cpp:299)"); return FLX_ERR_INVALID; }
         if (s.length == 0 || s.length > SCH_POS_MASK || s.seq_offset + s.length > pool_len) { set_error("seed outside the sequence pool"); return FLX_ERR_INVALID; }
         auto key = std::make_pair(s.length, s.num_errors);
@@ -331,7 +334,12 @@ int search_seeds_device(Lane* ctx, const u8* d_seq_pool_or_null, const u8* h_seq
     }
     if ((rc = h2d(ctx, ctx->scheme, scheme_table.data(), scheme_table.size() * 4))) return rc;
     if ((rc = h2d(ctx, ctx->seeds, dseeds.data(), dseeds.size() * sizeof(DevSeed)))) return rc;
-    if ((rc = ctx->stack.ensure(frames * sizeof(DevFrame)))) return rc;
+    // The DFS in the reference's order (frames on a per-seed stack in HBM) where the order of discovery matters: the raw-emission
+    // hook and first_reported, which want the first n rows; everywhere else the walk with its stack in LDS, whose hits carry keys
+    // that restore the emission order.
+    bool const ordered = raw_hits || cfg.anchor_choice_strategy == FLX_CHOICE_FIRST_REPORTED || max_length > fm_search_max_keyed_length() ||
+                         max_errors > 3 || getenv("FLX_FM_ORDERED");
+    if (ordered && (rc = ctx->stack.ensure(frames * sizeof(DevFrame)))) return rc;
     if ((rc = ctx->counters.ensure(64))) return rc;
 
     u32 const max_hits = raw_hits ? (u32)std::min<u64>(raw_max_hits, 0xFFFFFFF0u)
@@ -376,7 +384,7 @@ int search_seeds_device(Lane* ctx, const u8* d_seq_pool_or_null, const u8* h_seq
         }
         rc = timed_launch(ctx, "fm_search", 0, n_seeds, [&] {
             return DeviceApi::search(ctx->stream, ctx->ctx->didx, d_seq, ctx->scheme.as<u32>(), ctx->seeds.as<DevSeed>(), (u32)n_seeds,
-                                     max_hits, ctx->stack.as<DevFrame>(), ctx->hits.as<DevHit>(), (u32)std::min<u64>(hit_cap, 0xFFFFFFFFu),
+                                     max_hits, max_errors, ordered ? ctx->stack.as<DevFrame>() : nullptr, ctx->hits.as<DevHit>(), (u32)std::min<u64>(hit_cap, 0xFFFFFFFFu),
                                      ctx->counters.as<u32>(), device_select ? ctx->seed_cnt.as<u32>() : nullptr);
         });
         if (rc) return rc;
@@ -388,7 +396,7 @@ int search_seeds_device(Lane* ctx, const u8* d_seq_pool_or_null, const u8* h_seq
                                          (u32)std::min<u64>(cfg.max_num_anchors_soft, 0xFFFFFFFFu), cfg.erase_useless_anchors != 0, ctx->sel_stat.ptr,
                                          ctx->sel_n.as<u32>(), ctx->sel_off.as<u32>(), ctx->sel_out.as<DevOutAnchor>(), (u32)std::min<u64>(sel_cap, 0xFFFFFFFFu),
                                          ctx->sel_rows.as<u32>(), ctx->sel_row_off.as<u32>(), ctx->sel_sparse.as<DevOutAnchor>(),
-                                         (u32)std::min<u64>(sel_cap, 0xFFFFFFFFu), ctx->sel_tmp.ptr, scan_bytes);
+                                         (u32)std::min<u64>(sel_cap, 0xFFFFFFFFu), ctx->sel_tmp.ptr, scan_bytes, !ordered);
             });
             if (rc) return rc;
         }
@@ -406,11 +414,12 @@ int search_seeds_device(Lane* ctx, const u8* d_seq_pool_or_null, const u8* h_seq
         if (counters[0] > hit_cap) hit_cap = (u64)counters[0] + hit_slack;      // the number of hits is known now; run again
         else sel_cap = (u64)sel_rows_total + 1024;
     }
-    // fold the extension count into the kernel's accounting: 2 rank positions of one 128-byte block each
+    // fold the extension count into the kernel's accounting: SURVEY.md 8(d) prices a cursor extension at 2 x 64 B (rank data at both
+    // ends of the interval), whatever the block size of this build
     if (ctx->ctx->timing) {
         std::lock_guard<std::mutex> g(ctx->ctx->mu);
         auto it = ctx->ctx->stats.find("fm_search");
-        if (it != ctx->ctx->stats.end()) { it->second.algorithmic_bytes += (u64)counters[2] * 2 * sizeof(OccBlock); it->second.work_units += counters[2]; }
+        if (it != ctx->ctx->stats.end()) { it->second.algorithmic_bytes += (u64)counters[2] * 128; it->second.work_units += counters[2]; }
     }
     sprof.mark("kernel");
     // ---- what the device selected; host_seed[si] != 0: this seed still goes through the host code
@@ -451,6 +460,11 @@ int search_seeds_device(Lane* ctx, const u8* d_seq_pool_or_null, const u8* h_seq
         by_seed.resize(first[n_seeds]);
         if ((rc = d2h(ctx, by_seed.data(), ctx->grouped.ptr, (size_t)first[n_seeds] * sizeof(DevHit)))) return rc;
         if ((rc = ctx->sync())) return rc;
+        // the segments the device did not put into emission order (more than SEL_MAX hits) and the host is going to look at
+        if (!ordered)
+            for (u64 si = 0; si < n_seeds; ++si)
+                if (host_seed[si] && first[si + 1] - first[si] > 64)
+                    std::stable_sort(by_seed.begin() + first[si], by_seed.begin() + first[si + 1], [](DevHit const& a, DevHit const& b) { return a.key < b.key; });
         sprof.mark("d2h-hits");
     } else {
         u32 const n_slots = counters[0];      // reserved slots; unused ones carry seed 0xFFFFFFFF
@@ -464,6 +478,11 @@ int search_seeds_device(Lane* ctx, const u8* d_seq_pool_or_null, const u8* h_seq
         by_seed.resize(first[n_seeds]);
         hvec<u32> cursor(first.begin(), first.end() - 1);
         for (auto const& h : hits) if (h.seed != 0xFFFFFFFFu) by_seed[cursor[h.seed]++] = h;
+        // into the reference's emission order (the keys of the walk with its stack in LDS; the ordered walk's hits are in it already)
+        if (!ordered)
+            for (u64 si = 0; si < n_seeds; ++si)
+                if (first[si + 1] - first[si] > 1)
+                    std::stable_sort(by_seed.begin() + first[si], by_seed.begin() + first[si + 1], [](DevHit const& a, DevHit const& b) { return a.key < b.key; });
     }
     if (raw_hits) { *raw_hits = std::move(by_seed); return FLX_OK; }
     hvec<u32> todo;                           // the seeds the host selects for, ascending
