@@ -36,7 +36,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=12)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--reads-per-step", type=int, default=int(os.environ.get("FLX_BENCH_READS", 8192)), help="per GPU")
+    ap.add_argument("--reads-per-step", type=int, default=int(os.environ.get("FLX_BENCH_READS", 16384)), help="per GPU")
     ap.add_argument("--lanes", type=int, default=int(os.environ.get("FLX_LANES", 0)),
                     help="concurrent lanes (stream + host thread) per GPU; 0 = one per host core this rank can use, 4..16")
     ap.add_argument("--inflight", type=int, default=int(os.environ.get("FLX_BENCH_INFLIGHT", 3)),
@@ -282,7 +282,7 @@ def main():
             "config": {"workload": f"{args.genome / 1e9:.1f} Gb uniform random reference in {args.chromosomes} sequences (GRCh38 size; hg38 itself is "
                                    f"not available offline) + {B} reads/GPU/step of {args.read_length} bp @ {args.error_rate:.0%} error "
                                    "(BASELINE.json configs[3] shape per GPU, the metric's configuration)",
-                       "reads_per_step_per_gpu": B, "mean_read_length": round(mean_len, 1), "cli_flags": "defaults (-s 2 -M 500 -m 50 "
+                       "genome": args.genome, "reads_per_step_per_gpu": B, "mean_read_length": round(mean_len, 1), "cli_flags": "defaults (-s 2 -M 500 -m 50 "
                        "-g count_first -y round_robin -v 0.05)" + (" -I" if args.interval_optimization else ""),
                        "lanes_per_gpu": args.lanes, "steps_in_flight": args.inflight, "parallelism": f"read-sharded x{world}, index replicated"},
             "gbases_per_s": round(value * mean_len / 1e9, 5), "records": n_records, "index_build_s": round(index_s, 2),

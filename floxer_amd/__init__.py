@@ -158,6 +158,14 @@ class context:
     def reset_kernel_stats(self):
         check(lib().flx_ctx_reset_kernel_stats(self.h))
 
+    def path_counters(self, reset=False):
+        """seeds / anchors / requested DP work of all batches since the context was made (or the counters were reset)"""
+        pc = capi.PathCounters()
+        check(lib().flx_ctx_get_path_counters(self.h, C.byref(pc)))
+        if reset:
+            check(lib().flx_ctx_reset_path_counters(self.h))
+        return {n: int(getattr(pc, n)) for n, _ in capi.PathCounters._fields_ if n != "reserved"}
+
     def kernel_stats(self):
         arr = (capi.KernelStat * 32)()
         n = C.c_uint32(32)

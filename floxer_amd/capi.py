@@ -69,6 +69,12 @@ class Record(C.Structure):
                 ("num_errors", C.c_uint32), ("cigar_offset", C.c_uint64), ("cigar_length", C.c_uint32), ("reserved", C.c_uint32)]
 
 
+class PathCounters(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in ("seeds", "seeds_with_anchors", "seeds_excluded_by_hard_cap", "seeds_selected_on_host", "anchors",
+                                          "cursor_extensions", "inner_tests_requested", "root_alignments_requested",
+                                          "root_alignments_found", "records", "reads")] + [("reserved", C.c_uint64 * 5)]
+
+
 class KernelStat(C.Structure):
     _fields_ = [("name", C.c_char * 32), ("launches", C.c_uint64), ("device_ms", C.c_double), ("algorithmic_bytes", C.c_uint64),
                 ("work_units", C.c_uint64)]
@@ -83,7 +89,8 @@ EXPORTED = [
     "flx_search_groups", "flx_align_batch", "flx_params_default", "flx_align_reads", "flx_reads_upload", "flx_reads_free",
     "flx_align_reads_resident", "flx_run_num_records",
     "flx_run_num_cigar_words", "flx_run_copy", "flx_run_free", "flx_ctx_enable_kernel_timing", "flx_ctx_reset_kernel_stats",
-    "flx_ctx_get_kernel_stats", "flx_sam_open", "flx_sam_write", "flx_sam_close", "flx_sim_genome", "flx_sim_reads",
+    "flx_ctx_get_kernel_stats", "flx_sam_open", "flx_sam_write", "flx_sam_close", "flx_sim_genome", "flx_sim_reads", "flx_ctx_get_path_counters",
+    "flx_ctx_reset_path_counters",
 ]
 
 _lib = None
@@ -147,6 +154,8 @@ def lib():
     L.flx_sam_open.argtypes = [C.c_char_p, C.POINTER(C.c_char_p), u64p, C.c_uint32, C.POINTER(C.c_void_p)]
     L.flx_sam_write.argtypes = [C.c_void_p, C.POINTER(C.c_char_p), u8p, u64p, C.POINTER(C.c_char_p), C.POINTER(Record), C.c_uint64, u32p]
     L.flx_sam_close.argtypes = [C.c_void_p]
+    L.flx_ctx_get_path_counters.argtypes = [C.c_void_p, C.POINTER(PathCounters)]
+    L.flx_ctx_reset_path_counters.argtypes = [C.c_void_p]
     L.flx_sim_genome.argtypes = [C.c_uint64, C.c_uint64, u8p]
     L.flx_sim_reads.argtypes = [u8p, u64p, C.c_uint32, C.c_uint64, C.c_uint32, C.c_double, C.c_double, C.c_uint64, u8p, C.c_uint64,
                                 u64p, u32p, u64p, u8p]

@@ -217,4 +217,17 @@ int flx_ctx_get_kernel_stats(flx_ctx* ctx, flx_kernel_stat* out, uint32_t* n) {
     return FLX_OK;
 }
 
+int flx_ctx_get_path_counters(flx_ctx* ctx, flx_path_counters* out) {
+    if (!ctx || !out) { set_error("null argument"); return FLX_ERR_INVALID; }
+    std::lock_guard<std::mutex> g(ctx->mu);
+    *out = ctx->path;
+    return FLX_OK;
+}
+int flx_ctx_reset_path_counters(flx_ctx* ctx) {
+    if (!ctx) { set_error("null context"); return FLX_ERR_INVALID; }
+    std::lock_guard<std::mutex> g(ctx->mu);
+    ctx->path = flx_path_counters{};
+    return FLX_OK;
+}
+
 }  // extern "C"

@@ -77,6 +77,7 @@ struct flx_ctx {
     bool timing = false;
     std::map<std::string, flx_kernel_stat> stats;
     std::vector<std::string> stat_order;
+    flx_path_counters path{};        // guarded by mu
 
     // lanes are handed out one holder at a time, so calls on one context may overlap (each waits for a free lane)
     std::mutex lane_mu;

@@ -279,7 +279,7 @@ __device__ __forceinline__ void rank5(const OccBlock* __restrict__ tab, u32 pos,
 }
 
 // both ends of the interval [lo, lo + nlen): cl[c] = rows of the child of symbol c (c = 0..5), ab[c] = its lower bound on the
-// extended side (c = 1..5; ab[0] is not used)
+// extended side (symbol 0, the sequence delimiter, is only ever a match child: a read holding the character '$', input.cpp:165-176)
 __device__ __forceinline__ void extend_all(const DevIndex& idx, const OccBlock* __restrict__ tab, u32 lo, u32 nlen, u32 ab[6], u32 cl[6]) {
     u32 ra[5], rb[5];
     rank5(tab, lo, ra);
@@ -288,7 +288,7 @@ __device__ __forceinline__ void extend_all(const DevIndex& idx, const OccBlock* 
 #pragma unroll
     for (u32 c = 0; c < 5; ++c) { cl[c] = rb[c] - ra[c]; sum_a += ra[c]; sum_l += cl[c]; }
     cl[5] = nlen - sum_l;
-    ab[0] = 0;
+    ab[0] = ra[0];                                                    // C[0] = 0
 #pragma unroll
     for (u32 c = 1; c < 5; ++c) ab[c] = idx.C[c] + ra[c];
     ab[5] = idx.C[5] + (lo - sum_a);
@@ -324,7 +324,7 @@ constexpr u32 FM_GRAB = 64;
 constexpr u32 FM_HIT_GRAB = 64;
 constexpr u32 FM_MAX_WAVES = 4096;
 constexpr u32 FM_SEEDS_PER_WAVE = 256;      // a launch has at most n_seeds / this many waves, so that every wave gets several ranges
-constexpr u32 FM_FRAME_WORDS = 17;          // LDS frame: oth[1..5], end, abs[1..5], lb, lb_rev, state, mask, key lo, key hi
+constexpr u32 FM_FRAME_WORDS = 18;          // LDS frame: oth[1..5], end, abs[1..5], lb, lb_rev, state, mask, key lo, key hi, abs[0]
 constexpr u32 FM_KEY_BITS = 18;             // per error edge: (0x3FFF - x) << 4 | child index
 constexpr u32 FM_KEY_MAX_X = 0x3FFFu;
 
@@ -416,6 +416,7 @@ __device__ __forceinline__ u32 fm_child_mask(const u32 cl[6], u32 next_sym, bool
             else if (match_allowed) mask |= 1u;
         }
     }
+    if (next_sym == 0u && match_allowed && cl[0] > 0u) mask |= 1u;      // a '$' of the query matches a sequence delimiter
     if (insertion) mask |= 1u << 11;
     return mask;
 }
@@ -512,9 +513,9 @@ __global__ void __launch_bounds__(64) fm_search_kernel(DevIndex idx, const u8* _
                 ne = pe + 1;
                 info = del ? INFO_D : INFO_S;
             }
-            // sym is 1..5 for every child (a match of 0 or of a symbol > 5 is never a child)
-            u32 const c_oth = fr(lv, sym - 1u), c_end = fr(lv, sym), c_abs = fr(lv, 5u + sym);
+            // sym is 1..5 for every child but the match of a '$' (symbol 0: its cursor starts where the node's does)
             u32 const p_lb = fr(lv, 11), p_lbr = fr(lv, 12);
+            u32 const c_oth = sym ? fr(lv, sym - 1u) : (right ? p_lb : p_lbr), c_end = fr(lv, sym), c_abs = fr(lv, sym ? 5u + sym : 17u);
             u64 const pkey = (u64)fr(lv, 15) | ((u64)fr(lv, 16) << 32);
             if (ci == 11) { nlb = p_lb; nlbr = p_lbr; nlen = fr(lv, 5) - (right ? p_lb : p_lbr); }
             else { nlen = c_end - c_oth; nlb = right ? c_oth : c_abs; nlbr = right ? c_abs : c_oth; }
@@ -566,14 +567,15 @@ __global__ void __launch_bounds__(64) fm_search_kernel(DevIndex idx, const u8* _
             fr(lv, 13) = st_pack(nx, ne, nli, nri, next_sym, right);
             fr(lv, 14) = mask;
             fr(lv, 15) = (u32)nkey; fr(lv, 16) = (u32)(nkey >> 32);
+            fr(lv, 17) = ab[0];
             ++depth;
             need_child = true;
         } else {
             // only an exact extension is possible: continue in place (no frame)
-            if (next_sym == 0u || next_sym > 5u) { need_child = true; continue; }       // the sentinel never matches
-            u32 clen = cl[1], cabs = ab[1], coth = other + cl[0];
+            if (next_sym > 5u) { need_child = true; continue; }
+            u32 clen = cl[0], cabs = ab[0], coth = other;
 #pragma unroll
-            for (u32 c = 2; c < 6; ++c) {
+            for (u32 c = 1; c < 6; ++c) {
                 coth += c <= next_sym ? cl[c - 1u] : 0u;
                 bool const take = c == next_sym;
                 clen = take ? cl[c] : clen;
@@ -602,7 +604,7 @@ __global__ void __launch_bounds__(64) fm_search_ordered_kernel(DevIndex idx, con
                                                                const DevSeed* __restrict__ seeds, u32 n_seeds, u32 max_hits,
                                                                DevFrame* __restrict__ stack, DevHit* __restrict__ hits, u32 hit_cap,
                                                                u32* __restrict__ counters, u32* __restrict__ seed_cnt) {
-    __shared__ uint4 child[5][64];              // top frame: {abs, oth, len, -} of the child cursor of symbol s+1, per lane
+    __shared__ uint4 child[6][64];              // top frame: {abs, oth, len, -} of the child cursor of symbol s+1 (entry 5: symbol 0), per lane
     u32 q_next = 0, q_end = 0;
     bool queue_done = false;
     u32 h_next = 0, h_end = 0;
@@ -678,16 +680,19 @@ __global__ void __launch_bounds__(64) fm_search_ordered_kernel(DevIndex idx, con
                 --depth;
                 const uint4* __restrict__ g = stk + (depth - 1u) * 4u;
                 uint4 const v0 = g[0], v1 = g[1], v2 = g[2], v3 = g[3];
-                f_lb = v2.w; f_lbr = v3.x; f_len = v3.y; f_state = v3.z;
+                f_lb = v2.w; f_lbr = v3.x; f_state = v3.z;
                 f_mask = v3.w;                                             // never empty: see where frames are made
                 // bounds of the children on the other side: prefix sums of their lengths, symbol 0 first
-                u32 const o1 = (ST_RIGHT(f_state) ? f_lb : f_lbr) + v1.y;
+                u32 const o0 = ST_RIGHT(f_state) ? f_lb : f_lbr;
+                u32 const o1 = o0 + v1.y;
                 u32 const o2 = o1 + v1.z, o3 = o2 + v1.w, o4 = o3 + v2.x, o5 = o4 + v2.y;
+                f_len = o5 + v2.z - o0;                                    // the children's rows are the node's
                 child[0][lane] = uint4{v0.x, o1, v1.z, 0u};
                 child[1][lane] = uint4{v0.y, o2, v1.w, 0u};
                 child[2][lane] = uint4{v0.z, o3, v2.x, 0u};
                 child[3][lane] = uint4{v0.w, o4, v2.y, 0u};
                 child[4][lane] = uint4{v1.x, o5, v2.z, 0u};
+                child[5][lane] = uint4{v3.y, o0, v1.y, 0u};
             }
             u32 const ci = (u32)__ffs((int)f_mask) - 1u;
             f_mask &= f_mask - 1u;
@@ -704,7 +709,7 @@ __global__ void __launch_bounds__(64) fm_search_ordered_kernel(DevIndex idx, con
                 ne = pe + 1;
                 info = del ? INFO_D : INFO_S;
             }
-            uint4 const c = child[sym - 1u][lane];                         // sym is 1..5 for every child
+            uint4 const c = child[sym ? sym - 1u : 5u][lane];              // sym is 1..5 for every child but the match of a '$'
             if (ci == 11) { nlb = f_lb; nlbr = f_lbr; nlen = f_len; }
             else { nlen = c.z; nlb = right ? c.y : c.x; nlbr = right ? c.x : c.y; }
             nli = right ? ST_LI(st) : info;
@@ -755,7 +760,7 @@ __global__ void __launch_bounds__(64) fm_search_ordered_kernel(DevIndex idx, con
             g[0] = uint4{ab[1], ab[2], ab[3], ab[4]};
             g[1] = uint4{ab[5], cl[0], cl[1], cl[2]};
             g[2] = uint4{cl[3], cl[4], cl[5], nlb};
-            g[3] = uint4{nlbr, nlen, f_state, f_mask};
+            g[3] = uint4{nlbr, ab[0], f_state, f_mask};
             ++depth;
             u32 const o1 = other + cl[0], o2 = o1 + cl[1], o3 = o2 + cl[2], o4 = o3 + cl[3], o5 = o4 + cl[4];
             child[0][lane] = uint4{ab[1], o1, cl[1], 0u};
@@ -763,13 +768,14 @@ __global__ void __launch_bounds__(64) fm_search_ordered_kernel(DevIndex idx, con
             child[2][lane] = uint4{ab[3], o3, cl[3], 0u};
             child[3][lane] = uint4{ab[4], o4, cl[4], 0u};
             child[4][lane] = uint4{ab[5], o5, cl[5], 0u};
+            child[5][lane] = uint4{ab[0], other, cl[0], 0u};
             need_child = true;
         } else {
             // only an exact extension is possible: continue in place (no frame)
-            if (next_sym == 0u || next_sym > 5u) { need_child = true; continue; }       // the sentinel never matches
-            u32 clen = cl[1], cabs = ab[1], coth = other + cl[0];
+            if (next_sym > 5u) { need_child = true; continue; }
+            u32 clen = cl[0], cabs = ab[0], coth = other;
 #pragma unroll
-            for (u32 c = 2; c < 6; ++c) {
+            for (u32 c = 1; c < 6; ++c) {
                 coth += c <= next_sym ? cl[c - 1u] : 0u;
                 bool const take = c == next_sym;
                 clen = take ? cl[c] : clen;
@@ -1572,178 +1578,6 @@ __global__ void __launch_bounds__(64) ed_traceback_kernel(const u8* __restrict__
     }
 }
 
-// ------------------------------------------------------------------------------------------------ K5': traceback over a checkpointed trace
-// One lane walks one job. The trace bits of the word under the walker are recomputed on demand: from the word's nearest
-// checkpoint at or before step t - TB_WIN + 1 up to the walker's step t, with the stored carry-in bits standing in for the
-// rest of the column, and the last TB_WIN steps of {hp, vp} are kept in LDS. All lanes of a wave alternate between the
-// same two phases (recompute, then walk until the window or the word is left), so the wave stays converged.
-__global__ void __launch_bounds__(64) ed_traceback_ckpt_kernel(const u8* __restrict__ text, const u8* __restrict__ query,
-                                                               const u64* __restrict__ peq, const u64* __restrict__ trace,
-                                                               const DevTraceJob* __restrict__ jobs, u32 n_jobs,
-                                                               u32* __restrict__ cigar, DevTraceOut* __restrict__ out) {
-    // 22.5 KB of LDS per wave: seven waves per CU (with a 32-step window and the query symbols cached it was 44 KB, three waves
-    // per CU, and the kernel is bound by the latency of its lanes' serial chains)
-    __shared__ ulonglong2 win[TB_WIN][64];          // {hp, vp} of step t at win[t % TB_WIN][lane]
-    __shared__ u64 eqc[6][64];                      // equality masks of the cached word
-    __shared__ u64 refc[8][64];                     // reference symbols of the columns the cached window was computed over
-    int ref_base = 0;                               // column of refc[0] byte 0 (multiple of 8, may be negative)
-    u32 const lane = threadIdx.x & 63u;
-    u32 const id = blockIdx.x * 64u + lane;
-    bool const live = id < n_jobs;
-    DevTraceJob job;
-    if (live) job = jobs[id];
-    else { job.ref_off = job.q_off = job.trace_off = job.cigar_off = 0; job.n = 0; job.m = 0; job.lanes = 1; job.words_per_lane = 1; job.end_col = 0; job.cigar_cap = 0; job.out_index = 0; job.k = 0; }
-    const u8* __restrict__ r = text + job.ref_off;
-    u32* __restrict__ slab = cigar + job.cigar_off;
-    int const W = (int)job.words_per_lane, R = (int)job.lanes;
-    int const n = (int)job.n, m = (int)job.m, k = (int)job.k;
-    int const band_hi = n - m + k;
-    TraceLayout const tl = ckpt_trace_layout(job.n, job.m ? job.m : 1u, (u32)W, (u32)R);
-    const u32* __restrict__ carry = reinterpret_cast<const u32*>(reinterpret_cast<const ulonglong2*>(trace) + job.trace_off);
-    const ulonglong2* __restrict__ ckpt = reinterpret_cast<const ulonglong2*>(trace) + job.trace_off + tl.carry_slots;
-
-    u32 wpos = job.cigar_cap;
-    int i = m, j = (int)job.end_col;
-    u32 cur_op = 0xFFu, cur_len = 0;
-    bool overflow = false;
-    bool done = !live || i == 0;
-    int win_gw = -1, win_lo = 0, win_hi = -1;       // cached word and the steps [win_lo, win_hi] held in `win`
-    int eq_gw = -1;
-    auto emit = [&](u32 op, u32 len) {
-        if (op == cur_op) { cur_len += len; return; }
-        if (cur_len) { if (wpos == 0) overflow = true; else slab[--wpos] = (cur_len << 4) | cur_op; }
-        cur_op = op;
-        cur_len = len;
-    };
-
-    while (true) {
-        if (!done && j == 0) { emit(1u, (u32)i); i = 0; done = true; }       // only insertions remain
-        if (overflow) done = true;
-        if (__all(done)) break;
-        // ---- phase 1: lanes whose walker left the cached window recompute it
-        int gw = 0, g = 0, w = 0, t = 0;
-        bool need = false;
-        if (!done) {
-            gw = (i - 1) >> 6;
-            g = gw / W;
-            w = gw - g * W;
-            t = (j - 1) + g;
-            need = !(gw == win_gw && t >= win_lo && t <= win_hi);
-        }
-        if (need) {
-            int const p = g % R;
-            int const r0 = 64 * W * g, r1 = min(m, r0 + 64 * W);
-            int const c_lo = max(0, r0 - k), c_hi = min(n - 1, r1 - 1 + band_hi);
-            int const t_first = c_lo + g;
-            // equality masks of the word
-            if (gw != eq_gw) {
-                u64 const a = job.q_off >> 6;
-                u32 const sh = (u32)(job.q_off & 63u);
-                int const rows_left = m - gw * 64;
-#pragma unroll
-                for (u32 s = 0; s < 6; ++s) {
-                    u64 const lo = peq[(a + (u64)gw) * 6 + s];
-                    u64 const hi = peq[(a + (u64)gw + 1) * 6 + s];
-                    u64 v = sh ? (lo >> sh) | (hi << (64 - sh)) : lo;
-                    if (rows_left < 64) v &= (1ull << rows_left) - 1ull;
-                    eqc[s][lane] = v;
-                }
-                eq_gw = gw;
-            }
-            // start from the checkpoint at or before t - TB_WIN + 1 (or from the word's initial state if its window starts later)
-            int const want_lo = max(0, t - (int)TB_WIN + 1);
-            int t0 = (want_lo / (int)TRACE_CKPT) * (int)TRACE_CKPT;
-            u64 pv = ~0ull, mv = 0ull;
-            if (t_first <= t0) {
-                ulonglong2 const v = ckpt[((u64)(t0 / (int)TRACE_CKPT) * R + p) * W + w];
-                pv = v.x;
-                mv = v.y;
-            } else t0 = max(t0, min(t_first, want_lo));     // nothing happens to this word before its window starts
-            {
-                // reference symbols of columns t0-g .. t-g (at most TRACE_CKPT+TB_WIN-1 of them) into LDS in 8-byte pieces
-                int const first_col = max(t0 - g, 0);            // columns left of the window start are never active
-                ref_base = first_col & ~7;
-                const u64* const base = reinterpret_cast<const u64*>(((uintptr_t)(r + ref_base)) & ~(uintptr_t)7);
-                u32 const shb = (u32)(((uintptr_t)(r + ref_base)) & 7u) * 8u;
-                int const pieces = ((t - g) - ref_base) / 8 + 1;
-                u64 prev = base[0];
-                for (int x = 0; x < pieces && x < 8; ++x) {
-                    u64 const nxt = base[x + 1];
-                    refc[x][lane] = shb ? (prev >> shb) | (nxt << (64u - shb)) : prev;
-                    prev = nxt;
-                }
-            }
-            // the carry words of all 16-step blocks the recomputation touches (at most TRACE_CKPT+TB_WIN-1 steps: four blocks) are
-            // fetched up front, together with the checkpoint and the symbols: one memory latency per window instead of one per block
-            int const b0 = t0 / (int)TRACE_CARRY_STEPS, b1 = t / (int)TRACE_CARRY_STEPS;
-            u32 cwv[4];
-#pragma unroll
-            for (int x = 0; x < 4; ++x) cwv[x] = b0 + x <= b1 ? carry[((u64)(b0 + x) * R + p) * W + w] : 0u;
-#pragma unroll
-            for (int x = 0; x < 4; ++x) {
-                int const blk = b0 + x;
-                u32 const cw = cwv[x];
-                int const tt_hi = min(t, blk * (int)TRACE_CARRY_STEPS + (int)TRACE_CARRY_STEPS - 1);
-                for (int tt = max(t0, blk * (int)TRACE_CARRY_STEPS); tt <= tt_hi; ++tt) {
-                    int const cc = tt - g;
-                    if (cc >= c_lo && cc <= c_hi) {
-                        u32 const cb = (cw >> (2u * ((u32)tt % TRACE_CARRY_STEPS))) & 3u;
-                        u64 const c_hp = cb & 1u, c_hn = cb >> 1;
-                        u32 const ro = (u32)(cc - ref_base);
-                        u32 const rsym = (u32)(refc[ro >> 3][lane] >> (8u * (ro & 7u))) & 7u;
-                        u64 const eq = eqc[rsym][lane];
-                        u64 const x_ = eq | mv;
-                        u64 const sum = pv + (x_ & pv) + c_hn;
-                        u64 const d0 = (sum ^ pv) | x_;
-                        u64 const hn = pv & d0;
-                        u64 const hp = mv | ~(pv | d0);
-                        u64 const xh = (hp << 1) | c_hp;
-                        mv = xh & d0;
-                        pv = (hn << 1) | ~(xh | d0) | c_hn;
-                        ulonglong2 o;
-                        o.x = hp;
-                        o.y = pv;
-                        win[(u32)tt % TB_WIN][lane] = o;
-                    }
-                }
-            }
-            win_gw = gw;
-            win_lo = want_lo;
-            win_hi = t;
-        }
-        // ---- phase 2: walk while the cached window covers the walker
-        while (!done) {
-            if (j == 0) break;
-            int const cgw = (i - 1) >> 6;
-            int const cg = cgw / W;
-            int const ct = (j - 1) + cg;
-            if (cgw != win_gw || ct < win_lo || ct > win_hi) break;
-            u32 const bit = (u32)(i - 1) & 63u;
-            ulonglong2 const v = win[(u32)ct % TB_WIN][lane];
-            if ((v.y >> bit) & 1ull) { emit(1u, 1u); --i; }                        // up: query symbol unmatched (I)
-            else if ((v.x >> bit) & 1ull) { emit(2u, 1u); --j; }                   // left: reference symbol skipped (D)
-            else {                                                                    // diagonal: '=' or 'X' from the cached masks
-                u32 const ro = (u32)((j - 1) - ref_base);
-                u32 const rsym = (u32)(refc[ro >> 3][lane] >> (8u * (ro & 7u))) & 7u;
-                bool const same = rsym < 6u && ((eqc[rsym][lane] >> bit) & 1ull);     // Eq bit of this row = (query symbol == rsym)
-                emit(same ? 7u : 8u, 1u);
-                --i;
-                --j;
-            }
-            if (i == 0 || overflow) done = true;
-        }
-    }
-    if (live) {
-        if (!overflow && cur_len) { if (wpos == 0) overflow = true; else slab[--wpos] = (cur_len << 4) | cur_op; }
-        DevTraceOut o;
-        o.begin = (u32)j;
-        o.cigar_start = wpos;
-        o.cigar_len = overflow ? 0xFFFFFFFFu : job.cigar_cap - wpos;
-        o.pad = 0;
-        out[job.out_index] = o;
-    }
-}
-
 // ------------------------------------------------------------------------------------------------ K5: traceback over a checkpointed trace, one wave per job
 // The walk is serial, the recomputation of the trace is not: a path moves up its diagonal and drifts from it by one column per
 // indel only, so the (word, 16-step block) windows it is going to cross are known in advance. A round therefore recomputes 64
@@ -1952,13 +1786,9 @@ __global__ void __launch_bounds__(64) ed_traceback_wave_kernel(const u8* __restr
 int DeviceApi::traceback(void* stream, const u8* d_text, const u8* d_query, const u64* d_peq, const u64* d_trace, const DevTraceJob* d_jobs,
                          u32 n_jobs, bool checkpointed, u32* d_cigar, DevTraceOut* d_out) {
     if (n_jobs == 0) return 0;
-    static int const lane_per_job = getenv("FLX_TB_LANE_PER_JOB") ? 1 : 0;      // A/B: the round-1 form
-    if (checkpointed && !lane_per_job)
+    if (checkpointed)
         hipLaunchKernelGGL(ed_traceback_wave_kernel, dim3(n_jobs), dim3(64), 0, (hipStream_t)stream, d_text, d_peq, d_trace, d_jobs, n_jobs,
                            d_cigar, d_out);
-    else if (checkpointed)
-        hipLaunchKernelGGL(ed_traceback_ckpt_kernel, dim3((n_jobs + 63) / 64), dim3(64), 0, (hipStream_t)stream, d_text, d_query, d_peq,
-                           d_trace, d_jobs, n_jobs, d_cigar, d_out);
     else
         hipLaunchKernelGGL(ed_traceback_kernel, dim3(n_jobs), dim3(64), 0, (hipStream_t)stream, d_text, d_query, d_trace, d_jobs,
                            n_jobs, d_cigar, d_out);

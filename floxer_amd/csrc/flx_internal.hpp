@@ -97,7 +97,8 @@ struct DevSeed {
 struct DevFrame {       // 64 bytes: one branching node of the DFS, written when the node is made (four 16-byte stores of one lane)
     // v[0..4]   abs of the child cursors of symbols 1..5 on the extended side (C[c] + occ)
     // v[5..10]  number of rows of the children of symbols 0..5 (their bounds on the other side are prefix sums of these)
-    // v[11..14] { lb, lb_rev, len, state } of the node itself; state = x:20 | e:3 | linfo:2 | rinfo:2 | next_sym:3 | right:1
+    // v[11..14] { lb, lb_rev, abs of the child of symbol 0, state } of the node itself (its number of rows is the sum of its
+    //           children's); state = x:20 | e:3 | linfo:2 | rinfo:2 | next_sym:3 | right:1
     // v[15]     mask of the children not taken yet (rewritten when a frame is put on top of this one)
     u32 v[16];
 };
@@ -139,7 +140,6 @@ struct AlignShape { u32 words_per_lane; u32 lanes_per_job; u32 banded; };
 // trace bits over any step range can be recomputed from that by the traceback kernel (3.25 B instead of 48 B per step and lane).
 constexpr u32 TRACE_CARRY_STEPS = 16;   // steps per u32 of carry bits
 constexpr u32 TRACE_CKPT = 16;          // steps between two checkpoints
-constexpr u32 TB_WIN = 16;              // steps of recomputed trace the traceback keeps per job (LDS)
 struct TraceLayout { u64 steps, carry_words, carry_slots, ckpt_slots; };   // slots = 16-byte units; carry region first
 #if defined(__HIPCC__)
 #define FLX_HD __host__ __device__

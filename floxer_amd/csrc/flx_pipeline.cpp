@@ -422,6 +422,16 @@ int search_seeds_device(Lane* ctx, const u8* d_seq_pool_or_null, const u8* h_seq
         if (it != ctx->ctx->stats.end()) { it->second.algorithmic_bytes += (u64)counters[2] * 128; it->second.work_units += counters[2]; }
     }
     sprof.mark("kernel");
+    // path counters of this call (folded into the context's at every way out of the selection below)
+    u64 const n_extensions = counters[2];
+    auto count_path = [&](u64 on_host) {
+        u64 with = 0, excl = 0;
+        for (auto const& st : stats) { with += st.useful != 0; excl += st.fully_excluded != 0; }
+        std::lock_guard<std::mutex> g(ctx->ctx->mu);
+        flx_path_counters& pc = ctx->ctx->path;
+        pc.seeds += n_seeds; pc.seeds_with_anchors += with; pc.seeds_excluded_by_hard_cap += excl; pc.seeds_selected_on_host += on_host;
+        pc.anchors += anchors.size(); pc.cursor_extensions += n_extensions;
+    };
     // ---- what the device selected; host_seed[si] != 0: this seed still goes through the host code
     hvec<HostAnchor> dev_anchors;
     hvec<u8> host_seed;
@@ -448,7 +458,7 @@ int search_seeds_device(Lane* ctx, const u8* d_seq_pool_or_null, const u8* h_seq
             fprintf(stderr, "[fm_select] seeds %llu: with anchors %llu, excluded %llu, left to the host %llu; anchors %u\n", (unsigned long long)n_seeds,
                     (unsigned long long)with_anchors, (unsigned long long)excl, (unsigned long long)flagged, sel_total);
         }
-        if (!any) { anchors.swap(dev_anchors); return FLX_OK; }
+        if (!any) { anchors.swap(dev_anchors); count_path(0); return FLX_OK; }
     }
     // ---- the hits per seed in emission order: `by_seed`, seed si owns [first[si], first[si+1]). With device-side selection the
     //      device has grouped them already (only the seeds left to the host are looked at below); else the host groups them.
@@ -622,6 +632,7 @@ int search_seeds_device(Lane* ctx, const u8* d_seq_pool_or_null, const u8* h_seq
                    [](HostAnchor const& a, HostAnchor const& b) { return a.seed_index < b.seed_index; });
         anchors.swap(merged);
     }
+    count_path(todo.size());
     return FLX_OK;
 }
 
@@ -1664,6 +1675,7 @@ int align_slice(Lane* lane, const flx_params* P, const flx_reads* RD, u64 first_
     // current node is in the smallest size class still pending (PEX trees are unbalanced: the same node is reached after a
     // different number of steps from different leaves). All tests of a node size then share one launch, and identical
     // (window, node) tests requested by anchors that started at different depths are found by the de-duplication.
+    u64 n_inner_requested = 0;
     hvec<u32> climbing, selected, waiting, survivors;    // anchors that still have an inner node to test (in anchor order)
     double g_build_ms = 0;
     for (u32 ai = 0; ai < A.size(); ++ai) if (A[ai].alive && !A[ai].at_root) climbing.push_back(ai);
@@ -1691,6 +1703,7 @@ int align_slice(Lane* lane, const flx_params* P, const flx_reads* RD, u64 first_
             } else { wait.push_back(c); next_smallest = std::min(next_smallest, c.rows); }
         }
         g_build_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tb0).count();
+        n_inner_requested += reqs.size();
         if ((rc = run_exists_jobs(lane, d_text, d_peq, reqs, outs))) return rc;
         for (size_t i = 0; i < outs.size(); ++i) {
             AnchorState& a = A[sel[i].anchor];
@@ -1783,6 +1796,14 @@ int align_slice(Lane* lane, const flx_params* P, const flx_reads* RD, u64 first_
         if (!primary_written) run->records.push_back(flx_record{reads[r].read_index, 4u, -1, 0, 0, 0, 0, 0});
     }
     run->cigars = std::move(cig);
+    {
+        u64 found = 0;
+        for (auto const& rr : root_res) found += rr.exists;
+        std::lock_guard<std::mutex> g(ctx->mu);
+        flx_path_counters& pc = ctx->path;
+        pc.inner_tests_requested += n_inner_requested; pc.root_alignments_requested += root_reqs.size(); pc.root_alignments_found += found;
+        pc.records += run->records.size(); pc.reads += end_read - first_read;
+    }
     prof.mark("records");
     return FLX_OK;
 }
@@ -1811,10 +1832,10 @@ extern "C" int flx_align_reads_resident(flx_ctx* ctx, const flx_params* P, const
     u64 chunk_reads = n_reads >= 1024 * n_lanes ? big_chunk : std::max<u64>(64, (n_reads + n_lanes - 1) / n_lanes);
     if (const char* env = getenv("FLX_CHUNK_READS")) { u64 const v = strtoull(env, nullptr, 10); if (v >= 1) chunk_reads = v; }
     if (n_lanes == 1) chunk_reads = std::max<u64>(n_reads, 1);
-    // A chunk's workspaces grow with its bases, not its reads (the DFS stacks of K1 alone are ~150 bytes per read base): chunks are
-    // also cut at FLX_CHUNK_BASES read bases (default 12 M: ~1.8 GB of stacks per lane), so a batch of 100-kb reads gets more,
-    // smaller chunks instead of workspaces of tens of GB per lane.
-    u64 chunk_bases = 12ull << 20;
+    // A chunk's workspaces grow with its bases, not its reads (seeds, hits, requests, trace arena; with first_reported also the DFS
+    // stacks of the ordered K1, ~100 bytes per read base): chunks are also cut at FLX_CHUNK_BASES read bases (default 48 M), so a
+    // batch of 100-kb reads gets more, smaller chunks instead of workspaces of tens of GB per lane.
+    u64 chunk_bases = 48ull << 20;
     if (const char* env = getenv("FLX_CHUNK_BASES")) { u64 const v = strtoull(env, nullptr, 10); if (v >= 1) chunk_bases = v; }
     hvec<u64> chunk_first{0};                                // chunk c = reads [chunk_first[c], chunk_first[c + 1])
     {

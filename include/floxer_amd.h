@@ -214,6 +214,16 @@ int flx_ctx_enable_kernel_timing(flx_ctx* ctx, int enable);
 int flx_ctx_reset_kernel_stats(flx_ctx* ctx);
 int flx_ctx_get_kernel_stats(flx_ctx* ctx, flx_kernel_stat* out, uint32_t* n /* in: capacity, out: count */);
 
+/* Counters of the path since the context was made / they were reset (all batches of all host threads): how many seeds the device
+ * handled by itself, how much of the requested DP work was run after de-duplication. Cheap, always on. */
+typedef struct flx_path_counters {
+    uint64_t seeds, seeds_with_anchors, seeds_excluded_by_hard_cap, seeds_selected_on_host, anchors, cursor_extensions;
+    uint64_t inner_tests_requested, root_alignments_requested, root_alignments_found, records, reads;
+    uint64_t reserved[5];
+} flx_path_counters;
+int flx_ctx_get_path_counters(flx_ctx* ctx, flx_path_counters* out);
+int flx_ctx_reset_path_counters(flx_ctx* ctx);
+
 /* ------------------------------------------------------------------------------------------------ file boundary
  * FASTA/FASTQ in (input.cpp:36-148), SAM/BAM out (output.cpp:49-108, 197-212) — used by the floxer-compatible CLI. */
 typedef struct flx_sam_writer flx_sam_writer;

@@ -42,6 +42,16 @@ int main(int argc, char** argv) {
     unsigned long long n_blocks = bytes / 64;
     uint4* tab; hipMalloc(&tab, bytes); hipMemset(tab, 1, bytes);
     int const steps = 2000;
+    if (argc > 2) {
+        // calibration run for FETCH_SIZE: 4096 waves x 64 lanes x `steps` random 64-byte blocks, one 16-byte load each (K = 1), then
+        // two per block (K = 2): the counter per dispatch / blocks = bytes the counter tallies per block
+        unsigned* out; hipMalloc(&out, (size_t)4096 * 64 * 4);
+        hipLaunchKernelGGL((gather<1, 1>), dim3(4096), dim3(64), 0, 0, tab, n_blocks, steps, 1u, out);
+        hipLaunchKernelGGL((gather<2, 1>), dim3(4096), dim3(64), 0, 0, tab, n_blocks, steps, 1u, out);
+        hipDeviceSynchronize();
+        printf("calibration: each dispatch reads %.0f random 64-byte blocks of a %.1f GB table (K = 1, then K = 2 loads per block)\n", 4096.0 * 64 * steps, bytes / 1e9);
+        return 0;
+    }
     for (int waves : {4096, 8192}) {
         unsigned* out; hipMalloc(&out, (size_t)waves * 64 * 4);
         for (unsigned mod : {1u, 2u, 4u}) {

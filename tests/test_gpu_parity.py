@@ -629,3 +629,143 @@ def test_index_built_on_the_device_is_the_host_index(tmp_path):
     p1, p2 = str(tmp_path / "h.idx"), str(tmp_path / "d.idx")
     host.save(p1); dev.save(p2)
     assert open(p1, "rb").read() == open(p2, "rb").read()
+
+
+# ---------------------------------------------------------------- '$' in a read, repeat-rich text, scale
+def test_dollar_in_reads_and_seeds_matches_oracle(small_genome):
+    """input.cpp:165-176 maps '$' to rank 0, the rank of the sequence delimiters: search_ng21 extends a cursor with it like with any
+    other query symbol (it can only ever be a match child: the mismatch loops run over symbols 1..5), the aligner compares it like
+    any other rank. K1 emission and the whole path on reads holding rank 0, several references (so delimiters exist in the text)."""
+    refs, idx, ctx, oidx = small_genome
+    rng = np.random.default_rng(5)
+    pool, seeds = _make_seeds(rng, refs, 120, kmax=2, lens=(10, 40))
+    pool = pool.copy()
+    for off, ln, k, i in seeds[::3]:
+        pool[off + int(rng.integers(0, ln))] = 0                     # a '$' somewhere in every third seed
+    # seeds that run over the end of a reference into its delimiter: 'xxxx$' really occurs in the text
+    extra = []
+    for r in refs[:2]:
+        tail = np.concatenate([r[-14:], np.zeros(1, np.uint8)])
+        extra.append((len(pool), len(tail), 1, len(seeds) + len(extra)))
+        pool = np.concatenate([pool, tail])
+    seeds = seeds + extra
+    got = F.searcher(ctx).search_groups(pool, seeds, max_hits=501)
+    n_with_dollar_hits = 0
+    for si, (off, ln, k, _) in enumerate(seeds):
+        exp, _ = oidx.search_groups(pool[off:off + ln], k, 501)
+        mine = got[got[:, 0] == si][:, 1:]
+        assert mine.tolist() == exp.tolist(), (si, ln, k)
+        n_with_dollar_hits += int(len(exp) > 0 and (pool[off:off + ln] == 0).any())
+    assert n_with_dollar_hits >= 2                                   # the delimiter seeds are found
+    anchors, stats = F.searcher(ctx).search_seeds(pool, seeds)
+    exp_a, exp_s = oidx.search_seeds(pool, seeds)
+    assert anchors.tolist() == exp_a.tolist() and stats.tolist() == exp_s.tolist()
+    # whole path: reads with a '$' inside
+    genome = S.make_genome(150000, 3, seed=31)
+    reads, _, _ = S.make_reads(genome, 40, 900, 0.06, seed=32)
+    for i in range(0, 40, 4):
+        reads[i] = reads[i].copy()
+        reads[i][int(rng.integers(0, len(reads[i])))] = 0
+    ctx2 = F.context(F.fmindex(genome))
+    for kw, okw in [(dict(), dict()), (dict(interval_optimization=True), dict(interval_opt=True)), (dict(without_cigar=True), dict(without_cigar=True))]:
+        got_r = F.aligner(ctx2, F.params(error_probability=0.06, **kw)).align_reads(reads)
+        exp_r = O.Index(genome).run(reads, O.params(error_probability=0.06, **okw), threads=8)
+        assert got_r.records() == exp_r.records(), kw
+    ctx2.close()
+
+
+def _repeat_rich_reference(rng, n_bases):
+    """tandem repeats (units of 1..60 bp in arrays of up to 6 kb), a 300-bp family with thousands of diverged copies, low-complexity
+    stretches and runs of N between unique sequence"""
+    family = rng.integers(1, 5, size=300).astype(np.uint8)
+    parts, total = [], 0
+    while total < n_bases:
+        kind = int(rng.integers(0, 10))
+        if kind < 3:                                               # a family copy, 1..12 % diverged (mismatches and small indels)
+            c = family.copy()
+            n_mut = int(rng.integers(3, 36))
+            for _ in range(n_mut):
+                p = int(rng.integers(0, len(c)))
+                t = int(rng.integers(0, 3))
+                if t == 0:
+                    c[p] = rng.integers(1, 5)
+                elif t == 1:
+                    c = np.delete(c, p)
+                else:
+                    c = np.insert(c, p, rng.integers(1, 5))
+            piece = c
+        elif kind < 5:                                             # tandem repeat
+            unit = rng.integers(1, 5, size=int(rng.integers(1, 61))).astype(np.uint8)
+            piece = np.tile(unit, int(rng.integers(200, 6000)) // len(unit) + 1)
+        elif kind == 5:                                            # run of N
+            piece = np.full(int(rng.integers(5, 400)), 5, np.uint8)
+        elif kind == 6:                                            # two-letter low complexity
+            piece = rng.choice(np.array([1, 4], np.uint8), size=int(rng.integers(100, 1500)))
+        else:                                                      # unique sequence
+            piece = rng.integers(1, 5, size=int(rng.integers(300, 4000))).astype(np.uint8)
+        parts.append(piece.astype(np.uint8))
+        total += len(piece)
+    return np.concatenate(parts)[:n_bases]
+
+
+@pytest.mark.parametrize("kw,okw", [(dict(), dict()), (dict(interval_optimization=True), dict(interval_opt=True))])
+def test_repeat_rich_reference_matches_oracle(kw, okw, capsys):
+    """hg38 is repeat-rich: a text where a large share of the seeds runs into the soft cap (50 rows kept) or the hard cap (seed
+    excluded over 500 rows), the selection of truncated seeds goes through the host, and loci repeat. Records equal the oracle's,
+    default flags and -I; the share of seeds the host selected for is printed (and kept in profiles/ by the round's log)."""
+    rng = np.random.default_rng(2024)
+    genome = [_repeat_rich_reference(rng, 2_500_000), _repeat_rich_reference(rng, 1_500_000)]
+    fidx = F.fmindex(genome)
+    ctx = F.context(fidx)
+    oidx = O.Index(genome, imported=(fidx.suffix_array_u32(), fidx.bwt(False), fidx.bwt(True)))   # (oracle SA == product SA: test_host_cpu)
+    lines = []
+    for length, rate, n_reads, seed in [(5000, 0.08, 60, 1), (2000, 0.05, 120, 2)]:
+        reads, _, _ = S.make_reads(genome, n_reads, length, rate, seed=900 + seed)
+        ctx.path_counters(reset=True)
+        got = F.aligner(ctx, F.params(error_probability=rate, **kw)).align_reads(reads)
+        pc = ctx.path_counters()
+        exp = oidx.run(reads, O.params(error_probability=rate, **okw), threads=8)
+        assert got.skipped.tolist() == exp.skipped.tolist()
+        assert got.records() == exp.records(), (length, rate)
+        lines.append(f"repeat-rich {length} bp @ {rate:.0%} {kw or 'defaults'}: seeds {pc['seeds']}, with anchors {pc['seeds_with_anchors']}, excluded by the hard cap "
+                     f"{pc['seeds_excluded_by_hard_cap']} ({pc['seeds_excluded_by_hard_cap'] / pc['seeds']:.1%}), selected on the host "
+                     f"{pc['seeds_selected_on_host']} ({pc['seeds_selected_on_host'] / pc['seeds']:.2%}), anchors {pc['anchors']}, records {pc['records']}")
+        assert pc["seeds_excluded_by_hard_cap"] > 0.02 * pc["seeds"] and pc["seeds_selected_on_host"] > 0        # the caps really bite here
+    with capsys.disabled():
+        print("\n" + "\n".join(lines))
+    ctx.close()
+
+
+def test_scale_250mb_multi_sequence():
+    """BASELINE.json configs[2] size: 250 Mb in 5 sequences, index built on the GPU, 1024 reads of 10 kb @ 8 % (floxer defaults).
+    All reads: one primary at the simulated sequence / position / strand; CIGARs of a sample consistent with the texts; and
+    record-for-record equality with the oracle (its index laid out around the imported suffix array) on a sample of the reads."""
+    G, NSEQ, NR, L, rate = 250_000_000, 5, 1024, 10000, 0.08
+    pool, genome = S.make_genome_fast(G // NSEQ, NSEQ, seed=77)
+    (rpool, offs), (chrom, pos, rev) = S.make_reads_fast(pool, [G // NSEQ] * NSEQ, NR, L, rate, seed=78)
+    fidx = F.fmindex(genome, device=0)
+    ctx = F.context(fidx)
+    res = F.aligner(ctx, F.params(error_probability=rate)).align_reads((rpool, offs))
+    rows = res.rows
+    prim = rows[(rows[:, 1] & 256) == 0]
+    assert len(prim) == NR and (prim[:, 0] == np.arange(NR)).all()
+    assert ((prim[:, 1] & 4) == 0).all()
+    assert (prim[:, 2] == chrom).all() and (np.abs(prim[:, 3] - pos.astype(np.int64)) <= 0.1 * L).all()
+    assert (((prim[:, 1] & 16) != 0) == (rev != 0)).all()
+    sample = list(range(0, NR, 32))
+    reads = [rpool[int(offs[i]):int(offs[i + 1])] for i in sample]
+    sub = F.aligner(ctx, F.params(error_probability=rate)).align_reads(reads)
+    # the records of a read do not depend on its batch (compared as arrays: 45 k records as strings would take minutes)
+    def recs_of(result, read):
+        out = []
+        for r in result.rows[result.rows[:, 0] == read]:
+            out.append((int(r[1]), int(r[2]), int(r[3]), int(r[4]), result.cigars[r[5]: r[5] + r[6]].tobytes()))
+        return out
+    for j, i in enumerate(sample):
+        assert recs_of(sub, j) == recs_of(res, i)
+    sub_recs = sub.records()
+    _check_cigars(genome, reads, sub_recs, rate)
+    oidx = O.Index(genome, imported=(fidx.suffix_array_u32(), fidx.bwt(False), fidx.bwt(True)), pool=pool)
+    exp = oidx.run(reads, O.params(error_probability=rate), threads=16)
+    assert sub_recs == exp.records()
+    ctx.close()
