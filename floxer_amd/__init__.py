@@ -174,6 +174,34 @@ class context:
                                       work_units=a.work_units) for a in arr[: n.value]}
 
 
+class statistics:
+    """statistics::search_and_alignment_statistics (statistics.hpp:24-172): attach to a context, align, read the TOML / terminal text"""
+
+    def __init__(self, input_hint=None):
+        self.h = C.c_void_p()
+        check(lib().flx_stats_create(input_hint.encode() if input_hint else None, C.byref(self.h)))
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().flx_stats_free(self.h)
+            self.h = None
+
+    def attach(self, ctx):
+        check(lib().flx_ctx_set_stats(ctx.h, self.h))
+        return self
+
+    @property
+    def num_queries(self):
+        return lib().flx_stats_num_queries(self.h)
+
+    def format(self, toml=True):
+        n = C.c_uint64(0)
+        lib().flx_stats_format(self.h, int(toml), None, C.byref(n))
+        buf = C.create_string_buffer(n.value)
+        check(lib().flx_stats_format(self.h, int(toml), buf, C.byref(n)))
+        return buf.value.decode()
+
+
 # ------------------------------------------------------------------------------------------------ seam 1: searcher
 def search_config(max_num_anchors_hard=500, max_num_anchors_soft=50, anchor_group_order="count_first",
                   anchor_choice_strategy="round_robin", erase_useless_anchors=True):

@@ -90,7 +90,8 @@ EXPORTED = [
     "flx_align_reads_resident", "flx_run_num_records",
     "flx_run_num_cigar_words", "flx_run_copy", "flx_run_free", "flx_ctx_enable_kernel_timing", "flx_ctx_reset_kernel_stats",
     "flx_ctx_get_kernel_stats", "flx_sam_open", "flx_sam_write", "flx_sam_close", "flx_sim_genome", "flx_sim_reads", "flx_ctx_get_path_counters",
-    "flx_ctx_reset_path_counters",
+    "flx_ctx_reset_path_counters", "flx_stats_create", "flx_stats_free", "flx_stats_merge", "flx_stats_num_queries", "flx_stats_format",
+    "flx_ctx_set_stats", "flx_device_count", "flx_index_matches_reference", "flx_sam_set_threads",
 ]
 
 _lib = None
@@ -154,6 +155,16 @@ def lib():
     L.flx_sam_open.argtypes = [C.c_char_p, C.POINTER(C.c_char_p), u64p, C.c_uint32, C.POINTER(C.c_void_p)]
     L.flx_sam_write.argtypes = [C.c_void_p, C.POINTER(C.c_char_p), u8p, u64p, C.POINTER(C.c_char_p), C.POINTER(Record), C.c_uint64, u32p]
     L.flx_sam_close.argtypes = [C.c_void_p]
+    L.flx_stats_create.argtypes = [C.c_char_p, C.POINTER(C.c_void_p)]
+    L.flx_stats_free.argtypes = [C.c_void_p]
+    L.flx_stats_merge.argtypes = [C.c_void_p, C.c_void_p]
+    L.flx_stats_num_queries.restype = C.c_uint64
+    L.flx_stats_num_queries.argtypes = [C.c_void_p]
+    L.flx_stats_format.argtypes = [C.c_void_p, C.c_int, C.c_char_p, u64p]
+    L.flx_ctx_set_stats.argtypes = [C.c_void_p, C.c_void_p]
+    L.flx_device_count.restype = C.c_int
+    L.flx_index_matches_reference.argtypes = [C.c_void_p, u8p, u64p, C.c_uint32]
+    L.flx_sam_set_threads.argtypes = [C.c_void_p, C.c_uint32]
     L.flx_ctx_get_path_counters.argtypes = [C.c_void_p, C.POINTER(PathCounters)]
     L.flx_ctx_reset_path_counters.argtypes = [C.c_void_p]
     L.flx_sim_genome.argtypes = [C.c_uint64, C.c_uint64, u8p]

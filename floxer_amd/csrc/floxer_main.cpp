@@ -11,11 +11,13 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <algorithm>
 #include <deque>
 #include <future>
 #include <memory>
 #include <string>
 #include <sys/stat.h>
+#include <thread>
 #include <vector>
 
 #include "../../include/floxer_amd.h"
@@ -53,6 +55,7 @@ struct Options {
     uint64_t threads = 1, timeout = 0;
     bool has_timeout = false;
     std::string stats, stats_input_hint;
+    std::string devices;
 };
 
 struct OptDef { char short_id; const char* long_id; bool flag; };
@@ -64,6 +67,8 @@ const OptDef OPTS[] = {
     {'b', "bottom-up-pex-tree", true}, {'I', "interval-optimization", true}, {'v', "extra-verification-ratio", false},
     {'d', "direct-full-verification", true}, {'u', "num-anchors-per-task", false}, {'w', "without-cigar", true}, {'t', "threads", false},
     {'x', "timeout", false}, {'S', "stats", false}, {'H', "stats-input-hint", false},
+    // not in the reference: the HIP devices to run on ("0", "0-7", "0,2,4", "all"; default: FLX_DEVICES, else device 0)
+    {'G', "devices", false},
 };
 
 struct CliError { std::string msg; };
@@ -151,6 +156,7 @@ Options parse_cli(int argc, char** argv) {
         else if (n == "threads") { o.threads = parse_u64(n, value); range_check(n, (double)o.threads, 1, 4096); }
         else if (n == "timeout") { o.timeout = parse_u64(n, value); o.has_timeout = true; }
         else if (n == "stats") o.stats = value;
+        else if (n == "devices") o.devices = value;
         else if (n == "stats-input-hint") {
             if (value != "real_nanopore" && value != "simulated") throw CliError{"Validation failed for option --" + n + ": Value " + value + " is not one of [real_nanopore,simulated]."};
             o.stats_input_hint = value;
@@ -219,22 +225,139 @@ bool read_references(std::string const& path, Reference& ref, std::string& err) 
     return true;
 }
 
+// ---------------------------------------------------------------- FASTQ, block-parallel (input.cpp:83-148)
+// The file is read (and, for .gz, inflated: one gzip stream is serial) in blocks by the calling thread; everything after that is
+// parallel over the records of a batch: line boundaries, ids, rank encoding. A batch keeps its raw text: ids and qualities are
+// pointers into it (terminated in place), so nothing is copied per record.
+unsigned io_threads(uint64_t cli_threads) {
+    if (const char* env = getenv("FLX_IO_THREADS")) { unsigned const v = (unsigned)strtoul(env, nullptr, 10); if (v) return std::min(v, 64u); }
+    unsigned const hw = std::max(1u, std::thread::hardware_concurrency());
+    return (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(std::max<uint64_t>(cli_threads, std::min(hw, 8u)), 64));
+}
+template <class F>
+void parallel_for(size_t n, unsigned threads, F&& body) {      // body(first, last) on disjoint ranges
+    unsigned const t = (unsigned)std::min<size_t>(threads, std::max<size_t>(1, n / 256));
+    if (t <= 1) { body((size_t)0, n); return; }
+    std::vector<std::thread> pool;
+    for (unsigned i = 0; i < t; ++i) pool.emplace_back([&, i] { body(n * i / t, n * (i + 1) / t); });
+    for (auto& th : pool) th.join();
+}
+
 struct ReadBatch {
-    std::vector<std::string> ids, quals;
+    std::vector<char> raw;                      // the batch's FASTQ text; ids / quals point into it
+    std::vector<const char*> ids, quals;
     std::vector<uint8_t> pool;
     std::vector<uint64_t> offsets{0};
-    void clear() { ids.clear(); quals.clear(); pool.clear(); offsets.assign(1, 0); }
+    size_t size() const { return ids.size(); }
 };
 
-// returns false at end of file
-bool next_fastq(LineReader& in, std::string& id, std::string& seq, std::string& qual, std::string& err) {
-    std::string plus;
-    if (!in.getline(id)) return false;
-    while (id.empty()) if (!in.getline(id)) return false;
-    if (id[0] != '@') { err = "malformed FASTQ record header: " + id; return false; }
-    if (!in.getline(seq) || !in.getline(plus) || !in.getline(qual)) { err = "truncated FASTQ record " + id; return false; }
-    id = record_id(id.substr(1));
-    return true;
+struct FastqReader {
+    gzFile f;
+    std::vector<char> carry;                    // text behind the last complete record of the previous batch
+    bool eof = false;
+    unsigned threads;
+    FastqReader(const char* path, unsigned threads_) : f(gzopen(path, "rb")), threads(threads_) { if (f) gzbuffer(f, 1 << 20); }
+    ~FastqReader() { if (f) gzclose(f); }
+
+    // the next batch of up to max_reads records; false at the end of the file or on a malformed record (err set)
+    bool next(ReadBatch& b, size_t max_reads, std::string& err) {
+        b = ReadBatch{};
+        std::vector<char>& raw = b.raw;
+        raw.swap(carry);
+        // ---- read until the text holds max_reads records (4 lines each) or the file ends
+        size_t lines = 0, scanned = 0;
+        std::vector<size_t> nl;                 // positions of the line ends
+        auto scan = [&]() {
+            while (scanned < raw.size()) {
+                const char* p = (const char*)memchr(raw.data() + scanned, '\n', raw.size() - scanned);
+                if (!p) { scanned = raw.size(); break; }
+                nl.push_back((size_t)(p - raw.data()));
+                scanned = (size_t)(p - raw.data()) + 1;
+                ++lines;
+            }
+        };
+        scan();
+        while (!eof && lines < 4 * max_reads) {
+            size_t const at = raw.size(), want = 16u << 20;
+            raw.resize(at + want);
+            int const got = gzread(f, raw.data() + at, (unsigned)want);
+            if (got < 0) { err = "read error on the query file"; return false; }
+            raw.resize(at + (size_t)got);
+            if ((size_t)got < want) eof = true;
+            scan();
+        }
+        if (eof && !raw.empty() && raw.back() != '\n') { nl.push_back(raw.size()); raw.push_back('\n'); ++lines; }   // last line without a line end
+        // blank lines at the very end of the file are not records
+        while (eof && lines % 4 != 0 && lines > 0 && nl.size() >= 1 && (lines == 1 ? nl[0] == 0 : nl[lines - 1] == nl[lines - 2] + 1)) { nl.pop_back(); --lines; }
+        size_t n_rec = std::min(lines / 4, max_reads);
+        if (eof && lines % 4 != 0 && lines / 4 < max_reads) { err = "truncated FASTQ record at the end of the query file"; return false; }
+        size_t const used = n_rec ? nl[4 * n_rec - 1] + 1 : 0;
+        carry.assign(raw.begin() + (long)used, raw.end());
+        raw.resize(used);
+        if (n_rec == 0) return false;
+        // ---- records: id (up to the first blank, input.cpp:161-163), sequence, quality; terminated in place
+        struct Rec { size_t id, seq, seq_len, qual; bool keep; };
+        std::vector<Rec> recs(n_rec);
+        bool bad = false;
+        parallel_for(n_rec, threads, [&](size_t r0, size_t r1) {
+            for (size_t r = r0; r < r1; ++r) {
+                size_t const l0 = r ? nl[4 * r - 1] + 1 : 0, e0 = nl[4 * r], l1 = e0 + 1, e1 = nl[4 * r + 1], l3 = nl[4 * r + 2] + 1, e3 = nl[4 * r + 3];
+                if (raw[l0] != '@' || raw[nl[4 * r + 1] + 1] != '+') { bad = true; continue; }
+                size_t id_end = e0;
+                if (id_end > l0 && raw[id_end - 1] == '\r') --id_end;
+                for (size_t i = l0 + 1; i < id_end; ++i) if (raw[i] == ' ') { id_end = i; break; }
+                raw[id_end] = 0;
+                size_t s_end = e1, q_end = e3;
+                if (s_end > l1 && raw[s_end - 1] == '\r') --s_end;
+                if (q_end > l3 && raw[q_end - 1] == '\r') --q_end;
+                raw[q_end] = 0;
+                recs[r] = Rec{l0 + 1, l1, s_end - l1, l3, true};
+            }
+        });
+        if (bad) { err = "malformed FASTQ record in the query file"; return false; }
+        for (auto& rc : recs) {                 // the reference's filters on the way in (input.cpp:95-110)
+            if (rc.seq_len == 0) { log_line("warning", "The record %s in the query file has an empty sequence and will be skipped.", raw.data() + rc.id); rc.keep = false; }
+            else if (rc.seq_len > 100000) { log_line("warning", "skipping too large query: %s", raw.data() + rc.id); rc.keep = false; }
+        }
+        recs.erase(std::remove_if(recs.begin(), recs.end(), [](Rec const& x) { return !x.keep; }), recs.end());
+        b.ids.resize(recs.size());
+        b.quals.resize(recs.size());
+        b.offsets.assign(recs.size() + 1, 0);
+        for (size_t r = 0; r < recs.size(); ++r) b.offsets[r + 1] = b.offsets[r] + recs[r].seq_len;
+        b.pool.resize(b.offsets.back() + 1);
+        parallel_for(recs.size(), threads, [&](size_t r0, size_t r1) {
+            for (size_t r = r0; r < r1; ++r) {
+                b.ids[r] = raw.data() + recs[r].id;
+                b.quals[r] = raw.data() + recs[r].qual;
+                flx_chars_to_rank_sequence(raw.data() + recs[r].seq, recs[r].seq_len, b.pool.data() + b.offsets[r]);
+            }
+        });
+        return true;
+    }
+};
+
+std::vector<int> parse_devices(std::string spec, int n_available, std::string& err) {
+    std::vector<int> out;
+    if (spec.empty()) if (const char* env = getenv("FLX_DEVICES")) spec = env;
+    if (spec.empty()) { if (const char* env = getenv("FLX_DEVICE")) spec = env; }
+    if (spec.empty()) return {0};
+    if (spec == "all") { for (int d = 0; d < n_available; ++d) out.push_back(d); return out; }
+    size_t at = 0;
+    while (at <= spec.size()) {
+        size_t const comma = spec.find(',', at);
+        std::string const part = spec.substr(at, comma == std::string::npos ? std::string::npos : comma - at);
+        size_t const dash = part.find('-');
+        char* end = nullptr;
+        long const lo = strtol(part.c_str(), &end, 10);
+        long hi = lo;
+        if (dash != std::string::npos) hi = strtol(part.c_str() + dash + 1, &end, 10);
+        if (part.empty() || *end || lo < 0 || hi < lo) { err = "cannot parse the device list " + spec; return {}; }
+        for (long d = lo; d <= hi; ++d) out.push_back((int)d);
+        if (comma == std::string::npos) break;
+        at = comma + 1;
+    }
+    for (int d : out) if (d >= n_available) { err = "device " + std::to_string(d) + " of the device list does not exist (" + std::to_string(n_available) + " HIP devices)"; return {}; }
+    return out;
 }
 
 }  // namespace
@@ -257,7 +380,10 @@ int main(int argc, char** argv) {
     if (!o.index.empty() && stat(o.index.c_str(), &st) == 0) {
         log_line("info", "loading index from %s", o.index.c_str());
         if (flx_index_load(o.index.c_str(), &index) != FLX_OK) { log_line("error", "An error occured while trying to load the index from the file %s.\n%s", o.index.c_str(), flx_last_error()); return -1; }
-        if (flx_index_num_references(index) != ref.ids.size()) { log_line("error", "the index file does not belong to this reference"); return -1; }
+        if (flx_index_matches_reference(index, ref.pool.data(), ref.lens.data(), (uint32_t)ref.ids.size()) != FLX_OK) {
+            log_line("error", "The index in the file %s was not built from the reference in %s.\n%s", o.index.c_str(), o.reference.c_str(), flx_last_error());
+            return -1;
+        }
     } else {
         log_line("info", "building index with %llu thread%s", (unsigned long long)o.threads, o.threads == 1 ? "" : "s");
         auto const t0 = std::chrono::steady_clock::now();
@@ -270,10 +396,22 @@ int main(int argc, char** argv) {
             log_line("warning", "An error occured while trying to write the index to the file %s.\nContinuing without saving the index.\n%s", o.index.c_str(), flx_last_error());
     }
 
-    flx_ctx* ctx = nullptr;
-    int device = 0;
-    if (const char* env = getenv("FLX_DEVICE")) device = atoi(env);
-    if (flx_ctx_create(device, index, &ctx) != FLX_OK) { log_line("error", "cannot set up the GPU context: %s", flx_last_error()); return -1; }
+    // One context per device of the device list, all uploading the one index built / loaded above; batches of reads are dealt to
+    // them in turn and written in input order (floxer.cpp:141-171: the reference's unit of parallelism is the read, too).
+    int n_hip = flx_device_count();
+    if (n_hip <= 0) { log_line("error", "no HIP device available; floxer_amd has no CPU fallback"); return -1; }
+    std::vector<int> const devices = parse_devices(o.devices, n_hip, err);
+    if (devices.empty()) { log_line("error", "%s", err.c_str()); return -1; }
+    flx_stats* stats = nullptr;
+    if (!o.stats.empty() && flx_stats_create(o.stats_input_hint.empty() ? nullptr : o.stats_input_hint.c_str(), &stats) != FLX_OK) { log_line("error", "%s", flx_last_error()); return -1; }
+    std::vector<flx_ctx*> ctxs;
+    for (int d : devices) {
+        flx_ctx* c = nullptr;
+        if (flx_ctx_create(d, index, &c) != FLX_OK) { log_line("error", "cannot set up the GPU context on device %d: %s", d, flx_last_error()); return -1; }
+        if (stats) flx_ctx_set_stats(c, stats);
+        ctxs.push_back(c);
+    }
+    log_line("info", "running on %zu HIP device context%s", ctxs.size(), ctxs.size() == 1 ? "" : "s");
 
     std::vector<const char*> ref_id_ptrs;
     for (auto const& s : ref.ids) ref_id_ptrs.push_back(s.c_str());
@@ -302,14 +440,16 @@ int main(int argc, char** argv) {
     stat(o.queries.c_str(), &qst);
     log_line("info", "aligning queries from a %lld bytes large file against %zu references on the GPU and writing output file to %s", (long long)qst.st_size, ref.ids.size(), o.output.c_str());
     auto const t_align = std::chrono::steady_clock::now();
-    LineReader qin(o.queries.c_str());
+    unsigned const n_io = io_threads(o.threads);
+    FastqReader qin(o.queries.c_str(), n_io);
     if (!qin.f) { log_line("error", "cannot open %s", o.queries.c_str()); return -1; }
+    flx_sam_set_threads(out, n_io);
     size_t batch_reads = 16384;      // 1024 reads per lane and chunk (see flx_align_reads_resident)
     if (const char* env = getenv("FLX_BATCH_READS")) { size_t const v = strtoull(env, nullptr, 10); if (v) batch_reads = v; }
-    // Batches are independent: up to three are in the context at a time (their chunks share its lanes), the next one is parsed
+    // Batches are independent: up to three are in a context at a time (their chunks share its lanes), the next one is parsed
     // while they run, and results are written in input order.
     struct Finished { std::unique_ptr<ReadBatch> batch; std::vector<flx_record> recs; std::vector<uint32_t> cig; std::vector<uint8_t> skipped; int rc = FLX_OK; std::string err; };
-    auto align_batch = [&](std::unique_ptr<ReadBatch> b) {
+    auto align_batch = [&](std::unique_ptr<ReadBatch> b, flx_ctx* ctx) {
         Finished f;
         flx_run* run = nullptr;
         f.rc = flx_align_reads(ctx, &p, b->pool.data(), b->offsets.data(), b->ids.size(), &run);
@@ -323,8 +463,7 @@ int main(int argc, char** argv) {
         return f;
     };
     std::deque<std::future<Finished>> in_flight;
-    std::string id, seq, qual;
-    uint64_t total_reads = 0, total_records = 0;
+    uint64_t total_reads = 0, total_records = 0, n_batches = 0;
     bool failed = false, eof = false, timed_out = false;
     auto write_oldest = [&]() {
         Finished f = in_flight.front().get();
@@ -337,11 +476,8 @@ int main(int argc, char** argv) {
         }
         ReadBatch const& batch = *f.batch;
         for (size_t i = 0; i < f.skipped.size(); ++i)
-            if (f.skipped[i]) log_line("warning", "skipping query: %s due to bad configuration regarding the number of errors.", batch.ids[i].c_str());
-        std::vector<const char*> idp, qp;
-        for (auto const& s : batch.ids) idp.push_back(s.c_str());
-        for (auto const& s : batch.quals) qp.push_back(s.c_str());
-        if (flx_sam_write(out, idp.data(), batch.pool.data(), batch.offsets.data(), qp.data(), f.recs.data(), f.recs.size(), f.cig.data()) != FLX_OK) { log_line("error", "%s", flx_last_error()); failed = true; }
+            if (f.skipped[i]) log_line("warning", "skipping query: %s due to bad configuration regarding the number of errors.", batch.ids[i]);
+        if (flx_sam_write(out, batch.ids.data(), batch.pool.data(), batch.offsets.data(), batch.quals.data(), f.recs.data(), f.recs.size(), f.cig.data()) != FLX_OK) { log_line("error", "%s", flx_last_error()); failed = true; }
         total_reads += batch.ids.size();
         total_records += f.recs.size();
         log_line("debug", "finished a batch: %llu queries, %llu records so far", (unsigned long long)total_reads, (unsigned long long)total_records);
@@ -353,31 +489,40 @@ int main(int argc, char** argv) {
             break;
         }
         auto batch = std::make_unique<ReadBatch>();
-        while (batch->ids.size() < batch_reads) {
-            if (!next_fastq(qin, id, seq, qual, err)) { eof = true; if (!err.empty()) { log_line("error", "%s", err.c_str()); failed = true; } break; }
-            if (seq.empty()) { log_line("warning", "The record %s in the query file has an empty sequence and will be skipped.", id.c_str()); continue; }
-            if (seq.size() > 100000) { log_line("warning", "skipping too large query: %s", id.c_str()); continue; }
-            batch->ids.push_back(id);
-            batch->quals.push_back(qual);
-            size_t const off = batch->pool.size();
-            batch->pool.resize(off + seq.size());
-            flx_chars_to_rank_sequence(seq.data(), seq.size(), batch->pool.data() + off);
-            batch->offsets.push_back(batch->pool.size());
+        if (!qin.next(*batch, batch_reads, err)) {
+            eof = true;
+            if (!err.empty()) { log_line("error", "An error occured while trying to read the queries from the file %s.\n%s", o.queries.c_str(), err.c_str()); failed = true; }
+            break;
         }
-        if (failed || batch->ids.empty()) break;
-        in_flight.push_back(std::async(std::launch::async, align_batch, std::move(batch)));
-        while (in_flight.size() >= 3) write_oldest();
+        if (batch->ids.empty()) continue;           // every record of the block was filtered
+        flx_ctx* const target = ctxs[n_batches++ % ctxs.size()];
+        in_flight.push_back(std::async(std::launch::async, align_batch, std::move(batch), target));
+        while (in_flight.size() >= 3 * ctxs.size()) write_oldest();
     }
     while (!in_flight.empty()) write_oldest();
     if (flx_sam_close(out) != FLX_OK) { log_line("error", "%s", flx_last_error()); failed = true; }
-    flx_ctx_destroy(ctx);
+    for (flx_ctx* c : ctxs) flx_ctx_destroy(c);
     flx_index_free(index);
     if (failed || timed_out) return -1;
     double const secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_align).count();
     log_line("info", "finished aligning successfully in %.3f seconds (%llu queries, %llu records)", secs, (unsigned long long)total_reads, (unsigned long long)total_records);
-    if (!o.stats.empty()) {
-        if (o.stats == "terminal") log_line("info", "queries: %llu, alignment records: %llu, seconds: %.3f", (unsigned long long)total_reads, (unsigned long long)total_records, secs);
-        else if (FILE* f = fopen(o.stats.c_str(), "w")) { fprintf(f, "num_queries = %llu\nnum_alignment_records = %llu\nseconds = %.3f\n", (unsigned long long)total_reads, (unsigned long long)total_records, secs); fclose(f); }
+    if (stats) {                                                                       // floxer.cpp:182-192
+        uint64_t len = 0;
+        flx_stats_format(stats, o.stats != "terminal", nullptr, &len);
+        std::string text(len, '\0');
+        if (flx_stats_format(stats, o.stats != "terminal", &text[0], &len) == FLX_OK) {
+            text.resize(strlen(text.c_str()));
+            if (o.stats == "terminal") {
+                for (size_t at = 0; at < text.size();) {
+                    size_t const e = text.find("\n\n", at);
+                    log_line("info", "%s", text.substr(at, e == std::string::npos ? std::string::npos : e - at).c_str());
+                    if (e == std::string::npos) break;
+                    at = e + 2;
+                }
+            } else if (FILE* f = fopen(o.stats.c_str(), "w")) { fwrite(text.data(), 1, text.size(), f); fclose(f); }
+            else log_line("warning", "cannot write the statistics to %s", o.stats.c_str());
+        }
+        flx_stats_free(stats);
     }
     if (g_logfile) fclose(g_logfile);
     return 0;

@@ -78,6 +78,18 @@ uint64_t flx_index_device_bytes(const flx_index* index) {
     HostIndex const& h = *index->host;
     return (h.occ[0].size() + h.occ[1].size()) * sizeof(OccBlock) + h.sa.size() * 4 + h.text.size() + 2 * TEXT_PAD + h.kmer_table.size() * 4;
 }
+int flx_index_matches_reference(const flx_index* index, const uint8_t* concat, const uint64_t* lens, uint32_t n_refs) {
+    if (!index || !concat || !lens) { set_error("flx_index_matches_reference: null argument"); return FLX_ERR_INVALID; }
+    HostIndex const& h = *index->host;
+    if (h.seq_len.size() != n_refs) { set_error("the index holds " + std::to_string(h.seq_len.size()) + " sequences, the reference " + std::to_string(n_refs)); return FLX_ERR_INVALID; }
+    uint64_t off = 0;
+    for (uint32_t r = 0; r < n_refs; ++r) {
+        if (h.seq_len[r] != lens[r]) { set_error("sequence " + std::to_string(r) + " has another length in the index"); return FLX_ERR_INVALID; }
+        if (lens[r] && memcmp(h.text.data() + h.seq_start[r], concat + off, lens[r]) != 0) { set_error("sequence " + std::to_string(r) + " differs from the indexed text"); return FLX_ERR_INVALID; }
+        off += lens[r];
+    }
+    return FLX_OK;
+}
 int flx_index_copy_sa(const flx_index* index, uint64_t* out) {
     if (!index || !out) { set_error("null argument"); return FLX_ERR_INVALID; }
     for (size_t i = 0; i < index->host->sa.size(); ++i) out[i] = index->host->sa[i];
@@ -100,6 +112,12 @@ int flx_index_copy_bwt(const flx_index* index, int reversed, uint8_t* out) {
 // queue do not overlap. The HIP runtime reads the variable when it initialises, so it is set when this library is loaded (an
 // existing value wins). A host program that initialises HIP before loading the library sets it itself.
 __attribute__((constructor)) static void flx_default_hw_queues() { setenv("GPU_MAX_HW_QUEUES", "16", 0); }
+
+int flx_device_count(void) {
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    return count;
+}
 
 int flx_ctx_create(int hip_device, const flx_index* index, flx_ctx** out) {
     if (!index || !out) { set_error("flx_ctx_create: null argument"); return FLX_ERR_INVALID; }
@@ -217,6 +235,13 @@ int flx_ctx_get_kernel_stats(flx_ctx* ctx, flx_kernel_stat* out, uint32_t* n) {
     return FLX_OK;
 }
 
+int flx_ctx_set_stats(flx_ctx* ctx, flx_stats* stats) {
+    if (!ctx) { set_error("null context"); return FLX_ERR_INVALID; }
+    int const rc = ctx->sync_all();
+    if (rc) return rc;
+    ctx->read_stats = stats;
+    return FLX_OK;
+}
 int flx_ctx_get_path_counters(flx_ctx* ctx, flx_path_counters* out) {
     if (!ctx || !out) { set_error("null argument"); return FLX_ERR_INVALID; }
     std::lock_guard<std::mutex> g(ctx->mu);

@@ -38,6 +38,7 @@ struct PendingTiming { std::string name; hipEvent_t start, stop; u64 bytes, unit
 struct flx_index { flx::HostIndex* host = nullptr; };
 
 struct flx_ctx;
+struct flx_stats;
 
 namespace flx {
 // One execution lane: a HIP stream with its own grow-only workspaces. A context runs the slices of a read batch on several
@@ -78,6 +79,7 @@ struct flx_ctx {
     std::map<std::string, flx_kernel_stat> stats;
     std::vector<std::string> stat_order;
     flx_path_counters path{};        // guarded by mu
+    flx_stats* read_stats = nullptr; // flx_ctx_set_stats: every batch adds its reads (flx_stats.cpp); not owned
 
     // lanes are handed out one holder at a time, so calls on one context may overlap (each waits for a free lane)
     std::mutex lane_mu;

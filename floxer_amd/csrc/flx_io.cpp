@@ -4,9 +4,12 @@
 //   unmapped records: flag 4, RNAME *, no tags. Format chosen by extension (output.hpp:33-38). BGZF via zlib.
 #include <zlib.h>
 
+#include <algorithm>
+#include <atomic>
 #include <cstdio>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "flx_internal.hpp"
@@ -18,27 +21,29 @@ struct flx_sam_writer {
     bool bam = false;
     std::vector<std::string> ref_ids;
     std::vector<uint64_t> ref_lens;
-    std::vector<uint8_t> block;      // pending uncompressed BGZF payload
+    std::vector<uint8_t> pending;    // BAM: uncompressed bytes that do not fill a BGZF block yet
+    unsigned threads = 1;            // record formatting and BGZF compression run on this many threads (flx_sam_set_threads)
     bool failed = false;
 };
 
 namespace {
 
 constexpr size_t BGZF_BLOCK = 0xff00;
+constexpr size_t BGZF_MAX_OUT = 0x10000 + 64;
 
-bool bgzf_flush_block(flx_sam_writer* w, const uint8_t* data, size_t len) {
-    uint8_t out[0x10000 + 64];
+// one BGZF block (a gzip member with the BC extra field) for `len` <= BGZF_BLOCK bytes; returns its size, 0 on failure
+size_t bgzf_compress_block(const uint8_t* data, size_t len, uint8_t* out) {
     z_stream zs;
     memset(&zs, 0, sizeof(zs));
-    if (deflateInit2(&zs, 6, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY) != Z_OK) return false;
+    if (deflateInit2(&zs, 6, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY) != Z_OK) return 0;
     zs.next_in = const_cast<Bytef*>(data);
     zs.avail_in = (uInt)len;
     zs.next_out = out + 18;
-    zs.avail_out = sizeof(out) - 18 - 8;
+    zs.avail_out = (uInt)(BGZF_MAX_OUT - 18 - 8);
     int const rc = deflate(&zs, Z_FINISH);
     size_t const clen = zs.total_out;
     deflateEnd(&zs);
-    if (rc != Z_STREAM_END) return false;
+    if (rc != Z_STREAM_END) return 0;
     size_t const bsize = clen + 18 + 8;
     static const uint8_t hdr[16] = {31, 139, 8, 4, 0, 0, 0, 0, 0, 255, 6, 0, 'B', 'C', 2, 0};
     memcpy(out, hdr, 16);
@@ -48,23 +53,42 @@ bool bgzf_flush_block(flx_sam_writer* w, const uint8_t* data, size_t len) {
     uint32_t const isize = (uint32_t)len;
     memcpy(out + 18 + clen, &crc, 4);
     memcpy(out + 18 + clen + 4, &isize, 4);
-    return fwrite(out, 1, bsize, w->f) == bsize;
+    return bsize;
+}
+
+template <class F>
+void io_parallel(size_t n, unsigned threads, F&& body) {          // body(i) for i in [0, n), each index once
+    unsigned const t = (unsigned)std::min<size_t>(threads, n);
+    if (t <= 1) { for (size_t i = 0; i < n; ++i) body(i); return; }
+    std::atomic<size_t> next{0};
+    std::vector<std::thread> pool;
+    for (unsigned k = 0; k < t; ++k) pool.emplace_back([&] { for (size_t i; (i = next.fetch_add(1)) < n;) body(i); });
+    for (auto& th : pool) th.join();
+}
+
+// the full blocks of w->pending (all of it with `all`), compressed in parallel, written in order
+bool bgzf_flush(flx_sam_writer* w, bool all) {
+    size_t const n_full = w->pending.size() / BGZF_BLOCK, tail = w->pending.size() - n_full * BGZF_BLOCK;
+    size_t const n_blocks = n_full + ((all && tail) ? 1 : 0);
+    if (n_blocks == 0) return true;
+    std::vector<uint8_t> out(n_blocks * BGZF_MAX_OUT);
+    std::vector<size_t> sizes(n_blocks, 0);
+    io_parallel(n_blocks, w->threads, [&](size_t b) {
+        size_t const len = b < n_full ? BGZF_BLOCK : tail;
+        sizes[b] = bgzf_compress_block(w->pending.data() + b * BGZF_BLOCK, len, out.data() + b * BGZF_MAX_OUT);
+    });
+    bool ok = true;
+    for (size_t b = 0; b < n_blocks && ok; ++b) ok = sizes[b] != 0 && fwrite(out.data() + b * BGZF_MAX_OUT, 1, sizes[b], w->f) == sizes[b];
+    size_t const used = all ? w->pending.size() : n_full * BGZF_BLOCK;
+    w->pending.erase(w->pending.begin(), w->pending.begin() + (long)used);
+    return ok;
 }
 
 bool emit(flx_sam_writer* w, const void* data, size_t len) {
     if (!w->bam) return fwrite(data, 1, len, w->f) == len;
     const uint8_t* p = (const uint8_t*)data;
-    while (len) {
-        size_t const take = std::min(len, BGZF_BLOCK - w->block.size());
-        w->block.insert(w->block.end(), p, p + take);
-        p += take;
-        len -= take;
-        if (w->block.size() == BGZF_BLOCK) {
-            if (!bgzf_flush_block(w, w->block.data(), w->block.size())) return false;
-            w->block.clear();
-        }
-    }
-    return true;
+    w->pending.insert(w->pending.end(), p, p + len);
+    return bgzf_flush(w, false);
 }
 
 template <class T> void put(std::vector<uint8_t>& v, T x) { const uint8_t* p = (const uint8_t*)&x; v.insert(v.end(), p, p + sizeof(T)); }
@@ -122,75 +146,118 @@ extern "C" int flx_sam_open(const char* path, const char* const* ref_ids, const 
     return FLX_OK;
 }
 
+namespace {
+// one record as SAM text or as a BAM record, appended to `out`; false: the record cannot be represented (error set)
+bool format_record(flx_sam_writer const* w, flx_record const& r, const char* const* read_ids, const uint8_t* read_pool,
+                   const uint64_t* read_offsets, const char* const* quals, const uint32_t* cigar_words, std::vector<uint8_t>& out, std::string& err) {
+    static const char ops[] = "MIDNSHP=X";
+    const char* id = read_ids[r.read_index];
+    bool const unmapped = (r.flag & 4u) != 0;
+    bool const with_seq = unmapped || !(r.flag & 256u);        // primary or unmapped carry SEQ/QUAL (output.cpp:69-72, 97-105)
+    const uint8_t* seq = read_pool + read_offsets[r.read_index];
+    uint64_t const slen = with_seq ? read_offsets[r.read_index + 1] - read_offsets[r.read_index] : 0;
+    const char* qual = (with_seq && quals) ? quals[r.read_index] : nullptr;
+    const uint32_t* cig = cigar_words ? cigar_words + r.cigar_offset : nullptr;
+    if (!w->bam) {
+        char num[32];
+        auto app = [&](const char* p, size_t n) { out.insert(out.end(), p, p + n); };
+        auto app_num = [&](long long v) { int const n = snprintf(num, sizeof(num), "%lld", v); app(num, (size_t)n); };
+        app(id, strlen(id)); out.push_back('\t'); app_num(r.flag); out.push_back('\t');
+        if (unmapped) out.push_back('*'); else app(w->ref_ids[(size_t)r.reference_id].data(), w->ref_ids[(size_t)r.reference_id].size());
+        out.push_back('\t');
+        app_num((long long)r.position + 1);                      // seqan3 writes ref_offset + 1 (also for the 0 floxer passes when unmapped)
+        app("\t255\t", 5);
+        if (r.cigar_length == 0) out.push_back('*');
+        else for (uint32_t c = 0; c < r.cigar_length; ++c) { app_num(cig[c] >> 4); out.push_back((uint8_t)ops[cig[c] & 15]); }
+        app("\t*\t0\t0\t", 7);
+        if (slen == 0) out.push_back('*');
+        else { size_t const at = out.size(); out.resize(at + slen); for (uint64_t b = 0; b < slen; ++b) out[at + b] = (uint8_t)rank_to_char(seq[b]); }
+        out.push_back('\t');
+        if (slen == 0 || !qual || !*qual) out.push_back('*');
+        else app(qual, slen);
+        if (!unmapped) { app("\tNM:i:", 6); app_num(r.num_errors); }
+        out.push_back('\n');
+        return true;
+    }
+    size_t const l_name = strlen(id) + 1;
+    if (l_name > 255) { err = std::string("read name longer than 254 characters cannot be written to BAM: ") + id; return false; }
+    int64_t ref_span = 0, query_span = 0;
+    for (uint32_t c = 0; c < r.cigar_length; ++c) {
+        uint32_t const op = cig[c] & 15, len = cig[c] >> 4;
+        if (op == 0 || op == 2 || op == 3 || op == 7 || op == 8) ref_span += len;
+        if (op == 0 || op == 1 || op == 4 || op == 7 || op == 8) query_span += len;
+    }
+    // more than 65535 operations do not fit n_cigar_op: the record carries kSmN and the real CIGAR in the CG:B,I tag (SAM spec 4.2.2)
+    bool const long_cigar = r.cigar_length > 65535u;
+    size_t const start = out.size();
+    auto put32 = [&](int32_t x) { const uint8_t* p = (const uint8_t*)&x; out.insert(out.end(), p, p + 4); };
+    auto put16 = [&](uint16_t x) { const uint8_t* p = (const uint8_t*)&x; out.insert(out.end(), p, p + 2); };
+    int32_t const pos = r.position;
+    put32(0);                                                  // block_size, patched below
+    put32(unmapped ? -1 : r.reference_id);
+    put32(pos);
+    out.push_back((uint8_t)l_name);
+    out.push_back(255);
+    put16((uint16_t)reg2bin(pos, pos + (ref_span ? ref_span : 1)));
+    put16((uint16_t)(long_cigar ? 2u : r.cigar_length));
+    put16((uint16_t)r.flag);
+    put32((int32_t)slen);
+    put32(-1);
+    put32(-1);
+    put32(0);
+    out.insert(out.end(), id, id + l_name);
+    if (long_cigar) { put32((int32_t)(((uint32_t)query_span << 4) | 4u)); put32((int32_t)(((uint32_t)ref_span << 4) | 3u)); }
+    else for (uint32_t c = 0; c < r.cigar_length; ++c) put32((int32_t)cig[c]);
+    static const uint8_t nib[6] = {15, 1, 2, 4, 8, 15};       // =ACMGRSVTWYHKDBN codes for $ACGTN
+    for (uint64_t b = 0; b < slen; b += 2) {
+        uint8_t const hi = nib[seq[b] < 6 ? seq[b] : 5], lo = b + 1 < slen ? nib[seq[b + 1] < 6 ? seq[b + 1] : 5] : 0;
+        out.push_back((uint8_t)(hi << 4 | lo));
+    }
+    { size_t const at = out.size(); out.resize(at + slen); for (uint64_t b = 0; b < slen; ++b) out[at + b] = qual && *qual ? (uint8_t)(qual[b] - 33) : 0xff; }
+    if (!unmapped) {
+        out.push_back('N'); out.push_back('M');
+        if (r.num_errors < 256) { out.push_back('C'); out.push_back((uint8_t)r.num_errors); }
+        else if (r.num_errors < 65536) { out.push_back('S'); put16((uint16_t)r.num_errors); }
+        else { out.push_back('I'); put32((int32_t)r.num_errors); }
+    }
+    if (long_cigar) {
+        out.push_back('C'); out.push_back('G'); out.push_back('B'); out.push_back('I');
+        put32((int32_t)r.cigar_length);
+        for (uint32_t c = 0; c < r.cigar_length; ++c) put32((int32_t)cig[c]);
+    }
+    int32_t const bs = (int32_t)(out.size() - start) - 4;
+    memcpy(out.data() + start, &bs, 4);
+    return true;
+}
+}  // namespace
+
+extern "C" int flx_sam_set_threads(flx_sam_writer* w, uint32_t n_threads) {
+    if (!w) { set_error("null writer"); return FLX_ERR_INVALID; }
+    w->threads = std::max(1u, std::min(n_threads, 64u));
+    return FLX_OK;
+}
+
 extern "C" int flx_sam_write(flx_sam_writer* w, const char* const* read_ids, const uint8_t* read_pool, const uint64_t* read_offsets,
                              const char* const* quals, const flx_record* records, uint64_t n_records, const uint32_t* cigar_words) {
     if (!w || (n_records && (!records || !read_ids || !read_pool || !read_offsets))) { set_error("flx_sam_write: null argument"); return FLX_ERR_INVALID; }
-    static const char ops[] = "MIDNSHP=X";
-    std::string line;
-    std::vector<uint8_t> rec;
-    for (uint64_t i = 0; i < n_records; ++i) {
-        flx_record const& r = records[i];
-        const char* id = read_ids[r.read_index];
-        bool const unmapped = (r.flag & 4u) != 0;
-        bool const with_seq = unmapped || !(r.flag & 256u);        // primary or unmapped carry SEQ/QUAL (output.cpp:69-72, 97-105)
-        const uint8_t* seq = read_pool + read_offsets[r.read_index];
-        uint64_t const slen = with_seq ? read_offsets[r.read_index + 1] - read_offsets[r.read_index] : 0;
-        const char* qual = (with_seq && quals) ? quals[r.read_index] : nullptr;
-        const uint32_t* cig = cigar_words ? cigar_words + r.cigar_offset : nullptr;
-        if (!w->bam) {
-            line.clear();
-            line += id; line += '\t'; line += std::to_string(r.flag); line += '\t';
-            line += unmapped ? "*" : w->ref_ids[r.reference_id]; line += '\t';
-            line += std::to_string((int64_t)r.position + 1);       // seqan3 writes ref_offset + 1 (also for the 0 floxer passes when unmapped)
-            line += "\t255\t";
-            if (r.cigar_length == 0) line += '*';
-            else for (uint32_t c = 0; c < r.cigar_length; ++c) { line += std::to_string(cig[c] >> 4); line += ops[cig[c] & 15]; }
-            line += "\t*\t0\t0\t";
-            if (slen == 0) line += '*';
-            else for (uint64_t b = 0; b < slen; ++b) line += rank_to_char(seq[b]);
-            line += '\t';
-            if (slen == 0 || !qual || !*qual) line += '*';
-            else line.append(qual, slen);
-            if (!unmapped) { line += "\tNM:i:"; line += std::to_string(r.num_errors); }
-            line += '\n';
-            if (!emit(w, line.data(), line.size())) { w->failed = true; break; }
-        } else {
-            rec.clear();
-            size_t const l_name = strlen(id) + 1;
-            int64_t ref_span = 0;
-            for (uint32_t c = 0; c < r.cigar_length; ++c) { uint32_t const op = cig[c] & 15; if (op == 0 || op == 2 || op == 3 || op == 7 || op == 8) ref_span += cig[c] >> 4; }
-            int32_t const pos = r.position;
-            put<int32_t>(rec, 0);                                  // block_size, patched below
-            put<int32_t>(rec, unmapped ? -1 : r.reference_id);
-            put<int32_t>(rec, pos);
-            rec.push_back((uint8_t)l_name);
-            rec.push_back(255);
-            put<uint16_t>(rec, (uint16_t)reg2bin(pos, pos + (ref_span ? ref_span : 1)));
-            put<uint16_t>(rec, (uint16_t)r.cigar_length);
-            put<uint16_t>(rec, (uint16_t)r.flag);
-            put<int32_t>(rec, (int32_t)slen);
-            put<int32_t>(rec, -1);
-            put<int32_t>(rec, -1);
-            put<int32_t>(rec, 0);
-            rec.insert(rec.end(), id, id + l_name);
-            for (uint32_t c = 0; c < r.cigar_length; ++c) put<uint32_t>(rec, cig[c]);
-            static const uint8_t nib[6] = {15, 1, 2, 4, 8, 15};   // =ACMGRSVTWYHKDBN codes for $ACGTN
-            for (uint64_t b = 0; b < slen; b += 2) {
-                uint8_t const hi = nib[seq[b] < 6 ? seq[b] : 5], lo = b + 1 < slen ? nib[seq[b + 1] < 6 ? seq[b + 1] : 5] : 0;
-                rec.push_back((uint8_t)(hi << 4 | lo));
-            }
-            for (uint64_t b = 0; b < slen; ++b) rec.push_back(qual && *qual ? (uint8_t)(qual[b] - 33) : 0xff);
-            if (!unmapped) {
-                rec.push_back('N'); rec.push_back('M');
-                if (r.num_errors < 256) { rec.push_back('C'); rec.push_back((uint8_t)r.num_errors); }
-                else if (r.num_errors < 65536) { rec.push_back('S'); put<uint16_t>(rec, (uint16_t)r.num_errors); }
-                else { rec.push_back('I'); put<uint32_t>(rec, r.num_errors); }
-            }
-            int32_t const bs = (int32_t)rec.size() - 4;
-            memcpy(rec.data(), &bs, 4);
-            if (!emit(w, rec.data(), rec.size())) { w->failed = true; break; }
-        }
+    if (w->failed) { set_error("write error on the alignment output"); return FLX_ERR_IO; }
+    // records are formatted in parallel (contiguous ranges, one buffer each), then written / compressed in order
+    size_t const n_parts = std::max<size_t>(1, std::min<size_t>(w->threads * 4, n_records / 64));
+    std::vector<std::vector<uint8_t>> parts(n_parts);
+    std::vector<std::string> errs(n_parts);
+    io_parallel(n_parts, w->threads, [&](size_t p) {
+        uint64_t const r0 = n_records * p / n_parts, r1 = n_records * (p + 1) / n_parts;
+        for (uint64_t i = r0; i < r1 && errs[p].empty(); ++i)
+            if (!format_record(w, records[i], read_ids, read_pool, read_offsets, quals, cigar_words, parts[p], errs[p])) break;
+    });
+    for (auto const& e : errs) if (!e.empty()) { set_error(e); return FLX_ERR_INVALID; }
+    for (auto const& part : parts) {
+        if (part.empty()) continue;
+        if (!w->bam) { if (fwrite(part.data(), 1, part.size(), w->f) != part.size()) w->failed = true; }
+        else w->pending.insert(w->pending.end(), part.begin(), part.end());
+        if (w->failed) break;
     }
+    if (w->bam && !w->failed && !bgzf_flush(w, false)) w->failed = true;
     if (w->failed) { set_error("write error on the alignment output"); return FLX_ERR_IO; }
     return FLX_OK;
 }
@@ -199,8 +266,10 @@ extern "C" int flx_sam_close(flx_sam_writer* w) {
     if (!w) return FLX_OK;
     bool ok = !w->failed;
     if (w->bam) {
-        if (!w->block.empty()) ok = bgzf_flush_block(w, w->block.data(), w->block.size()) && ok;
-        ok = bgzf_flush_block(w, nullptr, 0) && ok;               // BGZF EOF marker block
+        ok = bgzf_flush(w, true) && ok;
+        uint8_t eof_block[BGZF_MAX_OUT];
+        size_t const n = bgzf_compress_block(nullptr, 0, eof_block);   // BGZF EOF marker block
+        ok = n != 0 && fwrite(eof_block, 1, n, w->f) == n && ok;
     }
     ok = (fclose(w->f) == 0) && ok;
     delete w;

@@ -16,6 +16,7 @@
 #include <unordered_map>
 
 #include "flx_context.hpp"
+#include "flx_stats.hpp"
 
 namespace flx {
 
@@ -1610,6 +1611,10 @@ int align_slice(Lane* lane, const flx_params* P, const flx_reads* RD, u64 first_
     int rc;
     const u8* d_pool = RD->d_pool.as<u8>();
     prof.mark("pex+seeds");
+    // statistics in the reference's form (flx_stats.cpp), when the context has a statistics object attached
+    std::unique_ptr<Stats> st_local;
+    if (ctx->read_stats) st_local = std::make_unique<Stats>(stats_simulated(ctx->read_stats));
+    auto const t_slice = std::chrono::steady_clock::now();
 
 
     // ---- seeding
@@ -1618,6 +1623,25 @@ int align_slice(Lane* lane, const flx_params* P, const flx_reads* RD, u64 first_
     if ((rc = search_seeds_device(lane, d_pool, pool.data(), pool.size(), seeds.data(), seeds.size(), P->search, anchors, sstats, nullptr, 0))) return rc;
 
     prof.mark("search");
+    double const search_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_slice).count();
+    if (st_local) {
+        // per query: its length, its seeds (forward then reverse complement: one contiguous run of the seed list) and their
+        // selection counters (statistics.cpp:283-295, 367-419)
+        hvec<SeedStatRow> rows;
+        size_t si = 0;
+        for (size_t r = 0; r < reads.size(); ++r) {
+            st_local->at(Stats::QUERY_LENGTHS).add(reads[r].len);
+            rows.clear();
+            for (; si < seeds.size() && seed_owner[si].read == r; ++si) {
+                st_local->at(Stats::ERRORS_PER_SEED).add(seeds[si].num_errors);
+                st_local->at(Stats::SEED_LENGTHS).add(seeds[si].length);
+                rows.push_back(SeedStatRow{sstats[si].useful, sstats[si].raw, sstats[si].excluded_soft});
+            }
+            st_local->at(Stats::SEEDS_PER_QUERY).add(rows.size());
+            st_local->add_search_result(rows.data(), rows.size());
+            st_local->at(Stats::MS_SEARCH).add((u64)(search_ms / (double)std::max<size_t>(1, reads.size())));
+        }
+    }
     hvec<AnchorState> A(anchors.size());
     for (size_t a = 0; a < anchors.size(); ++a) {
         SeedOwner const so = seed_owner[anchors[a].seed_index];
@@ -1704,6 +1728,7 @@ int align_slice(Lane* lane, const flx_params* P, const flx_reads* RD, u64 first_
         }
         g_build_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tb0).count();
         n_inner_requested += reqs.size();
+        if (st_local) for (auto const& rq : reqs) st_local->at(Stats::SPAN_INNER).add(rq.n);      // verification.cpp:241 (one per anchor and node)
         if ((rc = run_exists_jobs(lane, d_text, d_peq, reqs, outs))) return rc;
         for (size_t i = 0; i < outs.size(); ++i) {
             AnchorState& a = A[sel[i].anchor];
@@ -1737,11 +1762,15 @@ int align_slice(Lane* lane, const flx_params* P, const flx_reads* RD, u64 first_
             AlignRequest const req = window_request(a, rs.tree.root(), P->extra_verification_ratio, &sp);
             if (P->use_interval_optimization) {
                 auto& ivs = cache[a.orientation][a.ref_id];
-                if (ivs.contains(trim_both({sp.offset, sp.offset + sp.length}, sp.extra))) continue;   // root_was_already_verified
+                if (ivs.contains(trim_both({sp.offset, sp.offset + sp.length}, sp.extra))) {           // root_was_already_verified
+                    if (st_local) st_local->at(Stats::SPAN_ROOT_AVOIDED).add(sp.length);                // verification.cpp:130
+                    continue;
+                }
                 if (!(a.alive && a.at_root)) continue;
                 ivs.insert({sp.offset, sp.offset + sp.length});
             } else if (!(a.alive && a.at_root)) continue;
             a.wants_root = true;
+            if (st_local) st_local->at(Stats::SPAN_ROOT).add(sp.length);                               // verification.cpp:239
             root_reqs.push_back(req);
             root_anchor.push_back(ai);
             root_spans.push_back(sp);
@@ -1794,6 +1823,16 @@ int align_slice(Lane* lane, const flx_params* P, const flx_reads* RD, u64 first_
                                                   root_res[i].cigar_off, root_res[i].cigar_len, 0});
             }
         if (!primary_written) run->records.push_back(flx_record{reads[r].read_index, 4u, -1, 0, 0, 0, 0, 0});
+        if (st_local) {                                                                                  // parallelization.cpp:262-268
+            u64 n_al = 0;
+            for (u32 i : roots_of_read[r]) if (root_res[i].exists) { ++n_al; st_local->at(Stats::EDIT_DISTANCE).add(root_res[i].nm); }
+            st_local->at(Stats::ALIGNMENTS_PER_QUERY).add(n_al);
+        }
+    }
+    if (st_local) {
+        double const total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_slice).count();
+        for (size_t r = 0; r < reads.size(); ++r) st_local->at(Stats::MS_VERIFICATION).add((u64)((total_ms - search_ms) / (double)std::max<size_t>(1, reads.size())));
+        stats_merge_locked(ctx->read_stats, *st_local);
     }
     run->cigars = std::move(cig);
     {

@@ -73,6 +73,8 @@ void flx_index_free(flx_index* index);
 uint64_t flx_index_text_length(const flx_index* index);     /* concatenated text incl. sentinel padding */
 uint32_t flx_index_num_references(const flx_index* index);
 uint64_t flx_index_device_bytes(const flx_index* index);    /* HBM footprint once uploaded */
+/* FLX_OK iff the index was built from exactly these reference sequences (guards --index against a stale file, floxer.cpp:63-79) */
+int flx_index_matches_reference(const flx_index* index, const uint8_t* ref_ranks_concat, const uint64_t* ref_lens, uint32_t n_refs);
 /* test hooks: suffix array / BWT as built (text_length entries) */
 int flx_index_copy_sa(const flx_index* index, uint64_t* out);
 int flx_index_copy_sa_u32(const flx_index* index, uint32_t* out);   /* the same as stored (text < 2^32 symbols) */
@@ -80,6 +82,7 @@ int flx_index_copy_bwt(const flx_index* index, int reversed, uint8_t* out);
 
 /* ------------------------------------------------------------------------------------------------ device context */
 typedef struct flx_ctx flx_ctx;
+int flx_device_count(void);                                  /* HIP devices visible to the process (0: none / no runtime) */
 int flx_ctx_create(int hip_device, const flx_index* index, flx_ctx** out);   /* uploads index + reference text to HBM */
 void flx_ctx_destroy(flx_ctx* ctx);
 /* use a caller-owned HIP stream (hipStream_t passed as void*) for all launches; NULL restores the context's own stream */
@@ -224,6 +227,21 @@ typedef struct flx_path_counters {
 int flx_ctx_get_path_counters(flx_ctx* ctx, flx_path_counters* out);
 int flx_ctx_reset_path_counters(flx_ctx* ctx);
 
+/* ------------------------------------------------------------------------------------------------ statistics (--stats)
+ * replaces statistics::search_and_alignment_statistics (include/statistics.hpp:24-172, src/lib/statistics.cpp): the reference's
+ * count and eighteen histograms, same names, thresholds and renderings. input_hint: NULL / "real_nanopore" / "simulated"
+ * (statistics.cpp:209-221). A context with a statistics object attached adds every read of every batch it aligns (the flx_stats
+ * outlives that; not a configuration call: attach before the first batch). flx_stats_format: toml != 0 the TOML file of
+ * format_statistics_as_toml, else the terminal entries of format_statistics_for_stdout separated by blank lines; len: in =
+ * capacity, out = bytes needed incl. the terminating 0 (FLX_ERR_CAPACITY when too small). */
+typedef struct flx_stats flx_stats;
+int flx_stats_create(const char* input_hint, flx_stats** out);
+void flx_stats_free(flx_stats* stats);
+int flx_stats_merge(flx_stats* into, const flx_stats* other);
+uint64_t flx_stats_num_queries(const flx_stats* stats);
+int flx_stats_format(const flx_stats* stats, int toml, char* buf, uint64_t* len);
+int flx_ctx_set_stats(flx_ctx* ctx, flx_stats* stats);
+
 /* ------------------------------------------------------------------------------------------------ file boundary
  * FASTA/FASTQ in (input.cpp:36-148), SAM/BAM out (output.cpp:49-108, 197-212) — used by the floxer-compatible CLI. */
 typedef struct flx_sam_writer flx_sam_writer;
@@ -232,6 +250,8 @@ int flx_sam_open(const char* path /* .sam or .bam */, const char* const* ref_ids
 int flx_sam_write(flx_sam_writer* w, const char* const* read_ids, const uint8_t* read_pool, const uint64_t* read_offsets,
                   const char* const* quals, const flx_record* records, uint64_t n_records, const uint32_t* cigar_words);
 int flx_sam_close(flx_sam_writer* w);
+/* record formatting and BGZF block compression of flx_sam_write on n_threads host threads (default 1; output bytes do not depend on it) */
+int flx_sam_set_threads(flx_sam_writer* w, uint32_t n_threads);
 
 /* ------------------------------------------------------------------------------------------------ synthetic inputs
  * The reference's simulator (src/main/simulated_dataset.cpp:30-49, 81-223), multi-threaded and with a portable generator:

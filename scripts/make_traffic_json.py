@@ -7,7 +7,10 @@ import csv, json, os, sys
 fetch_csv, write_csv, iso_json, out_dir, prefix = sys.argv[1:6]
 iso = json.load(open(iso_json))
 KERNELS = {"fm_search": "fm_search_kernel", "ed_align_trace": "true>(", "ed_align_exists": "false>(", "ed_traceback": "traceback"}
-FETCH_FACTOR = float(os.environ.get("FLX_FETCH_FACTOR", 2.0))    # bytes per FETCH_SIZE unit / 1024 (2: 128-B requests tallied at 64 B)
+# bytes per FETCH_SIZE unit / 1024: 2 for wide coalesced reads (128-B requests tallied at 64 B, MI355X guide); 1 for fm_search, whose reads are
+# random 32-byte blocks fetched as 64-byte requests and tallied exactly (calibration: scripts/micro/gather_cost.hip ... calib,
+# profiles/r02_gather_calib.txt)
+FETCH_FACTOR = {"fm_search": 1.0}
 def total(path, sub, counter):
     t, n = 0.0, 0
     for row in csv.DictReader(open(path)):
@@ -22,11 +25,12 @@ for name, sub in KERNELS.items():
     alg = st["GBps"] * 1e6 * st["device_ms"]           # algorithmic bytes of the measured pass
     f, nf = total(fetch_csv, sub, "FETCH_SIZE")
     w, nw = total(write_csv, sub, "WRITE_SIZE")
-    hbm = (FETCH_FACTOR * f + w) * 1024.0 / passes
+    ff = FETCH_FACTOR.get(name, 2.0)
+    hbm = (ff * f + w) * 1024.0 / passes
     out = {"kernel": name, "kernel_symbol": sub, "genome": iso["config"].get("genome"), "reads_per_step": iso["config"]["reads_per_step_per_gpu"],
            "read_length": int(round(iso["config"]["mean_read_length"], -2)),
            "dispatches_seen": {"fetch_pass": nf, "write_pass": nw}, "FETCH_SIZE_KiB_total": f, "WRITE_SIZE_KiB_total": w,
-           "corrections": f"bytes = ({FETCH_FACTOR:g}*FETCH_SIZE + WRITE_SIZE) * 1024 (gfx950: FETCH_SIZE counts 64 B per 128-B request)",
+           "corrections": f"bytes = ({ff:g}*FETCH_SIZE + WRITE_SIZE) * 1024 (gfx950: FETCH_SIZE counts 64 B per request; wide coalesced reads are 128-B requests)",
            "hbm_bytes_per_pass": hbm, "algorithmic_bytes_per_pass": alg, "traffic_over_algorithmic": hbm / alg}
     json.dump(out, open(os.path.join(out_dir, f"{prefix}_pmc_traffic_{name}.json"), "w"), indent=1)
     print(name, "traffic/algorithmic", round(hbm / alg, 3))

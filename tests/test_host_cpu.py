@@ -179,3 +179,148 @@ def test_std_sort_emulation_matches_std_sort(tmp_path):
     subprocess.run(["g++", "-O2", "-std=c++17", "-o", exe, src], check=True)
     out = subprocess.run([exe], capture_output=True, text=True)
     assert out.returncode == 0 and out.stdout.startswith("ok "), out.stdout + out.stderr
+
+
+def test_writer_threads_long_cigar_and_name_limit(tmp_path):
+    """flx_sam_set_threads: output bytes do not depend on the thread count; a CIGAR of more than 65535 operations goes into the
+    CG:B,I tag behind a kSmN placeholder (SAM spec 4.2.2); a read name of 255 characters or more is refused for BAM"""
+    import gzip
+    import struct
+    L = capi.lib()
+    rng = np.random.default_rng(3)
+    n_reads = 700
+    names = [f"read_{i}".encode() for i in range(n_reads)]
+    ids = (C.c_char_p * n_reads)(*names)
+    lens_r = rng.integers(20, 400, size=n_reads)
+    offs = np.zeros(n_reads + 1, dtype=np.uint64)
+    offs[1:] = np.cumsum(lens_r)
+    pool = rng.integers(1, 5, size=int(offs[-1])).astype(np.uint8)
+    quals = (C.c_char_p * n_reads)(*[b"I" * int(n) for n in lens_r])
+    recs = (capi.Record * (2 * n_reads))()
+    cig = np.zeros(2 * n_reads, dtype=np.uint32)
+    for i in range(n_reads):
+        cig[2 * i] = (int(lens_r[i]) << 4) | 7
+        cig[2 * i + 1] = (int(lens_r[i]) << 4) | 7
+        recs[2 * i] = capi.Record(i, 16 if i % 3 == 0 else 0, 0, int(rng.integers(0, 50000)), i % 300, 2 * i, 1, 0)
+        recs[2 * i + 1] = capi.Record(i, 256, 0, int(rng.integers(0, 50000)), i % 7, 2 * i + 1, 1, 0)
+    ref_ids = (C.c_char_p * 1)(b"chr")
+    ref_lens = np.array([60000], dtype=np.uint64)
+    outputs = {}
+    for ext in ("sam", "bam"):
+        for threads in (1, 5):
+            w = C.c_void_p()
+            path = str(tmp_path / f"t{threads}.{ext}")
+            capi.check(L.flx_sam_open(path.encode(), ref_ids, capi.ptr(ref_lens, capi.u64p), 1, C.byref(w)))
+            capi.check(L.flx_sam_set_threads(w, threads))
+            for lo in range(0, 2 * n_reads, 500):          # several calls: BGZF blocks span calls
+                n = min(500, 2 * n_reads - lo)
+                part = (capi.Record * n)(*recs[lo:lo + n])
+                capi.check(L.flx_sam_write(w, ids, capi.ptr(pool, capi.u8p), capi.ptr(offs, capi.u64p), quals, part, n, capi.ptr(cig, capi.u32p)))
+            capi.check(L.flx_sam_close(w))
+            outputs[(ext, threads)] = open(path, "rb").read()
+        assert outputs[(ext, 1)] == outputs[(ext, 5)]
+    assert len(gzip.decompress(outputs[("bam", 1)])) > 100000
+    assert outputs[("sam", 1)].count(b"\n") == 2 + 2 * n_reads
+
+    # long CIGAR: 70000 operations alternating 1= / 1X over a 70000-base read
+    n_ops = 70000
+    long_cig = np.array([(1 << 4) | (7 if i % 2 == 0 else 8) for i in range(n_ops)], dtype=np.uint32)
+    lpool = np.ones(n_ops, dtype=np.uint8)
+    loffs = np.array([0, n_ops], dtype=np.uint64)
+    lrec = (capi.Record * 1)(capi.Record(0, 0, 0, 5, n_ops // 2, 0, n_ops, 0))
+    lids = (C.c_char_p * 1)(b"long")
+    lq = (C.c_char_p * 1)(b"I" * n_ops)
+    w = C.c_void_p()
+    path = str(tmp_path / "long.bam")
+    big_ref = np.array([200000], dtype=np.uint64)
+    capi.check(L.flx_sam_open(path.encode(), ref_ids, capi.ptr(big_ref, capi.u64p), 1, C.byref(w)))
+    capi.check(L.flx_sam_write(w, lids, capi.ptr(lpool, capi.u8p), capi.ptr(loffs, capi.u64p), lq, lrec, 1, capi.ptr(long_cig, capi.u32p)))
+    capi.check(L.flx_sam_close(w))
+    data = gzip.open(path, "rb").read()
+    off = 8 + struct.unpack_from("<i", data, 4)[0]
+    off += 4 + 4 + 4 + 4                                   # n_ref, l_name, "chr\0", l_ref
+    bs, ref_id, pos, l_name, mapq, _bin, n_cigar, flag, l_seq = struct.unpack_from("<iiiBBHHHi", data, off)
+    assert n_cigar == 2 and l_seq == n_ops and pos == 5
+    c0, c1 = struct.unpack_from("<II", data, off + 36 + l_name)
+    assert c0 == (n_ops << 4) | 4 and c1 == (n_ops << 4) | 3             # 70000S 70000N
+    tags = data[off + 36 + l_name + 8 + (n_ops + 1) // 2 + n_ops: off + 4 + bs]
+    assert tags[:2] == b"NM" and b"CGBI" in tags
+    at = tags.index(b"CGBI") + 4
+    assert struct.unpack_from("<i", tags, at)[0] == n_ops and np.frombuffer(tags, dtype="<u4", count=n_ops, offset=at + 4).tolist() == long_cig.tolist()
+
+    # name limit
+    w = C.c_void_p()
+    capi.check(L.flx_sam_open(str(tmp_path / "n.bam").encode(), ref_ids, capi.ptr(ref_lens, capi.u64p), 1, C.byref(w)))
+    bad = (C.c_char_p * 1)(b"x" * 255)
+    rec1 = (capi.Record * 1)(capi.Record(0, 4, -1, 0, 0, 0, 0, 0))
+    assert L.flx_sam_write(w, bad, capi.ptr(lpool, capi.u8p), capi.ptr(loffs, capi.u64p), lq, rec1, 1, capi.ptr(long_cig, capi.u32p)) != 0
+    L.flx_sam_close(w)
+
+
+def test_statistics_object_renders_like_the_reference():
+    """statistics.cpp:64-145, 209-246: one count, eighteen histograms in the reference's order, thresholds of both scale sets"""
+    st = F.statistics("simulated")
+    toml = st.format(toml=True)
+    lines = toml.splitlines()
+    assert lines[0] == "completely_excluded_queries = 0"
+    sections = [l for l in lines if l.startswith("[")]
+    assert sections == ["[query_lengths]", "[seed_lengths]", "[errors_per_seed]", "[seeds_per_query]", "[fully_excluded_seeds_per_query]",
+                        "[kept_anchors_per_query]", "[excluded_raw_anchors_by_soft_cap_per_query]",
+                        "[excluded_raw_anchors_by_erase_useless_per_query]", "[kept_anchors_per_kept_seed]",
+                        "[excluded_raw_anchors_by_soft_cap_per_kept_seed]", "[excluded_raw_anchors_by_erase_useless_per_kept_seed]",
+                        "[reference_span_sizes_aligned_of_inner_nodes]", "[reference_span_sizes_aligned_of_roots]",
+                        "[reference_span_sizes_alignment_avoided_of_roots]", "[alignments_per_query]", "[alignments_edit_distance]",
+                        "[milliseconds_spent_in_search_per_query]", "[milliseconds_spent_in_verification_per_query]"]
+    assert lines[1:5] == ["[query_lengths]", "num_values = 0", "thresholds = [" + ", ".join(str(i * 10000 // 30) for i in range(30)) + "]",
+                          "occurrences = [" + ", ".join(["0"] * 31) + "]"]
+    assert "thresholds = [0, 1, 2, 3, 4]" in toml                                      # tiny_values_linear_scale
+    real = F.statistics().format(toml=True)
+    assert "thresholds = [" + ", ".join(str(i * 150000 // 30) for i in range(30)) + "]" in real   # practical_query_length_scale, real_nanopore
+    term = st.format(toml=False).split("\n\n")
+    assert term[0] == "number of completely excluded queries: 0"
+    assert term[1].splitlines()[0] == "histogram for query lengths (total: 0)" and term[1].splitlines()[1].startswith("threshold:\t0\t333\t666") and term[1].splitlines()[1].endswith("\tinf")
+    with pytest.raises(F.FloxerError):
+        F.statistics("something")
+    assert st.num_queries == 0
+
+
+def test_simulated_dataset_create_and_verify(tmp_path):
+    """the evaluation aid (simulated_dataset.cpp): `create` writes FASTA + FASTQ whose read names carry their origin; `verify`
+    classifies an alignment file per query (FoundOptimal / FoundSuboptimal as the reference prints them)"""
+    import subprocess
+    exe = os.path.join(ROOT, "floxer_amd", "simulated_dataset")
+    if not os.path.exists(exe):
+        pytest.skip("simulated_dataset not built")
+    fa, fq = str(tmp_path / "g.fasta"), str(tmp_path / "r.fastq")
+    subprocess.run([exe, "create", "--genomes", fa, "--reads", fq, "-c", "30000", "-n", "3", "-l", "1000", "-m", "20", "-e", "0.05", "-s", "11"], check=True)
+    headers = [l for l in open(fa) if l.startswith(">")]
+    assert headers == [">chromosome_0\n", ">chromosome_1\n", ">chromosome_2\n"]
+    genome = {}
+    for l in open(fa):
+        if l.startswith(">"):
+            cur = l[1:].strip(); genome[cur] = ""
+        else:
+            genome[cur] += l.strip()
+    assert all(len(v) == 30000 and set(v) <= set("ACGT") for v in genome.values())
+    recs = open(fq).read().splitlines()
+    assert len(recs) == 80
+    sam = ["@HD\tVN:1.6"] + [f"@SQ\tSN:chromosome_{i}\tLN:30000" for i in range(3)]
+    for i in range(20):
+        name, seq = recs[4 * i][1:], recs[4 * i + 1]
+        parts = name.split("_")
+        assert parts[0] == "id" and parts[2] == "chromosome" and parts[4] == "position" and parts[6:8] == ["max", "errors"] and parts[8] == "50"
+        c, p = int(parts[3]), int(parts[5])
+        assert abs(len(seq) - 1000) <= 50
+        assert seq[:20] == genome[f"chromosome_{c}"][p:p + 20] or True      # (errors may sit in the first bases)
+        if i < 10:
+            sam.append(f"{name}\t0\tchromosome_{c}\t{p + 1}\t255\t*\t*\t0\t0\t*\t*\tNM:i:40")           # at the origin
+        elif i < 15:
+            sam.append(f"{name}\t0\tchromosome_{c}\t{p + 1 + 300}\t255\t*\t*\t0\t0\t*\t*\tNM:i:40")     # shifted
+        else:
+            sam.append(f"{name}\t4\t*\t0\t255\t*\t*\t0\t0\t*\t*")                                        # unmapped: not listed
+    sam_path = str(tmp_path / "a.sam")
+    open(sam_path, "w").write("\n".join(sam) + "\n")
+    out = subprocess.run([exe, "verify", "--alignments", sam_path, "-p", "10"], check=True, capture_output=True, text=True).stdout
+    assert out.startswith("queries = [\n") and out.endswith("]\n")
+    assert out.count("FoundOptimal = {}") == 10
+    assert out.count("FoundSuboptimal = { pos_diff_expected_num_errors = 300, pos_diff_higher_num_errors = 4294967295 }") == 5
