@@ -769,3 +769,89 @@ def test_scale_250mb_multi_sequence():
     exp = oidx.run(reads, O.params(error_probability=rate), threads=16)
     assert sub_recs == exp.records()
     ctx.close()
+
+
+def test_cli_devices_stats_fastq_forms_and_accuracy(tmp_path):
+    """The drop-in CLI beyond the reference's own test: (1) a FASTQ as plain text, gzip, with CR LF line ends and without a final
+    line end gives the same SAM; (2) two contexts (--devices 0,0: batches dealt in turn, written in input order) and several I/O
+    threads give the same records as one; SAM and BAM hold the same records; (3) --stats writes the reference's TOML (query count,
+    histogram totals consistent with the records); (4) --index is saved, reused, and refused for another reference;
+    (5) simulated_dataset verify finds every read of the simulated set at its origin."""
+    import gzip
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe, sim = os.path.join(root, "floxer_amd", "floxer"), os.path.join(root, "floxer_amd", "simulated_dataset")
+    fa, fq = str(tmp_path / "g.fasta"), str(tmp_path / "r.fastq")
+    subprocess.run([sim, "create", "--genomes", fa, "--reads", fq, "-c", "200000", "-n", "3", "-l", "2000", "-m", "300", "-e", "0.06", "-s", "5", "--revcomp-fraction", "0.5"], check=True)
+    text = open(fq).read()
+    forms = {"plain": fq, "gz": str(tmp_path / "r2.fastq.gz"), "crlf": str(tmp_path / "r3.fastq"), "noeol": str(tmp_path / "r4.fastq")}
+    with gzip.open(forms["gz"], "wt") as f:
+        f.write(text)
+    open(forms["crlf"], "w", newline="").write(text.replace("\n", "\r\n"))
+    open(forms["noeol"], "w").write(text.rstrip("\n"))
+
+    def run(queries, out, *extra, env=None):
+        cmd = [exe, "--reference", fa, "--queries", queries, "--output", out, "--error-probability", "0.06", *extra]
+        e = dict(os.environ, FLX_BATCH_READS="64", **(env or {}))       # several batches even for 300 reads
+        r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600, env=e)
+        assert r.stdout == b""
+        return r
+
+    def sam_records(path):
+        return [l for l in open(path).read().splitlines() if not l.startswith("@")]
+
+    base_out = str(tmp_path / "base.sam")
+    r = run(fq, base_out, "--threads", "1")
+    assert r.returncode == 0, r.stderr.decode()
+    base = sam_records(base_out)
+    assert len(base) >= 300
+    for name, path in forms.items():
+        if name == "plain":
+            continue
+        o = str(tmp_path / f"{name}.sam")
+        r = run(path, o, "--threads", "3")
+        assert r.returncode == 0, (name, r.stderr.decode())
+        assert sam_records(o) == base, name
+
+    # two contexts on the one GPU, five I/O threads, statistics, index saved
+    o2, toml, idx = str(tmp_path / "two.sam"), str(tmp_path / "stats.toml"), str(tmp_path / "g.index")
+    r = run(fq, o2, "--devices", "0,0", "--threads", "5", "--stats", toml, "--stats-input-hint", "simulated", "--index", idx)
+    assert r.returncode == 0, r.stderr.decode()
+    assert sam_records(o2) == base
+    assert b"2 HIP device contexts" in r.stderr
+    st = open(toml).read()
+    sect = {}
+    cur = None
+    for l in st.splitlines():
+        if l.startswith("["):
+            cur = l[1:-1]; sect[cur] = {}
+        elif cur and " = " in l:
+            k, v = l.split(" = ", 1); sect[cur][k] = v
+    assert st.splitlines()[0].startswith("completely_excluded_queries = ")
+    assert sect["query_lengths"]["num_values"] == "300" and sect["alignments_per_query"]["num_values"] == "300"
+    n_mapped = sum(1 for l in base if not int(l.split("\t")[1]) & 4)
+    assert int(sect["alignments_edit_distance"]["num_values"]) == n_mapped
+    assert int(sect["reference_span_sizes_aligned_of_roots"]["num_values"]) >= n_mapped
+    assert int(sect["seeds_per_query"]["min_value"]) > 0 and "mean" in sect["seed_lengths"]
+
+    # BAM holds the same records; the saved index is loaded (no build) and gives the same output
+    ob = str(tmp_path / "two.bam")
+    r = run(fq, ob, "--index", idx, "--threads", "4")
+    assert r.returncode == 0 and b"loading index" in r.stderr and b"building index" not in r.stderr
+    v_sam = subprocess.run([sim, "verify", "--alignments", base_out, "-p", "120"], check=True, capture_output=True, text=True).stdout
+    v_bam = subprocess.run([sim, "verify", "--alignments", ob, "-p", "120"], check=True, capture_output=True, text=True).stdout
+    assert v_sam == v_bam
+    assert v_sam.count("FoundOptimal = {}") == 300                                        # every simulated read at its origin
+
+    # the index of one reference is refused for another
+    fa2, fq2 = str(tmp_path / "h.fasta"), str(tmp_path / "h.fastq")
+    subprocess.run([sim, "create", "--genomes", fa2, "--reads", fq2, "-c", "200000", "-n", "3", "-l", "2000", "-m", "4", "-e", "0.06", "-s", "6"], check=True)
+    cmd = [exe, "--reference", fa2, "--queries", fq2, "--output", str(tmp_path / "x.sam"), "--error-probability", "0.06", "--index", idx]
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert r.returncode != 0 and b"was not built from the reference" in r.stderr
+
+    # a malformed query file is an error, not a silent truncation
+    bad = str(tmp_path / "bad.fastq")
+    open(bad, "w").write("\n".join(text.splitlines()[:-1]) + "\n")                        # the last record lacks its quality line
+    r = run(bad, str(tmp_path / "bad.sam"))
+    assert r.returncode != 0
