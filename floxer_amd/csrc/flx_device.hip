@@ -838,7 +838,7 @@ int DeviceApi::search(void* stream, const DevIndex& idx, const u8* d_seq, const 
 // their comparators tie (the same row reached through two groups gives two anchors of equal position) and the order of equal
 // elements shows in the result. Every seed not handled is flagged and goes through the host code.
 constexpr u32 SEL_MAX = 64;
-struct SelStat { u8 useful, raw, flag, excluded; };      // flag 1: the host selects this seed's anchors
+struct SelStat { u8 useful, raw, flag, excluded; u32 excluded_soft; };      // flag 1: the host selects this seed's anchors; = DevSelStat
 
 __global__ void __launch_bounds__(256) hit_scatter_kernel(const DevHit* __restrict__ hits, const u32* __restrict__ counters, u32 hit_cap,
                                                           const u32* __restrict__ offset, DevHit* __restrict__ grouped) {
@@ -852,22 +852,6 @@ __global__ void __launch_bounds__(256) hit_scatter_kernel(const DevHit* __restri
     }
 }
 
-// the hits of every seed the device selects for (at most SEL_MAX hits) into the reference's emission order (keys of
-// fm_search_kernel); one thread per seed, stable. Longer segments are left as they are: the host sorts the ones it looks at.
-__global__ void __launch_bounds__(256) seed_sort_kernel(DevHit* __restrict__ grouped, const u32* __restrict__ hit_offset, u32 n_seeds) {
-    u32 const sid = blockIdx.x * blockDim.x + threadIdx.x;
-    if (sid >= n_seeds) return;
-    u32 const g0 = hit_offset[sid], cnt = hit_offset[sid + 1] - g0;
-    if (cnt < 2u || cnt > 64u) return;
-    DevHit* __restrict__ g = grouped + g0;
-    for (u32 i = 1; i < cnt; ++i) {
-        DevHit const v = g[i];
-        u32 j = i;
-        while (j > 0 && v.key < g[j - 1].key) { g[j] = g[j - 1]; --j; }
-        if (j != i) g[j] = v;
-    }
-}
-
 struct SelGroup { u32 lb, len, errors; };
 struct SelAnchor { u64 pos; u32 ref; u32 errors; };
 
@@ -876,16 +860,27 @@ template <u32 CAP, bool WRITE>
 __device__ __forceinline__ bool select_seed(const DevHit* __restrict__ groups, u32 cnt, u32 total, const u32* __restrict__ sa, u32 n_text,
                                             const u64* __restrict__ seq_start, u32 n_ref, u32 erase, u32 sid, SelStat& st, u32& produced,
                                             DevOutAnchor* __restrict__ out, u32 at, u32 out_cap) {
-    // groups ordered by (count, errors) (search.cpp:200-212)
+    // the groups in search_n's emission order (the keys of fm_search_kernel; all 0 from the ordered kernel, whose hits are in it already:
+    // the insertion sort is stable), then ordered by (count, errors) (search.cpp:200-212)
     SelGroup g[CAP];
-    for (u32 i = 0; i < cnt; ++i) g[i] = SelGroup{groups[i].lb, groups[i].len, groups[i].errors};
+    {
+        u64 key[CAP];
+        for (u32 i = 0; i < cnt; ++i) {
+            DevHit const h = groups[i];
+            u32 j = i;
+            while (j > 0 && h.key < key[j - 1]) { key[j] = key[j - 1]; g[j] = g[j - 1]; --j; }
+            key[j] = h.key;
+            g[j] = SelGroup{h.lb, h.len, h.errors};
+        }
+    }
     if (!std_sort_emulated(g, (int)cnt, [](SelGroup const& x, SelGroup const& y) { return x.len != y.len ? x.len < y.len : x.errors < y.errors; })) return false;
     // rows round robin over the groups (search.cpp:239-272), located
     SelAnchor an[CAP];
     u32 kept = 0;
     bool bad = false;
+    // (`total` = the rows to keep: all of them, or the soft cap when the seed has more: the cycle then stops in the middle of a round)
     for (u32 round = 0; kept < total; ++round)
-        for (u32 gi = 0; gi < cnt; ++gi) {
+        for (u32 gi = 0; gi < cnt && kept < total; ++gi) {
             if (g[gi].len <= round) continue;
             u32 const row = g[gi].lb + round;
             u64 const p = row < n_text ? sa[row] : 0xFFFFFFFFull;
@@ -938,46 +933,67 @@ __device__ __forceinline__ bool select_seed(const DevHit* __restrict__ groups, u
     return true;
 }
 
-// rows a seed would select if this kernel handles it (its slots in the sparse anchor list), 0 otherwise
+// Every seed's class: nothing to select (no hit / over the hard cap / left to the host: its statistics are final here), light (at
+// most SEL_LIGHT groups and rows: the common case, one group of one row) or heavy (up to SEL_MAX groups, any number of rows up to
+// the hard cap of which the soft cap's worth is kept). rows[sid] = the slots the seed
+// gets in the sparse anchor list. Light and heavy seeds go on two lists (wave-aggregated appends; the order of a list does not
+// matter, every seed writes to its own slots): the few heavy seeds, whose threads run a hundred times longer on scratch arrays,
+// then do not sit in the waves of the light ones.
+constexpr u32 SEL_LIGHT = 8;
 __global__ void __launch_bounds__(256) seed_rows_kernel(const DevHit* __restrict__ grouped, const u32* __restrict__ hit_offset, u32 n_seeds,
-                                                        u32 hard_cap, u32 soft_cap, u32* __restrict__ rows) {
+                                                        u32 hard_cap, u32 soft_cap, u32* __restrict__ rows, SelStat* __restrict__ stat,
+                                                        u32* __restrict__ n_out, u32* __restrict__ lists, u32* __restrict__ list_counts) {
     u32 const sid = blockIdx.x * blockDim.x + threadIdx.x;
-    if (sid >= n_seeds) return;
-    u32 const g0 = hit_offset[sid], cnt = hit_offset[sid + 1] - g0;
-    u32 total = 0;
-    bool handled = cnt > 0 && cnt <= SEL_MAX;
-    for (u32 i = 0; handled && i < cnt; ++i) { u32 const l = grouped[g0 + i].len; if (l > SEL_MAX) handled = false; else total += l; }
-    rows[sid] = handled && total <= SEL_MAX && total <= soft_cap && total <= hard_cap ? total : 0u;
+    u32 cls = 0;                                             // 1 light, 2 heavy
+    if (sid < n_seeds) {
+        u32 const g0 = hit_offset[sid], cnt = hit_offset[sid + 1] - g0;
+        SelStat st{0, 0, 0, 0, 0};
+        u32 total = 0;
+        if (cnt > SEL_MAX) st.flag = 1;                     // more groups than the sort arrays hold: the host
+        else if (cnt > 0) {
+            u32 all = 0;
+            for (u32 i = 0; i < cnt; ++i) all += min(grouped[g0 + i].len, 0x1000000u);
+            total = min(all, soft_cap);                      // rows kept (search.cpp:239-272 stops at the soft cap)
+            if (all > hard_cap) st.excluded = 1;
+            else if (total > SEL_MAX) st.flag = 1;           // a soft cap beyond the anchor arrays: the host
+            else { cls = (cnt <= SEL_LIGHT && total <= SEL_LIGHT) ? 1u : 2u; st.excluded_soft = all - total; }
+        }
+        rows[sid] = cls ? total : 0u;
+        if (!cls) { stat[sid] = st; n_out[sid] = 0; }
+        else stat[sid].excluded_soft = st.excluded_soft;     // (the select kernels fill in the rest)
+    }
+#pragma unroll
+    for (u32 c = 1; c <= 2; ++c) {
+        u64 const m = __ballot(cls == c);
+        if (!m) continue;
+        u32 base = 0;
+        if (lane_id() == 0) base = atomicAdd(&list_counts[c - 1], (u32)__popcll(m));
+        base = (u32)__builtin_amdgcn_readfirstlane((int)base);
+        if (cls == c) lists[(c - 1) * n_seeds + base + (u32)__popcll(m & ((1ull << lane_id()) - 1ull))] = sid;
+    }
 }
 
-// one pass: every handled seed writes its anchors to its slots of the sparse list (row_offset), n_out says how many
-__global__ void __launch_bounds__(128) seed_select_kernel(const DevHit* __restrict__ grouped, const u32* __restrict__ hit_offset, u32 n_seeds,
-                                                          const u32* __restrict__ sa, u32 n_text, const u64* __restrict__ seq_start, u32 n_ref,
-                                                          u32 hard_cap, u32 soft_cap, u32 erase, SelStat* __restrict__ stat,
-                                                          u32* __restrict__ n_out, const u32* __restrict__ row_offset,
-                                                          DevOutAnchor* __restrict__ sparse, u32 sparse_cap) {
-    u32 const sid = blockIdx.x * blockDim.x + threadIdx.x;
-    if (sid >= n_seeds) return;
-    u32 const g0 = hit_offset[sid], cnt = hit_offset[sid + 1] - g0;
-    SelStat st{0, 0, 0, 0};
-    u32 produced = 0;
-    if (cnt > SEL_MAX) st.flag = 1;
-    else if (cnt > 0) {
-        u32 total = 0;
-        bool big = false;
-        for (u32 i = 0; i < cnt; ++i) { u32 const l = grouped[g0 + i].len; if (l > SEL_MAX) big = true; else total += l; }
-        if (big || total > SEL_MAX || total > soft_cap) st.flag = 1;           // a truncated selection: the host
-        else if (total > hard_cap) st.excluded = 1;
-        else {
-            u32 const at = row_offset[sid];
-            bool ok;
-            if (cnt <= 8 && total <= 8) ok = select_seed<8, true>(grouped + g0, cnt, total, sa, n_text, seq_start, n_ref, erase, sid, st, produced, sparse, at, sparse_cap);
-            else ok = select_seed<SEL_MAX, true>(grouped + g0, cnt, total, sa, n_text, seq_start, n_ref, erase, sid, st, produced, sparse, at, sparse_cap);
-            if (!ok) { st = SelStat{0, 0, 1, 0}; produced = 0; }
+// the seeds of one list: their anchors to their slots of the sparse list (row_offset), n_out says how many
+template <u32 CAP>
+__global__ void __launch_bounds__(64) seed_select_kernel(const u32* __restrict__ list, const u32* __restrict__ list_count,
+                                                         const DevHit* __restrict__ grouped, const u32* __restrict__ hit_offset,
+                                                         const u32* __restrict__ sa, u32 n_text, const u64* __restrict__ seq_start, u32 n_ref,
+                                                         u32 erase, SelStat* __restrict__ stat, u32* __restrict__ n_out,
+                                                         const u32* __restrict__ row_offset, const u32* __restrict__ rows,
+                                                         DevOutAnchor* __restrict__ sparse, u32 sparse_cap) {
+    u32 const n = *list_count;
+    for (u32 i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        u32 const sid = list[i];
+        u32 const g0 = hit_offset[sid], cnt = hit_offset[sid + 1] - g0;
+        SelStat st{0, 0, 0, 0, stat[sid].excluded_soft};
+        u32 produced = 0;
+        if (!select_seed<CAP, true>(grouped + g0, cnt, rows[sid], sa, n_text, seq_start, n_ref, erase, sid, st, produced, sparse, row_offset[sid], sparse_cap)) {
+            st = SelStat{0, 0, 1, 0, 0};
+            produced = 0;
         }
+        stat[sid] = st;
+        n_out[sid] = st.flag ? 0u : produced;
     }
-    stat[sid] = st;
-    n_out[sid] = st.flag ? 0u : produced;
 }
 
 __global__ void __launch_bounds__(256) seed_compact_kernel(const DevOutAnchor* __restrict__ sparse, const u32* __restrict__ row_offset,
@@ -998,21 +1014,26 @@ size_t DeviceApi::select_scan_bytes(u32 n_seeds) {
 int DeviceApi::select(void* stream, const DevHit* d_hits, const u32* d_counters, u32 hit_cap, u32* d_seed_cnt, u32* d_hit_offset,
                       DevHit* d_grouped, u32 n_seeds, const DevIndex& idx, const u64* d_seq_start, u32 n_ref, u32 hard_cap, u32 soft_cap,
                       bool erase, void* d_stat, u32* d_n_out, u32* d_out_offset, DevOutAnchor* d_out, u32 out_cap, u32* d_rows,
-                      u32* d_row_offset, DevOutAnchor* d_sparse, u32 sparse_cap, void* d_scan_tmp, size_t scan_bytes, bool sort_by_key) {
+                      u32* d_row_offset, DevOutAnchor* d_sparse, u32 sparse_cap, void* d_scan_tmp, size_t scan_bytes, u32* d_lists) {
     if (n_seeds == 0) return 0;
     hipStream_t s = (hipStream_t)stream;
     // d_seed_cnt, d_rows and d_n_out have n_seeds + 1 entries, the last one zero: the scans end with the totals
     hipError_t e = hipcub::DeviceScan::ExclusiveSum(d_scan_tmp, scan_bytes, d_seed_cnt, d_hit_offset, (int)n_seeds + 1, s);
     if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL(hit_scatter_kernel, dim3(2048), dim3(256), 0, s, d_hits, d_counters, hit_cap, d_hit_offset, d_grouped);
-    if (sort_by_key) hipLaunchKernelGGL(seed_sort_kernel, dim3((n_seeds + 255) / 256), dim3(256), 0, s, d_grouped, d_hit_offset, n_seeds);
-    hipLaunchKernelGGL(seed_rows_kernel, dim3((n_seeds + 255) / 256), dim3(256), 0, s, d_grouped, d_hit_offset, n_seeds, hard_cap, soft_cap, d_rows);
+    SelStat* const stat = reinterpret_cast<SelStat*>(d_stat);
+    u32* const list_counts = d_lists + 2 * (size_t)n_seeds;
+    if ((e = hipMemsetAsync(list_counts, 0, 8, s)) != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(seed_rows_kernel, dim3((n_seeds + 255) / 256), dim3(256), 0, s, d_grouped, d_hit_offset, n_seeds, hard_cap, soft_cap, d_rows,
+                       stat, d_n_out, d_lists, list_counts);
     if ((e = hipGetLastError()) != hipSuccess) return (int)e;
     e = hipcub::DeviceScan::ExclusiveSum(d_scan_tmp, scan_bytes, d_rows, d_row_offset, (int)n_seeds + 1, s);
     if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(seed_select_kernel, dim3((n_seeds + 127) / 128), dim3(128), 0, s, d_grouped, d_hit_offset, n_seeds, idx.sa, idx.n,
-                       d_seq_start, n_ref, hard_cap, soft_cap, erase ? 1u : 0u, reinterpret_cast<SelStat*>(d_stat), d_n_out, d_row_offset,
-                       d_sparse, sparse_cap);
+    // grids sized for the usual shares (a quarter of the seeds light, a per cent heavy); the kernels loop over their lists
+    hipLaunchKernelGGL((seed_select_kernel<SEL_LIGHT>), dim3(std::max(1u, (n_seeds / 4 + 63) / 64)), dim3(64), 0, s, d_lists, list_counts, d_grouped, d_hit_offset,
+                       idx.sa, idx.n, d_seq_start, n_ref, erase ? 1u : 0u, stat, d_n_out, d_row_offset, d_rows, d_sparse, sparse_cap);
+    hipLaunchKernelGGL((seed_select_kernel<SEL_MAX>), dim3(std::max(1u, (n_seeds / 64 + 63) / 64)), dim3(64), 0, s, d_lists + n_seeds, list_counts + 1, d_grouped,
+                       d_hit_offset, idx.sa, idx.n, d_seq_start, n_ref, erase ? 1u : 0u, stat, d_n_out, d_row_offset, d_rows, d_sparse, sparse_cap);
     if ((e = hipGetLastError()) != hipSuccess) return (int)e;
     e = hipcub::DeviceScan::ExclusiveSum(d_scan_tmp, scan_bytes, d_n_out, d_out_offset, (int)n_seeds + 1, s);
     if (e != hipSuccess) return (int)e;

@@ -108,6 +108,7 @@ static_assert(sizeof(DevFrame) == 64, "frame is four 16-byte slots");
 // key: position of the hit in search_n's emission order among the hits of its seed (see fm_search_kernel; 0 from the ordered kernel,
 // whose ordinals are the emission order already)
 struct DevHit { u32 seed, lb, len, errors; u64 key; };
+struct DevSelStat { u8 useful, raw, flag, excluded; u32 excluded_soft; };   // per seed, from the device-side selection
 struct DevOutAnchor { u32 seed_index, leaf, ref_id, errors; u64 pos; };   // = HostAnchor (leaf is filled by the host)
 
 // ------------------------------------------------------------------------------------------------ K3/K4: alignment
@@ -182,13 +183,14 @@ struct DeviceApi {
                       u32 n_seeds, u32 max_hits_per_seed, u32 frame_levels, DevFrame* d_stack, DevHit* d_hits, u32 hit_cap,
                       u32* d_counters, u32* d_seed_cnt = nullptr);
     // anchor selection on the device (see seed_select_kernel). d_seed_cnt, d_hit_offset, d_n_out, d_out_offset: n_seeds + 1 entries
-    // (the caller zeroes the last entry of d_seed_cnt and d_n_out); d_stat: 4 bytes per seed {useful, raw, flag, excluded};
-    // d_grouped: as many entries as d_hits; d_out: one entry per selected anchor (at most the number of rows of the handled seeds)
+    // (the caller zeroes the last entry of d_seed_cnt and d_n_out); d_stat: one DevSelStat per seed;
+    // d_grouped: as many entries as d_hits; d_out: one entry per selected anchor (at most the number of rows of the handled seeds);
+    // d_lists: 2 * n_seeds + 2 entries (the lists of light and heavy seeds and their lengths)
     static size_t select_scan_bytes(u32 n_seeds);
     static int select(void* stream, const DevHit* d_hits, const u32* d_counters, u32 hit_cap, u32* d_seed_cnt, u32* d_hit_offset,
                       DevHit* d_grouped, u32 n_seeds, const DevIndex& idx, const u64* d_seq_start, u32 n_ref, u32 hard_cap, u32 soft_cap,
                       bool erase, void* d_stat, u32* d_n_out, u32* d_out_offset, DevOutAnchor* d_out, u32 out_cap, u32* d_rows,
-                      u32* d_row_offset, DevOutAnchor* d_sparse, u32 sparse_cap, void* d_scan_tmp, size_t scan_bytes, bool sort_by_key);
+                      u32* d_row_offset, DevOutAnchor* d_sparse, u32 sparse_cap, void* d_scan_tmp, size_t scan_bytes, u32* d_lists);
     static int locate(void* stream, const DevIndex& idx, const u32* d_rows, u32 n, u32* d_out);
     // d_lastrow (banded TRACE launches only, may be null): D[m][c] of every computed column c, 0xFFFF elsewhere (pre-filled by the caller)
     static int align(void* stream, const u8* d_text, const u64* d_peq, const DevAlignJob* d_jobs, u32 n_jobs, AlignShape shape,

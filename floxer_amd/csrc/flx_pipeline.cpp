@@ -80,7 +80,7 @@ hipEvent_t Lane::get_event() {
 hvec<DeviceBuffer*> lane_workspaces(Lane& l) {
     return {&l.seq, &l.seq_rev, &l.peq, &l.peq_rev, &l.scheme, &l.seeds, &l.stack, &l.hits, &l.counters, &l.rows, &l.rows_out, &l.jobs,
             &l.job_out, &l.trace, &l.tjobs, &l.tjob_out, &l.cigar, &l.user_text, &l.user_text_rev, &l.lastrow, &l.row_windows, &l.row_out,
-            &l.seed_cnt, &l.hit_off, &l.grouped, &l.sel_stat, &l.sel_n, &l.sel_off, &l.sel_out, &l.sel_tmp, &l.sel_rows, &l.sel_row_off, &l.sel_sparse};
+            &l.seed_cnt, &l.hit_off, &l.grouped, &l.sel_stat, &l.sel_n, &l.sel_off, &l.sel_out, &l.sel_tmp, &l.sel_rows, &l.sel_row_off, &l.sel_sparse, &l.sel_lists};
 }
 std::vector<DeviceBuffer*> Lane::workspaces() { auto v = lane_workspaces(*this); return std::vector<DeviceBuffer*>(v.begin(), v.end()); }
 int Lane::size_like(Lane& other) {
@@ -354,17 +354,18 @@ int search_seeds_device(Lane* ctx, const u8* d_seq_pool_or_null, const u8* h_seq
     bool const device_select = !raw_hits && cfg.anchor_group_order == FLX_ORDER_COUNT_FIRST && cfg.anchor_choice_strategy == FLX_CHOICE_ROUND_ROBIN &&
                                cfg.max_num_anchors_soft >= 1 && !getenv("FLX_HOST_SELECT");
     size_t const scan_bytes = device_select ? DeviceApi::select_scan_bytes((u32)n_seeds) : 0;
-    hvec<u32> sel_stat;                       // per seed {useful, raw, flag, excluded} bytes
+    hvec<DevSelStat> sel_stat;                // per seed
     u32 sel_total = 0, sel_rows_total = 0;
     if (device_select) {
         if ((rc = ctx->seed_cnt.ensure((n_seeds + 1) * 4))) return rc;
         if ((rc = ctx->hit_off.ensure((n_seeds + 1) * 4))) return rc;
-        if ((rc = ctx->sel_stat.ensure(n_seeds * 4 + 16))) return rc;
+        if ((rc = ctx->sel_stat.ensure(n_seeds * sizeof(DevSelStat) + 16))) return rc;
         if ((rc = ctx->sel_n.ensure((n_seeds + 1) * 4))) return rc;
         if ((rc = ctx->sel_off.ensure((n_seeds + 1) * 4))) return rc;
         if ((rc = ctx->sel_rows.ensure((n_seeds + 1) * 4))) return rc;
         if ((rc = ctx->sel_row_off.ensure((n_seeds + 1) * 4))) return rc;
         if ((rc = ctx->sel_tmp.ensure(scan_bytes + 64))) return rc;
+        if ((rc = ctx->sel_lists.ensure((2 * n_seeds + 2) * 4))) return rc;
         sel_stat.resize(n_seeds);
     }
     u32 counters[16];
@@ -397,7 +398,7 @@ int search_seeds_device(Lane* ctx, const u8* d_seq_pool_or_null, const u8* h_seq
                                          (u32)std::min<u64>(cfg.max_num_anchors_soft, 0xFFFFFFFFu), cfg.erase_useless_anchors != 0, ctx->sel_stat.ptr,
                                          ctx->sel_n.as<u32>(), ctx->sel_off.as<u32>(), ctx->sel_out.as<DevOutAnchor>(), (u32)std::min<u64>(sel_cap, 0xFFFFFFFFu),
                                          ctx->sel_rows.as<u32>(), ctx->sel_row_off.as<u32>(), ctx->sel_sparse.as<DevOutAnchor>(),
-                                         (u32)std::min<u64>(sel_cap, 0xFFFFFFFFu), ctx->sel_tmp.ptr, scan_bytes, !ordered);
+                                         (u32)std::min<u64>(sel_cap, 0xFFFFFFFFu), ctx->sel_tmp.ptr, scan_bytes, ctx->sel_lists.as<u32>());
             });
             if (rc) return rc;
         }
@@ -405,7 +406,7 @@ int search_seeds_device(Lane* ctx, const u8* d_seq_pool_or_null, const u8* h_seq
         if (device_select) {
             if ((rc = d2h(ctx, &sel_total, (char*)ctx->sel_off.ptr + n_seeds * 4, 4))) return rc;
             if ((rc = d2h(ctx, &sel_rows_total, (char*)ctx->sel_row_off.ptr + n_seeds * 4, 4))) return rc;
-            if ((rc = d2h(ctx, sel_stat.data(), ctx->sel_stat.ptr, n_seeds * 4))) return rc;
+            if ((rc = d2h(ctx, sel_stat.data(), ctx->sel_stat.ptr, n_seeds * sizeof(DevSelStat)))) return rc;
         }
         if ((rc = ctx->sync())) return rc;
         if (getenv("FLX_SEARCH_DEBUG")) fprintf(stderr, "[fm_search] seeds %llu ext %u wave-iterations %u (max per wave %u) busy pair-iterations %u, after the queue ran dry %u (max %u)\n", (unsigned long long)n_seeds, counters[2], counters[4], counters[5], counters[6], counters[8], counters[9]);
@@ -447,15 +448,14 @@ int search_seeds_device(Lane* ctx, const u8* d_seq_pool_or_null, const u8* h_seq
         host_seed.assign(n_seeds, 0);
         bool any = false;
         for (u64 si = 0; si < n_seeds; ++si) {
-            u32 const st = sel_stat[si];
-            u8 const useful = (u8)st, raw = (u8)(st >> 8), flag = (u8)(st >> 16), excl = (u8)(st >> 24);
-            if (flag) { host_seed[si] = 1; any = true; }
-            else stats[si] = SeedStats{useful, raw, 0, excl};
+            DevSelStat const st = sel_stat[si];
+            if (st.flag) { host_seed[si] = 1; any = true; }
+            else stats[si] = SeedStats{st.useful, st.raw, st.excluded_soft, st.excluded};
         }
         sprof.mark("device-select");
         if (getenv("FLX_SEARCH_DEBUG")) {
             u64 flagged = 0, with_anchors = 0, excl = 0;
-            for (u64 si = 0; si < n_seeds; ++si) { u32 const st = sel_stat[si]; flagged += (st >> 16) & 1; with_anchors += (st & 0xFF) != 0; excl += (st >> 24) & 1; }
+            for (u64 si = 0; si < n_seeds; ++si) { DevSelStat const st = sel_stat[si]; flagged += st.flag; with_anchors += st.useful != 0; excl += st.excluded; }
             fprintf(stderr, "[fm_select] seeds %llu: with anchors %llu, excluded %llu, left to the host %llu; anchors %u\n", (unsigned long long)n_seeds,
                     (unsigned long long)with_anchors, (unsigned long long)excl, (unsigned long long)flagged, sel_total);
         }
@@ -471,10 +471,10 @@ int search_seeds_device(Lane* ctx, const u8* d_seq_pool_or_null, const u8* h_seq
         by_seed.resize(first[n_seeds]);
         if ((rc = d2h(ctx, by_seed.data(), ctx->grouped.ptr, (size_t)first[n_seeds] * sizeof(DevHit)))) return rc;
         if ((rc = ctx->sync())) return rc;
-        // the segments the device did not put into emission order (more than SEL_MAX hits) and the host is going to look at
+        // the segments the host is going to look at, into emission order (the device sorts its own seeds' hits where it reads them)
         if (!ordered)
             for (u64 si = 0; si < n_seeds; ++si)
-                if (host_seed[si] && first[si + 1] - first[si] > 64)
+                if (host_seed[si] && first[si + 1] - first[si] > 1)
                     std::stable_sort(by_seed.begin() + first[si], by_seed.begin() + first[si + 1], [](DevHit const& a, DevHit const& b) { return a.key < b.key; });
         sprof.mark("d2h-hits");
     } else {
