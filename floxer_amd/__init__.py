@@ -101,6 +101,33 @@ class fmindex:
     def save(self, path):
         check(lib().flx_index_save(self.h, path.encode()))
 
+    # ---- the index as an HBM image + a small host part: how a job replicates it across its GPUs (floxer_amd/distributed.py)
+    def meta(self):
+        n = C.c_uint64(0)
+        lib().flx_index_meta_export(self.h, None, C.byref(n))
+        buf = np.zeros(n.value, dtype=np.uint8)
+        check(lib().flx_index_meta_export(self.h, ptr(buf, u8p), C.byref(n)))
+        return buf.tobytes()
+
+    @classmethod
+    def from_meta(cls, meta):
+        """an index without arrays (sequence starts / lengths and symbol counts only): for context(index, image=...)"""
+        self = cls.__new__(cls)
+        self.h = C.c_void_p()
+        buf = np.frombuffer(meta, dtype=np.uint8).copy()
+        check(lib().flx_index_meta_import(ptr(buf, u8p), len(buf), C.byref(self.h)))
+        return self
+
+    def image_layout(self):
+        """bytes of the five device buffers of the index's HBM image"""
+        out = np.zeros(5, dtype=np.uint64)
+        check(lib().flx_index_image_layout(self.h, ptr(out, u64p)))
+        return [int(x) for x in out]
+
+    def image_upload(self, device, pointers):
+        arr = (C.c_void_p * 5)(*[C.c_void_p(int(p)) for p in pointers])
+        check(lib().flx_index_image_upload(self.h, int(device), arr))
+
     def __del__(self):
         if getattr(self, "h", None):
             lib().flx_index_free(self.h)
@@ -137,10 +164,17 @@ class fmindex:
 class context:
     """One HIP device + stream + HBM-resident index."""
 
-    def __init__(self, index, device=0):
+    def __init__(self, index, device=0, image=None):
+        """image: five device buffers holding the index's HBM image (objects with data_ptr(), e.g. torch uint8 tensors; kept alive by
+        this object), as uploaded by fmindex.image_upload or received from another rank; None: the context uploads its own."""
         self.index = index
+        self.image = image
         self.h = C.c_void_p()
-        check(lib().flx_ctx_create(device, index.h, C.byref(self.h)))
+        if image is None:
+            check(lib().flx_ctx_create(device, index.h, C.byref(self.h)))
+        else:
+            arr = (C.c_void_p * 5)(*[C.c_void_p(int(b.data_ptr())) for b in image])
+            check(lib().flx_ctx_create_on_image(device, index.h, arr, C.byref(self.h)))
 
     def close(self):
         if getattr(self, "h", None):

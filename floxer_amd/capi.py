@@ -91,7 +91,8 @@ EXPORTED = [
     "flx_run_num_cigar_words", "flx_run_copy", "flx_run_free", "flx_ctx_enable_kernel_timing", "flx_ctx_reset_kernel_stats",
     "flx_ctx_get_kernel_stats", "flx_sam_open", "flx_sam_write", "flx_sam_close", "flx_sim_genome", "flx_sim_reads", "flx_ctx_get_path_counters",
     "flx_ctx_reset_path_counters", "flx_stats_create", "flx_stats_free", "flx_stats_merge", "flx_stats_num_queries", "flx_stats_format",
-    "flx_ctx_set_stats", "flx_device_count", "flx_index_matches_reference", "flx_sam_set_threads",
+    "flx_ctx_set_stats", "flx_device_count", "flx_index_matches_reference", "flx_sam_set_threads", "flx_index_image_layout",
+    "flx_index_image_upload", "flx_index_meta_export", "flx_index_meta_import", "flx_ctx_create_on_image",
 ]
 
 _lib = None
@@ -132,6 +133,11 @@ def lib():
     L.flx_index_copy_bwt.argtypes = [C.c_void_p, C.c_int, u8p]
     L.flx_ctx_create.argtypes = [C.c_int, C.c_void_p, C.POINTER(C.c_void_p)]
     L.flx_ctx_destroy.argtypes = [C.c_void_p]
+    L.flx_index_image_layout.argtypes = [C.c_void_p, u64p]
+    L.flx_index_image_upload.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]
+    L.flx_index_meta_export.argtypes = [C.c_void_p, u8p, u64p]
+    L.flx_index_meta_import.argtypes = [u8p, C.c_uint64, C.POINTER(C.c_void_p)]
+    L.flx_ctx_create_on_image.argtypes = [C.c_int, C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]
     L.flx_ctx_set_stream.argtypes = [C.c_void_p, C.c_void_p]
     L.flx_search_seeds.argtypes = [C.c_void_p, u8p, C.c_uint64, C.POINTER(Seed), C.c_uint64, C.POINTER(SearchConfig),
                                    C.POINTER(Anchor), u64p, C.POINTER(SeedStats)]

@@ -26,6 +26,10 @@ namespace flx {
 struct DeviceBuffer {
     void* ptr = nullptr;
     size_t cap = 0;
+    DeviceBuffer() = default;
+    DeviceBuffer(DeviceBuffer const&) = delete;
+    DeviceBuffer& operator=(DeviceBuffer const&) = delete;
+    ~DeviceBuffer() { release(); }   // (error paths drop half-made owners: nothing stays allocated)
     int ensure(size_t bytes);      // grow-only; contents are NOT preserved
     void release();
     template <class T> T* as() const { return reinterpret_cast<T*>(ptr); }
@@ -35,7 +39,6 @@ struct PendingTiming { std::string name; hipEvent_t start, stop; u64 bytes, unit
 
 }  // namespace flx
 
-struct flx_index { flx::HostIndex* host = nullptr; };
 
 struct flx_ctx;
 struct flx_stats;
@@ -65,6 +68,7 @@ struct Lane {
 }  // namespace flx
 
 struct flx_ctx {
+    ~flx_ctx();                      // releases streams, workspaces and the index image it owns (also on a half-made context)
     int device = 0;
     const flx::HostIndex* hidx = nullptr;
     flx::DevIndex didx{};

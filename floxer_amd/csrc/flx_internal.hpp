@@ -226,3 +226,5 @@ int save_host_index(const HostIndex& idx, const char* path);
 HostIndex* load_host_index(const char* path);
 
 }  // namespace flx
+
+struct flx_index { flx::HostIndex* host = nullptr; };

@@ -1291,7 +1291,12 @@ int ensure_reversed_text(Lane* lane) {
     std::lock_guard<std::mutex> g(ctx->mu);
     if (ctx->text_rev_ready) return FLX_OK;
     HostIndex const& H = *ctx->hidx;
-    hvec<u8> rev(H.text.rbegin(), H.text.rend());
+    hvec<u8> rev(H.n);
+    if (H.text.size() == H.n) std::reverse_copy(H.text.begin(), H.text.end(), rev.begin());
+    else {                                       // a context on a received image: the text is in HBM only
+        FLX_HIP(hipMemcpy(rev.data(), ctx->didx.text, H.n, hipMemcpyDeviceToHost));
+        std::reverse(rev.begin(), rev.end());
+    }
     const u8* first = nullptr;
     int rc = upload_padded(lane, ctx->text_rev, rev.data(), rev.size(), &first);
     if (rc) return rc;
@@ -1515,6 +1520,11 @@ struct flx_reads {
     mutable bool peq_built = false;
     mutable flx::DeviceBuffer d_peq;
     mutable hipEvent_t peq_event = nullptr;      // recorded behind K0; every lane's stream waits for it before its first DP launch
+    // --without-cigar aligns the reversed sequences (alignment.cpp:115-145): the reversed pool and its Peq planes, made by the first
+    // chunk that needs them and shared like d_peq
+    mutable bool rev_built = false;
+    mutable flx::DeviceBuffer d_pool_rev, d_peq_rev;
+    mutable hipEvent_t rev_event = nullptr;
 };
 
 extern "C" int flx_reads_upload(flx_ctx* ctx, const uint8_t* read_pool, const uint64_t* read_offsets, uint64_t n_reads, flx_reads** out) {
@@ -1557,7 +1567,10 @@ extern "C" void flx_reads_free(flx_reads* reads) {
     if (reads->ctx) (void)hipSetDevice(reads->ctx->device);
     reads->d_pool.release();
     reads->d_peq.release();
+    reads->d_pool_rev.release();
+    reads->d_peq_rev.release();
     if (reads->peq_event) (void)hipEventDestroy(reads->peq_event);
+    if (reads->rev_event) (void)hipEventDestroy(reads->rev_event);
     delete reads;
 }
 
@@ -1784,15 +1797,27 @@ int align_slice(Lane* lane, const flx_params* P, const flx_reads* RD, u64 first_
     hvec<u32> cig;
     if (P->without_cigar) {
         if ((rc = ensure_reversed_text(lane))) return rc;
-        hvec<u8> qrev(pool.rbegin(), pool.rend());
-        if ((rc = h2d(lane, lane->seq_rev, qrev.data(), qrev.size(), 64))) return rc;
-        if ((rc = build_peq(lane, lane->seq_rev.as<u8>(), qrev.size(), lane->peq_rev))) return rc;
+        {
+            std::lock_guard<std::mutex> g(RD->peq_mu);
+            if (!RD->rev_built) {
+                hvec<u8> qrev(pool.rbegin(), pool.rend());
+                if ((rc = RD->d_pool_rev.ensure(qrev.size() + 256))) return rc;
+                FLX_HIP(hipMemcpyAsync(RD->d_pool_rev.ptr, qrev.data(), qrev.size(), hipMemcpyHostToDevice, lane->stream));
+                FLX_HIP(hipMemsetAsync((char*)RD->d_pool_rev.ptr + qrev.size(), 0, 192, lane->stream));
+                if ((rc = build_peq(lane, RD->d_pool_rev.as<u8>(), qrev.size(), RD->d_peq_rev))) return rc;
+                if (!RD->rev_event) FLX_HIP(hipEventCreateWithFlags(&RD->rev_event, hipEventDisableTiming));
+                FLX_HIP(hipEventRecord(RD->rev_event, lane->stream));
+                FLX_HIP(hipStreamSynchronize(lane->stream));        // qrev leaves scope
+                RD->rev_built = true;
+            }
+        }
+        FLX_HIP(hipStreamWaitEvent(lane->stream, RD->rev_event, 0));
         hvec<AlignRequest> rev(root_reqs.size());
         for (size_t i = 0; i < rev.size(); ++i)
             rev[i] = AlignRequest{H.n - root_reqs[i].ref_off - root_reqs[i].n, pool.size() - root_reqs[i].q_off - root_reqs[i].m,
                                   root_reqs[i].n, root_reqs[i].m, root_reqs[i].k};
         hvec<DevAlignOut> outs;
-        if ((rc = run_score_jobs(lane, ctx->text_rev.as<u8>() + TEXT_PAD, lane->peq_rev.as<u64>(), rev, outs, "ed_align_exists"))) return rc;
+        if ((rc = run_score_jobs(lane, ctx->text_rev.as<u8>() + TEXT_PAD, RD->d_peq_rev.as<u64>(), rev, outs, "ed_align_exists"))) return rc;
         for (size_t i = 0; i < outs.size(); ++i)
             if (outs[i].score != 0xFFFFFFFFu) { root_res[i].exists = true; root_res[i].nm = outs[i].score; root_res[i].start = root_spans[i].offset + (root_reqs[i].n - outs[i].end_col); }
     } else {
@@ -1859,6 +1884,7 @@ extern "C" int flx_align_reads_resident(flx_ctx* ctx, const flx_params* P, const
     PhaseTimer dprof("dispatch");
     auto run = std::make_unique<flx_run>();
     run->skipped.assign(n_reads, 0);
+    if (n_reads == 0) { *out = run.release(); return FLX_OK; }       // an empty batch is an empty run
     // reads are independent units (parallelization.cpp:77-87): the batch is cut into contiguous chunks and every lane (a host
     // thread with its own stream and workspaces) takes the next chunk when it is done with its last one.
     size_t n_lanes = ctx->external_stream ? 1 : ctx->lanes.size();

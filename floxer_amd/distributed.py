@@ -93,6 +93,34 @@ def gather_records(rows, cigars, read_offset, rank, world, device=None):
     return None
 
 
+def replicate_index(references, rank, world, device):
+    """The FM index of a multi-rank job, replicated per GPU: rank 0 builds it (suffix arrays, BWTs, occurrence tables
+    on its GPU) and uploads its HBM image into five device buffers; the buffers go to every other rank's HBM with RCCL broadcasts
+    over xGMI, the small host part (sequence starts / lengths, symbol counts) with an object broadcast. No rank but the first ever
+    holds the index in host memory, builds it or reads a file. Returns (index, image): `context(index, device, image=image)`.
+    world == 1: (index, None)."""
+    import floxer_amd as F
+    if world == 1:
+        return F.fmindex(references, device=device), None
+    import torch
+    import torch.distributed as dist
+    dev = torch.device("cuda", device)
+    index, payload = None, [None]
+    if rank == 0:
+        index = F.fmindex(references, device=device)
+        payload = [(index.meta(), index.image_layout())]
+    dist.broadcast_object_list(payload, src=0)
+    meta, sizes = payload[0]
+    image = [torch.empty(int(n), dtype=torch.uint8, device=dev) for n in sizes]
+    if rank == 0:
+        index.image_upload(device, [b.data_ptr() for b in image])
+    for b in image:
+        dist.broadcast(b, src=0)
+    if rank != 0:
+        index = F.fmindex.from_meta(meta)
+    return index, image
+
+
 def build_index_once(references, rank, world, device=None, tag=None):
     """The FM index of a multi-rank job: built once (rank 0; suffix arrays / BWTs / occurrence tables on HIP device `device`, on the
     host when it is None), written to a file in shared memory, loaded by the other ranks, removed again. world == 1: just built.

@@ -85,6 +85,18 @@ typedef struct flx_ctx flx_ctx;
 int flx_device_count(void);                                  /* HIP devices visible to the process (0: none / no runtime) */
 int flx_ctx_create(int hip_device, const flx_index* index, flx_ctx** out);   /* uploads index + reference text to HBM */
 void flx_ctx_destroy(flx_ctx* ctx);
+/* Index replicas across the GPUs of a job (the FM index is replicated per GPU). The HBM image of an index is five
+ * device buffers (occurrence table of the text, of the reversed text, suffix array, text with its guard bytes, k-mer table). A rank
+ * that built or loaded the index uploads the image into buffers it owns (flx_index_image_upload), sends them to the other ranks
+ * (RCCL broadcast over xGMI: floxer_amd/distributed.py) together with the small host part (flx_index_meta_export), and every rank
+ * makes its context on its copy (flx_ctx_create_on_image; the buffers must outlive the context): no rank but the first holds the
+ * index in host memory, builds it or reads it from a file. */
+typedef struct flx_index_image { uint64_t bytes[5]; } flx_index_image;
+int flx_index_image_layout(const flx_index* index, flx_index_image* out);
+int flx_index_image_upload(const flx_index* index, int hip_device, void* const device_buffers[5]);
+int flx_index_meta_export(const flx_index* index, uint8_t* buf, uint64_t* len /* in: capacity, out: needed */);
+int flx_index_meta_import(const uint8_t* buf, uint64_t len, flx_index** out);   /* an index without arrays: for flx_ctx_create_on_image */
+int flx_ctx_create_on_image(int hip_device, const flx_index* index, void* const device_buffers[5], flx_ctx** out);
 /* use a caller-owned HIP stream (hipStream_t passed as void*) for all launches; NULL restores the context's own stream */
 int flx_ctx_set_stream(flx_ctx* ctx, void* hip_stream);
 

@@ -855,3 +855,40 @@ def test_cli_devices_stats_fastq_forms_and_accuracy(tmp_path):
     open(bad, "w").write("\n".join(text.splitlines()[:-1]) + "\n")                        # the last record lacks its quality line
     r = run(bad, str(tmp_path / "bad.sam"))
     assert r.returncode != 0
+
+
+def test_empty_batch_is_an_empty_run(small_genome):
+    refs, idx, ctx, oidx = small_genome
+    for kw in (dict(), dict(without_cigar=True)):
+        res = F.aligner(ctx, F.params(error_probability=0.05, **kw)).align_reads([])
+        assert res.n_records == 0 and len(res.cigars) == 0
+    rr = F.resident_reads(ctx, [])
+    assert F.aligner(ctx, F.params(error_probability=0.05)).align_reads(rr).n_records == 0
+    rr.close()
+
+
+def test_context_on_an_index_image_and_two_contexts():
+    """flx_ctx_create_on_image: the index's HBM image in caller-owned device buffers (what floxer_amd.distributed.replicate_index
+    hands to every rank after the RCCL broadcast), with the full index and with the array-less index made from its meta block;
+    two contexts on one image at once (the CLI's --devices / a rank's second context): identical records, also with --without-cigar
+    (the reversed text then comes from HBM)"""
+    import torch
+    genome = S.make_genome(300000, 3, seed=51)
+    reads, _, _ = S.make_reads(genome, 80, 1500, 0.06, seed=52)
+    idx = F.fmindex(genome, device=0)
+    base_ctx = F.context(idx)
+    light = F.fmindex.from_meta(idx.meta())
+    image = [torch.empty(n, dtype=torch.uint8, device="cuda:0") for n in idx.image_layout()]
+    idx.image_upload(0, [b.data_ptr() for b in image])
+    a, b = F.context(idx, image=image), F.context(light, image=image)
+    for kw in (dict(), dict(without_cigar=True), dict(interval_optimization=True)):
+        p = F.params(error_probability=0.06, **kw)
+        base = F.aligner(base_ctx, p).align_reads(reads).records()
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(2) as pool:
+            fa, fb = pool.submit(F.aligner(a, p).align_reads, reads), pool.submit(F.aligner(b, p).align_reads, reads)
+            assert fa.result().records() == base and fb.result().records() == base
+    with pytest.raises(F.FloxerError):
+        F.context(light)                                   # an index without arrays cannot upload itself
+    for c in (a, b, base_ctx):
+        c.close()

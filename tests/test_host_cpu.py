@@ -324,3 +324,33 @@ def test_simulated_dataset_create_and_verify(tmp_path):
     assert out.startswith("queries = [\n") and out.endswith("]\n")
     assert out.count("FoundOptimal = {}") == 10
     assert out.count("FoundSuboptimal = { pos_diff_expected_num_errors = 300, pos_diff_higher_num_errors = 4294967295 }") == 5
+
+
+def test_index_meta_roundtrip_and_image_layout():
+    """the small host part of an index that travels with its HBM image to the other ranks of a job (flx_index_meta_export / import)"""
+    refs = [np.array([1, 2, 3, 4] * 25, np.uint8), np.array([4, 3, 2, 1, 5] * 7, np.uint8)]
+    idx = F.fmindex(refs)
+    meta = idx.meta()
+    light = F.fmindex.from_meta(meta)
+    assert light.text_length == idx.text_length and light.num_references == 2
+    assert light.meta() == meta
+    sizes = idx.image_layout()
+    n = idx.text_length
+    assert sizes == light.image_layout() == [(n // 32 + 1) * 32, (n // 32 + 1) * 32, 4 * n, n + 2 * 128 + 16, 4 ** 8 * 3 * 4]
+    assert sum(sizes) == idx.device_bytes + 16
+    with pytest.raises(F.FloxerError):
+        F.fmindex.from_meta(b"\0" * 96)
+    import torch
+    if not torch.cuda.is_available():
+        with pytest.raises(F.FloxerError):
+            F.context(light)                               # no arrays and no GPU: loud either way
+
+
+def test_sanitizers(tmp_path):
+    """ASan + UBSan over the HIP-free host sources of the product and over the oracle (tests/sanitize; GPU ASan is not available on
+    the pool)"""
+    import subprocess
+    r = subprocess.run(["make", "-C", os.path.join(ROOT, "tests", "sanitize"), "check"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
+    out = r.stdout.decode()
+    assert r.returncode == 0, out[-3000:]
+    assert "sanitize_host ok" in out and "sanitize_oracle ok" in out
