@@ -805,18 +805,24 @@ static u32 fm_seeds_per_wave() {
     return v;
 }
 
-static u32 fm_max_waves() {
-    static u32 const v = [] { const char* e = getenv("FLX_FM_MAX_WAVES"); u32 const x = e ? (u32)strtoul(e, nullptr, 10) : 0u; return x ? x : FM_MAX_WAVES; }();
-    return v;
+// K1 is bound by the memory system's request rate, the DP kernels by VALU issue: they overlap well on one CU, but only while K1's
+// waves leave registers and wave slots free. A context with several lanes (several K1 launches in flight at a time) therefore caps
+// each launch at a share of the 4096 waves one launch needs to saturate the memory system alone (FLX_FM_MAX_WAVES overrides;
+// 16 lanes, 3.1 Gb / 10 kb: 63.5 k reads/s at 4096 waves per launch, 69.5 k at 1024).
+static u32 fm_max_waves(u32 concurrent_launches) {
+    static u32 const v = [] { const char* e = getenv("FLX_FM_MAX_WAVES"); return e ? (u32)strtoul(e, nullptr, 10) : 0u; }();
+    if (v) return v;
+    return FM_MAX_WAVES / std::max(1u, std::min(concurrent_launches, 4u));
 }
 
 u32 fm_search_max_keyed_length() { return FM_KEY_MAX_X; }
 
 int DeviceApi::search(void* stream, const DevIndex& idx, const u8* d_seq, const u32* d_scheme, const DevSeed* d_seeds, u32 n_seeds,
-                      u32 max_hits_per_seed, u32 frame_levels, DevFrame* d_stack, DevHit* d_hits, u32 hit_cap, u32* d_counters, u32* d_seed_cnt) {
+                      u32 max_hits_per_seed, u32 frame_levels, DevFrame* d_stack, DevHit* d_hits, u32 hit_cap, u32* d_counters, u32* d_seed_cnt,
+                      u32 concurrent_launches) {
     if (n_seeds == 0) return 0;
     u32 const spw = fm_seeds_per_wave();
-    dim3 const grid(std::min<u32>((n_seeds + spw - 1) / spw, fm_max_waves()));
+    dim3 const grid(std::min<u32>((n_seeds + spw - 1) / spw, fm_max_waves(concurrent_launches)));
     if (d_stack)      // the reference's DFS order, stack in HBM
         hipLaunchKernelGGL(fm_search_ordered_kernel, grid, dim3(64), 0, (hipStream_t)stream, idx, d_seq, d_scheme, d_seeds, n_seeds,
                            max_hits_per_seed, d_stack, d_hits, hit_cap, d_counters, d_seed_cnt);

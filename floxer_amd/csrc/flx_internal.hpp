@@ -178,10 +178,11 @@ struct DeviceApi {
     // d_seed_cnt (may be null): number of hits of every seed; each hit then carries its ordinal within its seed in errors >> 8.
     // d_stack == nullptr: the DFS with error children first and its frames in LDS (frame_levels = largest error count of a seed;
     // hits carry keys that restore the emission order; every seed shorter than fm_search_max_keyed_length()); else the DFS in the
-    // reference's order with DevSeed::stack_off / frames into d_stack.
+    // reference's order with DevSeed::stack_off / frames into d_stack. concurrent_launches: searches the caller keeps in flight at a
+    // time on other streams (the launch takes a share of the waves).
     static int search(void* stream, const DevIndex& idx, const u8* d_seq, const u32* d_scheme, const DevSeed* d_seeds,
                       u32 n_seeds, u32 max_hits_per_seed, u32 frame_levels, DevFrame* d_stack, DevHit* d_hits, u32 hit_cap,
-                      u32* d_counters, u32* d_seed_cnt = nullptr);
+                      u32* d_counters, u32* d_seed_cnt = nullptr, u32 concurrent_launches = 1);
     // anchor selection on the device (see seed_select_kernel). d_seed_cnt, d_hit_offset, d_n_out, d_out_offset: n_seeds + 1 entries
     // (the caller zeroes the last entry of d_seed_cnt and d_n_out); d_stat: one DevSelStat per seed;
     // d_grouped: as many entries as d_hits; d_out: one entry per selected anchor (at most the number of rows of the handled seeds);

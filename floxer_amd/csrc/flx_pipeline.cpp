@@ -387,7 +387,8 @@ int search_seeds_device(Lane* ctx, const u8* d_seq_pool_or_null, const u8* h_seq
         rc = timed_launch(ctx, "fm_search", 0, n_seeds, [&] {
             return DeviceApi::search(ctx->stream, ctx->ctx->didx, d_seq, ctx->scheme.as<u32>(), ctx->seeds.as<DevSeed>(), (u32)n_seeds,
                                      max_hits, max_errors, ordered ? ctx->stack.as<DevFrame>() : nullptr, ctx->hits.as<DevHit>(), (u32)std::min<u64>(hit_cap, 0xFFFFFFFFu),
-                                     ctx->counters.as<u32>(), device_select ? ctx->seed_cnt.as<u32>() : nullptr);
+                                     ctx->counters.as<u32>(), device_select ? ctx->seed_cnt.as<u32>() : nullptr,
+                                     ctx->ctx->external_stream ? 1u : (u32)ctx->ctx->lanes.size());
         });
         if (rc) return rc;
         if (device_select) {
@@ -1470,7 +1471,8 @@ struct ReadState {
     u64 read_index;
     u32 len, k;
     u64 pool_off[2];            // forward, reverse complement
-    PexTree tree;
+    const PexTree* tree_ptr = nullptr;      // reads of one length share one tree (it depends on (length, errors) only)
+    PexTree const& tree_ref() const { return *tree_ptr; }
     hvec<u32> anchor_ids[2];
 };
 
@@ -1599,6 +1601,7 @@ int align_slice(Lane* lane, const flx_params* P, const flx_reads* RD, u64 first_
     hvec<flx_seed> seeds;
     struct SeedOwner { u32 read; u8 orientation; };
     hvec<SeedOwner> seed_owner;
+    std::map<std::pair<u64, u64>, std::unique_ptr<PexTree>> tree_cache;      // (length, errors) -> tree
     for (u64 i = first_read; i < end_read; ++i) {
         u64 const len = RD->lens[i];
         if (len == 0 || len > 100000) { run->skipped[i] = 1; continue; }                       // input.cpp:95-110
@@ -1609,12 +1612,17 @@ int align_slice(Lane* lane, const flx_params* P, const flx_reads* RD, u64 first_
         rs.read_index = i;
         rs.len = (u32)len;
         rs.k = (u32)k;
-        rs.tree = build_pex_tree(len, k, P->pex_seed_num_errors, P->bottom_up_pex_tree_building != 0);
+        {
+            auto it = tree_cache.find(std::make_pair(len, k));
+            if (it == tree_cache.end())
+                it = tree_cache.emplace(std::make_pair(len, k), std::make_unique<PexTree>(build_pex_tree(len, k, P->pex_seed_num_errors, P->bottom_up_pex_tree_building != 0))).first;
+            rs.tree_ptr = it->second.get();
+        }
         rs.pool_off[0] = RD->pool_off[i];
         rs.pool_off[1] = RD->pool_off[i] + len;
         for (int o = 0; o < 2; ++o)
-            for (u64 l = 0; l < rs.tree.leaves.size(); l += P->seed_sampling_step_size) {      // pex.cpp:258-277
-                flx_pex_node const& leaf = rs.tree.leaves[l];
+            for (u64 l = 0; l < rs.tree_ref().leaves.size(); l += P->seed_sampling_step_size) {      // pex.cpp:258-277
+                flx_pex_node const& leaf = rs.tree_ref().leaves[l];
                 seeds.push_back(flx_seed{rs.pool_off[o] + leaf.from, leaf.to - leaf.from + 1, leaf.num_errors, (u32)l, 0});
                 seed_owner.push_back(SeedOwner{(u32)reads.size(), (u8)o});
             }
@@ -1692,7 +1700,7 @@ int align_slice(Lane* lane, const flx_params* P, const flx_reads* RD, u64 first_
 
     auto window_request = [&](AnchorState const& a, flx_pex_node const& node, double ratio, Span* span_out) {
         ReadState const& rs = reads[a.read];
-        flx_pex_node const& leaf = rs.tree.leaves[a.leaf];
+        flx_pex_node const& leaf = rs.tree_ref().leaves[a.leaf];
         Span const sp = compute_span(a.pos, node, leaf.from, H.seq_len[a.ref_id], ratio);
         if (span_out) *span_out = sp;
         return AlignRequest{H.seq_start[a.ref_id] + sp.offset, rs.pool_off[a.orientation] + node.from, (u32)sp.length,
@@ -1703,10 +1711,10 @@ int align_slice(Lane* lane, const flx_params* P, const flx_reads* RD, u64 first_
     //      not depend on the interval cache, so all anchors climb together; an anchor stops at its first failing node.
     for (auto& a : A) {
         ReadState const& rs = reads[a.read];
-        flx_pex_node const& leaf = rs.tree.leaves[a.leaf];
+        flx_pex_node const& leaf = rs.tree_ref().leaves[a.leaf];
         if (P->direct_full_verification || leaf.parent_id == FLX_NULL_ID) { a.at_root = true; continue; }   // verification.cpp:23-42, 52-72
         a.node = leaf.parent_id;
-        if (rs.tree.inner[a.node].parent_id == FLX_NULL_ID) a.at_root = true;
+        if (rs.tree_ref().inner[a.node].parent_id == FLX_NULL_ID) a.at_root = true;
     }
     // Anchors do not wait for each other and their tests do not depend on any order, so a round tests the anchors whose
     // current node is in the smallest size class still pending (PEX trees are unbalanced: the same node is reached after a
@@ -1718,7 +1726,7 @@ int align_slice(Lane* lane, const flx_params* P, const flx_reads* RD, u64 first_
     for (u32 ai = 0; ai < A.size(); ++ai) if (A[ai].alive && !A[ai].at_root) climbing.push_back(ai);
     hvec<AlignRequest> reqs;
     hvec<DevAlignOut> outs;
-    auto rows_of = [&](AnchorState const& a) { flx_pex_node const& nd = reads[a.read].tree.inner[a.node]; return nd.to - nd.from + 1; };
+    auto rows_of = [&](AnchorState const& a) { flx_pex_node const& nd = reads[a.read].tree_ref().inner[a.node]; return nd.to - nd.from + 1; };
     // `climbing` carries each anchor's node size next to its index (the rounds scan it): {anchor, rows}
     struct Climber { u32 anchor, rows; };
     hvec<Climber> climbers, sel, wait, surv;
@@ -1736,7 +1744,7 @@ int align_slice(Lane* lane, const flx_params* P, const flx_reads* RD, u64 first_
         for (Climber const& c : climbers) {                  // both parts stay in anchor order
             if (c.rows <= limit) {
                 sel.push_back(c);
-                reqs.push_back(window_request(A[c.anchor], reads[A[c.anchor].read].tree.inner[A[c.anchor].node], 0.0, nullptr));
+                reqs.push_back(window_request(A[c.anchor], reads[A[c.anchor].read].tree_ref().inner[A[c.anchor].node], 0.0, nullptr));
             } else { wait.push_back(c); next_smallest = std::min(next_smallest, c.rows); }
         }
         g_build_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tb0).count();
@@ -1746,8 +1754,8 @@ int align_slice(Lane* lane, const flx_params* P, const flx_reads* RD, u64 first_
         for (size_t i = 0; i < outs.size(); ++i) {
             AnchorState& a = A[sel[i].anchor];
             if (outs[i].score == 0xFFFFFFFFu) { a.alive = false; continue; }
-            a.node = reads[a.read].tree.inner[a.node].parent_id;
-            if (reads[a.read].tree.inner[a.node].parent_id == FLX_NULL_ID) a.at_root = true;
+            a.node = reads[a.read].tree_ref().inner[a.node].parent_id;
+            if (reads[a.read].tree_ref().inner[a.node].parent_id == FLX_NULL_ID) a.at_root = true;
             else { u32 const r = rows_of(a); surv.push_back(Climber{sel[i].anchor, r}); next_smallest = std::min(next_smallest, r); }
         }
         climbers.resize(wait.size() + surv.size());
@@ -1772,7 +1780,7 @@ int align_slice(Lane* lane, const flx_params* P, const flx_reads* RD, u64 first_
             AnchorState& a = A[ai];
             ReadState const& rs = reads[a.read];
             Span sp;
-            AlignRequest const req = window_request(a, rs.tree.root(), P->extra_verification_ratio, &sp);
+            AlignRequest const req = window_request(a, rs.tree_ref().root(), P->extra_verification_ratio, &sp);
             if (P->use_interval_optimization) {
                 auto& ivs = cache[a.orientation][a.ref_id];
                 if (ivs.contains(trim_both({sp.offset, sp.offset + sp.length}, sp.extra))) {           // root_was_already_verified
