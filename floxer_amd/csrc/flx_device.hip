@@ -808,11 +808,11 @@ static u32 fm_seeds_per_wave() {
 // K1 is bound by the memory system's request rate, the DP kernels by VALU issue: they overlap well on one CU, but only while K1's
 // waves leave registers and wave slots free. A context with several lanes (several K1 launches in flight at a time) therefore caps
 // each launch at a share of the 4096 waves one launch needs to saturate the memory system alone (FLX_FM_MAX_WAVES overrides;
-// 16 lanes, 3.1 Gb / 10 kb: 63.5 k reads/s at 4096 waves per launch, 69.5 k at 1024).
+// 16 lanes, 3.1 Gb / 10 kb: 63.5 k reads/s at 4096 waves per launch, 69.5 k at 1024, 70.6 k at 512).
 static u32 fm_max_waves(u32 concurrent_launches) {
     static u32 const v = [] { const char* e = getenv("FLX_FM_MAX_WAVES"); return e ? (u32)strtoul(e, nullptr, 10) : 0u; }();
     if (v) return v;
-    return FM_MAX_WAVES / std::max(1u, std::min(concurrent_launches, 4u));
+    return FM_MAX_WAVES / std::max(1u, std::min(concurrent_launches, 8u));
 }
 
 u32 fm_search_max_keyed_length() { return FM_KEY_MAX_X; }
