@@ -12,7 +12,10 @@
 #include <cstdlib>
 #include <cstring>
 #include <algorithm>
+#include <atomic>
+#include <condition_variable>
 #include <deque>
+#include <mutex>
 #include <future>
 #include <memory>
 #include <string>
@@ -462,27 +465,47 @@ int main(int argc, char** argv) {
         f.batch = std::move(b);
         return f;
     };
-    std::deque<std::future<Finished>> in_flight;
+    // Three stages run side by side: this thread parses the next batch, the batches in flight are aligned (one task each), a writer
+    // thread takes them in input order and formats / compresses / writes them (itself on the writer's I/O threads).
+    std::deque<std::future<Finished>> in_flight;           // guarded by q_mu
+    std::mutex q_mu;
+    std::condition_variable q_cv;
+    bool no_more = false;
     uint64_t total_reads = 0, total_records = 0, n_batches = 0;
-    bool failed = false, eof = false, timed_out = false;
-    auto write_oldest = [&]() {
-        Finished f = in_flight.front().get();
-        in_flight.pop_front();
-        if (failed) return;
+    std::atomic<bool> failed{false};
+    bool eof = false, timed_out = false;
+    auto write_one = [&](Finished& f) {
+        if (failed.load()) return;
         if (f.rc != FLX_OK) {
             log_line("error", "An error occurred while aligning a batch of queries.\nShutting down. The output file is likely incomplete. Error message:\n%s", f.err.c_str());
-            failed = true;
+            failed.store(true);
             return;
         }
         ReadBatch const& batch = *f.batch;
         for (size_t i = 0; i < f.skipped.size(); ++i)
             if (f.skipped[i]) log_line("warning", "skipping query: %s due to bad configuration regarding the number of errors.", batch.ids[i]);
-        if (flx_sam_write(out, batch.ids.data(), batch.pool.data(), batch.offsets.data(), batch.quals.data(), f.recs.data(), f.recs.size(), f.cig.data()) != FLX_OK) { log_line("error", "%s", flx_last_error()); failed = true; }
+        if (flx_sam_write(out, batch.ids.data(), batch.pool.data(), batch.offsets.data(), batch.quals.data(), f.recs.data(), f.recs.size(), f.cig.data()) != FLX_OK) { log_line("error", "%s", flx_last_error()); failed.store(true); }
         total_reads += batch.ids.size();
         total_records += f.recs.size();
         log_line("debug", "finished a batch: %llu queries, %llu records so far", (unsigned long long)total_reads, (unsigned long long)total_records);
     };
-    while (!eof && !failed) {
+    std::thread writer([&] {
+        while (true) {
+            std::future<Finished> next;
+            {
+                std::unique_lock<std::mutex> g(q_mu);
+                q_cv.wait(g, [&] { return !in_flight.empty() || no_more; });
+                if (in_flight.empty()) return;
+                next = std::move(in_flight.front());
+                in_flight.pop_front();
+            }
+            q_cv.notify_all();
+            Finished f = next.get();
+            write_one(f);
+        }
+    });
+    size_t const max_in_flight = 3 * ctxs.size() + 1;
+    while (!eof && !failed.load()) {
         if (o.has_timeout && std::chrono::duration<double>(std::chrono::steady_clock::now() - t_align).count() > (double)o.timeout) {
             log_line("warning", "Timeout happened. Shutting down now. The output file might be incomplete.");
             timed_out = true;
@@ -491,19 +514,25 @@ int main(int argc, char** argv) {
         auto batch = std::make_unique<ReadBatch>();
         if (!qin.next(*batch, batch_reads, err)) {
             eof = true;
-            if (!err.empty()) { log_line("error", "An error occured while trying to read the queries from the file %s.\n%s", o.queries.c_str(), err.c_str()); failed = true; }
+            if (!err.empty()) { log_line("error", "An error occured while trying to read the queries from the file %s.\n%s", o.queries.c_str(), err.c_str()); failed.store(true); }
             break;
         }
         if (batch->ids.empty()) continue;           // every record of the block was filtered
         flx_ctx* const target = ctxs[n_batches++ % ctxs.size()];
-        in_flight.push_back(std::async(std::launch::async, align_batch, std::move(batch), target));
-        while (in_flight.size() >= 3 * ctxs.size()) write_oldest();
+        {
+            std::unique_lock<std::mutex> g(q_mu);
+            q_cv.wait(g, [&] { return in_flight.size() < max_in_flight; });
+            in_flight.push_back(std::async(std::launch::async, align_batch, std::move(batch), target));
+        }
+        q_cv.notify_all();
     }
-    while (!in_flight.empty()) write_oldest();
-    if (flx_sam_close(out) != FLX_OK) { log_line("error", "%s", flx_last_error()); failed = true; }
+    { std::lock_guard<std::mutex> g(q_mu); no_more = true; }
+    q_cv.notify_all();
+    writer.join();
+    if (flx_sam_close(out) != FLX_OK) { log_line("error", "%s", flx_last_error()); failed.store(true); }
     for (flx_ctx* c : ctxs) flx_ctx_destroy(c);
     flx_index_free(index);
-    if (failed || timed_out) return -1;
+    if (failed.load() || timed_out) return -1;
     double const secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_align).count();
     log_line("info", "finished aligning successfully in %.3f seconds (%llu queries, %llu records)", secs, (unsigned long long)total_reads, (unsigned long long)total_records);
     if (stats) {                                                                       // floxer.cpp:182-192

@@ -7,6 +7,7 @@
 #include <algorithm>
 #include <atomic>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <thread>
@@ -31,11 +32,19 @@ namespace {
 constexpr size_t BGZF_BLOCK = 0xff00;
 constexpr size_t BGZF_MAX_OUT = 0x10000 + 64;
 
+// Without --interval-optimization a 10-kb read yields some forty records with a 1600-operation CIGAR each: 6 KB of BAM per
+// record, and deflating them is what the end-to-end rate of the CLI is made of. Level 1 by default (FLX_BGZF_LEVEL = 0..9
+// overrides): the records differ from zlib's default level by ~15 % in size and by 4x in time (scripts/cli_throughput.sh).
+int bgzf_level() {
+    static int const v = [] { const char* e = getenv("FLX_BGZF_LEVEL"); int const x = e ? atoi(e) : 1; return x < 0 ? 0 : x > 9 ? 9 : x; }();
+    return v;
+}
+
 // one BGZF block (a gzip member with the BC extra field) for `len` <= BGZF_BLOCK bytes; returns its size, 0 on failure
 size_t bgzf_compress_block(const uint8_t* data, size_t len, uint8_t* out) {
     z_stream zs;
     memset(&zs, 0, sizeof(zs));
-    if (deflateInit2(&zs, 6, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY) != Z_OK) return 0;
+    if (deflateInit2(&zs, bgzf_level(), Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY) != Z_OK) return 0;
     zs.next_in = const_cast<Bytef*>(data);
     zs.avail_in = (uInt)len;
     zs.next_out = out + 18;
@@ -159,9 +168,15 @@ bool format_record(flx_sam_writer const* w, flx_record const& r, const char* con
     const char* qual = (with_seq && quals) ? quals[r.read_index] : nullptr;
     const uint32_t* cig = cigar_words ? cigar_words + r.cigar_offset : nullptr;
     if (!w->bam) {
-        char num[32];
+        char num[24];
         auto app = [&](const char* p, size_t n) { out.insert(out.end(), p, p + n); };
-        auto app_num = [&](long long v) { int const n = snprintf(num, sizeof(num), "%lld", v); app(num, (size_t)n); };
+        auto app_num = [&](long long v) {                        // (a CIGAR is a thousand numbers per record)
+            unsigned long long u = v < 0 ? 0ull - (unsigned long long)v : (unsigned long long)v;
+            char* e = num + sizeof(num), * p = e;
+            do { *--p = (char)('0' + u % 10); u /= 10; } while (u);
+            if (v < 0) *--p = '-';
+            app(p, (size_t)(e - p));
+        };
         app(id, strlen(id)); out.push_back('\t'); app_num(r.flag); out.push_back('\t');
         if (unmapped) out.push_back('*'); else app(w->ref_ids[(size_t)r.reference_id].data(), w->ref_ids[(size_t)r.reference_id].size());
         out.push_back('\t');
@@ -207,7 +222,7 @@ bool format_record(flx_sam_writer const* w, flx_record const& r, const char* con
     put32(0);
     out.insert(out.end(), id, id + l_name);
     if (long_cigar) { put32((int32_t)(((uint32_t)query_span << 4) | 4u)); put32((int32_t)(((uint32_t)ref_span << 4) | 3u)); }
-    else for (uint32_t c = 0; c < r.cigar_length; ++c) put32((int32_t)cig[c]);
+    else { size_t const at = out.size(); out.resize(at + 4 * (size_t)r.cigar_length); memcpy(out.data() + at, cig, 4 * (size_t)r.cigar_length); }
     static const uint8_t nib[6] = {15, 1, 2, 4, 8, 15};       // =ACMGRSVTWYHKDBN codes for $ACGTN
     for (uint64_t b = 0; b < slen; b += 2) {
         uint8_t const hi = nib[seq[b] < 6 ? seq[b] : 5], lo = b + 1 < slen ? nib[seq[b + 1] < 6 ? seq[b + 1] : 5] : 0;

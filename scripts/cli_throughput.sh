@@ -19,13 +19,14 @@ run() {   # name, queries, output, extra flags
     $BIN/floxer --reference $W/g.fasta --queries $2 --output $3 --error-probability 0.08 --index $W/g.index --threads 16 $4 2> $W/$1.err
     local t1=$(date +%s.%N)
     local align=$(grep -o "finished aligning successfully in [0-9.]* seconds" $W/$1.err | grep -o "[0-9.]*" | head -1)
-    echo "$1: wall $(echo "$t1 - $t0" | bc) s, aligning phase $align s -> $(echo "$M / $align" | bc) reads/s end to end ($(grep -o "([0-9]* queries, [0-9]* records)" $W/$1.err))" | tee -a $OUT/cli_throughput.txt
+    python3 -c "print('$1: wall %.1f s, aligning phase %.2f s -> %.0f reads/s end to end' % ($t1 - $t0, $align, $M / $align), '$(grep -o "([0-9]* queries, [0-9]* records)" $W/$1.err)')" | tee -a $OUT/cli_throughput.txt
 }
 run index_build_and_first_run $W/r.fastq $W/o0.bam ""
 run fastq_to_bam $W/r.fastq $W/o1.bam ""
 run fastq_gz_to_bam $W/r.fastq.gz $W/o2.bam ""
 run fastq_to_sam $W/r.fastq $W/o3.sam ""
 run fastq_to_bam_interval_optimization $W/r.fastq $W/o4.bam "--interval-optimization"
+FLX_BGZF_LEVEL=6 run fastq_to_bam_zlib_level_6 $W/r.fastq $W/o5.bam ""
 cmp $W/o1.bam $W/o2.bam && echo "plain and gz input give the same BAM" | tee -a $OUT/cli_throughput.txt
 $BIN/simulated_dataset verify --alignments $W/o4.bam -p $((L / 10)) > $W/verify.txt 2> $W/verify.err
 echo "accuracy (-I run): $(grep -c FoundOptimal $W/verify.txt) of $M FoundOptimal; $(cat $W/verify.err)" | tee -a $OUT/cli_throughput.txt
