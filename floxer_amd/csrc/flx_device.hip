@@ -1413,7 +1413,10 @@ static AlignShape choose_align_shape_uncached(u32 nw, i64 width, bool band, bool
             if (!ok && band) ok = (i64)64 * w * (r - 1) + r + 1 > width;   // group g + r starts after group g has ended
             if (!ok) continue;
             // throughput form: cost ~ wave slots consumed (words per lane times lanes reserved), fewer words per lane on ties;
-            // parallel form: fewest words per lane first (shortest dependent chain per step, most waves), then fewest lanes
+            // parallel form: fewest words per lane first (shortest dependent chain per step, most waves), then fewest lanes.
+            // (A cost by instructions issued, r * (35 + 25 w), which prefers four words per lane over one at the same w * r, made
+            // the existence tests a third slower: more distinct shapes per round = more launches, and fewer resident waves per CU
+            // with the larger LDS tables; measured in round 2, gpurun_out r02u.)
             u64 const cost = parallel ? (u64)w * 1000 + r : (u64)w * r * 1000 + w;
             if (cost < best_cost) { best_cost = cost; best = AlignShape{w, r, band ? 1u : 0u}; }
         }

@@ -704,7 +704,7 @@ void dedup_requests(hvec<AlignRequest> const& reqs, hvec<AlignRequest>& uniq, hv
 // single launch.
 u64 align_few_waves() {          // FLX_ALIGN_FEW_WAVES overrides the threshold (tests force either form)
     const char* env = getenv("FLX_ALIGN_FEW_WAVES");
-    return env ? strtoull(env, nullptr, 10) : 2048;
+    return env ? strtoull(env, nullptr, 10) : 512;
 }
 int choose_shapes(hvec<AlignRequest> const& reqs, hvec<AlignShape>& shapes) {
     shapes.resize(reqs.size());
