@@ -1063,6 +1063,196 @@ int DeviceApi::locate(void* stream, const DevIndex& idx, const u32* d_rows, u32 
     return (int)hipGetLastError();
 }
 
+// ================================================================================================ verification rounds on the device
+// (see VrBuffers in flx_internal.hpp) The request of an anchor at an inner node: verification.cpp:157-184 with ratio 0, i.e.
+// base = m + 2e + 1, start = max(0, pos - (leaf_from - node_from) - e), length = min(base, reflen - start).
+// key1 = query offset << 20 | rows (identifies (read, orientation, node)), key2 = reference offset << 20 | window length.
+constexpr u32 VR_SHIFT = 20;
+
+__global__ void __launch_bounds__(256) vr_select_kernel(const DevVrAnchor* __restrict__ anchors, const DevVrNode* __restrict__ nodes,
+                                                        const u32* __restrict__ node, const u8* __restrict__ status, u32 n_anchors, u32 limit,
+                                                        u64* __restrict__ key1, u64* __restrict__ key2, u32* __restrict__ idx) {
+    u32 const i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_anchors) return;
+    u64 k1 = ~0ull, k2 = ~0ull;
+    if (status[i] == VR_CLIMBING) {
+        DevVrAnchor const a = anchors[i];
+        DevVrNode const nd = nodes[a.tree_base + node[i]];
+        if (nd.rows <= limit) {
+            i64 const start_signed = a.diag_rel + (i64)nd.from - (i64)nd.errors;
+            u64 const start = start_signed > 0 ? (u64)start_signed : 0ull;
+            u64 const base = (u64)nd.rows + 2ull * nd.errors + 1ull;
+            u64 const len = min(base, a.seq_len - start);
+            k1 = ((a.q_base + nd.from) << VR_SHIFT) | nd.rows;
+            k2 = ((a.seq_start + start) << VR_SHIFT) | len;
+        }
+    }
+    key1[i] = k1;
+    key2[i] = k2;
+    idx[i] = i;
+}
+__global__ void __launch_bounds__(256) vr_gather_kernel(const u64* __restrict__ src, const u32* __restrict__ order, u32 n, u64* __restrict__ dst) {
+    u32 const i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = src[order[i]];
+}
+// sorted requests: head of a distinct request, head of a run of one node's requests; the count of real requests
+__global__ void __launch_bounds__(256) vr_flag_requests_kernel(const u64* __restrict__ key1s, const u64* __restrict__ key2s, u32 n,
+                                                               u32* __restrict__ flag_u, u32* __restrict__ scalars) {
+    u32 const i = blockIdx.x * blockDim.x + threadIdx.x;
+    bool real = false;
+    if (i < n) {
+        real = key1s[i] != ~0ull;
+        flag_u[i] = real && (i == 0 || key1s[i] != key1s[i - 1] || key2s[i] != key2s[i - 1]) ? 1u : 0u;
+    }
+    u64 const m = __ballot(real);
+    if (m && lane_id() == 0) atomicAdd(&scalars[VR_N_REQ], (u32)__popcll(m));
+}
+// the distinct requests: their keys, one anchor that asked, and the first reference offset of their node's run
+__global__ void __launch_bounds__(256) vr_scatter_unique_kernel(const u64* __restrict__ key1s, const u64* __restrict__ key2s, const u32* __restrict__ idxs,
+                                                                const u32* __restrict__ flag_u, const u32* __restrict__ uid, u32 n,
+                                                                u64* __restrict__ ukey1, u64* __restrict__ ukey2, u32* __restrict__ urep,
+                                                                u32* __restrict__ scalars) {
+    u32 const i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    if (flag_u[i]) { u32 const u = uid[i] - 1u; ukey1[u] = key1s[i]; ukey2[u] = key2s[i]; urep[u] = idxs[i]; }
+    if (i == n - 1) scalars[VR_N_UNIQ] = uid[i];                         // inclusive scan: the last entry is the number of distinct requests
+}
+// run_first[u] = index of the first distinct request of u's node (filled in two steps: heads write themselves, a max-scan spreads)
+__global__ void __launch_bounds__(256) vr_run_heads_kernel(const u64* __restrict__ ukey1, const u32* __restrict__ scalars, u32* __restrict__ run_first) {
+    u32 const u = blockIdx.x * blockDim.x + threadIdx.x;
+    if (u >= scalars[VR_N_UNIQ]) return;
+    run_first[u] = (u == 0 || ukey1[u] != ukey1[u - 1]) ? u : 0u;
+}
+// Clusters: the distinct windows of one node whose starts fall into the same bucket of max(8, rows / 8) columns counted from the
+// node's first window (a cluster then spans at most that much: its union window stays a small multiple of the node's own)
+__global__ void __launch_bounds__(256) vr_flag_clusters_kernel(const u64* __restrict__ ukey1, const u64* __restrict__ ukey2, const u32* __restrict__ run_first,
+                                                               const u32* __restrict__ scalars, u32* __restrict__ flag_c) {
+    u32 const u = blockIdx.x * blockDim.x + threadIdx.x;
+    if (u >= scalars[VR_N_UNIQ]) return;
+    u32 f = 1;
+    if (u > 0 && run_first[u] == run_first[u - 1]) {
+        u64 const first = ukey2[run_first[u]] >> VR_SHIFT;
+        u64 const d = max((u64)8, (ukey1[u] & ((1ull << VR_SHIFT) - 1ull)) / 8ull);
+        f = ((ukey2[u] >> VR_SHIFT) - first) / d != ((ukey2[u - 1] >> VR_SHIFT) - first) / d ? 1u : 0u;
+    }
+    flag_c[u] = f;
+}
+__global__ void __launch_bounds__(256) vr_cluster_starts_kernel(const u32* __restrict__ flag_c, const u32* __restrict__ cid, u32* __restrict__ scalars,
+                                                                u32* __restrict__ cstart) {
+    u32 const u = blockIdx.x * blockDim.x + threadIdx.x;
+    u32 const n = scalars[VR_N_UNIQ];
+    if (u >= n) return;
+    if (flag_c[u]) cstart[cid[u] - 1u] = u;
+    if (u == n - 1) { scalars[VR_N_CLUSTERS] = cid[u]; cstart[cid[u]] = n; }
+}
+// a cluster's jobs: the window itself (one member), or the intersection of its windows (if not empty) and their union
+__global__ void __launch_bounds__(256) vr_jobs_kernel(const u64* __restrict__ ukey1, const u64* __restrict__ ukey2, const u32* __restrict__ urep,
+                                                      const u32* __restrict__ cstart, const DevVrAnchor* __restrict__ anchors,
+                                                      const DevVrNode* __restrict__ nodes, const u32* __restrict__ node, const u32* __restrict__ scalars,
+                                                      DevVrJob* __restrict__ jobs) {
+    u32 const c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= scalars[VR_N_CLUSTERS]) return;
+    u32 const u0 = cstart[c], u1 = cstart[c + 1];
+    u64 const mask = (1ull << VR_SHIFT) - 1ull;
+    u64 const k1 = ukey1[u0];
+    u32 const rep = urep[u0];
+    u32 const k = nodes[anchors[rep].tree_base + node[rep]].errors;
+    u64 lo_start = ukey2[u0] >> VR_SHIFT, hi_start = lo_start, lo_end = lo_start + (ukey2[u0] & mask), hi_end = lo_end;
+    for (u32 u = u0 + 1; u < u1; ++u) {
+        u64 const st = ukey2[u] >> VR_SHIFT, en = st + (ukey2[u] & mask);
+        hi_start = max(hi_start, st);
+        lo_end = min(lo_end, en);
+        hi_end = max(hi_end, en);
+    }
+    DevVrJob a{0, k1 >> VR_SHIFT, 0, (u32)(k1 & mask), k, 0}, b = a;
+    if (u1 - u0 == 1) { a.ref_off = lo_start; a.n = (u32)(hi_end - lo_start); }
+    else {
+        if (lo_end > hi_start) { a.ref_off = hi_start; a.n = (u32)(lo_end - hi_start); }
+        b.ref_off = lo_start;
+        b.n = (u32)(hi_end - lo_start);
+    }
+    jobs[2 * c] = a;
+    jobs[2 * c + 1] = b;
+}
+__global__ void __launch_bounds__(256) vr_apply_kernel(const u64* __restrict__ key1s, const u32* __restrict__ idxs, const u32* __restrict__ uid,
+                                                       const u32* __restrict__ cid, const u8* __restrict__ state, const u8* __restrict__ override_,
+                                                       const DevVrAnchor* __restrict__ anchors, const DevVrNode* __restrict__ nodes, u32 n,
+                                                       u32* __restrict__ node, u8* __restrict__ status) {
+    u32 const i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n || key1s[i] == ~0ull) return;
+    u32 const u = uid[i] - 1u;
+    u8 dec = override_ ? override_[u] : (u8)0;
+    if (!dec) dec = state[cid[u] - 1u];
+    u32 const a = idxs[i];
+    if (dec == 1) {
+        u32 const tb = anchors[a].tree_base;
+        u32 const parent = nodes[tb + node[a]].parent;
+        node[a] = parent;
+        if (nodes[tb + parent].parent == 0xFFFFFFFFu) status[a] = VR_AT_ROOT;
+    } else status[a] = VR_DEAD;
+}
+__global__ void __launch_bounds__(256) vr_next_kernel(const DevVrAnchor* __restrict__ anchors, const DevVrNode* __restrict__ nodes, const u32* __restrict__ node,
+                                                      const u8* __restrict__ status, u32 n, u32* __restrict__ scalars) {
+    u32 const i = blockIdx.x * blockDim.x + threadIdx.x;
+    bool const climbing = i < n && status[i] == VR_CLIMBING;
+    u32 rows = 0xFFFFFFFFu;
+    if (climbing) rows = nodes[anchors[i].tree_base + node[i]].rows;
+    u64 const m = __ballot(climbing);
+    if (!m) return;
+    u32 const wmin = (u32)~wave_max_u32(~rows);
+    if (lane_id() == 0) { atomicAdd(&scalars[VR_N_CLIMBING], (u32)__popcll(m)); atomicMin(&scalars[VR_SMALLEST], wmin); }
+}
+
+size_t DeviceApi::vr_tmp_bytes(u32 n) {
+    size_t a = 0, b = 0, c = 0;
+    (void)rocprim::radix_sort_pairs(nullptr, a, (u64*)nullptr, (u64*)nullptr, (u32*)nullptr, (u32*)nullptr, (size_t)n, 0u, 64u, (hipStream_t)nullptr);
+    (void)hipcub::DeviceScan::InclusiveSum(nullptr, b, (const u32*)nullptr, (u32*)nullptr, (int)n);
+    (void)hipcub::DeviceScan::InclusiveScan(nullptr, c, (const u32*)nullptr, (u32*)nullptr, hipcub::Max(), (int)n);
+    return std::max(a, std::max(b, c)) + 256;
+}
+
+int DeviceApi::vr_round_requests(void* stream, VrBuffers const& B, u32 n, u32 limit) {
+    if (n == 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    hipError_t e;
+    unsigned const blocks = (n + 255) / 256;
+    if ((e = hipMemsetAsync(B.scalars, 0, 3 * 4, s)) != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(vr_select_kernel, dim3(blocks), dim3(256), 0, s, B.anchors, B.nodes, B.node, B.status, n, limit, B.key1, B.key2, B.idx);
+    // order by (key1, key2): a stable sort by key2, then by key1 (LSD); the anchor index rides along, the other key is gathered
+    size_t tb = B.tmp_bytes;
+    if ((e = rocprim::radix_sort_pairs(B.tmp, tb, B.key2, B.key_mid, B.idx, B.idx_mid, (size_t)n, 0u, 52u, s)) != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(vr_gather_kernel, dim3(blocks), dim3(256), 0, s, B.key1, B.idx_mid, n, B.key2s);          // key1 in key2 order (key2s as scratch)
+    tb = B.tmp_bytes;
+    if ((e = rocprim::radix_sort_pairs(B.tmp, tb, B.key2s, B.key1s, B.idx_mid, B.idxs, (size_t)n, 0u, 64u, s)) != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(vr_gather_kernel, dim3(blocks), dim3(256), 0, s, B.key2, B.idxs, n, B.key2s);
+    hipLaunchKernelGGL(vr_flag_requests_kernel, dim3(blocks), dim3(256), 0, s, B.key1s, B.key2s, n, B.flag_u, B.scalars);
+    tb = B.tmp_bytes;
+    if ((e = hipcub::DeviceScan::InclusiveSum(B.tmp, tb, B.flag_u, B.uid, (int)n, s)) != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(vr_scatter_unique_kernel, dim3(blocks), dim3(256), 0, s, B.key1s, B.key2s, B.idxs, B.flag_u, B.uid, n, B.ukey1, B.ukey2, B.urep, B.scalars);
+    // (the kernels below run over at most n distinct requests and stop at the device-side count)
+    hipLaunchKernelGGL(vr_run_heads_kernel, dim3(blocks), dim3(256), 0, s, B.ukey1, B.scalars, B.run_first);
+    tb = B.tmp_bytes;
+    if ((e = hipcub::DeviceScan::InclusiveScan(B.tmp, tb, B.run_first, B.run_first, hipcub::Max(), (int)n, s)) != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(vr_flag_clusters_kernel, dim3(blocks), dim3(256), 0, s, B.ukey1, B.ukey2, B.run_first, B.scalars, B.flag_c);
+    tb = B.tmp_bytes;
+    if ((e = hipcub::DeviceScan::InclusiveSum(B.tmp, tb, B.flag_c, B.cid, (int)n, s)) != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(vr_cluster_starts_kernel, dim3(blocks), dim3(256), 0, s, B.flag_c, B.cid, B.scalars, B.cstart);
+    hipLaunchKernelGGL(vr_jobs_kernel, dim3(blocks), dim3(256), 0, s, B.ukey1, B.ukey2, B.urep, B.cstart, B.anchors, B.nodes, B.node, B.scalars, B.jobs);
+    return (int)hipGetLastError();
+}
+
+int DeviceApi::vr_round_apply(void* stream, VrBuffers const& B, u32 n, const u8* d_state, const u8* d_override) {
+    if (n == 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    unsigned const blocks = (n + 255) / 256;
+    hipLaunchKernelGGL(vr_apply_kernel, dim3(blocks), dim3(256), 0, s, B.key1s, B.idxs, B.uid, B.cid, d_state, d_override, B.anchors, B.nodes, n, B.node, B.status);
+    hipError_t e = hipMemsetAsync(B.scalars + VR_N_CLIMBING, 0, 4, s);
+    if (e == hipSuccess) e = hipMemsetAsync(B.scalars + VR_SMALLEST, 0xFF, 4, s);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(vr_next_kernel, dim3(blocks), dim3(256), 0, s, B.anchors, B.nodes, B.node, B.status, n, B.scalars);
+    return (int)hipGetLastError();
+}
+
 // ================================================================================================ K3/K4: edit-distance DP
 // Myers/Hyyro bit-vector columns, semi-global (free reference ends). One job occupies G = lanes_per_job consecutive lanes,
 // lane g owns W consecutive 64-row words of the column. Lanes run skewed: at step t lane g computes reference column

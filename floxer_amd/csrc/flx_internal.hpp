@@ -133,6 +133,36 @@ struct DevTraceJob {
 };
 struct DevTraceOut { u32 begin; u32 cigar_start; u32 cigar_len; u32 pad; };   // cigar_start relative to the slab
 
+// ------------------------------------------------------------------------------------------------ verification rounds on the device
+// The inner PEX levels as device-resident state: every anchor of a chunk with the node it is about to test; a round builds the
+// requests of the anchors in the current node-size class, sorts them, finds the distinct ones and the clusters of windows of one
+// locus, and hands the host a job list (one or two existence tests per cluster); the host launches K3 on it and returns one
+// decision per cluster; an apply step moves the anchors up their trees.
+struct DevVrAnchor {            // 48 bytes
+    i64 diag_rel;               // anchor position minus the leaf's first query row (relative to its reference sequence, may be < 0)
+    u64 seq_start, seq_len;     // the reference sequence in the padded text
+    u64 q_base;                 // pool offset of the read in the anchor's orientation
+    u32 tree_base;              // first node of the read's tree in the node table
+    u32 pad;
+};
+struct DevVrNode { u32 parent, from, rows, errors; };          // parent = index within the tree, 0xFFFFFFFF for the root
+struct DevVrJob { u64 ref_off, q_off; u32 n, m, k, pad; };     // n == 0: unused slot
+enum : u8 { VR_CLIMBING = 0, VR_DEAD = 1, VR_AT_ROOT = 2 };
+enum : u32 { VR_N_REQ = 0, VR_N_UNIQ = 1, VR_N_CLUSTERS = 2, VR_N_CLIMBING = 3, VR_SMALLEST = 4 };
+struct VrBuffers {
+    const DevVrAnchor* anchors; const DevVrNode* nodes;
+    u32* node; u8* status;                       // per anchor, mutable
+    u64 *key1, *key2, *key1s, *key2s;            // per anchor: request keys, unsorted / sorted (key1 = ~0: not in this round)
+    u32 *idx, *idx_mid, *idxs;                   // per anchor: anchor index through the two sort passes
+    u64* key_mid;
+    u32 *flag_u, *uid, *flag_c, *cid, *run_first;// per sorted request / per distinct request
+    u64 *ukey1, *ukey2; u32* urep;               // per distinct request: keys and one anchor that asked for it
+    u32* cstart;                                 // per cluster: its first distinct request (n_clusters + 1 entries)
+    DevVrJob* jobs;                              // two slots per cluster: {the window itself | the intersection}, {the union}
+    u32* scalars;                                // VR_*
+    void* tmp; size_t tmp_bytes;
+};
+
 // launch geometry for one alignment job shape
 struct AlignShape { u32 words_per_lane; u32 lanes_per_job; u32 banded; };
 
@@ -196,6 +226,12 @@ struct DeviceApi {
     // d_lastrow (banded TRACE launches only, may be null): D[m][c] of every computed column c, 0xFFFF elsewhere (pre-filled by the caller)
     static int align(void* stream, const u8* d_text, const u64* d_peq, const DevAlignJob* d_jobs, u32 n_jobs, AlignShape shape,
                      bool trace, u64* d_trace, DevAlignOut* d_out, u16* d_lastrow = nullptr);
+    // verification rounds (see VrBuffers). requests: everything up to the job list of the round whose node-size limit is `limit`
+    // (scalars VR_N_REQ / VR_N_UNIQ / VR_N_CLUSTERS are set); apply: d_state = one decision per cluster (1 pass, 2 fail, 0: look at
+    // d_override, one per distinct request, may be null), then scalars VR_N_CLIMBING / VR_SMALLEST for the next round
+    static size_t vr_tmp_bytes(u32 n_anchors);
+    static int vr_round_requests(void* stream, VrBuffers const& B, u32 n_anchors, u32 limit);
+    static int vr_round_apply(void* stream, VrBuffers const& B, u32 n_anchors, const u8* d_state, const u8* d_override);
     static int lastrow_min(void* stream, const u16* d_lastrow, const DevRowWindow* d_windows, u32 n_windows, DevAlignOut* d_out);
     static int traceback(void* stream, const u8* d_text, const u8* d_query, const u64* d_peq, const u64* d_trace,
                          const DevTraceJob* d_jobs, u32 n_jobs, bool checkpointed, u32* d_cigar, DevTraceOut* d_out);

@@ -80,7 +80,7 @@ hipEvent_t Lane::get_event() {
 hvec<DeviceBuffer*> lane_workspaces(Lane& l) {
     return {&l.seq, &l.seq_rev, &l.peq, &l.peq_rev, &l.scheme, &l.seeds, &l.stack, &l.hits, &l.counters, &l.rows, &l.rows_out, &l.jobs,
             &l.job_out, &l.trace, &l.tjobs, &l.tjob_out, &l.cigar, &l.user_text, &l.user_text_rev, &l.lastrow, &l.row_windows, &l.row_out,
-            &l.seed_cnt, &l.hit_off, &l.grouped, &l.sel_stat, &l.sel_n, &l.sel_off, &l.sel_out, &l.sel_tmp, &l.sel_rows, &l.sel_row_off, &l.sel_sparse, &l.sel_lists};
+            &l.seed_cnt, &l.hit_off, &l.grouped, &l.sel_stat, &l.sel_n, &l.sel_off, &l.sel_out, &l.sel_tmp, &l.sel_rows, &l.sel_row_off, &l.sel_sparse, &l.sel_lists, &l.vr, &l.vr_state, &l.vr_override};
 }
 std::vector<DeviceBuffer*> Lane::workspaces() { auto v = lane_workspaces(*this); return std::vector<DeviceBuffer*>(v.begin(), v.end()); }
 int Lane::size_like(Lane& other) {
@@ -1724,45 +1724,186 @@ int align_slice(Lane* lane, const flx_params* P, const flx_reads* RD, u64 first_
     hvec<u32> climbing, selected, waiting, survivors;    // anchors that still have an inner node to test (in anchor order)
     double g_build_ms = 0;
     for (u32 ai = 0; ai < A.size(); ++ai) if (A[ai].alive && !A[ai].at_root) climbing.push_back(ai);
+    // The rounds run with the anchors' state resident on the device (requests, de-duplication, clusters and the moves up the trees
+    // are kernels; the host launches K3 on each round's job list and decides per cluster). FLX_HOST_ROUNDS=1, or a statistics
+    // object on the context (it wants every request's window), selects the host form below; both give the same records.
+    static int const host_rounds = getenv("FLX_HOST_ROUNDS") ? 1 : 0;
+    if (!host_rounds && !st_local && !climbing.empty()) {
+        u32 const n = (u32)A.size();
+        // ---- node table of the chunk's trees, anchors
+        std::map<const PexTree*, u32> tree_base;
+        hvec<DevVrNode> nodes;
+        for (auto const& kv : tree_cache) {
+            PexTree const& t = *kv.second;
+            tree_base[&t] = (u32)nodes.size();
+            for (auto const& nd : t.inner) nodes.push_back(DevVrNode{nd.parent_id, nd.from, nd.to - nd.from + 1, nd.num_errors});
+        }
+        if (nodes.empty()) nodes.push_back(DevVrNode{0xFFFFFFFFu, 0, 1, 0});
+        hvec<DevVrAnchor> da(n);
+        hvec<u32> h_node(n);
+        hvec<u8> h_status(n);
+        u32 n_climbing = 0, smallest = 0xFFFFFFFFu;
+        for (u32 i = 0; i < n; ++i) {
+            AnchorState const& a = A[i];
+            ReadState const& rs = reads[a.read];
+            flx_pex_node const& leaf = rs.tree_ref().leaves[a.leaf];
+            u32 const tb = tree_base[rs.tree_ptr];
+            da[i] = DevVrAnchor{(i64)a.pos - (i64)leaf.from, H.seq_start[a.ref_id], H.seq_len[a.ref_id], rs.pool_off[a.orientation], tb, 0};
+            bool const climbs = a.alive && !a.at_root;
+            h_node[i] = climbs ? a.node : 0u;
+            h_status[i] = climbs ? VR_CLIMBING : a.at_root ? VR_AT_ROOT : VR_DEAD;
+            if (climbs) { ++n_climbing; smallest = std::min(smallest, nodes[tb + a.node].rows); }
+        }
+        // ---- one device buffer cut into the arrays of VrBuffers
+        size_t const tmp_bytes = DeviceApi::vr_tmp_bytes(n);
+        size_t off = 0;
+        auto take = [&](size_t bytes) { size_t const at = off; off += (bytes + 255) & ~(size_t)255; return at; };
+        size_t const o_anchors = take((size_t)n * sizeof(DevVrAnchor)), o_nodes = take(nodes.size() * sizeof(DevVrNode)), o_node = take((size_t)n * 4),
+                     o_status = take(n), o_key1 = take((size_t)n * 8), o_key2 = take((size_t)n * 8), o_key1s = take((size_t)n * 8), o_key2s = take((size_t)n * 8),
+                     o_key_mid = take((size_t)n * 8), o_idx = take((size_t)n * 4), o_idx_mid = take((size_t)n * 4), o_idxs = take((size_t)n * 4),
+                     o_flag_u = take((size_t)n * 4), o_uid = take((size_t)n * 4), o_flag_c = take((size_t)n * 4), o_cid = take((size_t)n * 4),
+                     o_run = take((size_t)n * 4), o_ukey1 = take((size_t)n * 8), o_ukey2 = take((size_t)n * 8), o_urep = take((size_t)n * 4),
+                     o_cstart = take(((size_t)n + 1) * 4), o_jobs = take((size_t)n * 2 * sizeof(DevVrJob)), o_scalars = take(64), o_tmp = take(tmp_bytes);
+        if ((rc = lane->vr.ensure(off))) return rc;
+        char* const base = (char*)lane->vr.ptr;
+        VrBuffers B{};
+        B.anchors = (const DevVrAnchor*)(base + o_anchors); B.nodes = (const DevVrNode*)(base + o_nodes); B.node = (u32*)(base + o_node); B.status = (u8*)(base + o_status);
+        B.key1 = (u64*)(base + o_key1); B.key2 = (u64*)(base + o_key2); B.key1s = (u64*)(base + o_key1s); B.key2s = (u64*)(base + o_key2s); B.key_mid = (u64*)(base + o_key_mid);
+        B.idx = (u32*)(base + o_idx); B.idx_mid = (u32*)(base + o_idx_mid); B.idxs = (u32*)(base + o_idxs);
+        B.flag_u = (u32*)(base + o_flag_u); B.uid = (u32*)(base + o_uid); B.flag_c = (u32*)(base + o_flag_c); B.cid = (u32*)(base + o_cid); B.run_first = (u32*)(base + o_run);
+        B.ukey1 = (u64*)(base + o_ukey1); B.ukey2 = (u64*)(base + o_ukey2); B.urep = (u32*)(base + o_urep); B.cstart = (u32*)(base + o_cstart);
+        B.jobs = (DevVrJob*)(base + o_jobs); B.scalars = (u32*)(base + o_scalars); B.tmp = base + o_tmp; B.tmp_bytes = tmp_bytes;
+        FLX_HIP(hipMemcpyAsync(base + o_anchors, da.data(), (size_t)n * sizeof(DevVrAnchor), hipMemcpyHostToDevice, lane->stream));
+        FLX_HIP(hipMemcpyAsync(base + o_nodes, nodes.data(), nodes.size() * sizeof(DevVrNode), hipMemcpyHostToDevice, lane->stream));
+        FLX_HIP(hipMemcpyAsync(base + o_node, h_node.data(), (size_t)n * 4, hipMemcpyHostToDevice, lane->stream));
+        FLX_HIP(hipMemcpyAsync(base + o_status, h_status.data(), n, hipMemcpyHostToDevice, lane->stream));
+        if ((rc = lane->vr_state.ensure(n + 64))) return rc;
+        if ((rc = lane->vr_override.ensure(n + 64))) return rc;
+        hvec<DevVrJob> vjobs;
+        hvec<AlignRequest> jobs;
+        hvec<u32> job_cluster;
+        hvec<DevAlignOut> jouts;
+        hvec<u8> state, override_;
+        hvec<u64> uk1, uk2;
+        hvec<u32> cstart;
+        u64 const mask = (1ull << 20) - 1ull;
+        while (n_climbing > 0) {
+            u64 const limit = (u64)smallest + smallest / 2;
+            int const e1 = DeviceApi::vr_round_requests(lane->stream, B, n, (u32)std::min<u64>(limit, 0xFFFFFFFFu));
+            if (e1) { set_error(std::string("verification round: ") + hipGetErrorString((hipError_t)e1)); return FLX_ERR_NO_DEVICE; }
+            u32 sc[3] = {0, 0, 0};
+            if ((rc = d2h(lane, sc, B.scalars, 12))) return rc;
+            if ((rc = lane->sync())) return rc;
+            u32 const n_uniq = sc[VR_N_UNIQ], n_clusters = sc[VR_N_CLUSTERS];
+            n_inner_requested += sc[VR_N_REQ];
+            vjobs.resize((size_t)n_clusters * 2);
+            if (n_clusters) {
+                if ((rc = d2h(lane, vjobs.data(), B.jobs, vjobs.size() * sizeof(DevVrJob)))) return rc;
+                if ((rc = lane->sync())) return rc;
+            }
+            jobs.clear();
+            job_cluster.clear();
+            for (u32 c = 0; c < n_clusters; ++c)
+                for (u32 slot = 0; slot < 2; ++slot) {
+                    DevVrJob const& j = vjobs[2 * (size_t)c + slot];
+                    if (j.n == 0) continue;
+                    jobs.push_back(AlignRequest{j.ref_off, j.q_off, j.n, j.m, j.k});
+                    job_cluster.push_back(c | (slot ? 0x80000000u : 0u));
+                }
+            if ((rc = run_score_jobs_unique(lane, d_text, d_peq, jobs, jouts, "ed_align_exists"))) return rc;
+            // a cluster's decision: its own window / the intersection holds an alignment -> all members pass; the union holds none
+            // -> all fail; else (rare) the members one by one
+            state.assign(n_clusters, 0);
+            for (size_t j = 0; j < jobs.size(); ++j) {
+                u32 const c = job_cluster[j] & 0x7FFFFFFFu;
+                bool const is_union = job_cluster[j] >> 31, found = jouts[j].score != 0xFFFFFFFFu;
+                if (!is_union) { if (found) state[c] = 1; else if (vjobs[2 * (size_t)c + 1].n == 0) state[c] = 2; }
+                else if (!found) state[c] = 2;
+            }
+            bool any_undecided = false;
+            for (u32 c = 0; c < n_clusters; ++c) any_undecided |= state[c] == 0;
+            const u8* d_override = nullptr;
+            if (any_undecided) {
+                uk1.resize(n_uniq); uk2.resize(n_uniq); cstart.resize((size_t)n_clusters + 1);
+                if ((rc = d2h(lane, uk1.data(), B.ukey1, (size_t)n_uniq * 8))) return rc;
+                if ((rc = d2h(lane, uk2.data(), B.ukey2, (size_t)n_uniq * 8))) return rc;
+                if ((rc = d2h(lane, cstart.data(), B.cstart, ((size_t)n_clusters + 1) * 4))) return rc;
+                if ((rc = lane->sync())) return rc;
+                jobs.clear();
+                hvec<u32> job_uniq;
+                for (u32 c = 0; c < n_clusters; ++c) {
+                    if (state[c] != 0) continue;
+                    u32 const k = vjobs[2 * (size_t)c + 1].k;
+                    for (u32 u = cstart[c]; u < cstart[c + 1]; ++u) {
+                        jobs.push_back(AlignRequest{uk2[u] >> 20, uk1[u] >> 20, (u32)(uk2[u] & mask), (u32)(uk1[u] & mask), k});
+                        job_uniq.push_back(u);
+                    }
+                }
+                if ((rc = run_score_jobs_unique(lane, d_text, d_peq, jobs, jouts, "ed_align_exists"))) return rc;
+                override_.assign(n_uniq, 0);
+                for (size_t j = 0; j < jobs.size(); ++j) override_[job_uniq[j]] = jouts[j].score != 0xFFFFFFFFu ? 1 : 2;
+                FLX_HIP(hipMemcpyAsync(lane->vr_override.ptr, override_.data(), n_uniq, hipMemcpyHostToDevice, lane->stream));
+                d_override = lane->vr_override.as<u8>();
+            }
+            if (n_clusters) FLX_HIP(hipMemcpyAsync(lane->vr_state.ptr, state.data(), n_clusters, hipMemcpyHostToDevice, lane->stream));
+            int const e2 = DeviceApi::vr_round_apply(lane->stream, B, n, lane->vr_state.as<u8>(), d_override);
+            if (e2) { set_error(std::string("verification round: ") + hipGetErrorString((hipError_t)e2)); return FLX_ERR_NO_DEVICE; }
+            u32 nx[2] = {0, 0};
+            if ((rc = d2h(lane, nx, B.scalars + VR_N_CLIMBING, 8))) return rc;
+            if ((rc = lane->sync())) return rc;                       // (also: state / override_ may be rewritten now)
+            if (sc[VR_N_REQ] == 0 && nx[0] >= n_climbing) { set_error("verification rounds do not advance"); return FLX_ERR_INTERNAL; }
+            n_climbing = nx[0];
+            smallest = nx[1];
+        }
+        if ((rc = d2h(lane, h_status.data(), B.status, n))) return rc;
+        if ((rc = d2h(lane, h_node.data(), B.node, (size_t)n * 4))) return rc;
+        if ((rc = lane->sync())) return rc;
+        for (u32 i = 0; i < n; ++i) {
+            AnchorState& a = A[i];
+            if (h_status[i] == VR_DEAD && a.alive && !a.at_root) a.alive = false;
+            else if (h_status[i] == VR_AT_ROOT && !a.at_root) { a.at_root = true; a.node = h_node[i]; }
+        }
+    } else {
     hvec<AlignRequest> reqs;
-    hvec<DevAlignOut> outs;
-    auto rows_of = [&](AnchorState const& a) { flx_pex_node const& nd = reads[a.read].tree_ref().inner[a.node]; return nd.to - nd.from + 1; };
-    // `climbing` carries each anchor's node size next to its index (the rounds scan it): {anchor, rows}
-    struct Climber { u32 anchor, rows; };
-    hvec<Climber> climbers, sel, wait, surv;
-    u32 smallest = 0xFFFFFFFFu;
-    climbers.reserve(climbing.size());
-    for (u32 ai : climbing) { u32 const r = rows_of(A[ai]); climbers.push_back(Climber{ai, r}); smallest = std::min(smallest, r); }
-    while (!climbers.empty()) {
-        u64 const limit = (u64)smallest + smallest / 2;
-        auto const tb0 = std::chrono::steady_clock::now();
-        sel.clear();
-        wait.clear();
-        surv.clear();
-        reqs.clear();
-        u32 next_smallest = 0xFFFFFFFFu;
-        for (Climber const& c : climbers) {                  // both parts stay in anchor order
-            if (c.rows <= limit) {
-                sel.push_back(c);
-                reqs.push_back(window_request(A[c.anchor], reads[A[c.anchor].read].tree_ref().inner[A[c.anchor].node], 0.0, nullptr));
-            } else { wait.push_back(c); next_smallest = std::min(next_smallest, c.rows); }
+        hvec<DevAlignOut> outs;
+        auto rows_of = [&](AnchorState const& a) { flx_pex_node const& nd = reads[a.read].tree_ref().inner[a.node]; return nd.to - nd.from + 1; };
+        // `climbing` carries each anchor's node size next to its index (the rounds scan it): {anchor, rows}
+        struct Climber { u32 anchor, rows; };
+        hvec<Climber> climbers, sel, wait, surv;
+        u32 smallest = 0xFFFFFFFFu;
+        climbers.reserve(climbing.size());
+        for (u32 ai : climbing) { u32 const r = rows_of(A[ai]); climbers.push_back(Climber{ai, r}); smallest = std::min(smallest, r); }
+        while (!climbers.empty()) {
+            u64 const limit = (u64)smallest + smallest / 2;
+            auto const tb0 = std::chrono::steady_clock::now();
+            sel.clear();
+            wait.clear();
+            surv.clear();
+            reqs.clear();
+            u32 next_smallest = 0xFFFFFFFFu;
+            for (Climber const& c : climbers) {                  // both parts stay in anchor order
+                if (c.rows <= limit) {
+                    sel.push_back(c);
+                    reqs.push_back(window_request(A[c.anchor], reads[A[c.anchor].read].tree_ref().inner[A[c.anchor].node], 0.0, nullptr));
+                } else { wait.push_back(c); next_smallest = std::min(next_smallest, c.rows); }
+            }
+            g_build_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tb0).count();
+            n_inner_requested += reqs.size();
+            if (st_local) for (auto const& rq : reqs) st_local->at(Stats::SPAN_INNER).add(rq.n);      // verification.cpp:241 (one per anchor and node)
+            if ((rc = run_exists_jobs(lane, d_text, d_peq, reqs, outs))) return rc;
+            for (size_t i = 0; i < outs.size(); ++i) {
+                AnchorState& a = A[sel[i].anchor];
+                if (outs[i].score == 0xFFFFFFFFu) { a.alive = false; continue; }
+                a.node = reads[a.read].tree_ref().inner[a.node].parent_id;
+                if (reads[a.read].tree_ref().inner[a.node].parent_id == FLX_NULL_ID) a.at_root = true;
+                else { u32 const r = rows_of(a); surv.push_back(Climber{sel[i].anchor, r}); next_smallest = std::min(next_smallest, r); }
+            }
+            climbers.resize(wait.size() + surv.size());
+            std::merge(wait.begin(), wait.end(), surv.begin(), surv.end(), climbers.begin(), [](Climber const& x, Climber const& y) { return x.anchor < y.anchor; });
+            smallest = next_smallest;
         }
-        g_build_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tb0).count();
-        n_inner_requested += reqs.size();
-        if (st_local) for (auto const& rq : reqs) st_local->at(Stats::SPAN_INNER).add(rq.n);      // verification.cpp:241 (one per anchor and node)
-        if ((rc = run_exists_jobs(lane, d_text, d_peq, reqs, outs))) return rc;
-        for (size_t i = 0; i < outs.size(); ++i) {
-            AnchorState& a = A[sel[i].anchor];
-            if (outs[i].score == 0xFFFFFFFFu) { a.alive = false; continue; }
-            a.node = reads[a.read].tree_ref().inner[a.node].parent_id;
-            if (reads[a.read].tree_ref().inner[a.node].parent_id == FLX_NULL_ID) a.at_root = true;
-            else { u32 const r = rows_of(a); surv.push_back(Climber{sel[i].anchor, r}); next_smallest = std::min(next_smallest, r); }
-        }
-        climbers.resize(wait.size() + surv.size());
-        std::merge(wait.begin(), wait.end(), surv.begin(), surv.end(), climbers.begin(), [](Climber const& x, Climber const& y) { return x.anchor < y.anchor; });
-        smallest = next_smallest;
-    }
 
+    }
     prof.mark("inner-levels");
     if (prof.on) {
         fprintf(stderr, "[flx host profile] exists rounds: dedup=%.2f cluster=%.2f gpu-round-trip=%.2f scatter=%.2f build-requests=%.2f ms\n",

@@ -892,3 +892,37 @@ def test_context_on_an_index_image_and_two_contexts():
         F.context(light)                                   # an index without arrays cannot upload itself
     for c in (a, b, base_ctx):
         c.close()
+
+
+def test_device_rounds_equal_host_rounds():
+    """The inner PEX levels with the anchors' state on the device (requests, de-duplication, clusters, moves up the trees as kernels)
+    against the host form of the same rounds (taken when a statistics object is attached: it wants every request's window), on a
+    text with copied segments (loci that share windows, clusters that are not decided by their intersection / union), several
+    references, three read shapes, defaults / -I / -d / bottom-up trees"""
+    genome = S.make_genome(400_000, 4, seed=61)
+    rng = np.random.default_rng(9)
+    for g in genome:
+        for _ in range(8):
+            a, b, ln = rng.integers(0, len(g) - 6000), rng.integers(0, len(g) - 6000), int(rng.integers(300, 5000))
+            g[b:b + ln] = g[a:a + ln]
+            if ln > 1000:                                    # a diverged copy next to the exact one
+                c = int(rng.integers(0, len(g) - 6000))
+                g[c:c + ln] = g[a:a + ln]
+                for p in rng.integers(0, ln, size=ln // 25):
+                    g[c + p] = rng.integers(1, 5)
+    idx = F.fmindex(genome)
+    dev_ctx, host_ctx = F.context(idx), F.context(idx)
+    stats = F.statistics("simulated").attach(host_ctx)
+    n_total = 0
+    for length, rate, n_reads, seed in [(3000, 0.08, 120, 1), (800, 0.05, 200, 2), (6000, 0.04, 40, 3)]:
+        reads, _, _ = S.make_reads(genome, n_reads, length, rate, seed=700 + seed)
+        for kw in (dict(), dict(interval_optimization=True), dict(direct_full_verification=True), dict(bottom_up_pex_tree=True)):
+            p = F.params(error_probability=rate, **kw)
+            dev_ctx.path_counters(reset=True); host_ctx.path_counters(reset=True)
+            a = F.aligner(dev_ctx, p).align_reads(reads)
+            b = F.aligner(host_ctx, p).align_reads(reads)
+            assert a.records() == b.records(), (length, kw)
+            assert dev_ctx.path_counters()["inner_tests_requested"] == host_ctx.path_counters()["inner_tests_requested"]
+            n_total += n_reads
+    assert stats.num_queries == n_total
+    dev_ctx.close(); host_ctx.close()
