@@ -93,6 +93,12 @@ struct flx_ctx {
     void release_lane(flx::Lane* lane);
     void warm_one_cold_lane(flx::Lane* like);   // gives one lane that never ran the workspace sizes of `like` (still held)
 
+    // K1 launches in flight at a time (see search_seeds_device): a counting semaphore
+    int k1_tokens = 0;               // guarded by lane_mu; 0 = unlimited
+    int k1_running = 0;
+    void k1_acquire();
+    void k1_release();
+
     flx::Lane* lane0() { return lanes[0].get(); }
     int sync_all();
     void account(const char* name, flx::u64 bytes, flx::u64 units, hipEvent_t start, hipEvent_t stop);   // caller holds mu

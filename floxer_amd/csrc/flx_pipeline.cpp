@@ -183,6 +183,17 @@ void flx_ctx::release_lane(flx::Lane* lane) {
     { std::lock_guard<std::mutex> g(lane_mu); free_lanes.push_back(lane->id); }
     lane_cv.notify_all();
 }
+void flx_ctx::k1_acquire() {
+    if (k1_tokens <= 0) return;
+    std::unique_lock<std::mutex> g(lane_mu);
+    lane_cv.wait(g, [&] { return k1_running < k1_tokens; });
+    ++k1_running;
+}
+void flx_ctx::k1_release() {
+    if (k1_tokens <= 0) return;
+    { std::lock_guard<std::mutex> g(lane_mu); --k1_running; }
+    lane_cv.notify_all();
+}
 int flx_ctx::sync_all() {
     for (auto& l : lanes) { int rc = l->sync(); if (rc) return rc; }
     return FLX_OK;
@@ -370,7 +381,9 @@ int search_seeds_device(Lane* ctx, const u8* d_seq_pool_or_null, const u8* h_seq
     }
     u32 counters[16];
     u64 sel_cap = 0;                          // entries of the selected-anchor list
+    struct K1Token { flx_ctx* c; explicit K1Token(flx_ctx* c_) : c(c_) { c->k1_acquire(); } ~K1Token() { c->k1_release(); } };
     for (int attempt = 0;; ++attempt) {
+        K1Token const token(ctx->ctx);           // (held until this attempt's kernels have finished)
         sel_cap = std::max(sel_cap, hit_cap);
         if ((rc = ctx->hits.ensure(hit_cap * sizeof(DevHit)))) return rc;
         FLX_HIP(hipMemsetAsync(ctx->counters.ptr, 0, 64, ctx->stream));
