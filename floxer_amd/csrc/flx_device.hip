@@ -1063,6 +1063,14 @@ int DeviceApi::locate(void* stream, const DevIndex& idx, const u32* d_rows, u32 
     return (int)hipGetLastError();
 }
 
+// launch shapes of the DP kernels (K3/K4 below): words per lane a kernel is instantiated for; FLX_NO_BAND=1 computes whole matrices
+static const u32 kWordsPerLane[] = {1, 2, 3, 4, 5, 6, 8, 13, 25};
+
+static bool use_band() {
+    static int const v = getenv("FLX_NO_BAND") ? 0 : 1;
+    return v != 0;
+}
+
 // ================================================================================================ verification rounds on the device
 // (see VrBuffers in flx_internal.hpp) The request of an anchor at an inner node: verification.cpp:157-184 with ratio 0, i.e.
 // base = m + 2e + 1, start = max(0, pos - (leaf_from - node_from) - e), length = min(base, reflen - start).
@@ -1174,6 +1182,163 @@ __global__ void __launch_bounds__(256) vr_jobs_kernel(const u64* __restrict__ uk
     jobs[2 * c] = a;
     jobs[2 * c + 1] = b;
 }
+// ---- the round's job list grouped by launch shape (the rules of choose_align_shape / choose_shapes, evaluated per job here)
+__device__ __constant__ u32 kVrWords[9] = {1, 2, 3, 4, 5, 6, 8, 13, 25};
+constexpr u32 VR_LOG2R = 7;             // lanes per job 1 .. 64
+
+__device__ __forceinline__ bool vr_shape_holds(u32 nw, i64 width, u32 w, u32 r, bool band) {
+    return (nw + w - 1u) / w <= r || (band && (i64)64 * w * (r - 1u) + r + 1 > width);
+}
+// cheapest class of a job; `parallel`: fewest words per lane first (see choose_align_shape_uncached)
+__device__ u32 vr_shape_class(u32 nw, i64 width, bool band, bool parallel) {
+    u32 best = VR_NO_CLASS;
+    u64 best_cost = ~0ull;
+    for (u32 wi = 0; wi < 9u; ++wi)
+        for (u32 lr = 0; lr < VR_LOG2R; ++lr) {
+            u32 const w = kVrWords[wi], r = 1u << lr;
+            if (!vr_shape_holds(nw, width, w, r, band)) continue;
+            u64 const cost = parallel ? (u64)w * 1000ull + r : (u64)w * r * 1000ull + w;
+            if (cost < best_cost) { best_cost = cost; best = wi * VR_LOG2R + lr; }
+        }
+    return best;
+}
+__device__ u64 vr_word_steps(u32 n, u32 m, u32 k, u32 W, bool band) {          // job_word_steps of flx_pipeline.cpp
+    u64 const nw = (m + 63u) / 64u;
+    if (!band) return (u64)n * nw;
+    i64 const band_hi = (i64)n - (i64)m + (i64)k;
+    u64 total = 0;
+    for (i64 g = 0; g * W < (i64)nw; ++g) {
+        i64 const r0 = 64 * (i64)W * g, r1 = min((i64)m, r0 + 64 * (i64)W);
+        i64 const lo = max((i64)0, r0 - (i64)k), hi = min((i64)n - 1, r1 - 1 + band_hi);
+        if (hi >= lo) total += (u64)(hi - lo + 1) * (u64)min((i64)W, (i64)nw - g * W);
+    }
+    return total;
+}
+__device__ __forceinline__ u64 wave_sum_u64(u64 v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    return v;
+}
+// Adds, for every class present in the wave, the members' count (and optionally two 64-bit sums) with one atomic per class and wave.
+// `cls` = VR_NO_CLASS: the lane takes no part.
+__device__ __forceinline__ void vr_class_add(u32 cls, u32* __restrict__ count, u64* __restrict__ sum_a, u64 a, u64* __restrict__ sum_b, u64 b) {
+    u64 todo = __ballot(cls != VR_NO_CLASS);
+    while (todo) {
+        u32 const leader = (u32)__ffsll((long long)todo) - 1u;
+        u32 const c = (u32)__shfl((int)cls, (int)leader);
+        bool const mine = cls == c;
+        u64 const members = __ballot(mine);
+        u64 const sa = sum_a ? wave_sum_u64(mine ? a : 0ull) : 0ull;
+        u64 const sb = sum_b ? wave_sum_u64(mine ? b : 0ull) : 0ull;
+        if (lane_id() == leader) {
+            atomicAdd(&count[c], (u32)__popcll(members));
+            if (sum_a) atomicAdd((unsigned long long*)&sum_a[c], (unsigned long long)sa);
+            if (sum_b) atomicAdd((unsigned long long*)&sum_b[c], (unsigned long long)sb);
+        }
+        todo &= ~members;
+    }
+}
+__global__ void __launch_bounds__(256) vr_shape_kernel(const DevVrJob* __restrict__ jobs, const u32* __restrict__ scalars, u32 band,
+                                                       u8* __restrict__ job_class, DevVrPlan* __restrict__ plan) {
+    u32 const j = blockIdx.x * blockDim.x + threadIdx.x;
+    u32 cls = VR_NO_CLASS, par = 0, lanes = 0;
+    if (j < 2u * scalars[VR_N_CLUSTERS]) {
+        DevVrJob const job = jobs[j];
+        if (job.n != 0) {
+            u32 const nw = (job.m + 63u) / 64u;
+            i64 const width = (i64)job.n - (i64)job.m + 2 * (i64)job.k;
+            cls = vr_shape_class(nw, width, band != 0, false);
+            if (cls == VR_NO_CLASS) plan->unsupported = 1;
+            else {
+                lanes = 1u << (cls % VR_LOG2R);
+                par = vr_shape_class(nw, width, band != 0, true) / VR_LOG2R;
+            }
+        }
+        job_class[j] = (u8)cls;
+    }
+    vr_class_add(cls, plan->count_first, nullptr, 0, nullptr, 0);
+    u32 const wl = wave_sum_u32(lanes), wp = wave_max_u32(par);
+    if (lane_id() == 0 && wl) { atomicAdd((unsigned long long*)&plan->lanes, (unsigned long long)wl); atomicMax(&plan->par_w_index, wp); }
+}
+// A launch lasts at least as long as its longest job: the jobs of a class with fewer than 64 members join the most frequent class
+// of at least 64 that can hold them (choose_shapes). Then the per-class totals and the lanes per job of the one-launch form.
+__global__ void __launch_bounds__(256) vr_regroup_kernel(const DevVrJob* __restrict__ jobs, const u32* __restrict__ scalars, u32 band,
+                                                         u8* __restrict__ job_class, DevVrPlan* __restrict__ plan) {
+    u32 const j = blockIdx.x * blockDim.x + threadIdx.x;
+    u32 cls = VR_NO_CLASS, par_r = 0;
+    u64 steps = 0, bytes = 0, common_steps = 0;
+    if (j < 2u * scalars[VR_N_CLUSTERS]) {
+        cls = job_class[j];
+        if (cls != VR_NO_CLASS) {
+            DevVrJob const job = jobs[j];
+            u32 const nw = (job.m + 63u) / 64u;
+            i64 const width = (i64)job.n - (i64)job.m + 2 * (i64)job.k;
+            if (plan->count_first[cls] < 64u) {
+                u32 best_n = 0, best = cls;
+                for (u32 c = 0; c < 9u * VR_LOG2R; ++c) {
+                    u32 const cnt = plan->count_first[c];
+                    if (cnt >= 64u && cnt > best_n && vr_shape_holds(nw, width, kVrWords[c / VR_LOG2R], 1u << (c % VR_LOG2R), band != 0)) { best_n = cnt; best = c; }
+                }
+                cls = best;
+                job_class[j] = (u8)cls;
+            }
+            steps = vr_word_steps(job.n, job.m, job.k, kVrWords[cls / VR_LOG2R], band != 0);
+            bytes = (u64)job.n + job.m;
+            u32 const W = kVrWords[plan->par_w_index];
+            common_steps = vr_word_steps(job.n, job.m, job.k, W, band != 0);
+            par_r = 1;
+            while (par_r < 64u && !vr_shape_holds(nw, width, W, par_r, band != 0)) par_r *= 2u;
+        }
+    }
+    vr_class_add(cls, plan->count, plan->word_steps, steps, plan->bytes, bytes);
+    u64 const cs = wave_sum_u64(common_steps);
+    u32 const pr = wave_max_u32(par_r);
+    if (lane_id() == 0 && pr) { atomicAdd((unsigned long long*)&plan->common_word_steps, (unsigned long long)cs); atomicMax(&plan->par_r, pr); }
+}
+__global__ void __launch_bounds__(64) vr_plan_kernel(DevVrPlan* __restrict__ plan) {
+    if (threadIdx.x != 0) return;
+    u32 at = 0;
+    for (u32 c = 0; c < VR_CLASSES; ++c) { plan->start[c] = at; plan->cursor[c] = at; at += plan->count[c]; }
+    plan->n_jobs = at;
+}
+__global__ void __launch_bounds__(256) vr_emit_kernel(const DevVrJob* __restrict__ jobs, const u32* __restrict__ scalars, const u8* __restrict__ job_class,
+                                                      DevVrPlan* __restrict__ plan, DevAlignJob* __restrict__ out) {
+    u32 const j = blockIdx.x * blockDim.x + threadIdx.x;
+    u32 const cls = j < 2u * scalars[VR_N_CLUSTERS] ? (u32)job_class[j] : VR_NO_CLASS;
+    // one cursor grab per class and wave; the members keep their order within the wave
+    u64 todo = __ballot(cls != VR_NO_CLASS);
+    u32 pos = 0;
+    while (todo) {
+        u32 const leader = (u32)__ffsll((long long)todo) - 1u;
+        u32 const c = (u32)__shfl((int)cls, (int)leader);
+        u64 const members = __ballot(cls == c);
+        u32 base = 0;
+        if (lane_id() == leader) base = atomicAdd(&plan->cursor[c], (u32)__popcll(members));
+        base = (u32)__shfl((int)base, (int)leader);
+        if (cls == c) pos = base + (u32)__popcll(members & ((1ull << lane_id()) - 1ull));
+        todo &= ~members;
+    }
+    if (cls == VR_NO_CLASS) return;
+    DevVrJob const job = jobs[j];
+    out[pos] = DevAlignJob{job.ref_off, job.q_off, 0, job.n, job.m, job.k, j, 0};
+}
+// a cluster's decision: its own window / the intersection holds an alignment -> all members pass; the union holds none -> all
+// fail; else (rare) the members one by one (state 0)
+__global__ void __launch_bounds__(256) vr_decide_kernel(const DevVrJob* __restrict__ jobs, const DevAlignOut* __restrict__ outs, u32* __restrict__ scalars,
+                                                        u8* __restrict__ state) {
+    u32 const c = blockIdx.x * blockDim.x + threadIdx.x;
+    bool undecided = false;
+    if (c < scalars[VR_N_CLUSTERS]) {
+        bool const has_a = jobs[2 * c].n != 0, has_b = jobs[2 * c + 1].n != 0;
+        u8 st = 0;
+        if (has_a) { if (outs[2 * c].score != 0xFFFFFFFFu) st = 1; else if (!has_b) st = 2; }
+        if (st == 0 && has_b && outs[2 * c + 1].score == 0xFFFFFFFFu) st = 2;
+        state[c] = st;
+        undecided = st == 0;
+    }
+    u64 const m = __ballot(undecided);
+    if (m && lane_id() == 0) atomicAdd(&scalars[VR_N_UNDECIDED], (u32)__popcll(m));
+}
 __global__ void __launch_bounds__(256) vr_apply_kernel(const u64* __restrict__ key1s, const u32* __restrict__ idxs, const u32* __restrict__ uid,
                                                        const u32* __restrict__ cid, const u8* __restrict__ state, const u8* __restrict__ override_,
                                                        const DevVrAnchor* __restrict__ anchors, const DevVrNode* __restrict__ nodes, u32 n,
@@ -1217,6 +1382,8 @@ int DeviceApi::vr_round_requests(void* stream, VrBuffers const& B, u32 n, u32 li
     hipError_t e;
     unsigned const blocks = (n + 255) / 256;
     if ((e = hipMemsetAsync(B.scalars, 0, 3 * 4, s)) != hipSuccess) return (int)e;
+    if ((e = hipMemsetAsync(B.scalars + VR_N_UNDECIDED, 0, 4, s)) != hipSuccess) return (int)e;
+    if ((e = hipMemsetAsync(B.plan, 0, sizeof(DevVrPlan), s)) != hipSuccess) return (int)e;
     hipLaunchKernelGGL(vr_select_kernel, dim3(blocks), dim3(256), 0, s, B.anchors, B.nodes, B.node, B.status, n, limit, B.key1, B.key2, B.idx);
     // order by (key1, key2): a stable sort by key2, then by key1 (LSD); the anchor index rides along, the other key is gathered
     size_t tb = B.tmp_bytes;
@@ -1238,14 +1405,31 @@ int DeviceApi::vr_round_requests(void* stream, VrBuffers const& B, u32 n, u32 li
     if ((e = hipcub::DeviceScan::InclusiveSum(B.tmp, tb, B.flag_c, B.cid, (int)n, s)) != hipSuccess) return (int)e;
     hipLaunchKernelGGL(vr_cluster_starts_kernel, dim3(blocks), dim3(256), 0, s, B.flag_c, B.cid, B.scalars, B.cstart);
     hipLaunchKernelGGL(vr_jobs_kernel, dim3(blocks), dim3(256), 0, s, B.ukey1, B.ukey2, B.urep, B.cstart, B.anchors, B.nodes, B.node, B.scalars, B.jobs);
+    // the job list by launch shape (two slots per cluster, at most n clusters)
+    unsigned const job_blocks = (2 * n + 255) / 256;
+    u32 const band = use_band() ? 1u : 0u;
+    hipLaunchKernelGGL(vr_shape_kernel, dim3(job_blocks), dim3(256), 0, s, B.jobs, B.scalars, band, B.job_class, B.plan);
+    hipLaunchKernelGGL(vr_regroup_kernel, dim3(job_blocks), dim3(256), 0, s, B.jobs, B.scalars, band, B.job_class, B.plan);
+    hipLaunchKernelGGL(vr_plan_kernel, dim3(1), dim3(64), 0, s, B.plan);
+    hipLaunchKernelGGL(vr_emit_kernel, dim3(job_blocks), dim3(256), 0, s, B.jobs, B.scalars, B.job_class, B.plan, B.align_jobs);
     return (int)hipGetLastError();
 }
 
-int DeviceApi::vr_round_apply(void* stream, VrBuffers const& B, u32 n, const u8* d_state, const u8* d_override) {
+AlignShape DeviceApi::vr_class_shape(u32 shape_class) {
+    return AlignShape{kWordsPerLane[shape_class / 7u], 1u << (shape_class % 7u), use_band() ? 1u : 0u};
+}
+
+int DeviceApi::vr_round_decide(void* stream, VrBuffers const& B, u32 n) {
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(vr_decide_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, B.jobs, B.outs, B.scalars, B.state);
+    return (int)hipGetLastError();
+}
+
+int DeviceApi::vr_round_apply(void* stream, VrBuffers const& B, u32 n, const u8* d_override) {
     if (n == 0) return 0;
     hipStream_t s = (hipStream_t)stream;
     unsigned const blocks = (n + 255) / 256;
-    hipLaunchKernelGGL(vr_apply_kernel, dim3(blocks), dim3(256), 0, s, B.key1s, B.idxs, B.uid, B.cid, d_state, d_override, B.anchors, B.nodes, n, B.node, B.status);
+    hipLaunchKernelGGL(vr_apply_kernel, dim3(blocks), dim3(256), 0, s, B.key1s, B.idxs, B.uid, B.cid, B.state, d_override, B.anchors, B.nodes, n, B.node, B.status);
     hipError_t e = hipMemsetAsync(B.scalars + VR_N_CLIMBING, 0, 4, s);
     if (e == hipSuccess) e = hipMemsetAsync(B.scalars + VR_SMALLEST, 0xFF, 4, s);
     if (e != hipSuccess) return (int)e;
@@ -1586,12 +1770,6 @@ __global__ void __launch_bounds__(64) ed_band_kernel(const u8* __restrict__ text
     }
 }
 
-static const u32 kWordsPerLane[] = {1, 2, 3, 4, 5, 6, 8, 13, 25};
-
-static bool use_band() {
-    static int const v = getenv("FLX_NO_BAND") ? 0 : 1;
-    return v != 0;
-}
 
 static AlignShape choose_align_shape_uncached(u32 nw, i64 width, bool band, bool parallel) {
     AlignShape best{0, 0, 0};

@@ -136,8 +136,9 @@ struct DevTraceOut { u32 begin; u32 cigar_start; u32 cigar_len; u32 pad; };   //
 // ------------------------------------------------------------------------------------------------ verification rounds on the device
 // The inner PEX levels as device-resident state: every anchor of a chunk with the node it is about to test; a round builds the
 // requests of the anchors in the current node-size class, sorts them, finds the distinct ones and the clusters of windows of one
-// locus, and hands the host a job list (one or two existence tests per cluster); the host launches K3 on it and returns one
-// decision per cluster; an apply step moves the anchors up their trees.
+// locus, and writes the job list (one or two existence tests per cluster) grouped by launch shape, with the counts the host needs
+// to launch K3 on it (DevVrPlan); a decide step turns the K3 results into one decision per cluster; an apply step moves the
+// anchors up their trees. Per round the host reads a plan and two or three scalars, nothing per anchor or per job.
 struct DevVrAnchor {            // 48 bytes
     i64 diag_rel;               // anchor position minus the leaf's first query row (relative to its reference sequence, may be < 0)
     u64 seq_start, seq_len;     // the reference sequence in the padded text
@@ -148,7 +149,23 @@ struct DevVrAnchor {            // 48 bytes
 struct DevVrNode { u32 parent, from, rows, errors; };          // parent = index within the tree, 0xFFFFFFFF for the root
 struct DevVrJob { u64 ref_off, q_off; u32 n, m, k, pad; };     // n == 0: unused slot
 enum : u8 { VR_CLIMBING = 0, VR_DEAD = 1, VR_AT_ROOT = 2 };
-enum : u32 { VR_N_REQ = 0, VR_N_UNIQ = 1, VR_N_CLUSTERS = 2, VR_N_CLIMBING = 3, VR_SMALLEST = 4 };
+enum : u32 { VR_N_REQ = 0, VR_N_UNIQ = 1, VR_N_CLUSTERS = 2, VR_N_CLIMBING = 3, VR_SMALLEST = 4, VR_N_UNDECIDED = 5 };
+// The launch plan of a round's job list. A shape class is (index into the words-per-lane table) * 7 + log2(lanes per job); the
+// jobs are stored class by class, `count` of them from `start` on. `lanes`, `par_w`, `par_r` describe the one-launch form the host
+// uses when the round has few jobs (choose_shapes in flx_pipeline.cpp is the host form of the same rules).
+constexpr u32 VR_CLASSES = 64, VR_NO_CLASS = 0xFF;
+struct DevVrPlan {
+    u32 count_first[VR_CLASSES];     // jobs whose own cheapest shape is this class
+    u32 count[VR_CLASSES];           // after the jobs of rare classes joined a common one that can hold them
+    u32 start[VR_CLASSES];
+    u32 cursor[VR_CLASSES];
+    u64 word_steps[VR_CLASSES];      // accounting: DP word-steps and sequence bytes of the class's launch
+    u64 bytes[VR_CLASSES];
+    u64 lanes;                       // lanes the jobs occupy in their own cheapest shapes
+    u64 common_word_steps;           // word-steps of the one-launch form (words per lane = par_w)
+    u32 par_w_index, par_r;          // one-launch form: words-per-lane table index and lanes per job that hold every job
+    u32 n_jobs, unsupported;         // unsupported != 0: a query longer than any shape holds
+};
 struct VrBuffers {
     const DevVrAnchor* anchors; const DevVrNode* nodes;
     u32* node; u8* status;                       // per anchor, mutable
@@ -159,6 +176,11 @@ struct VrBuffers {
     u64 *ukey1, *ukey2; u32* urep;               // per distinct request: keys and one anchor that asked for it
     u32* cstart;                                 // per cluster: its first distinct request (n_clusters + 1 entries)
     DevVrJob* jobs;                              // two slots per cluster: {the window itself | the intersection}, {the union}
+    u8* job_class;                               // per slot: its shape class (VR_NO_CLASS: unused slot)
+    DevAlignJob* align_jobs;                     // the used slots as K3 jobs, class by class; out_index = the slot
+    DevAlignOut* outs;                           // K3 results per slot
+    u8* state;                                   // per cluster: 1 pass, 2 fail, 0 undecided (its members one by one)
+    DevVrPlan* plan;
     u32* scalars;                                // VR_*
     void* tmp; size_t tmp_bytes;
 };
@@ -226,12 +248,15 @@ struct DeviceApi {
     // d_lastrow (banded TRACE launches only, may be null): D[m][c] of every computed column c, 0xFFFF elsewhere (pre-filled by the caller)
     static int align(void* stream, const u8* d_text, const u64* d_peq, const DevAlignJob* d_jobs, u32 n_jobs, AlignShape shape,
                      bool trace, u64* d_trace, DevAlignOut* d_out, u16* d_lastrow = nullptr);
-    // verification rounds (see VrBuffers). requests: everything up to the job list of the round whose node-size limit is `limit`
-    // (scalars VR_N_REQ / VR_N_UNIQ / VR_N_CLUSTERS are set); apply: d_state = one decision per cluster (1 pass, 2 fail, 0: look at
-    // d_override, one per distinct request, may be null), then scalars VR_N_CLIMBING / VR_SMALLEST for the next round
+    // verification rounds (see VrBuffers). requests: everything up to the job list of the round whose node-size limit is `limit`,
+    // grouped by launch shape (scalars VR_N_REQ / VR_N_UNIQ / VR_N_CLUSTERS and the plan are set); decide: B.state from B.outs
+    // (scalar VR_N_UNDECIDED); apply: B.state = one decision per cluster (1 pass, 2 fail, 0: look at d_override, one per distinct
+    // request, may be null), then scalars VR_N_CLIMBING / VR_SMALLEST for the next round
     static size_t vr_tmp_bytes(u32 n_anchors);
     static int vr_round_requests(void* stream, VrBuffers const& B, u32 n_anchors, u32 limit);
-    static int vr_round_apply(void* stream, VrBuffers const& B, u32 n_anchors, const u8* d_state, const u8* d_override);
+    static int vr_round_decide(void* stream, VrBuffers const& B, u32 n_anchors);
+    static int vr_round_apply(void* stream, VrBuffers const& B, u32 n_anchors, const u8* d_override);
+    static AlignShape vr_class_shape(u32 shape_class);
     static int lastrow_min(void* stream, const u16* d_lastrow, const DevRowWindow* d_windows, u32 n_windows, DevAlignOut* d_out);
     static int traceback(void* stream, const u8* d_text, const u8* d_query, const u64* d_peq, const u64* d_trace,
                          const DevTraceJob* d_jobs, u32 n_jobs, bool checkpointed, u32* d_cigar, DevTraceOut* d_out);

@@ -4,6 +4,7 @@
 #include <algorithm>
 #include <atomic>
 #include <chrono>
+#include <ctime>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -49,23 +50,34 @@ using namespace flx;
 namespace {
 // FLX_HOST_PROFILE=1 prints wall-clock milliseconds of the host phases of flx_align_reads_resident to stderr
 struct PhaseTimer {
+    struct Row { const char* name; double wall, cpu; };
     bool on;
     std::chrono::steady_clock::time_point t;
-    hvec<std::pair<const char*, double>> rows;
+    double cpu_t = 0;
+    hvec<Row> rows;
     const char* what;
-    explicit PhaseTimer(const char* what_ = "slice") : on(getenv("FLX_HOST_PROFILE") != nullptr), t(std::chrono::steady_clock::now()), what(what_) {}
+    static double thread_cpu_ms() {
+        timespec ts{};
+        clock_gettime(CLOCK_THREAD_CPUTIME_ID, &ts);
+        return (double)ts.tv_sec * 1e3 + (double)ts.tv_nsec * 1e-6;
+    }
+    explicit PhaseTimer(const char* what_ = "slice") : on(getenv("FLX_HOST_PROFILE") != nullptr), t(std::chrono::steady_clock::now()), what(what_) {
+        if (on) cpu_t = thread_cpu_ms();
+    }
     void mark(const char* name) {
         if (!on) return;
         auto const now = std::chrono::steady_clock::now();
-        rows.emplace_back(name, std::chrono::duration<double, std::milli>(now - t).count());
+        double const cpu_now = thread_cpu_ms();
+        rows.push_back({name, std::chrono::duration<double, std::milli>(now - t).count(), cpu_now - cpu_t});
         t = now;
+        cpu_t = cpu_now;
     }
-    ~PhaseTimer() {
+    ~PhaseTimer() {                                  // name=wall/cpu of the calling thread, milliseconds
         if (!on) return;
-        double total = 0;
-        for (auto& r : rows) total += r.second;
-        fprintf(stderr, "[flx host profile] %s total %.2f ms:", what, total);
-        for (auto& r : rows) fprintf(stderr, " %s=%.2f", r.first, r.second);
+        double total = 0, cpu = 0;
+        for (auto& r : rows) { total += r.wall; cpu += r.cpu; }
+        fprintf(stderr, "[flx host profile] %s total %.2f/%.2f ms:", what, total, cpu);
+        for (auto& r : rows) fprintf(stderr, " %s=%.2f/%.2f", r.name, r.wall, r.cpu);
         fprintf(stderr, "\n");
     }
 };
@@ -80,7 +92,7 @@ hipEvent_t Lane::get_event() {
 hvec<DeviceBuffer*> lane_workspaces(Lane& l) {
     return {&l.seq, &l.seq_rev, &l.peq, &l.peq_rev, &l.scheme, &l.seeds, &l.stack, &l.hits, &l.counters, &l.rows, &l.rows_out, &l.jobs,
             &l.job_out, &l.trace, &l.tjobs, &l.tjob_out, &l.cigar, &l.user_text, &l.user_text_rev, &l.lastrow, &l.row_windows, &l.row_out,
-            &l.seed_cnt, &l.hit_off, &l.grouped, &l.sel_stat, &l.sel_n, &l.sel_off, &l.sel_out, &l.sel_tmp, &l.sel_rows, &l.sel_row_off, &l.sel_sparse, &l.sel_lists, &l.vr, &l.vr_state, &l.vr_override};
+            &l.seed_cnt, &l.hit_off, &l.grouped, &l.sel_stat, &l.sel_n, &l.sel_off, &l.sel_out, &l.sel_tmp, &l.sel_rows, &l.sel_row_off, &l.sel_sparse, &l.sel_lists, &l.vr, &l.vr_override};
 }
 std::vector<DeviceBuffer*> Lane::workspaces() { auto v = lane_workspaces(*this); return std::vector<DeviceBuffer*>(v.begin(), v.end()); }
 int Lane::size_like(Lane& other) {
@@ -127,11 +139,15 @@ int Lane::wait_idle() {
     if (spin) { FLX_HIP(hipStreamSynchronize(stream)); return FLX_OK; }
     if (!sync_event) FLX_HIP(hipEventCreateWithFlags(&sync_event, hipEventDisableTiming));
     FLX_HIP(hipEventRecord(sync_event, stream));
-    for (unsigned waited = 0;; ++waited) {
+    // (the sleeps grow with the time already waited: a long kernel is not polled thousands of times, a short one is not overslept
+    // by more than a fifth of its duration)
+    static unsigned const max_sleep = getenv("FLX_POLL_MAX_US") ? (unsigned)atoi(getenv("FLX_POLL_MAX_US")) : 400u;
+    for (unsigned sleep_us = 20;;) {
         hipError_t const e = hipEventQuery(sync_event);
         if (e == hipSuccess) break;
         if (e != hipErrorNotReady) { set_error(std::string("hipEventQuery: ") + hipGetErrorString(e)); return FLX_ERR_NO_DEVICE; }
-        std::this_thread::sleep_for(std::chrono::microseconds(waited < 4 ? 20 : 60));
+        std::this_thread::sleep_for(std::chrono::microseconds(sleep_us));
+        sleep_us = std::min(max_sleep, sleep_us + sleep_us / 4 + 1);
     }
     return FLX_OK;
 }
@@ -775,12 +791,15 @@ int run_score_jobs_unique(Lane* ctx, const u8* d_text, const u64* d_peq, hvec<Al
                           hvec<DevAlignOut>& outs, const char* kernel_name) {
     outs.assign(reqs.size(), DevAlignOut{0xFFFFFFFFu, 0});
     if (reqs.empty()) return FLX_OK;
+    PhaseTimer jprof("score-jobs");
     std::map<ShapeKey, hvec<u32>> by_shape;
     {
         hvec<AlignShape> shapes;
         if (int const rc = choose_shapes(reqs, shapes)) return rc;
+        jprof.mark("shapes");
         for (u32 i = 0; i < reqs.size(); ++i) by_shape[ShapeKey{shapes[i].words_per_lane, shapes[i].lanes_per_job, shapes[i].banded}].push_back(i);
     }
+    jprof.mark("by-shape");
     hvec<DevAlignJob> jobs;
     jobs.reserve(reqs.size());
     struct Launch { ShapeKey key; u32 first, count; u64 word_steps, bytes; };
@@ -796,6 +815,7 @@ int run_score_jobs_unique(Lane* ctx, const u8* d_text, const u64* d_peq, hvec<Al
         }
         launches.push_back(l);
     }
+    jprof.mark("job-list");
     int rc;
     if ((rc = h2d(ctx, ctx->jobs, jobs.data(), jobs.size() * sizeof(DevAlignJob)))) return rc;
     if ((rc = ctx->job_out.ensure(reqs.size() * sizeof(DevAlignOut)))) return rc;
@@ -808,7 +828,10 @@ int run_score_jobs_unique(Lane* ctx, const u8* d_text, const u64* d_peq, hvec<Al
         if (rc) return rc;
     }
     if ((rc = d2h(ctx, outs.data(), ctx->job_out.ptr, reqs.size() * sizeof(DevAlignOut)))) return rc;
-    return ctx->sync();
+    jprof.mark("launch");
+    rc = ctx->sync();
+    jprof.mark("wait");
+    return rc;
 }
 
 int run_score_jobs(Lane* ctx, const u8* d_text, const u64* d_peq, hvec<AlignRequest> const& reqs,
@@ -1743,6 +1766,7 @@ int align_slice(Lane* lane, const flx_params* P, const flx_reads* RD, u64 first_
     static int const host_rounds = getenv("FLX_HOST_ROUNDS") ? 1 : 0;
     if (!host_rounds && !st_local && !climbing.empty()) {
         u32 const n = (u32)A.size();
+        PhaseTimer vprof("rounds");
         // ---- node table of the chunk's trees, anchors
         std::map<const PexTree*, u32> tree_base;
         hvec<DevVrNode> nodes;
@@ -1776,7 +1800,10 @@ int align_slice(Lane* lane, const flx_params* P, const flx_reads* RD, u64 first_
                      o_key_mid = take((size_t)n * 8), o_idx = take((size_t)n * 4), o_idx_mid = take((size_t)n * 4), o_idxs = take((size_t)n * 4),
                      o_flag_u = take((size_t)n * 4), o_uid = take((size_t)n * 4), o_flag_c = take((size_t)n * 4), o_cid = take((size_t)n * 4),
                      o_run = take((size_t)n * 4), o_ukey1 = take((size_t)n * 8), o_ukey2 = take((size_t)n * 8), o_urep = take((size_t)n * 4),
-                     o_cstart = take(((size_t)n + 1) * 4), o_jobs = take((size_t)n * 2 * sizeof(DevVrJob)), o_scalars = take(64), o_tmp = take(tmp_bytes);
+                     o_cstart = take(((size_t)n + 1) * 4), o_jobs = take((size_t)n * 2 * sizeof(DevVrJob)), o_scalars = take(64), o_tmp = take(tmp_bytes),
+                     o_class = take((size_t)n * 2), o_ajobs = take((size_t)n * 2 * sizeof(DevAlignJob)), o_outs = take((size_t)n * 2 * sizeof(DevAlignOut)),
+                     o_state = take(n), o_plan = take(sizeof(DevVrPlan));
+        vprof.mark("anchor-table");
         if ((rc = lane->vr.ensure(off))) return rc;
         char* const base = (char*)lane->vr.ptr;
         VrBuffers B{};
@@ -1786,58 +1813,67 @@ int align_slice(Lane* lane, const flx_params* P, const flx_reads* RD, u64 first_
         B.flag_u = (u32*)(base + o_flag_u); B.uid = (u32*)(base + o_uid); B.flag_c = (u32*)(base + o_flag_c); B.cid = (u32*)(base + o_cid); B.run_first = (u32*)(base + o_run);
         B.ukey1 = (u64*)(base + o_ukey1); B.ukey2 = (u64*)(base + o_ukey2); B.urep = (u32*)(base + o_urep); B.cstart = (u32*)(base + o_cstart);
         B.jobs = (DevVrJob*)(base + o_jobs); B.scalars = (u32*)(base + o_scalars); B.tmp = base + o_tmp; B.tmp_bytes = tmp_bytes;
+        B.job_class = (u8*)(base + o_class); B.align_jobs = (DevAlignJob*)(base + o_ajobs); B.outs = (DevAlignOut*)(base + o_outs);
+        B.state = (u8*)(base + o_state); B.plan = (DevVrPlan*)(base + o_plan);
         FLX_HIP(hipMemcpyAsync(base + o_anchors, da.data(), (size_t)n * sizeof(DevVrAnchor), hipMemcpyHostToDevice, lane->stream));
         FLX_HIP(hipMemcpyAsync(base + o_nodes, nodes.data(), nodes.size() * sizeof(DevVrNode), hipMemcpyHostToDevice, lane->stream));
         FLX_HIP(hipMemcpyAsync(base + o_node, h_node.data(), (size_t)n * 4, hipMemcpyHostToDevice, lane->stream));
         FLX_HIP(hipMemcpyAsync(base + o_status, h_status.data(), n, hipMemcpyHostToDevice, lane->stream));
-        if ((rc = lane->vr_state.ensure(n + 64))) return rc;
         if ((rc = lane->vr_override.ensure(n + 64))) return rc;
         hvec<DevVrJob> vjobs;
         hvec<AlignRequest> jobs;
-        hvec<u32> job_cluster;
         hvec<DevAlignOut> jouts;
         hvec<u8> state, override_;
         hvec<u64> uk1, uk2;
         hvec<u32> cstart;
+        DevVrPlan plan;
         u64 const mask = (1ull << 20) - 1ull;
+        vprof.mark("upload");
         while (n_climbing > 0) {
             u64 const limit = (u64)smallest + smallest / 2;
             int const e1 = DeviceApi::vr_round_requests(lane->stream, B, n, (u32)std::min<u64>(limit, 0xFFFFFFFFu));
             if (e1) { set_error(std::string("verification round: ") + hipGetErrorString((hipError_t)e1)); return FLX_ERR_NO_DEVICE; }
             u32 sc[3] = {0, 0, 0};
             if ((rc = d2h(lane, sc, B.scalars, 12))) return rc;
+            if ((rc = d2h(lane, &plan, B.plan, sizeof(plan)))) return rc;
             if ((rc = lane->sync())) return rc;
             u32 const n_uniq = sc[VR_N_UNIQ], n_clusters = sc[VR_N_CLUSTERS];
             n_inner_requested += sc[VR_N_REQ];
-            vjobs.resize((size_t)n_clusters * 2);
-            if (n_clusters) {
-                if ((rc = d2h(lane, vjobs.data(), B.jobs, vjobs.size() * sizeof(DevVrJob)))) return rc;
-                if ((rc = lane->sync())) return rc;
-            }
-            jobs.clear();
-            job_cluster.clear();
-            for (u32 c = 0; c < n_clusters; ++c)
-                for (u32 slot = 0; slot < 2; ++slot) {
-                    DevVrJob const& j = vjobs[2 * (size_t)c + slot];
-                    if (j.n == 0) continue;
-                    jobs.push_back(AlignRequest{j.ref_off, j.q_off, j.n, j.m, j.k});
-                    job_cluster.push_back(c | (slot ? 0x80000000u : 0u));
+            vprof.mark("requests-wait");
+            if (plan.unsupported) { set_error("query longer than the supported maximum"); return FLX_ERR_UNSUPPORTED; }
+            // K3 on the round's job list where the device left it: one launch per shape class, or (few jobs: they would leave most
+            // SIMDs without a wave) one launch in the common shape with the fewest words per lane
+            if (plan.n_jobs) {
+                auto launch = [&](u32 first, u32 count, AlignShape shape, u64 bytes, u64 word_steps) {
+                    return timed_launch(lane, "ed_align_exists", bytes, word_steps, [&] {
+                        return DeviceApi::align(lane->stream, d_text, d_peq, B.align_jobs + first, count, shape, false, nullptr, B.outs);
+                    });
+                };
+                if (plan.lanes / 64 >= align_few_waves()) {
+                    for (u32 c = 0; c < VR_CLASSES; ++c)
+                        if (plan.count[c] && (rc = launch(plan.start[c], plan.count[c], DeviceApi::vr_class_shape(c), plan.bytes[c], plan.word_steps[c]))) return rc;
+                } else {
+                    u32 log2_r = 0;
+                    while ((1u << log2_r) < plan.par_r) ++log2_r;
+                    u64 bytes = 0;
+                    for (u32 c = 0; c < VR_CLASSES; ++c) bytes += plan.bytes[c];
+                    if ((rc = launch(0, plan.n_jobs, DeviceApi::vr_class_shape(plan.par_w_index * 7u + log2_r), bytes, plan.common_word_steps))) return rc;
                 }
-            if ((rc = run_score_jobs_unique(lane, d_text, d_peq, jobs, jouts, "ed_align_exists"))) return rc;
-            // a cluster's decision: its own window / the intersection holds an alignment -> all members pass; the union holds none
-            // -> all fail; else (rare) the members one by one
-            state.assign(n_clusters, 0);
-            for (size_t j = 0; j < jobs.size(); ++j) {
-                u32 const c = job_cluster[j] & 0x7FFFFFFFu;
-                bool const is_union = job_cluster[j] >> 31, found = jouts[j].score != 0xFFFFFFFFu;
-                if (!is_union) { if (found) state[c] = 1; else if (vjobs[2 * (size_t)c + 1].n == 0) state[c] = 2; }
-                else if (!found) state[c] = 2;
             }
-            bool any_undecided = false;
-            for (u32 c = 0; c < n_clusters; ++c) any_undecided |= state[c] == 0;
+            int const e3 = DeviceApi::vr_round_decide(lane->stream, B, n);
+            if (e3) { set_error(std::string("verification round: ") + hipGetErrorString((hipError_t)e3)); return FLX_ERR_NO_DEVICE; }
+            u32 n_undecided = 0;
+            if ((rc = d2h(lane, &n_undecided, B.scalars + VR_N_UNDECIDED, 4))) return rc;
+            if ((rc = lane->sync())) return rc;
+            vprof.mark("score");
             const u8* d_override = nullptr;
-            if (any_undecided) {
+            if (n_undecided) {
+                // (rare) the members of the undecided clusters one by one: their requests come to the host
+                vjobs.resize((size_t)n_clusters * 2);
+                state.resize(n_clusters);
                 uk1.resize(n_uniq); uk2.resize(n_uniq); cstart.resize((size_t)n_clusters + 1);
+                if ((rc = d2h(lane, vjobs.data(), B.jobs, vjobs.size() * sizeof(DevVrJob)))) return rc;
+                if ((rc = d2h(lane, state.data(), B.state, n_clusters))) return rc;
                 if ((rc = d2h(lane, uk1.data(), B.ukey1, (size_t)n_uniq * 8))) return rc;
                 if ((rc = d2h(lane, uk2.data(), B.ukey2, (size_t)n_uniq * 8))) return rc;
                 if ((rc = d2h(lane, cstart.data(), B.cstart, ((size_t)n_clusters + 1) * 4))) return rc;
@@ -1857,9 +1893,9 @@ int align_slice(Lane* lane, const flx_params* P, const flx_reads* RD, u64 first_
                 for (size_t j = 0; j < jobs.size(); ++j) override_[job_uniq[j]] = jouts[j].score != 0xFFFFFFFFu ? 1 : 2;
                 FLX_HIP(hipMemcpyAsync(lane->vr_override.ptr, override_.data(), n_uniq, hipMemcpyHostToDevice, lane->stream));
                 d_override = lane->vr_override.as<u8>();
+                vprof.mark("undecided");
             }
-            if (n_clusters) FLX_HIP(hipMemcpyAsync(lane->vr_state.ptr, state.data(), n_clusters, hipMemcpyHostToDevice, lane->stream));
-            int const e2 = DeviceApi::vr_round_apply(lane->stream, B, n, lane->vr_state.as<u8>(), d_override);
+            int const e2 = DeviceApi::vr_round_apply(lane->stream, B, n, d_override);
             if (e2) { set_error(std::string("verification round: ") + hipGetErrorString((hipError_t)e2)); return FLX_ERR_NO_DEVICE; }
             u32 nx[2] = {0, 0};
             if ((rc = d2h(lane, nx, B.scalars + VR_N_CLIMBING, 8))) return rc;
@@ -1867,6 +1903,7 @@ int align_slice(Lane* lane, const flx_params* P, const flx_reads* RD, u64 first_
             if (sc[VR_N_REQ] == 0 && nx[0] >= n_climbing) { set_error("verification rounds do not advance"); return FLX_ERR_INTERNAL; }
             n_climbing = nx[0];
             smallest = nx[1];
+            vprof.mark("apply-wait");
         }
         if ((rc = d2h(lane, h_status.data(), B.status, n))) return rc;
         if ((rc = d2h(lane, h_node.data(), B.node, (size_t)n * 4))) return rc;
@@ -1876,6 +1913,7 @@ int align_slice(Lane* lane, const flx_params* P, const flx_reads* RD, u64 first_
             if (h_status[i] == VR_DEAD && a.alive && !a.at_root) a.alive = false;
             else if (h_status[i] == VR_AT_ROOT && !a.at_root) { a.at_root = true; a.node = h_node[i]; }
         }
+        vprof.mark("read-back");
     } else {
     hvec<AlignRequest> reqs;
         hvec<DevAlignOut> outs;
