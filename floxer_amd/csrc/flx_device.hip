@@ -242,6 +242,10 @@ done:
 }
 
 // ================================================================================================ K1: FM search
+static u32 fm_priority() {              // FLX_FM_PRIO=0: the search waves at the default issue priority (measurements)
+    static u32 const v = getenv("FLX_FM_PRIO") ? (u32)atoi(getenv("FLX_FM_PRIO")) : 0u;
+    return v;
+}
 // One lane serves one seed. A rank query reads one 32-byte block (32 BWT positions: five absolute counters + three bit-planes)
 // with two 16-byte loads and pop-counts the positions below the offset (v_bcnt accumulates onto the counters); the count of
 // symbol 5 is what is left of the interval. A cursor extension is two rank queries (both ends of the interval, usually in the same
@@ -424,8 +428,12 @@ __device__ __forceinline__ u32 fm_child_mask(const u32 cl[6], u32 next_sym, bool
 __global__ void __launch_bounds__(64) fm_search_kernel(DevIndex idx, const u8* __restrict__ seq, const u32* __restrict__ scheme,
                                                        const DevSeed* __restrict__ seeds, u32 n_seeds, u32 max_hits, u32 levels,
                                                        DevHit* __restrict__ hits, u32 hit_cap, u32* __restrict__ counters,
-                                                       u32* __restrict__ seed_cnt) {
+                                                       u32* __restrict__ seed_cnt, u32 prio) {
     extern __shared__ u32 lds[];                // frames: [level][FM_FRAME_WORDS][64 lanes]
+    // This kernel issues few instructions and lives on memory requests in flight; the DP kernels it shares the CUs with issue
+    // VALU work back to back. Ahead of them in the issue arbitration, its waves keep their requests flowing and cost the DP waves
+    // next to nothing.
+    if (prio) __builtin_amdgcn_s_setprio(3);
     u32 q_next = 0, q_end = 0;                  // wave-uniform: the unserved rest of the last grabbed seed range
     bool queue_done = false;
     u32 h_next = 0, h_end = 0;                  // wave-uniform: the unwritten rest of the last reserved range of hit slots
@@ -433,7 +441,7 @@ __global__ void __launch_bounds__(64) fm_search_kernel(DevIndex idx, const u8* _
     u64 const lanes_below = (1ull << lane) - 1ull;
     auto fr = [&](u32 level, u32 word) -> u32& { return lds[(level * FM_FRAME_WORDS + word) * 64u + lane]; };
 
-    u32 n_ext = 0, n_iter = 0, n_busy_iter = 0, n_tail_iter = 0;
+    u32 n_ext = 0, n_iter = 0, n_busy_iter = 0, n_tail_iter = 0, n_single = 0;
     bool busy = false, exhausted = false;
     u32 sid = 0, srch = 0, num_searches = 0, len = 0, ct = 0;
     const u8* __restrict__ q = seq;
@@ -552,6 +560,7 @@ __global__ void __launch_bounds__(64) fm_search_kernel(DevIndex idx, const u8* _
         u32 ab[6], cl[6];
         extend_all(idx, idx.occ[right], lo, nlen, ab, cl);
         ++n_ext;
+        n_single += nlen == 1u ? 1u : 0u;
 
         if (mismatch_allowed) {
             // this node branches: its frame goes on top of the frames of the error edges taken so far (at most `ne` of them)
@@ -592,8 +601,9 @@ __global__ void __launch_bounds__(64) fm_search_kernel(DevIndex idx, const u8* _
     { u32 const at = h_next + lane; if (at < h_end && at < hit_cap) hits[at] = DevHit{0xFFFFFFFFu, 0u, 0u, 0u, 0ull}; }
     n_ext = wave_sum_u32(n_ext);
     n_busy_iter = wave_sum_u32(n_busy_iter);
+    n_single = wave_sum_u32(n_single);
     if (lane == 0) {
-        atomicAdd(&counters[2], n_ext); atomicAdd(&counters[6], n_busy_iter);
+        atomicAdd(&counters[2], n_ext); atomicAdd(&counters[6], n_busy_iter); atomicAdd(&counters[3], n_single);
         atomicAdd(&counters[4], n_iter); atomicMax(&counters[5], n_iter); atomicAdd(&counters[8], n_tail_iter); atomicMax(&counters[9], n_tail_iter);
     }
 }
@@ -830,7 +840,7 @@ int DeviceApi::search(void* stream, const DevIndex& idx, const u8* d_seq, const 
         u32 const levels = std::max(1u, frame_levels);
         size_t const lds = (size_t)levels * FM_FRAME_WORDS * 64 * sizeof(u32);
         hipLaunchKernelGGL(fm_search_kernel, grid, dim3(64), lds, (hipStream_t)stream, idx, d_seq, d_scheme, d_seeds, n_seeds,
-                           max_hits_per_seed, levels, d_hits, hit_cap, d_counters, d_seed_cnt);
+                           max_hits_per_seed, levels, d_hits, hit_cap, d_counters, d_seed_cnt, fm_priority());
     }
     return (int)hipGetLastError();
 }
@@ -1602,7 +1612,11 @@ __global__ void __launch_bounds__(64) ed_band_kernel(const u8* __restrict__ text
     int const Lg = (nw + W - 1) / W;                      // word groups
     int const band_hi = n - m + k;                        // largest useful diagonal (col - row, 1-based)
     u32 const src_lane = (lane & ~(R - 1u)) | ((lane - 1u) & (R - 1u));
-    u8* const ring = lds_sym + job_slot * 256u;
+    // (jobs of at most four lanes: the lanes of a job are at most a few columns apart, half the ring does; with 16 to 64 jobs per
+    // wave the rings are most of the wave's LDS, and LDS is what limits how many DP waves fit next to the search kernel's)
+    u32 const ring_mask = log2_r <= 2u ? 127u : 255u;
+    int const ring_lead = log2_r <= 2u ? 40 : 88;
+    u8* const ring = lds_sym + job_slot * (ring_mask + 1u);
 
     int g = (int)p;                                       // current group of this lane
     int c_lo = 0, c_hi = -1;
@@ -1646,7 +1660,7 @@ __global__ void __launch_bounds__(64) ed_band_kernel(const u8* __restrict__ text
     u32 const my_steps = valid ? (u32)(n + Lg - 1) : 0u;
     u32 const t_max = wave_max_u32(my_steps);
 
-    // Reference symbols travel through the LDS ring (column c at ring[c & 255]) so that the step loop issues no global
+    // Reference symbols travel through the LDS ring (column c at ring[c & ring_mask]) so that the step loop issues no global
     // loads: a load in the loop would make every step wait for the previous step's trace stores (loads and stores share
     // vmcnt). The R lanes of a job refill 64 columns at a time, far ahead of the newest column any of them needs.
     const u8* __restrict__ ref = text + job.ref_off;
@@ -1657,7 +1671,7 @@ __global__ void __launch_bounds__(64) ed_band_kernel(const u8* __restrict__ text
         for (u32 i = 0; i < per_lane; ++i) {
             int const c = loaded + (int)(p * per_lane + i);
             u8 const v = (valid && c < n) ? ref[c] : (u8)7;
-            ring[(u32)c & 255u] = v;
+            ring[(u32)c & ring_mask] = v;
         }
         loaded += 64;
     };
@@ -1689,7 +1703,7 @@ __global__ void __launch_bounds__(64) ed_band_kernel(const u8* __restrict__ text
                 int const f_hi = min(n - 1, fr1 - 1 + band_hi);
                 if ((int)t - g_front > f_hi) ++g_front; else break;
             }
-            if ((int)t - g_front + 88 > loaded && loaded < n) { refill(); __builtin_amdgcn_s_waitcnt(0); }
+            if ((int)t - g_front + ring_lead > loaded && loaded < n) { refill(); __builtin_amdgcn_s_waitcnt(0); }
         }
         int c = (int)t - g;
         if (has_group && c > c_hi && g + (int)R < Lg) {
@@ -1708,7 +1722,7 @@ __global__ void __launch_bounds__(64) ed_band_kernel(const u8* __restrict__ text
         u32 const cin_raw = (u32)__shfl((int)cout, (int)src_lane);
         bool const active = has_group && c >= c_lo && c <= c_hi;
         if (active) {
-            u32 const sym = ring[(u32)c & 255u];
+            u32 const sym = ring[(u32)c & ring_mask];
             u32 const cin = g == 0 ? 0u : cin_raw;
             u64 c_hp = (cin >> 1) & 1u, c_hn = (cin >> 2) & 1u;
             if (!started) {
@@ -1821,7 +1835,7 @@ static int launch_align(hipStream_t s, const u8* d_text, const u64* d_peq, const
                         bool banded, u64* d_trace, DevAlignOut* d_out, u16* d_lastrow) {
     u32 const jobs_per_wave = 64u >> log2_g;
     u32 const blocks = (n_jobs + jobs_per_wave - 1) / jobs_per_wave;
-    size_t const lds = (size_t)6 * 64 * W * sizeof(u64) + (banded ? (size_t)jobs_per_wave * 256 : 0);
+    size_t const lds = (size_t)6 * 64 * W * sizeof(u64) + (banded ? (size_t)jobs_per_wave * (log2_g <= 2u ? 128 : 256) : 0);
 #define FLX_LAUNCH(KERNEL)                                                                                                           \
     do {                                                                                                                             \
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&KERNEL), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);     \
