@@ -1809,6 +1809,11 @@ AlignShape choose_align_shape(u32 n, u32 m, u32 k, bool parallel) {
     u32 const nw = (m + 63) / 64;
     bool const band = use_band();
     i64 const width = (i64)n - (i64)m + 2 * (i64)k;       // diagonals that matter, minus one
+    if (const char* forced = getenv("FLX_FORCE_SHAPE")) {   // "W,R": measurements of one launch shape (scripts/shape_cost.py)
+        u32 w = 0, r = 0;
+        if (sscanf(forced, "%u,%u", &w, &r) == 2 && w && r && ((nw + w - 1) / w <= r || (band && (i64)64 * w * (r - 1) + r + 1 > width)))
+            return AlignShape{w, r, band ? 1u : 0u};
+    }
     // the jobs of one verification level repeat a handful of (words, band width) pairs: small direct-mapped memo per thread
     struct Entry { u32 nw; i64 width; AlignShape shape; bool valid; };
     thread_local Entry memo[2][256] = {};
