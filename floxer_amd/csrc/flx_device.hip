@@ -1085,14 +1085,18 @@ static bool use_band() {
 // (see VrBuffers in flx_internal.hpp) The request of an anchor at an inner node: verification.cpp:157-184 with ratio 0, i.e.
 // base = m + 2e + 1, start = max(0, pos - (leaf_from - node_from) - e), length = min(base, reflen - start).
 // key1 = query offset << 20 | rows (identifies (read, orientation, node)), key2 = reference offset << 20 | window length.
+// The requests are ordered by one radix sort on (node name, window start): the node's name = (query ordinal << node_bits | node
+// index), the start a 32-bit text offset; a node and a start determine the window's length (same sequence, same clip), so equal
+// sort keys are equal requests, and the distinct windows of a node come out by start.
 constexpr u32 VR_SHIFT = 20;
 
 __global__ void __launch_bounds__(256) vr_select_kernel(const DevVrAnchor* __restrict__ anchors, const DevVrNode* __restrict__ nodes,
                                                         const u32* __restrict__ node, const u8* __restrict__ status, u32 n_anchors, u32 limit,
-                                                        u64* __restrict__ key1, u64* __restrict__ key2, u32* __restrict__ idx) {
+                                                        u32 node_bits, u64* __restrict__ key1, u64* __restrict__ key2, u64* __restrict__ sort_key,
+                                                        u32* __restrict__ idx) {
     u32 const i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_anchors) return;
-    u64 k1 = ~0ull, k2 = ~0ull;
+    u64 k1 = ~0ull, k2 = ~0ull, ks = ~0ull;
     if (status[i] == VR_CLIMBING) {
         DevVrAnchor const a = anchors[i];
         DevVrNode const nd = nodes[a.tree_base + node[i]];
@@ -1103,10 +1107,12 @@ __global__ void __launch_bounds__(256) vr_select_kernel(const DevVrAnchor* __res
             u64 const len = min(base, a.seq_len - start);
             k1 = ((a.q_base + nd.from) << VR_SHIFT) | nd.rows;
             k2 = ((a.seq_start + start) << VR_SHIFT) | len;
+            ks = ((((u64)a.query << node_bits) | node[i]) << 32) | ((a.seq_start + start) & 0xFFFFFFFFull);
         }
     }
     key1[i] = k1;
     key2[i] = k2;
+    sort_key[i] = ks;
     idx[i] = i;
 }
 __global__ void __launch_bounds__(256) vr_gather_kernel(const u64* __restrict__ src, const u32* __restrict__ order, u32 n, u64* __restrict__ dst) {
@@ -1114,25 +1120,24 @@ __global__ void __launch_bounds__(256) vr_gather_kernel(const u64* __restrict__ 
     if (i < n) dst[i] = src[order[i]];
 }
 // sorted requests: head of a distinct request, head of a run of one node's requests; the count of real requests
-__global__ void __launch_bounds__(256) vr_flag_requests_kernel(const u64* __restrict__ key1s, const u64* __restrict__ key2s, u32 n,
-                                                               u32* __restrict__ flag_u, u32* __restrict__ scalars) {
+__global__ void __launch_bounds__(256) vr_flag_requests_kernel(const u64* __restrict__ keys, u32 n, u32* __restrict__ flag_u, u32* __restrict__ scalars) {
     u32 const i = blockIdx.x * blockDim.x + threadIdx.x;
     bool real = false;
     if (i < n) {
-        real = key1s[i] != ~0ull;
-        flag_u[i] = real && (i == 0 || key1s[i] != key1s[i - 1] || key2s[i] != key2s[i - 1]) ? 1u : 0u;
+        real = keys[i] != ~0ull;
+        flag_u[i] = real && (i == 0 || keys[i] != keys[i - 1]) ? 1u : 0u;
     }
     u64 const m = __ballot(real);
     if (m && lane_id() == 0) atomicAdd(&scalars[VR_N_REQ], (u32)__popcll(m));
 }
 // the distinct requests: their keys, one anchor that asked, and the first reference offset of their node's run
-__global__ void __launch_bounds__(256) vr_scatter_unique_kernel(const u64* __restrict__ key1s, const u64* __restrict__ key2s, const u32* __restrict__ idxs,
+__global__ void __launch_bounds__(256) vr_scatter_unique_kernel(const u64* __restrict__ key1, const u64* __restrict__ key2, const u32* __restrict__ idxs,
                                                                 const u32* __restrict__ flag_u, const u32* __restrict__ uid, u32 n,
                                                                 u64* __restrict__ ukey1, u64* __restrict__ ukey2, u32* __restrict__ urep,
                                                                 u32* __restrict__ scalars) {
     u32 const i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    if (flag_u[i]) { u32 const u = uid[i] - 1u; ukey1[u] = key1s[i]; ukey2[u] = key2s[i]; urep[u] = idxs[i]; }
+    if (flag_u[i]) { u32 const u = uid[i] - 1u, a = idxs[i]; ukey1[u] = key1[a]; ukey2[u] = key2[a]; urep[u] = a; }
     if (i == n - 1) scalars[VR_N_UNIQ] = uid[i];                         // inclusive scan: the last entry is the number of distinct requests
 }
 // run_first[u] = index of the first distinct request of u's node (filled in two steps: heads write themselves, a max-scan spreads)
@@ -1386,7 +1391,7 @@ size_t DeviceApi::vr_tmp_bytes(u32 n) {
     return std::max(a, std::max(b, c)) + 256;
 }
 
-int DeviceApi::vr_round_requests(void* stream, VrBuffers const& B, u32 n, u32 limit) {
+int DeviceApi::vr_round_requests(void* stream, VrBuffers const& B, u32 n, u32 limit, u32 query_bits, u32 node_bits) {
     if (n == 0) return 0;
     hipStream_t s = (hipStream_t)stream;
     hipError_t e;
@@ -1394,18 +1399,14 @@ int DeviceApi::vr_round_requests(void* stream, VrBuffers const& B, u32 n, u32 li
     if ((e = hipMemsetAsync(B.scalars, 0, 3 * 4, s)) != hipSuccess) return (int)e;
     if ((e = hipMemsetAsync(B.scalars + VR_N_UNDECIDED, 0, 4, s)) != hipSuccess) return (int)e;
     if ((e = hipMemsetAsync(B.plan, 0, sizeof(DevVrPlan), s)) != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(vr_select_kernel, dim3(blocks), dim3(256), 0, s, B.anchors, B.nodes, B.node, B.status, n, limit, B.key1, B.key2, B.idx);
-    // order by (key1, key2): a stable sort by key2, then by key1 (LSD); the anchor index rides along, the other key is gathered
+    hipLaunchKernelGGL(vr_select_kernel, dim3(blocks), dim3(256), 0, s, B.anchors, B.nodes, B.node, B.status, n, limit, node_bits, B.key1, B.key2, B.key_mid, B.idx);
+    // order by (node, window start): one sort over the bits in use; the anchor index rides along
     size_t tb = B.tmp_bytes;
-    if ((e = rocprim::radix_sort_pairs(B.tmp, tb, B.key2, B.key_mid, B.idx, B.idx_mid, (size_t)n, 0u, 52u, s)) != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(vr_gather_kernel, dim3(blocks), dim3(256), 0, s, B.key1, B.idx_mid, n, B.key2s);          // key1 in key2 order (key2s as scratch)
-    tb = B.tmp_bytes;
-    if ((e = rocprim::radix_sort_pairs(B.tmp, tb, B.key2s, B.key1s, B.idx_mid, B.idxs, (size_t)n, 0u, 64u, s)) != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(vr_gather_kernel, dim3(blocks), dim3(256), 0, s, B.key2, B.idxs, n, B.key2s);
-    hipLaunchKernelGGL(vr_flag_requests_kernel, dim3(blocks), dim3(256), 0, s, B.key1s, B.key2s, n, B.flag_u, B.scalars);
+    if ((e = rocprim::radix_sort_pairs(B.tmp, tb, B.key_mid, B.key1s, B.idx, B.idxs, (size_t)n, 0u, std::min(64u, 32u + node_bits + query_bits), s)) != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(vr_flag_requests_kernel, dim3(blocks), dim3(256), 0, s, B.key1s, n, B.flag_u, B.scalars);
     tb = B.tmp_bytes;
     if ((e = hipcub::DeviceScan::InclusiveSum(B.tmp, tb, B.flag_u, B.uid, (int)n, s)) != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(vr_scatter_unique_kernel, dim3(blocks), dim3(256), 0, s, B.key1s, B.key2s, B.idxs, B.flag_u, B.uid, n, B.ukey1, B.ukey2, B.urep, B.scalars);
+    hipLaunchKernelGGL(vr_scatter_unique_kernel, dim3(blocks), dim3(256), 0, s, B.key1, B.key2, B.idxs, B.flag_u, B.uid, n, B.ukey1, B.ukey2, B.urep, B.scalars);
     // (the kernels below run over at most n distinct requests and stop at the device-side count)
     hipLaunchKernelGGL(vr_run_heads_kernel, dim3(blocks), dim3(256), 0, s, B.ukey1, B.scalars, B.run_first);
     tb = B.tmp_bytes;
@@ -1785,6 +1786,158 @@ __global__ void __launch_bounds__(64) ed_band_kernel(const u8* __restrict__ text
 }
 
 
+// ------------------------------------------------------------------------------------------------ banded existence test, 16 columns per step
+// The same band, groups, ring of lanes and skew as ed_band_kernel, for launches that want no trace: a lane takes 16 columns of its
+// group per step (the reference symbols of the block sit in four registers, the carries of 16 columns cross to the next lane as
+// one word), so the per-step work of ed_band_kernel (ring read, lane shuffle, window tests, start logic) is paid once per 16
+// columns and the only LDS access per column and word is the equality mask. Windows are widened to whole blocks (cells outside
+// the band may be computed, from exact or over-estimated inputs: both are over-estimates there, as in ed_band_kernel); a group
+// keeps going for the block in which the next group starts, whose start value D[last row of this group][column before that
+// block] travels with the carries.
+template <int W>
+__global__ void __launch_bounds__(64) ed_exists_block_kernel(const u8* __restrict__ text, const u64* __restrict__ peq,
+                                                             const DevAlignJob* __restrict__ jobs, u32 n_jobs, u32 log2_r,
+                                                             DevAlignOut* __restrict__ out) {
+    // LDS: [7 symbols][64 lanes][W words] equality masks; symbol 6 (columns past the end of the window) matches nothing
+    extern __shared__ __attribute__((aligned(16))) u64 lds_eq[];
+    u32 const lane = lane_id();
+    u32 const R = 1u << log2_r;
+    u32 const p = lane & (R - 1u);
+    u32 const jobs_per_wave = 64u >> log2_r;
+    u32 const job_id = blockIdx.x * jobs_per_wave + (lane >> log2_r);
+    bool valid = job_id < n_jobs;
+    DevAlignJob job;
+    if (valid) job = jobs[job_id];
+    else { job.ref_off = 0; job.q_off = 0; job.trace_off = 0; job.n = 0; job.m = 1; job.k = 0; job.out_index = 0; }
+    int const n = (int)job.n, m = (int)job.m, k = (int)job.k;
+    if (valid && (n == 0 || n + k < m)) {
+        // no column at all: all m rows are insertions; fewer columns than m - k: no alignment within k
+        if (p == 0u) { DevAlignOut o; o.score = (n == 0 && m <= k) ? (u32)m : 0xFFFFFFFFu; o.end_col = 0u; out[job.out_index] = o; }
+        valid = false;
+    }
+    int const nw = (m + 63) >> 6;
+    int const Lg = (nw + W - 1) / W;
+    int const band_hi = n - m + k;
+    u32 const src_lane = (lane & ~(R - 1u)) | ((lane - 1u) & (R - 1u));
+#pragma unroll
+    for (int w = 0; w < W; ++w) lds_eq[(6u * 64u + lane) * W + w] = 0ull;
+
+    int g = (int)p;
+    int b_lo = 0, b_hi = -1, rows_g = 0;
+    u32 keep_shift = 63u;                                 // bit of the group's last row in word keep_w (the bottom row of the matrix for the last group)
+    int keep_w = W - 1;
+    u64 vp[W], vn[W];
+    auto enter_group = [&]() {
+        int const r0 = 64 * W * g;
+        int const r1 = min(m, r0 + 64 * W);
+        rows_g = r1 - r0;
+        b_lo = max(0, r0 - k) >> 4;
+        b_hi = min(n - 1, r1 - 1 + band_hi) >> 4;
+        if (g + 1 < Lg) b_hi = max(b_hi, max(0, r1 - k) >> 4);
+        bool const last = g == Lg - 1;
+        keep_w = last ? (nw - 1) - g * W : W - 1;
+        keep_shift = last ? (u32)(m - 1) & 63u : 63u;
+        u64 const a = job.q_off >> 6;
+        u32 const sh = (u32)(job.q_off & 63u);
+#pragma unroll
+        for (int w = 0; w < W; ++w) {
+            int const gw = g * W + w;
+#pragma unroll
+            for (u32 s = 0; s < 6; ++s) {
+                u64 v = 0;
+                if (gw < nw) {
+                    u64 const lo = peq[(a + gw) * 6 + s];
+                    u64 const hi = peq[(a + gw + 1) * 6 + s];
+                    v = sh ? (lo >> sh) | (hi << (64 - sh)) : lo;
+                    int const rows_left = m - gw * 64;
+                    if (rows_left < 64) v &= (1ull << rows_left) - 1ull;
+                }
+                lds_eq[(s * 64u + lane) * W + w] = v;
+            }
+            vp[w] = ~0ull;
+            vn[w] = 0ull;
+        }
+    };
+    bool const has_group = valid && g < Lg;
+    if (has_group) enter_group();
+    else {
+#pragma unroll
+        for (int w = 0; w < W; ++w) { vp[w] = ~0ull; vn[w] = 0ull; }
+    }
+    u32 const my_steps = valid ? (u32)(((n - 1) >> 4) + Lg) : 0u;
+    u32 const t_max = wave_max_u32(my_steps);
+    const u8* __restrict__ ref = text + job.ref_off;
+
+    u32 cw_out = 0x55555555u;                             // what an idle lane hands down: horizontal +1 in every column
+    int botv_out = 0;
+    int bot = 0, best = m, best_col = 0;
+    for (u32 T = 0; T < t_max; ++T) {
+        int b = (int)T - g;
+        if (has_group && b > b_hi && g + (int)R < Lg) {   // this lane's group is finished: group g + R starts strictly later
+            g += (int)R;
+            enter_group();
+            b = (int)T - g;
+        }
+        u32 cw_in = (u32)__shfl((int)cw_out, (int)src_lane);
+        int botv_in = __shfl(botv_out, (int)src_lane);
+        bool const active = has_group && b >= b_lo && b <= b_hi;
+        if (active) {
+            if (g == 0) { cw_in = 0u; botv_in = 0; }      // the row above the matrix: D = 0 in every column
+            if (b == b_lo) bot = botv_in + rows_g;        // column left of the window: all vertical deltas +1 below the group above
+            int const bot_start = bot;
+            bool const last = g == Lg - 1;
+            uint4 tq;
+            __builtin_memcpy(&tq, ref + 16 * b, 16);
+            u32 const quad[4] = {tq.x, tq.y, tq.z, tq.w};
+            u32 cw = 0;
+#pragma unroll
+            for (int qd = 0; qd < 4; ++qd) {
+#pragma unroll 1
+                for (int i = 0; i < 4; ++i) {
+                    int const j = 4 * qd + i;
+                    int const c = 16 * b + j;
+                    u32 sym = (quad[qd] >> (8 * i)) & 0xFFu;
+                    sym = c < n ? sym : 6u;
+                    u64 c_hp = (cw_in >> (2 * j)) & 1u, c_hn = (cw_in >> (2 * j + 1)) & 1u;
+                    const u64* __restrict__ eqp = &lds_eq[(sym * 64u + lane) * W];
+                    u64 hp_keep = 0, hn_keep = 0;
+#pragma unroll
+                    for (int w = 0; w < W; ++w) {
+                        u64 const eq = eqp[w];
+                        u64 const pv = vp[w], mv = vn[w];
+                        u64 const x = eq | mv;
+                        u64 const tt = pv + (x & pv) + c_hn;
+                        u64 const d0 = (tt ^ pv) | x;
+                        u64 const hn = pv & d0;
+                        u64 const hp = mv | ~(pv | d0);
+                        u64 const xh = (hp << 1) | c_hp;
+                        vn[w] = xh & d0;
+                        vp[w] = (hn << 1) | ~(xh | d0) | c_hn;
+                        c_hp = hp >> 63;
+                        c_hn = hn >> 63;
+                        if (w == keep_w) { hp_keep = hp; hn_keep = hn; }
+                    }
+                    cw |= ((u32)c_hp | ((u32)c_hn << 1)) << (2 * j);
+                    bot += (int)((u32)(hp_keep >> keep_shift) & 1u) - (int)((u32)(hn_keep >> keep_shift) & 1u);
+                    if (last && c < n && bot <= best) { best = bot; best_col = c + 1; }
+                }
+            }
+            cw_out = cw;
+            botv_out = bot_start;
+        } else {
+            cw_out = 0x55555555u;
+            botv_out = 0;
+        }
+    }
+    if (valid && has_group && g == Lg - 1) {
+        DevAlignOut o;
+        o.score = best <= k ? (u32)best : 0xFFFFFFFFu;
+        o.end_col = (u32)best_col;
+        out[job.out_index] = o;
+    }
+}
+
+
 static AlignShape choose_align_shape_uncached(u32 nw, i64 width, bool band, bool parallel) {
     AlignShape best{0, 0, 0};
     u64 best_cost = ~0ull;
@@ -1835,6 +1988,10 @@ u64 align_trace_slots(u32 n, u32 m, AlignShape sh) {
     return ((u64)n + groups - 1) * groups * sh.words_per_lane;
 }
 
+static bool exists_block_form() {            // FLX_EXISTS_STEPWISE=1: existence tests through ed_band_kernel (one column per step)
+    static int const v = getenv("FLX_EXISTS_STEPWISE") ? 0 : 1;
+    return v != 0;
+}
 template <int W>
 static int launch_align(hipStream_t s, const u8* d_text, const u64* d_peq, const DevAlignJob* d_jobs, u32 n_jobs, u32 log2_g, bool trace,
                         bool banded, u64* d_trace, DevAlignOut* d_out, u16* d_lastrow) {
@@ -1846,6 +2003,12 @@ static int launch_align(hipStream_t s, const u8* d_text, const u64* d_peq, const
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&KERNEL), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);     \
         hipLaunchKernelGGL((KERNEL), dim3(blocks), dim3(64), lds, s, d_text, d_peq, d_jobs, n_jobs, log2_g, d_trace, d_out, d_lastrow); \
     } while (0)
+    if (banded && !trace && !d_lastrow && exists_block_form()) {
+        size_t const lds_b = (size_t)7 * 64 * W * sizeof(u64);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ed_exists_block_kernel<W>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_b);
+        hipLaunchKernelGGL((ed_exists_block_kernel<W>), dim3(blocks), dim3(64), lds_b, s, d_text, d_peq, d_jobs, n_jobs, log2_g, d_out);
+        return (int)hipGetLastError();
+    }
     if (banded) { if (trace) FLX_LAUNCH((ed_band_kernel<W, true>)); else FLX_LAUNCH((ed_band_kernel<W, false>)); }
     else { if (trace) FLX_LAUNCH((ed_align_kernel<W, true>)); else FLX_LAUNCH((ed_align_kernel<W, false>)); }
 #undef FLX_LAUNCH

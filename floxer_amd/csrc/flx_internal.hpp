@@ -144,7 +144,7 @@ struct DevVrAnchor {            // 48 bytes
     u64 seq_start, seq_len;     // the reference sequence in the padded text
     u64 q_base;                 // pool offset of the read in the anchor's orientation
     u32 tree_base;              // first node of the read's tree in the node table
-    u32 pad;
+    u32 query;                  // ordinal of (read, orientation) in the chunk: with the node's index it names the node in a sort key
 };
 struct DevVrNode { u32 parent, from, rows, errors; };          // parent = index within the tree, 0xFFFFFFFF for the root
 struct DevVrJob { u64 ref_off, q_off; u32 n, m, k, pad; };     // n == 0: unused slot
@@ -169,9 +169,10 @@ struct DevVrPlan {
 struct VrBuffers {
     const DevVrAnchor* anchors; const DevVrNode* nodes;
     u32* node; u8* status;                       // per anchor, mutable
-    u64 *key1, *key2, *key1s, *key2s;            // per anchor: request keys, unsorted / sorted (key1 = ~0: not in this round)
-    u32 *idx, *idx_mid, *idxs;                   // per anchor: anchor index through the two sort passes
-    u64* key_mid;
+    u64 *key1, *key2;                            // per anchor: the request {query offset << 20 | rows, reference offset << 20 | window length}
+    u64 *key_mid, *key1s;                        // per anchor: sort key (node name << 32 | window start; ~0: not in this round), unsorted / sorted
+    u64* key2s;                                  // (unused)
+    u32 *idx, *idx_mid, *idxs;                   // per anchor: anchor index, unsorted / (unused) / in sorted order
     u32 *flag_u, *uid, *flag_c, *cid, *run_first;// per sorted request / per distinct request
     u64 *ukey1, *ukey2; u32* urep;               // per distinct request: keys and one anchor that asked for it
     u32* cstart;                                 // per cluster: its first distinct request (n_clusters + 1 entries)
@@ -248,12 +249,13 @@ struct DeviceApi {
     // d_lastrow (banded TRACE launches only, may be null): D[m][c] of every computed column c, 0xFFFF elsewhere (pre-filled by the caller)
     static int align(void* stream, const u8* d_text, const u64* d_peq, const DevAlignJob* d_jobs, u32 n_jobs, AlignShape shape,
                      bool trace, u64* d_trace, DevAlignOut* d_out, u16* d_lastrow = nullptr);
-    // verification rounds (see VrBuffers). requests: everything up to the job list of the round whose node-size limit is `limit`,
+    // verification rounds (see VrBuffers). query_bits / node_bits: bits that hold every DevVrAnchor::query / node index of the chunk.
+    // requests: everything up to the job list of the round whose node-size limit is `limit`,
     // grouped by launch shape (scalars VR_N_REQ / VR_N_UNIQ / VR_N_CLUSTERS and the plan are set); decide: B.state from B.outs
     // (scalar VR_N_UNDECIDED); apply: B.state = one decision per cluster (1 pass, 2 fail, 0: look at d_override, one per distinct
     // request, may be null), then scalars VR_N_CLIMBING / VR_SMALLEST for the next round
     static size_t vr_tmp_bytes(u32 n_anchors);
-    static int vr_round_requests(void* stream, VrBuffers const& B, u32 n_anchors, u32 limit);
+    static int vr_round_requests(void* stream, VrBuffers const& B, u32 n_anchors, u32 limit, u32 query_bits, u32 node_bits);
     static int vr_round_decide(void* stream, VrBuffers const& B, u32 n_anchors);
     static int vr_round_apply(void* stream, VrBuffers const& B, u32 n_anchors, const u8* d_override);
     static AlignShape vr_class_shape(u32 shape_class);

@@ -1776,6 +1776,11 @@ int align_slice(Lane* lane, const flx_params* P, const flx_reads* RD, u64 first_
             for (auto const& nd : t.inner) nodes.push_back(DevVrNode{nd.parent_id, nd.from, nd.to - nd.from + 1, nd.num_errors});
         }
         if (nodes.empty()) nodes.push_back(DevVrNode{0xFFFFFFFFu, 0, 1, 0});
+        auto bits_for = [](u64 count) { u32 b = 1; while ((1ull << b) < count) ++b; return b; };      // bits that hold 0 .. count - 1
+        size_t max_nodes = 1;
+        for (auto const& kv : tree_cache) max_nodes = std::max(max_nodes, kv.second->inner.size());
+        u32 const query_bits = bits_for(2 * reads.size()), node_bits = bits_for(max_nodes);
+        if (query_bits + node_bits > 32) { set_error("verification rounds: node names do not fit their sort key"); return FLX_ERR_INTERNAL; }
         hvec<DevVrAnchor> da(n);
         hvec<u32> h_node(n);
         hvec<u8> h_status(n);
@@ -1785,7 +1790,8 @@ int align_slice(Lane* lane, const flx_params* P, const flx_reads* RD, u64 first_
             ReadState const& rs = reads[a.read];
             flx_pex_node const& leaf = rs.tree_ref().leaves[a.leaf];
             u32 const tb = tree_base[rs.tree_ptr];
-            da[i] = DevVrAnchor{(i64)a.pos - (i64)leaf.from, H.seq_start[a.ref_id], H.seq_len[a.ref_id], rs.pool_off[a.orientation], tb, 0};
+            da[i] = DevVrAnchor{(i64)a.pos - (i64)leaf.from, H.seq_start[a.ref_id], H.seq_len[a.ref_id], rs.pool_off[a.orientation], tb,
+                                2u * a.read + a.orientation};
             bool const climbs = a.alive && !a.at_root;
             h_node[i] = climbs ? a.node : 0u;
             h_status[i] = climbs ? VR_CLIMBING : a.at_root ? VR_AT_ROOT : VR_DEAD;
@@ -1831,7 +1837,7 @@ int align_slice(Lane* lane, const flx_params* P, const flx_reads* RD, u64 first_
         vprof.mark("upload");
         while (n_climbing > 0) {
             u64 const limit = (u64)smallest + smallest / 2;
-            int const e1 = DeviceApi::vr_round_requests(lane->stream, B, n, (u32)std::min<u64>(limit, 0xFFFFFFFFu));
+            int const e1 = DeviceApi::vr_round_requests(lane->stream, B, n, (u32)std::min<u64>(limit, 0xFFFFFFFFu), query_bits, node_bits);
             if (e1) { set_error(std::string("verification round: ") + hipGetErrorString((hipError_t)e1)); return FLX_ERR_NO_DEVICE; }
             u32 sc[3] = {0, 0, 0};
             if ((rc = d2h(lane, sc, B.scalars, 12))) return rc;

@@ -1,0 +1,40 @@
+#!/usr/bin/env python3
+"""Concurrency of the kernels in a rocprofv3 kernel trace (CSV): for the time of the last n search launches, how long k launches of
+the search kernel ran at once, how long nothing ran, and every kernel family's busy time (union of its launches).
+usage: trace_concurrency.py kernel_trace.csv [n_search_launches]"""
+import csv, sys, collections
+rows = list(csv.DictReader(open(sys.argv[1])))
+n_last = int(sys.argv[2]) if len(sys.argv) > 2 else 64          # window = from the start of the n-th last search launch to the end of the last
+ev = [(int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]) for r in rows]
+fm = sorted((s, e) for s, e, k in ev if "fm_search" in k)
+t0 = fm[-min(n_last, len(fm))][0]
+t_end = max(e for _, e in fm)
+ev = [(s, min(e, t_end), k) for s, e, k in ev if s < t_end]
+ev = [(max(s, t0), e, k) for s, e, k in ev if e > t0]
+span = t_end - t0
+def family(k):
+    for f in ("fm_search", "ed_band_kernel", "ed_exists_block", "ed_align_kernel", "ed_traceback", "seed_select", "seed_rows", "hit_scatter", "vr_", "lastrow", "rocprim", "hipcub"):
+        if f in k: return f
+    return "other"
+def union(iv):
+    iv.sort(); tot = 0; cs, ce = None, None
+    for s, e in iv:
+        if cs is None: cs, ce = s, e
+        elif s <= ce: ce = max(ce, e)
+        else: tot += ce - cs; cs, ce = s, e
+    if cs is not None: tot += ce - cs
+    return tot
+fam = collections.defaultdict(list)
+for s, e, k in ev: fam[family(k)].append((s, e))
+print(f"window {span / 1e6:.1f} ms, {len(ev)} launches")
+print(f"any kernel running: {union([(s, e) for s, e, _ in ev]) / span:.3f} of the time")
+for f, iv in sorted(fam.items(), key=lambda kv: -sum(e - s for s, e in kv[1])):
+    print(f"  {f:18s} launches {len(iv):6d}  sum {sum(e - s for s, e in iv) / 1e6:9.1f} ms  union {union(list(iv)) / span:.3f} of the time")
+# distribution of concurrent search launches
+pts = []
+for s, e in fam["fm_search"]: pts += [(s, 1), (e, -1)]
+pts.sort(); cur = 0; last = t0; hist = collections.Counter()
+for t, d in pts:
+    hist[cur] += t - last; last = t; cur += d
+hist[cur] += t_end - last
+print("concurrent fm_search launches: " + "  ".join(f"{k}: {v / span:.3f}" for k, v in sorted(hist.items())))
