@@ -771,6 +771,37 @@ def test_scale_250mb_multi_sequence():
     ctx.close()
 
 
+def test_scale_grch38_size_truth_cigars_and_batch_invariance():
+    """The metric's configuration (BASELINE.json configs[3] shape): 3.1 Gb in 25 sequences, index built on the GPU, 10-kb reads @ 8 %,
+    floxer defaults. The oracle cannot take this size in test time, so the properties the domain offers: every read has exactly one
+    primary, at the simulated sequence / position / strand; the CIGARs of a sample are consistent with the two texts and their edit
+    counts equal NM; a read's records do not depend on the batch it arrives in; `-I` keeps the primary of every read."""
+    G, NSEQ, NR, L, rate = 3_100_000_000, 25, 512, 10000, 0.08
+    pool, genome = S.make_genome_fast(G // NSEQ, NSEQ, seed=91)
+    (rpool, offs), (chrom, pos, rev) = S.make_reads_fast(pool, [G // NSEQ] * NSEQ, NR, L, rate, seed=92)
+    ctx = F.context(F.fmindex(genome, device=0))
+    res = F.aligner(ctx, F.params(error_probability=rate)).align_reads((rpool, offs))
+    rows = res.rows
+    prim = rows[(rows[:, 1] & 256) == 0]
+    assert len(prim) == NR and (prim[:, 0] == np.arange(NR)).all()
+    assert ((prim[:, 1] & 4) == 0).all()
+    assert (prim[:, 2] == chrom).all() and (np.abs(prim[:, 3] - pos.astype(np.int64)) <= 0.1 * L).all()
+    assert (((prim[:, 1] & 16) != 0) == (rev != 0)).all()
+    sample = list(range(0, NR, 64))
+    reads = [rpool[int(offs[i]):int(offs[i + 1])] for i in sample]
+    sub = F.aligner(ctx, F.params(error_probability=rate)).align_reads(reads)
+
+    def recs_of(result, read):
+        return [(int(r[1]), int(r[2]), int(r[3]), int(r[4]), result.cigars[r[5]: r[5] + r[6]].tobytes()) for r in result.rows[result.rows[:, 0] == read]]
+    for j, i in enumerate(sample):
+        assert recs_of(sub, j) == recs_of(res, i)
+    _check_cigars(genome, reads, sub.records(), rate)
+    opt = F.aligner(ctx, F.params(error_probability=rate, interval_optimization=True)).align_reads((rpool, offs))
+    oprim = opt.rows[(opt.rows[:, 1] & 256) == 0]
+    assert len(oprim) == NR and (oprim[:, 2] == chrom).all() and (np.abs(oprim[:, 3] - pos.astype(np.int64)) <= 0.1 * L).all()
+    ctx.close()
+
+
 def test_cli_devices_stats_fastq_forms_and_accuracy(tmp_path):
     """The drop-in CLI beyond the reference's own test: (1) a FASTQ as plain text, gzip, with CR LF line ends and without a final
     line end gives the same SAM; (2) two contexts (--devices 0,0: batches dealt in turn, written in input order) and several I/O
