@@ -6,7 +6,7 @@ Usage: make_traffic_json.py fetch.csv write.csv isolated.json out_dir prefix"""
 import csv, json, os, sys
 fetch_csv, write_csv, iso_json, out_dir, prefix = sys.argv[1:6]
 iso = json.load(open(iso_json))
-KERNELS = {"fm_search": "fm_search_kernel", "ed_align_trace": "true>(", "ed_align_exists": "false>(", "ed_traceback": "traceback"}
+KERNELS = {"fm_search": "fm_search_kernel", "ed_align_trace": "true>(", "ed_align_exists": "ed_exists_block_kernel", "ed_traceback": "traceback"}
 # bytes per FETCH_SIZE unit / 1024: 2 for wide coalesced reads (128-B requests tallied at 64 B, MI355X guide); 1 for fm_search, whose reads are
 # random 32-byte blocks fetched as 64-byte requests and tallied exactly (calibration: scripts/micro/gather_cost.hip ... calib,
 # profiles/r02_gather_calib.txt)
