@@ -1115,10 +1115,6 @@ __global__ void __launch_bounds__(256) vr_select_kernel(const DevVrAnchor* __res
     sort_key[i] = ks;
     idx[i] = i;
 }
-__global__ void __launch_bounds__(256) vr_gather_kernel(const u64* __restrict__ src, const u32* __restrict__ order, u32 n, u64* __restrict__ dst) {
-    u32 const i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) dst[i] = src[order[i]];
-}
 // sorted requests: head of a distinct request, head of a run of one node's requests; the count of real requests
 __global__ void __launch_bounds__(256) vr_flag_requests_kernel(const u64* __restrict__ keys, u32 n, u32* __restrict__ flag_u, u32* __restrict__ scalars) {
     u32 const i = blockIdx.x * blockDim.x + threadIdx.x;

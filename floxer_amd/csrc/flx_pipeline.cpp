@@ -731,6 +731,11 @@ void dedup_requests(hvec<AlignRequest> const& reqs, hvec<AlignRequest>& uniq, hv
 // Shapes for the jobs of one call. Many jobs: each gets the shape that costs the fewest wave slots. Few jobs (they would leave
 // most SIMDs without a wave): all get one common shape with the fewest words per lane, i.e. more, shorter-running waves and a
 // single launch.
+// a round tests the nodes of [smallest, smallest * span / 100] rows (FLX_ROUND_SPAN overrides the percentage)
+u64 round_span_percent() {
+    static u64 const v = getenv("FLX_ROUND_SPAN") ? std::max<u64>(100, strtoull(getenv("FLX_ROUND_SPAN"), nullptr, 10)) : 150;
+    return v;
+}
 u64 align_few_waves() {          // FLX_ALIGN_FEW_WAVES overrides the threshold (tests force either form)
     const char* env = getenv("FLX_ALIGN_FEW_WAVES");
     return env ? strtoull(env, nullptr, 10) : 512;
@@ -1802,8 +1807,8 @@ int align_slice(Lane* lane, const flx_params* P, const flx_reads* RD, u64 first_
         size_t off = 0;
         auto take = [&](size_t bytes) { size_t const at = off; off += (bytes + 255) & ~(size_t)255; return at; };
         size_t const o_anchors = take((size_t)n * sizeof(DevVrAnchor)), o_nodes = take(nodes.size() * sizeof(DevVrNode)), o_node = take((size_t)n * 4),
-                     o_status = take(n), o_key1 = take((size_t)n * 8), o_key2 = take((size_t)n * 8), o_key1s = take((size_t)n * 8), o_key2s = take((size_t)n * 8),
-                     o_key_mid = take((size_t)n * 8), o_idx = take((size_t)n * 4), o_idx_mid = take((size_t)n * 4), o_idxs = take((size_t)n * 4),
+                     o_status = take(n), o_key1 = take((size_t)n * 8), o_key2 = take((size_t)n * 8), o_key1s = take((size_t)n * 8),
+                     o_key_mid = take((size_t)n * 8), o_idx = take((size_t)n * 4), o_idxs = take((size_t)n * 4),
                      o_flag_u = take((size_t)n * 4), o_uid = take((size_t)n * 4), o_flag_c = take((size_t)n * 4), o_cid = take((size_t)n * 4),
                      o_run = take((size_t)n * 4), o_ukey1 = take((size_t)n * 8), o_ukey2 = take((size_t)n * 8), o_urep = take((size_t)n * 4),
                      o_cstart = take(((size_t)n + 1) * 4), o_jobs = take((size_t)n * 2 * sizeof(DevVrJob)), o_scalars = take(64), o_tmp = take(tmp_bytes),
@@ -1814,8 +1819,8 @@ int align_slice(Lane* lane, const flx_params* P, const flx_reads* RD, u64 first_
         char* const base = (char*)lane->vr.ptr;
         VrBuffers B{};
         B.anchors = (const DevVrAnchor*)(base + o_anchors); B.nodes = (const DevVrNode*)(base + o_nodes); B.node = (u32*)(base + o_node); B.status = (u8*)(base + o_status);
-        B.key1 = (u64*)(base + o_key1); B.key2 = (u64*)(base + o_key2); B.key1s = (u64*)(base + o_key1s); B.key2s = (u64*)(base + o_key2s); B.key_mid = (u64*)(base + o_key_mid);
-        B.idx = (u32*)(base + o_idx); B.idx_mid = (u32*)(base + o_idx_mid); B.idxs = (u32*)(base + o_idxs);
+        B.key1 = (u64*)(base + o_key1); B.key2 = (u64*)(base + o_key2); B.key1s = (u64*)(base + o_key1s); B.key_mid = (u64*)(base + o_key_mid);
+        B.idx = (u32*)(base + o_idx); B.idxs = (u32*)(base + o_idxs);
         B.flag_u = (u32*)(base + o_flag_u); B.uid = (u32*)(base + o_uid); B.flag_c = (u32*)(base + o_flag_c); B.cid = (u32*)(base + o_cid); B.run_first = (u32*)(base + o_run);
         B.ukey1 = (u64*)(base + o_ukey1); B.ukey2 = (u64*)(base + o_ukey2); B.urep = (u32*)(base + o_urep); B.cstart = (u32*)(base + o_cstart);
         B.jobs = (DevVrJob*)(base + o_jobs); B.scalars = (u32*)(base + o_scalars); B.tmp = base + o_tmp; B.tmp_bytes = tmp_bytes;
@@ -1836,7 +1841,7 @@ int align_slice(Lane* lane, const flx_params* P, const flx_reads* RD, u64 first_
         u64 const mask = (1ull << 20) - 1ull;
         vprof.mark("upload");
         while (n_climbing > 0) {
-            u64 const limit = (u64)smallest + smallest / 2;
+            u64 const limit = (u64)smallest * round_span_percent() / 100;
             int const e1 = DeviceApi::vr_round_requests(lane->stream, B, n, (u32)std::min<u64>(limit, 0xFFFFFFFFu), query_bits, node_bits);
             if (e1) { set_error(std::string("verification round: ") + hipGetErrorString((hipError_t)e1)); return FLX_ERR_NO_DEVICE; }
             u32 sc[3] = {0, 0, 0};
@@ -1931,7 +1936,7 @@ int align_slice(Lane* lane, const flx_params* P, const flx_reads* RD, u64 first_
         climbers.reserve(climbing.size());
         for (u32 ai : climbing) { u32 const r = rows_of(A[ai]); climbers.push_back(Climber{ai, r}); smallest = std::min(smallest, r); }
         while (!climbers.empty()) {
-            u64 const limit = (u64)smallest + smallest / 2;
+            u64 const limit = (u64)smallest * round_span_percent() / 100;
             auto const tb0 = std::chrono::steady_clock::now();
             sel.clear();
             wait.clear();
