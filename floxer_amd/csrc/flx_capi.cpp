@@ -98,12 +98,13 @@ int make_context(int hip_device, const flx_index* index, void* const image[5], b
         ctx->free_lanes.push_back((int)l);
     }
     // K1 launches in flight at a time: with every lane free to start its search the GPU swings between phases where K1's waves
-    // (memory-bound, long-lived) hold most wave slots and phases where only the VALU-bound DP kernels run; about 2048 K1 waves at a
-    // time keep the mix steady (16 lanes, 3.1 Gb / 10 kb: 70.1 k reads/s unlimited, 75.1 k with 4 x 512 waves). FLX_K1_CONCURRENT
-    // overrides (0 = unlimited).
+    // (memory-bound, long-lived) hold most wave slots and phases where only the VALU-bound DP kernels run; about 3072 K1 waves at a
+    // time keep the mix steady (16 lanes, 3.1 Gb / 10 kb: 74.7 k reads/s unlimited, 73-75 k with 4 x 512 waves, 78-79.5 k with 6 x 512;
+    // while the existence tests still kept a 16-KB symbol ring per wave in LDS, 4 x 512 was the best). FLX_K1_CONCURRENT overrides
+    // (0 = unlimited).
     {
         size_t const share = 4096 / std::max<size_t>(1, std::min<size_t>(n_lanes, 8));
-        ctx->k1_tokens = n_lanes >= 2 ? (int)std::max<size_t>(1, 2048 / share) : 0;
+        ctx->k1_tokens = n_lanes >= 2 ? (int)std::max<size_t>(1, 3072 / share) : 0;
         if (const char* env = getenv("FLX_K1_CONCURRENT")) ctx->k1_tokens = atoi(env);
     }
     FLX_HIP(hipStreamCreateWithFlags(&ctx->upload_stream, hipStreamNonBlocking));
