@@ -99,9 +99,8 @@ int make_context(int hip_device, const flx_index* index, void* const image[5], b
     }
     // K1 launches in flight at a time: with every lane free to start its search the GPU swings between phases where K1's waves
     // (memory-bound, long-lived) hold most wave slots and phases where only the VALU-bound DP kernels run; about 3072 K1 waves at a
-    // time keep the mix steady (16 lanes, 3.1 Gb / 10 kb: 74.7 k reads/s unlimited, 73-75 k with 4 x 512 waves, 78-79.5 k with 6 x 512;
-    // while the existence tests still kept a 16-KB symbol ring per wave in LDS, 4 x 512 was the best). FLX_K1_CONCURRENT overrides
-    // (0 = unlimited).
+    // time keep the mix steady (16 lanes, 3.1 Gb / 10 kb: 74.7 k reads/s unlimited, 73-75 k with 4 x 512 waves, 78-79.5 k with 6 x 512,
+    // 75-76 k with 7 or 8; with the rounds' job lists still on the host 4 x 512 was the best). FLX_K1_CONCURRENT overrides (0 = unlimited).
     {
         size_t const share = 4096 / std::max<size_t>(1, std::min<size_t>(n_lanes, 8));
         ctx->k1_tokens = n_lanes >= 2 ? (int)std::max<size_t>(1, 3072 / share) : 0;
