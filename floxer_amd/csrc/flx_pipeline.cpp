@@ -141,7 +141,7 @@ int Lane::wait_idle() {
     FLX_HIP(hipEventRecord(sync_event, stream));
     // (the sleeps grow with the time already waited: a long kernel is not polled thousands of times, a short one is not overslept
     // by more than a fifth of its duration)
-    static unsigned const max_sleep = getenv("FLX_POLL_MAX_US") ? (unsigned)atoi(getenv("FLX_POLL_MAX_US")) : 400u;
+    static unsigned const max_sleep = getenv("FLX_POLL_MAX_US") ? (unsigned)atoi(getenv("FLX_POLL_MAX_US")) : 1000u;
     for (unsigned sleep_us = 20;;) {
         hipError_t const e = hipEventQuery(sync_event);
         if (e == hipSuccess) break;

@@ -556,6 +556,25 @@ def test_root_unions_and_their_fallback():
     assert forced == exp.records()
 
 
+def test_existence_kernel_forms_give_the_same_records():
+    """the existence tests run 16 columns per step (ed_exists_block_kernel) by default and one column per step (ed_band_kernel) with
+    FLX_EXISTS_STEPWISE=1; the switch is read once per process, so the second form runs in a child: same records, both equal to
+    the oracle's, on reads whose trees reach every launch shape of the lower levels and the ring-scheduled upper ones"""
+    import subprocess, sys, json
+    genome = S.make_genome(500000, 2, seed=161)
+    reads, _, _ = S.make_reads(genome, 24, 6000, 0.08, seed=162)
+    exp = O.Index(genome).run(reads, O.params(error_probability=0.08), threads=8)
+    ctx = F.context(F.fmindex(genome))
+    assert F.aligner(ctx, F.params(error_probability=0.08)).align_reads(reads).records() == exp.records()
+    ctx.close()
+    code = ("import sys, json; sys.path.insert(0, %r); import floxer_amd as F; from floxer_amd import simulate as S;"
+            "g = S.make_genome(500000, 2, seed=161); r, _, _ = S.make_reads(g, 24, 6000, 0.08, seed=162);"
+            "c = F.context(F.fmindex(g)); print(json.dumps(F.aligner(c, F.params(error_probability=0.08)).align_reads(r).records()))"
+            % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, FLX_EXISTS_STEPWISE="1"), capture_output=True, text=True, check=True)
+    assert [tuple(r) for r in json.loads(out.stdout.strip().split("\n")[-1])] == exp.records()
+
+
 def test_caller_owned_stream():
     """flx_ctx_set_stream: every launch goes to the caller's HIP stream (one lane); results do not change"""
     import ctypes
