@@ -1093,8 +1093,15 @@ constexpr u32 VR_SHIFT = 20;
 __global__ void __launch_bounds__(256) vr_select_kernel(const DevVrAnchor* __restrict__ anchors, const DevVrNode* __restrict__ nodes,
                                                         const u32* __restrict__ node, const u8* __restrict__ status, u32 n_anchors, u32 limit,
                                                         u32 node_bits, u64* __restrict__ key1, u64* __restrict__ key2, u64* __restrict__ sort_key,
-                                                        u32* __restrict__ idx) {
+                                                        u32* __restrict__ idx, u32* __restrict__ scalars, DevVrPlan* __restrict__ plan) {
     u32 const i = blockIdx.x * blockDim.x + threadIdx.x;
+    // (first kernel of a round: the counters and the plan the later kernels of the round add to start from zero)
+    if (blockIdx.x == 0) {
+        if (threadIdx.x < 3u) scalars[threadIdx.x] = 0u;
+        if (threadIdx.x == 3u) scalars[VR_N_UNDECIDED] = 0u;
+        u32* const words = reinterpret_cast<u32*>(plan);
+        for (u32 w = threadIdx.x; w < (u32)(sizeof(DevVrPlan) / 4); w += blockDim.x) words[w] = 0u;
+    }
     if (i >= n_anchors) return;
     u64 k1 = ~0ull, k2 = ~0ull, ks = ~0ull;
     if (status[i] == VR_CLIMBING) {
@@ -1353,8 +1360,9 @@ __global__ void __launch_bounds__(256) vr_decide_kernel(const DevVrJob* __restri
 __global__ void __launch_bounds__(256) vr_apply_kernel(const u64* __restrict__ key1s, const u32* __restrict__ idxs, const u32* __restrict__ uid,
                                                        const u32* __restrict__ cid, const u8* __restrict__ state, const u8* __restrict__ override_,
                                                        const DevVrAnchor* __restrict__ anchors, const DevVrNode* __restrict__ nodes, u32 n,
-                                                       u32* __restrict__ node, u8* __restrict__ status) {
+                                                       u32* __restrict__ node, u8* __restrict__ status, u32* __restrict__ scalars) {
     u32 const i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0) { scalars[VR_N_CLIMBING] = 0u; scalars[VR_SMALLEST] = 0xFFFFFFFFu; }      // vr_next_kernel, the next launch, counts into them
     if (i >= n || key1s[i] == ~0ull) return;
     u32 const u = uid[i] - 1u;
     u8 dec = override_ ? override_[u] : (u8)0;
@@ -1392,10 +1400,9 @@ int DeviceApi::vr_round_requests(void* stream, VrBuffers const& B, u32 n, u32 li
     hipStream_t s = (hipStream_t)stream;
     hipError_t e;
     unsigned const blocks = (n + 255) / 256;
-    if ((e = hipMemsetAsync(B.scalars, 0, 3 * 4, s)) != hipSuccess) return (int)e;
-    if ((e = hipMemsetAsync(B.scalars + VR_N_UNDECIDED, 0, 4, s)) != hipSuccess) return (int)e;
-    if ((e = hipMemsetAsync(B.plan, 0, sizeof(DevVrPlan), s)) != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(vr_select_kernel, dim3(blocks), dim3(256), 0, s, B.anchors, B.nodes, B.node, B.status, n, limit, node_bits, B.key1, B.key2, B.key_mid, B.idx);
+    static_assert(sizeof(DevVrPlan) % 4 == 0, "the plan is zeroed word by word");
+    hipLaunchKernelGGL(vr_select_kernel, dim3(blocks), dim3(256), 0, s, B.anchors, B.nodes, B.node, B.status, n, limit, node_bits, B.key1, B.key2, B.key_mid, B.idx,
+                       B.scalars, B.plan);
     // order by (node, window start): one sort over the bits in use; the anchor index rides along
     size_t tb = B.tmp_bytes;
     if ((e = rocprim::radix_sort_pairs(B.tmp, tb, B.key_mid, B.key1s, B.idx, B.idxs, (size_t)n, 0u, std::min(64u, 32u + node_bits + query_bits), s)) != hipSuccess) return (int)e;
@@ -1436,10 +1443,7 @@ int DeviceApi::vr_round_apply(void* stream, VrBuffers const& B, u32 n, const u8*
     if (n == 0) return 0;
     hipStream_t s = (hipStream_t)stream;
     unsigned const blocks = (n + 255) / 256;
-    hipLaunchKernelGGL(vr_apply_kernel, dim3(blocks), dim3(256), 0, s, B.key1s, B.idxs, B.uid, B.cid, B.state, d_override, B.anchors, B.nodes, n, B.node, B.status);
-    hipError_t e = hipMemsetAsync(B.scalars + VR_N_CLIMBING, 0, 4, s);
-    if (e == hipSuccess) e = hipMemsetAsync(B.scalars + VR_SMALLEST, 0xFF, 4, s);
-    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(vr_apply_kernel, dim3(blocks), dim3(256), 0, s, B.key1s, B.idxs, B.uid, B.cid, B.state, d_override, B.anchors, B.nodes, n, B.node, B.status, B.scalars);
     hipLaunchKernelGGL(vr_next_kernel, dim3(blocks), dim3(256), 0, s, B.anchors, B.nodes, B.node, B.status, n, B.scalars);
     return (int)hipGetLastError();
 }
