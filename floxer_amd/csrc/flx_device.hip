@@ -1256,11 +1256,12 @@ __device__ __forceinline__ void vr_class_add(u32 cls, u32* __restrict__ count, u
         todo &= ~members;
     }
 }
-__global__ void __launch_bounds__(256) vr_shape_kernel(const DevVrJob* __restrict__ jobs, const u32* __restrict__ scalars, u32 band,
+// (job slots of the kernels below: [0, per_count * *count), e.g. two per cluster, one per distinct request)
+__global__ void __launch_bounds__(256) vr_shape_kernel(const DevVrJob* __restrict__ jobs, const u32* __restrict__ count, u32 per_count, u32 band,
                                                        u8* __restrict__ job_class, DevVrPlan* __restrict__ plan) {
     u32 const j = blockIdx.x * blockDim.x + threadIdx.x;
     u32 cls = VR_NO_CLASS, par = 0, lanes = 0;
-    if (j < 2u * scalars[VR_N_CLUSTERS]) {
+    if (j < per_count * *count) {
         DevVrJob const job = jobs[j];
         if (job.n != 0) {
             u32 const nw = (job.m + 63u) / 64u;
@@ -1280,12 +1281,12 @@ __global__ void __launch_bounds__(256) vr_shape_kernel(const DevVrJob* __restric
 }
 // A launch lasts at least as long as its longest job: the jobs of a class with fewer than 64 members join the most frequent class
 // of at least 64 that can hold them (choose_shapes). Then the per-class totals and the lanes per job of the one-launch form.
-__global__ void __launch_bounds__(256) vr_regroup_kernel(const DevVrJob* __restrict__ jobs, const u32* __restrict__ scalars, u32 band,
+__global__ void __launch_bounds__(256) vr_regroup_kernel(const DevVrJob* __restrict__ jobs, const u32* __restrict__ count, u32 per_count, u32 band,
                                                          u8* __restrict__ job_class, DevVrPlan* __restrict__ plan) {
     u32 const j = blockIdx.x * blockDim.x + threadIdx.x;
     u32 cls = VR_NO_CLASS, par_r = 0;
     u64 steps = 0, bytes = 0, common_steps = 0;
-    if (j < 2u * scalars[VR_N_CLUSTERS]) {
+    if (j < per_count * *count) {
         cls = job_class[j];
         if (cls != VR_NO_CLASS) {
             DevVrJob const job = jobs[j];
@@ -1319,10 +1320,10 @@ __global__ void __launch_bounds__(64) vr_plan_kernel(DevVrPlan* __restrict__ pla
     for (u32 c = 0; c < VR_CLASSES; ++c) { plan->start[c] = at; plan->cursor[c] = at; at += plan->count[c]; }
     plan->n_jobs = at;
 }
-__global__ void __launch_bounds__(256) vr_emit_kernel(const DevVrJob* __restrict__ jobs, const u32* __restrict__ scalars, const u8* __restrict__ job_class,
+__global__ void __launch_bounds__(256) vr_emit_kernel(const DevVrJob* __restrict__ jobs, const u32* __restrict__ count, u32 per_count, const u8* __restrict__ job_class,
                                                       DevVrPlan* __restrict__ plan, DevAlignJob* __restrict__ out) {
     u32 const j = blockIdx.x * blockDim.x + threadIdx.x;
-    u32 const cls = j < 2u * scalars[VR_N_CLUSTERS] ? (u32)job_class[j] : VR_NO_CLASS;
+    u32 const cls = j < per_count * *count ? (u32)job_class[j] : VR_NO_CLASS;
     // one cursor grab per class and wave; the members keep their order within the wave
     u64 todo = __ballot(cls != VR_NO_CLASS);
     u32 pos = 0;
@@ -1422,10 +1423,58 @@ int DeviceApi::vr_round_requests(void* stream, VrBuffers const& B, u32 n, u32 li
     // the job list by launch shape (two slots per cluster, at most n clusters)
     unsigned const job_blocks = (2 * n + 255) / 256;
     u32 const band = use_band() ? 1u : 0u;
-    hipLaunchKernelGGL(vr_shape_kernel, dim3(job_blocks), dim3(256), 0, s, B.jobs, B.scalars, band, B.job_class, B.plan);
-    hipLaunchKernelGGL(vr_regroup_kernel, dim3(job_blocks), dim3(256), 0, s, B.jobs, B.scalars, band, B.job_class, B.plan);
+    hipLaunchKernelGGL(vr_shape_kernel, dim3(job_blocks), dim3(256), 0, s, B.jobs, B.scalars + VR_N_CLUSTERS, 2u, band, B.job_class, B.plan);
+    hipLaunchKernelGGL(vr_regroup_kernel, dim3(job_blocks), dim3(256), 0, s, B.jobs, B.scalars + VR_N_CLUSTERS, 2u, band, B.job_class, B.plan);
     hipLaunchKernelGGL(vr_plan_kernel, dim3(1), dim3(64), 0, s, B.plan);
-    hipLaunchKernelGGL(vr_emit_kernel, dim3(job_blocks), dim3(256), 0, s, B.jobs, B.scalars, B.job_class, B.plan, B.align_jobs);
+    hipLaunchKernelGGL(vr_emit_kernel, dim3(job_blocks), dim3(256), 0, s, B.jobs, B.scalars + VR_N_CLUSTERS, 2u, B.job_class, B.plan, B.align_jobs);
+    return (int)hipGetLastError();
+}
+
+// The members of the undecided clusters one by one: a job per distinct request of such a cluster (slot = the request's index),
+// grouped by launch shape like the round's first list (the plan is rewritten); B.jobs is reused for the member jobs.
+__global__ void __launch_bounds__(256) vr_member_jobs_kernel(const u64* __restrict__ ukey1, const u64* __restrict__ ukey2, const u32* __restrict__ cid,
+                                                             const u8* __restrict__ state, const u32* __restrict__ scalars, DevVrJob* __restrict__ jobs,
+                                                             u32* __restrict__ member_k, DevVrPlan* __restrict__ plan) {
+    u32 const u = blockIdx.x * blockDim.x + threadIdx.x;
+    if (blockIdx.x == 0) {
+        u32* const words = reinterpret_cast<u32*>(plan);
+        for (u32 w = threadIdx.x; w < (u32)(sizeof(DevVrPlan) / 4); w += blockDim.x) words[w] = 0u;
+    }
+    if (u >= scalars[VR_N_UNIQ]) return;
+    u64 const mask = (1ull << VR_SHIFT) - 1ull;
+    DevVrJob j{ukey2[u] >> VR_SHIFT, ukey1[u] >> VR_SHIFT, 0u, (u32)(ukey1[u] & mask), member_k[u], 0u};
+    if (state[cid[u] - 1u] == 0) j.n = (u32)(ukey2[u] & mask);
+    jobs[u] = j;
+}
+// (before the round's job list is overwritten: the error bound of every distinct request = that of its cluster's jobs)
+__global__ void __launch_bounds__(256) vr_member_k_kernel(const DevVrJob* __restrict__ jobs, const u32* __restrict__ cid, const u32* __restrict__ scalars,
+                                                          u32* __restrict__ member_k) {
+    u32 const u = blockIdx.x * blockDim.x + threadIdx.x;
+    if (u < scalars[VR_N_UNIQ]) member_k[u] = jobs[2u * (cid[u] - 1u) + 1u].k;
+}
+__global__ void __launch_bounds__(256) vr_override_kernel(const DevVrJob* __restrict__ jobs, const DevAlignOut* __restrict__ outs, const u32* __restrict__ scalars,
+                                                          u8* __restrict__ override_) {
+    u32 const u = blockIdx.x * blockDim.x + threadIdx.x;
+    if (u >= scalars[VR_N_UNIQ]) return;
+    override_[u] = jobs[u].n == 0 ? (u8)0 : outs[u].score != 0xFFFFFFFFu ? (u8)1 : (u8)2;
+}
+
+int DeviceApi::vr_round_members(void* stream, VrBuffers const& B, u32 n, u32* d_member_k) {
+    if (n == 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    unsigned const blocks = (n + 255) / 256;
+    u32 const band = use_band() ? 1u : 0u;
+    hipLaunchKernelGGL(vr_member_k_kernel, dim3(blocks), dim3(256), 0, s, B.jobs, B.cid, B.scalars, d_member_k);
+    hipLaunchKernelGGL(vr_member_jobs_kernel, dim3(blocks), dim3(256), 0, s, B.ukey1, B.ukey2, B.cid, B.state, B.scalars, B.jobs, d_member_k, B.plan);
+    hipLaunchKernelGGL(vr_shape_kernel, dim3(blocks), dim3(256), 0, s, B.jobs, B.scalars + VR_N_UNIQ, 1u, band, B.job_class, B.plan);
+    hipLaunchKernelGGL(vr_regroup_kernel, dim3(blocks), dim3(256), 0, s, B.jobs, B.scalars + VR_N_UNIQ, 1u, band, B.job_class, B.plan);
+    hipLaunchKernelGGL(vr_plan_kernel, dim3(1), dim3(64), 0, s, B.plan);
+    hipLaunchKernelGGL(vr_emit_kernel, dim3(blocks), dim3(256), 0, s, B.jobs, B.scalars + VR_N_UNIQ, 1u, B.job_class, B.plan, B.align_jobs);
+    return (int)hipGetLastError();
+}
+int DeviceApi::vr_round_override(void* stream, VrBuffers const& B, u32 n, u8* d_override) {
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(vr_override_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, B.jobs, B.outs, B.scalars, d_override);
     return (int)hipGetLastError();
 }
 

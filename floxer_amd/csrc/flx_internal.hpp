@@ -138,7 +138,8 @@ struct DevTraceOut { u32 begin; u32 cigar_start; u32 cigar_len; u32 pad; };   //
 // requests of the anchors in the current node-size class, sorts them, finds the distinct ones and the clusters of windows of one
 // locus, and writes the job list (one or two existence tests per cluster) grouped by launch shape, with the counts the host needs
 // to launch K3 on it (DevVrPlan); a decide step turns the K3 results into one decision per cluster; an apply step moves the
-// anchors up their trees. Per round the host reads a plan and two or three scalars, nothing per anchor or per job.
+// anchors up their trees (the members of undecided clusters go through a second job list first). Per round the host reads a plan
+// or two and three scalars, nothing per anchor or per job.
 struct DevVrAnchor {            // 48 bytes
     i64 diag_rel;               // anchor position minus the leaf's first query row (relative to its reference sequence, may be < 0)
     u64 seq_start, seq_len;     // the reference sequence in the padded text
@@ -256,6 +257,11 @@ struct DeviceApi {
     static size_t vr_tmp_bytes(u32 n_anchors);
     static int vr_round_requests(void* stream, VrBuffers const& B, u32 n_anchors, u32 limit, u32 query_bits, u32 node_bits);
     static int vr_round_decide(void* stream, VrBuffers const& B, u32 n_anchors);
+    // undecided clusters: members: one job per distinct request of such a cluster replaces the round's job list (B.jobs, slot = the
+    // request's index; B.plan rewritten; d_member_k: one word per anchor of scratch); override: d_override[request] = 1 pass, 2 fail,
+    // 0 not a member, from B.outs
+    static int vr_round_members(void* stream, VrBuffers const& B, u32 n_anchors, u32* d_member_k);
+    static int vr_round_override(void* stream, VrBuffers const& B, u32 n_anchors, u8* d_override);
     static int vr_round_apply(void* stream, VrBuffers const& B, u32 n_anchors, const u8* d_override);
     static AlignShape vr_class_shape(u32 shape_class);
     static int lastrow_min(void* stream, const u16* d_lastrow, const DevRowWindow* d_windows, u32 n_windows, DevAlignOut* d_out);

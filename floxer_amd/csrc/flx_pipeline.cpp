@@ -1831,14 +1831,7 @@ int align_slice(Lane* lane, const flx_params* P, const flx_reads* RD, u64 first_
         FLX_HIP(hipMemcpyAsync(base + o_node, h_node.data(), (size_t)n * 4, hipMemcpyHostToDevice, lane->stream));
         FLX_HIP(hipMemcpyAsync(base + o_status, h_status.data(), n, hipMemcpyHostToDevice, lane->stream));
         if ((rc = lane->vr_override.ensure(n + 64))) return rc;
-        hvec<DevVrJob> vjobs;
-        hvec<AlignRequest> jobs;
-        hvec<DevAlignOut> jouts;
-        hvec<u8> state, override_;
-        hvec<u64> uk1, uk2;
-        hvec<u32> cstart;
         DevVrPlan plan;
-        u64 const mask = (1ull << 20) - 1ull;
         vprof.mark("upload");
         while (n_climbing > 0) {
             u64 const limit = (u64)smallest * round_span_percent() / 100;
@@ -1848,13 +1841,13 @@ int align_slice(Lane* lane, const flx_params* P, const flx_reads* RD, u64 first_
             if ((rc = d2h(lane, sc, B.scalars, 12))) return rc;
             if ((rc = d2h(lane, &plan, B.plan, sizeof(plan)))) return rc;
             if ((rc = lane->sync())) return rc;
-            u32 const n_uniq = sc[VR_N_UNIQ], n_clusters = sc[VR_N_CLUSTERS];
             n_inner_requested += sc[VR_N_REQ];
             vprof.mark("requests-wait");
-            if (plan.unsupported) { set_error("query longer than the supported maximum"); return FLX_ERR_UNSUPPORTED; }
-            // K3 on the round's job list where the device left it: one launch per shape class, or (few jobs: they would leave most
-            // SIMDs without a wave) one launch in the common shape with the fewest words per lane
-            if (plan.n_jobs) {
+            // K3 on a job list where the device left it: one launch per shape class, or (few jobs: they would leave most SIMDs without
+            // a wave) one launch in the common shape with the fewest words per lane
+            auto launch_plan = [&]() -> int {
+                if (plan.unsupported) { set_error("query longer than the supported maximum"); return FLX_ERR_UNSUPPORTED; }
+                if (!plan.n_jobs) return FLX_OK;
                 auto launch = [&](u32 first, u32 count, AlignShape shape, u64 bytes, u64 word_steps) {
                     return timed_launch(lane, "ed_align_exists", bytes, word_steps, [&] {
                         return DeviceApi::align(lane->stream, d_text, d_peq, B.align_jobs + first, count, shape, false, nullptr, B.outs);
@@ -1862,15 +1855,17 @@ int align_slice(Lane* lane, const flx_params* P, const flx_reads* RD, u64 first_
                 };
                 if (plan.lanes / 64 >= align_few_waves()) {
                     for (u32 c = 0; c < VR_CLASSES; ++c)
-                        if (plan.count[c] && (rc = launch(plan.start[c], plan.count[c], DeviceApi::vr_class_shape(c), plan.bytes[c], plan.word_steps[c]))) return rc;
-                } else {
-                    u32 log2_r = 0;
-                    while ((1u << log2_r) < plan.par_r) ++log2_r;
-                    u64 bytes = 0;
-                    for (u32 c = 0; c < VR_CLASSES; ++c) bytes += plan.bytes[c];
-                    if ((rc = launch(0, plan.n_jobs, DeviceApi::vr_class_shape(plan.par_w_index * 7u + log2_r), bytes, plan.common_word_steps))) return rc;
+                        if (plan.count[c])
+                            if (int const r = launch(plan.start[c], plan.count[c], DeviceApi::vr_class_shape(c), plan.bytes[c], plan.word_steps[c])) return r;
+                    return FLX_OK;
                 }
-            }
+                u32 log2_r = 0;
+                while ((1u << log2_r) < plan.par_r) ++log2_r;
+                u64 bytes = 0;
+                for (u32 c = 0; c < VR_CLASSES; ++c) bytes += plan.bytes[c];
+                return launch(0, plan.n_jobs, DeviceApi::vr_class_shape(plan.par_w_index * 7u + log2_r), bytes, plan.common_word_steps);
+            };
+            if ((rc = launch_plan())) return rc;
             int const e3 = DeviceApi::vr_round_decide(lane->stream, B, n);
             if (e3) { set_error(std::string("verification round: ") + hipGetErrorString((hipError_t)e3)); return FLX_ERR_NO_DEVICE; }
             u32 n_undecided = 0;
@@ -1879,30 +1874,14 @@ int align_slice(Lane* lane, const flx_params* P, const flx_reads* RD, u64 first_
             vprof.mark("score");
             const u8* d_override = nullptr;
             if (n_undecided) {
-                // (rare) the members of the undecided clusters one by one: their requests come to the host
-                vjobs.resize((size_t)n_clusters * 2);
-                state.resize(n_clusters);
-                uk1.resize(n_uniq); uk2.resize(n_uniq); cstart.resize((size_t)n_clusters + 1);
-                if ((rc = d2h(lane, vjobs.data(), B.jobs, vjobs.size() * sizeof(DevVrJob)))) return rc;
-                if ((rc = d2h(lane, state.data(), B.state, n_clusters))) return rc;
-                if ((rc = d2h(lane, uk1.data(), B.ukey1, (size_t)n_uniq * 8))) return rc;
-                if ((rc = d2h(lane, uk2.data(), B.ukey2, (size_t)n_uniq * 8))) return rc;
-                if ((rc = d2h(lane, cstart.data(), B.cstart, ((size_t)n_clusters + 1) * 4))) return rc;
+                // the members of the undecided clusters one by one: a second job list, made, run and read on the device as well
+                int const e4 = DeviceApi::vr_round_members(lane->stream, B, n, B.flag_u);        // (flag_u: free since the distinct requests were scattered)
+                if (e4) { set_error(std::string("verification round: ") + hipGetErrorString((hipError_t)e4)); return FLX_ERR_NO_DEVICE; }
+                if ((rc = d2h(lane, &plan, B.plan, sizeof(plan)))) return rc;
                 if ((rc = lane->sync())) return rc;
-                jobs.clear();
-                hvec<u32> job_uniq;
-                for (u32 c = 0; c < n_clusters; ++c) {
-                    if (state[c] != 0) continue;
-                    u32 const k = vjobs[2 * (size_t)c + 1].k;
-                    for (u32 u = cstart[c]; u < cstart[c + 1]; ++u) {
-                        jobs.push_back(AlignRequest{uk2[u] >> 20, uk1[u] >> 20, (u32)(uk2[u] & mask), (u32)(uk1[u] & mask), k});
-                        job_uniq.push_back(u);
-                    }
-                }
-                if ((rc = run_score_jobs_unique(lane, d_text, d_peq, jobs, jouts, "ed_align_exists"))) return rc;
-                override_.assign(n_uniq, 0);
-                for (size_t j = 0; j < jobs.size(); ++j) override_[job_uniq[j]] = jouts[j].score != 0xFFFFFFFFu ? 1 : 2;
-                FLX_HIP(hipMemcpyAsync(lane->vr_override.ptr, override_.data(), n_uniq, hipMemcpyHostToDevice, lane->stream));
+                if ((rc = launch_plan())) return rc;
+                int const e5 = DeviceApi::vr_round_override(lane->stream, B, n, lane->vr_override.as<u8>());
+                if (e5) { set_error(std::string("verification round: ") + hipGetErrorString((hipError_t)e5)); return FLX_ERR_NO_DEVICE; }
                 d_override = lane->vr_override.as<u8>();
                 vprof.mark("undecided");
             }
