@@ -97,6 +97,13 @@ int make_context(int hip_device, const flx_index* index, void* const image[5], b
         ctx->lanes.push_back(std::move(lane));
         ctx->free_lanes.push_back((int)l);
     }
+    // the host lists' blocks page-locked for DMA (FLX_NO_PIN=1: pageable, the runtime stages every copy)
+    if (!getenv("FLX_NO_PIN"))
+        host_pool_pin_hook = [](void* p, size_t bytes, int pin) {
+            if (pin) (void)hipHostRegister(p, bytes, hipHostRegisterPortable);
+            else (void)hipHostUnregister(p);
+            (void)hipGetLastError();      // (a block that could not be locked is simply pageable)
+        };
     // K1 launches in flight at a time: with every lane free to start its search the GPU swings between phases where K1's waves
     // (memory-bound, long-lived) hold most wave slots and phases where only the VALU-bound DP kernels run; about 3072 K1 waves at a
     // time keep the mix steady (16 lanes, 3.1 Gb / 10 kb: 74.7 k reads/s unlimited, 73-75 k with 4 x 512 waves, 78-79.5 k with 6 x 512,

@@ -26,6 +26,10 @@ void set_error(const std::string& msg);
 // (default 16384).
 void* host_pool_get(size_t bytes);
 void host_pool_put(void* p, size_t bytes);
+// Called for every block the pool takes from / returns to the C library (pin = 1 / 0). The device side of the library sets it to
+// page-lock the blocks (hipHostRegister): the lists then go to and come from the GPU by DMA instead of through the runtime's
+// staging copies. Null in the HIP-free builds.
+extern void (*host_pool_pin_hook)(void* p, size_t bytes, int pin);
 template <class T>
 struct PoolAlloc {
     using value_type = T;
