@@ -1643,6 +1643,15 @@ int align_slice(Lane* lane, const flx_params* P, const flx_reads* RD, u64 first_
     struct SeedOwner { u32 read; u8 orientation; };
     hvec<SeedOwner> seed_owner;
     std::map<std::pair<u64, u64>, std::unique_ptr<PexTree>> tree_cache;      // (length, errors) -> tree
+    {
+        // (the lists below grow to a seed per ~40 read bases: sized once instead of doubling their way up)
+        u64 bases = 0;
+        for (u64 i = first_read; i < end_read; ++i) bases += RD->lens[i];
+        u64 const guess = 2 * (bases / 32 + (end_read - first_read)) / std::max<u64>(1, P->seed_sampling_step_size) + 64;
+        seeds.reserve(guess);
+        seed_owner.reserve(guess);
+        reads.reserve(end_read - first_read);
+    }
     for (u64 i = first_read; i < end_read; ++i) {
         u64 const len = RD->lens[i];
         if (len == 0 || len > 100000) { run->skipped[i] = 1; continue; }                       // input.cpp:95-110
