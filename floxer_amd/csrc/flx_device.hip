@@ -1388,11 +1388,74 @@ __global__ void __launch_bounds__(256) vr_next_kernel(const DevVrAnchor* __restr
     if (lane_id() == 0) { atomicAdd(&scalars[VR_N_CLIMBING], (u32)__popcll(m)); atomicMin(&scalars[VR_SMALLEST], wmin); }
 }
 
+// Inclusive scans (sum / max) of the rounds' flag arrays in two launches without any waiting between blocks: every block reduces
+// its tile, then every block scans its tile again behind the reduction of the tiles before it (a few hundred words it adds up
+// itself). The library scans are single-pass with decoupled look-back: their blocks spin on their predecessors' results, which on a
+// GPU filled with other lanes' kernels made a 1.2 M-element scan take a millisecond and burn issue slots meanwhile (11 % of the
+// kernel time of a run went into them); an onesweep radix sort in place of rocprim's merge sort for the same reason cost 10 % of the
+// throughput.
+constexpr u32 SCAN_ITEMS = 8, SCAN_TILE = 256 * SCAN_ITEMS;
+template <bool MAX> __device__ __forceinline__ u32 scan_op(u32 a, u32 b) { return MAX ? max(a, b) : a + b; }
+template <bool MAX>
+__device__ __forceinline__ u32 block_reduce_256(u32 v, u32* __restrict__ lds4) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = scan_op<MAX>(v, (u32)__shfl_xor((int)v, off));
+    if (lane_id() == 0) lds4[threadIdx.x >> 6] = v;
+    __syncthreads();
+    u32 const r = scan_op<MAX>(scan_op<MAX>(lds4[0], lds4[1]), scan_op<MAX>(lds4[2], lds4[3]));
+    __syncthreads();
+    return r;
+}
+template <bool MAX>
+__global__ void __launch_bounds__(256) vr_scan_reduce_kernel(const u32* __restrict__ in, u32 n, u32* __restrict__ tile_total) {
+    __shared__ u32 lds4[4];
+    u32 const base = blockIdx.x * SCAN_TILE + threadIdx.x * SCAN_ITEMS;
+    u32 v = 0;
+#pragma unroll
+    for (u32 j = 0; j < SCAN_ITEMS; ++j) if (base + j < n) v = scan_op<MAX>(v, in[base + j]);
+    u32 const total = block_reduce_256<MAX>(v, lds4);
+    if (threadIdx.x == 0) tile_total[blockIdx.x] = total;
+}
+template <bool MAX>
+__global__ void __launch_bounds__(256) vr_scan_apply_kernel(const u32* __restrict__ in, u32 n, const u32* __restrict__ tile_total, u32* __restrict__ out) {
+    __shared__ u32 lds4[4];
+    __shared__ u32 wave_total[4];
+    u32 before = 0;                                       // the tiles before this one
+    for (u32 t = threadIdx.x; t < blockIdx.x; t += 256u) before = scan_op<MAX>(before, tile_total[t]);
+    before = block_reduce_256<MAX>(before, lds4);
+    u32 const base = blockIdx.x * SCAN_TILE + threadIdx.x * SCAN_ITEMS;
+    u32 item[SCAN_ITEMS];
+    u32 run = 0;
+#pragma unroll
+    for (u32 j = 0; j < SCAN_ITEMS; ++j) { run = scan_op<MAX>(run, base + j < n ? in[base + j] : 0u); item[j] = run; }
+    // exclusive scan of the threads' totals: within the wave by shuffles, across the four waves through LDS
+    u32 incl = run;
+#pragma unroll
+    for (u32 off = 1; off < 64u; off <<= 1) {
+        u32 const up = (u32)__shfl_up((int)incl, off);
+        if (lane_id() >= off) incl = scan_op<MAX>(incl, up);
+    }
+    if (lane_id() == 63u) wave_total[threadIdx.x >> 6] = incl;
+    __syncthreads();
+    u32 prefix = before;
+    for (u32 w = 0; w < (threadIdx.x >> 6); ++w) prefix = scan_op<MAX>(prefix, wave_total[w]);
+    u32 const excl = (u32)__shfl_up((int)incl, 1);
+    if (lane_id() > 0) prefix = scan_op<MAX>(prefix, excl);
+#pragma unroll
+    for (u32 j = 0; j < SCAN_ITEMS; ++j) if (base + j < n) out[base + j] = scan_op<MAX>(prefix, item[j]);
+}
+template <bool MAX>
+static void vr_inclusive_scan(hipStream_t s, const u32* in, u32* out, u32 n, u32* tile_total) {
+    unsigned const tiles = (n + SCAN_TILE - 1) / SCAN_TILE;
+    hipLaunchKernelGGL((vr_scan_reduce_kernel<MAX>), dim3(tiles), dim3(256), 0, s, in, n, tile_total);
+    hipLaunchKernelGGL((vr_scan_apply_kernel<MAX>), dim3(tiles), dim3(256), 0, s, in, n, tile_total, out);
+}
+
 size_t DeviceApi::vr_tmp_bytes(u32 n) {
     size_t a = 0, b = 0, c = 0;
     (void)rocprim::radix_sort_pairs(nullptr, a, (u64*)nullptr, (u64*)nullptr, (u32*)nullptr, (u32*)nullptr, (size_t)n, 0u, 64u, (hipStream_t)nullptr);
-    (void)hipcub::DeviceScan::InclusiveSum(nullptr, b, (const u32*)nullptr, (u32*)nullptr, (int)n);
-    (void)hipcub::DeviceScan::InclusiveScan(nullptr, c, (const u32*)nullptr, (u32*)nullptr, hipcub::Max(), (int)n);
+    b = ((size_t)n / SCAN_TILE + 1) * sizeof(u32);       // tile totals of vr_inclusive_scan
+    c = 0;
     return std::max(a, std::max(b, c)) + 256;
 }
 
@@ -1408,16 +1471,13 @@ int DeviceApi::vr_round_requests(void* stream, VrBuffers const& B, u32 n, u32 li
     size_t tb = B.tmp_bytes;
     if ((e = rocprim::radix_sort_pairs(B.tmp, tb, B.key_mid, B.key1s, B.idx, B.idxs, (size_t)n, 0u, std::min(64u, 32u + node_bits + query_bits), s)) != hipSuccess) return (int)e;
     hipLaunchKernelGGL(vr_flag_requests_kernel, dim3(blocks), dim3(256), 0, s, B.key1s, n, B.flag_u, B.scalars);
-    tb = B.tmp_bytes;
-    if ((e = hipcub::DeviceScan::InclusiveSum(B.tmp, tb, B.flag_u, B.uid, (int)n, s)) != hipSuccess) return (int)e;
+    vr_inclusive_scan<false>(s, B.flag_u, B.uid, n, (u32*)B.tmp);
     hipLaunchKernelGGL(vr_scatter_unique_kernel, dim3(blocks), dim3(256), 0, s, B.key1, B.key2, B.idxs, B.flag_u, B.uid, n, B.ukey1, B.ukey2, B.urep, B.scalars);
     // (the kernels below run over at most n distinct requests and stop at the device-side count)
     hipLaunchKernelGGL(vr_run_heads_kernel, dim3(blocks), dim3(256), 0, s, B.ukey1, B.scalars, B.run_first);
-    tb = B.tmp_bytes;
-    if ((e = hipcub::DeviceScan::InclusiveScan(B.tmp, tb, B.run_first, B.run_first, hipcub::Max(), (int)n, s)) != hipSuccess) return (int)e;
+    vr_inclusive_scan<true>(s, B.run_first, B.run_first, n, (u32*)B.tmp);
     hipLaunchKernelGGL(vr_flag_clusters_kernel, dim3(blocks), dim3(256), 0, s, B.ukey1, B.ukey2, B.run_first, B.scalars, B.flag_c);
-    tb = B.tmp_bytes;
-    if ((e = hipcub::DeviceScan::InclusiveSum(B.tmp, tb, B.flag_c, B.cid, (int)n, s)) != hipSuccess) return (int)e;
+    vr_inclusive_scan<false>(s, B.flag_c, B.cid, n, (u32*)B.tmp);
     hipLaunchKernelGGL(vr_cluster_starts_kernel, dim3(blocks), dim3(256), 0, s, B.flag_c, B.cid, B.scalars, B.cstart);
     hipLaunchKernelGGL(vr_jobs_kernel, dim3(blocks), dim3(256), 0, s, B.ukey1, B.ukey2, B.urep, B.cstart, B.anchors, B.nodes, B.node, B.scalars, B.jobs);
     // the job list by launch shape (two slots per cluster, at most n clusters)
