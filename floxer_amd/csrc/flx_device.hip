@@ -845,6 +845,78 @@ int DeviceApi::search(void* stream, const DevIndex& idx, const u8* d_seq, const 
     return (int)hipGetLastError();
 }
 
+// Scans (sum / max, inclusive / exclusive) of the pipeline's flag and count arrays in two launches without any waiting between blocks: every block reduces
+// its tile, then every block scans its tile again behind the reduction of the tiles before it (a few hundred words it adds up
+// itself). The library scans are single-pass with decoupled look-back: their blocks spin on their predecessors' results, which on a
+// GPU filled with other lanes' kernels made a 1.2 M-element scan take a millisecond and burn issue slots meanwhile (11 % of the
+// kernel time of a run went into them); an onesweep radix sort in place of rocprim's merge sort for the same reason cost 10 % of the
+// throughput.
+constexpr u32 SCAN_ITEMS = 8, SCAN_TILE = 256 * SCAN_ITEMS;
+template <bool MAX> __device__ __forceinline__ u32 scan_op(u32 a, u32 b) { return MAX ? max(a, b) : a + b; }
+template <bool MAX>
+__device__ __forceinline__ u32 block_reduce_256(u32 v, u32* __restrict__ lds4) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = scan_op<MAX>(v, (u32)__shfl_xor((int)v, off));
+    if (lane_id() == 0) lds4[threadIdx.x >> 6] = v;
+    __syncthreads();
+    u32 const r = scan_op<MAX>(scan_op<MAX>(lds4[0], lds4[1]), scan_op<MAX>(lds4[2], lds4[3]));
+    __syncthreads();
+    return r;
+}
+template <bool MAX>
+__global__ void __launch_bounds__(256) vr_scan_reduce_kernel(const u32* __restrict__ in, u32 n, u32* __restrict__ tile_total) {
+    __shared__ u32 lds4[4];
+    u32 const base = blockIdx.x * SCAN_TILE + threadIdx.x * SCAN_ITEMS;
+    u32 v = 0;
+#pragma unroll
+    for (u32 j = 0; j < SCAN_ITEMS; ++j) if (base + j < n) v = scan_op<MAX>(v, in[base + j]);
+    u32 const total = block_reduce_256<MAX>(v, lds4);
+    if (threadIdx.x == 0) tile_total[blockIdx.x] = total;
+}
+template <bool MAX, bool EXCLUSIVE = false>
+__global__ void __launch_bounds__(256) vr_scan_apply_kernel(const u32* __restrict__ in, u32 n, const u32* __restrict__ tile_total, u32* __restrict__ out) {
+    __shared__ u32 lds4[4];
+    __shared__ u32 wave_total[4];
+    u32 before = 0;                                       // the tiles before this one
+    for (u32 t = threadIdx.x; t < blockIdx.x; t += 256u) before = scan_op<MAX>(before, tile_total[t]);
+    before = block_reduce_256<MAX>(before, lds4);
+    u32 const base = blockIdx.x * SCAN_TILE + threadIdx.x * SCAN_ITEMS;
+    u32 item[SCAN_ITEMS];
+    u32 run = 0;
+#pragma unroll
+    for (u32 j = 0; j < SCAN_ITEMS; ++j) {
+        if (EXCLUSIVE) item[j] = run;
+        run = scan_op<MAX>(run, base + j < n ? in[base + j] : 0u);
+        if (!EXCLUSIVE) item[j] = run;
+    }
+    // exclusive scan of the threads' totals: within the wave by shuffles, across the four waves through LDS
+    u32 incl = run;
+#pragma unroll
+    for (u32 off = 1; off < 64u; off <<= 1) {
+        u32 const up = (u32)__shfl_up((int)incl, off);
+        if (lane_id() >= off) incl = scan_op<MAX>(incl, up);
+    }
+    if (lane_id() == 63u) wave_total[threadIdx.x >> 6] = incl;
+    __syncthreads();
+    u32 prefix = before;
+    for (u32 w = 0; w < (threadIdx.x >> 6); ++w) prefix = scan_op<MAX>(prefix, wave_total[w]);
+    u32 const excl = (u32)__shfl_up((int)incl, 1);
+    if (lane_id() > 0) prefix = scan_op<MAX>(prefix, excl);
+#pragma unroll
+    for (u32 j = 0; j < SCAN_ITEMS; ++j) if (base + j < n) out[base + j] = scan_op<MAX>(prefix, item[j]);
+}
+template <bool MAX>
+static void vr_inclusive_scan(hipStream_t s, const u32* in, u32* out, u32 n, u32* tile_total) {
+    unsigned const tiles = (n + SCAN_TILE - 1) / SCAN_TILE;
+    hipLaunchKernelGGL((vr_scan_reduce_kernel<MAX>), dim3(tiles), dim3(256), 0, s, in, n, tile_total);
+    hipLaunchKernelGGL((vr_scan_apply_kernel<MAX, false>), dim3(tiles), dim3(256), 0, s, in, n, tile_total, out);
+}
+static void exclusive_sum(hipStream_t s, const u32* in, u32* out, u32 n, u32* tile_total) {
+    unsigned const tiles = (n + SCAN_TILE - 1) / SCAN_TILE;
+    hipLaunchKernelGGL((vr_scan_reduce_kernel<false>), dim3(tiles), dim3(256), 0, s, in, n, tile_total);
+    hipLaunchKernelGGL((vr_scan_apply_kernel<false, true>), dim3(tiles), dim3(256), 0, s, in, n, tile_total, out);
+}
+
 // ================================================================================================ K1b: anchor selection
 // hits -> per-seed segments in emission order (a scan over the seeds' hit counts + a scatter by the ordinal each hit carries),
 // then one thread per seed does what search.cpp:190-318 does with the seed's groups: hard cap, group order, rows round robin,
@@ -1022,9 +1094,7 @@ __global__ void __launch_bounds__(256) seed_compact_kernel(const DevOutAnchor* _
 }
 
 size_t DeviceApi::select_scan_bytes(u32 n_seeds) {
-    size_t bytes = 0;
-    (void)hipcub::DeviceScan::ExclusiveSum(nullptr, bytes, (const u32*)nullptr, (u32*)nullptr, (int)n_seeds + 1);
-    return bytes;
+    return ((size_t)(n_seeds + 1) / SCAN_TILE + 1) * sizeof(u32);        // tile totals of exclusive_sum
 }
 
 int DeviceApi::select(void* stream, const DevHit* d_hits, const u32* d_counters, u32 hit_cap, u32* d_seed_cnt, u32* d_hit_offset,
@@ -1034,8 +1104,8 @@ int DeviceApi::select(void* stream, const DevHit* d_hits, const u32* d_counters,
     if (n_seeds == 0) return 0;
     hipStream_t s = (hipStream_t)stream;
     // d_seed_cnt, d_rows and d_n_out have n_seeds + 1 entries, the last one zero: the scans end with the totals
-    hipError_t e = hipcub::DeviceScan::ExclusiveSum(d_scan_tmp, scan_bytes, d_seed_cnt, d_hit_offset, (int)n_seeds + 1, s);
-    if (e != hipSuccess) return (int)e;
+    hipError_t e = hipSuccess;
+    exclusive_sum(s, d_seed_cnt, d_hit_offset, n_seeds + 1, (u32*)d_scan_tmp);
     hipLaunchKernelGGL(hit_scatter_kernel, dim3(2048), dim3(256), 0, s, d_hits, d_counters, hit_cap, d_hit_offset, d_grouped);
     SelStat* const stat = reinterpret_cast<SelStat*>(d_stat);
     u32* const list_counts = d_lists + 2 * (size_t)n_seeds;
@@ -1043,16 +1113,14 @@ int DeviceApi::select(void* stream, const DevHit* d_hits, const u32* d_counters,
     hipLaunchKernelGGL(seed_rows_kernel, dim3((n_seeds + 255) / 256), dim3(256), 0, s, d_grouped, d_hit_offset, n_seeds, hard_cap, soft_cap, d_rows,
                        stat, d_n_out, d_lists, list_counts);
     if ((e = hipGetLastError()) != hipSuccess) return (int)e;
-    e = hipcub::DeviceScan::ExclusiveSum(d_scan_tmp, scan_bytes, d_rows, d_row_offset, (int)n_seeds + 1, s);
-    if (e != hipSuccess) return (int)e;
+    exclusive_sum(s, d_rows, d_row_offset, n_seeds + 1, (u32*)d_scan_tmp);
     // grids sized for the usual shares (a quarter of the seeds light, a per cent heavy); the kernels loop over their lists
     hipLaunchKernelGGL((seed_select_kernel<SEL_LIGHT>), dim3(std::max(1u, (n_seeds / 4 + 63) / 64)), dim3(64), 0, s, d_lists, list_counts, d_grouped, d_hit_offset,
                        idx.sa, idx.n, d_seq_start, n_ref, erase ? 1u : 0u, stat, d_n_out, d_row_offset, d_rows, d_sparse, sparse_cap);
     hipLaunchKernelGGL((seed_select_kernel<SEL_MAX>), dim3(std::max(1u, (n_seeds / 64 + 63) / 64)), dim3(64), 0, s, d_lists + n_seeds, list_counts + 1, d_grouped,
                        d_hit_offset, idx.sa, idx.n, d_seq_start, n_ref, erase ? 1u : 0u, stat, d_n_out, d_row_offset, d_rows, d_sparse, sparse_cap);
     if ((e = hipGetLastError()) != hipSuccess) return (int)e;
-    e = hipcub::DeviceScan::ExclusiveSum(d_scan_tmp, scan_bytes, d_n_out, d_out_offset, (int)n_seeds + 1, s);
-    if (e != hipSuccess) return (int)e;
+    exclusive_sum(s, d_n_out, d_out_offset, n_seeds + 1, (u32*)d_scan_tmp);
     hipLaunchKernelGGL(seed_compact_kernel, dim3((n_seeds + 255) / 256), dim3(256), 0, s, d_sparse, d_row_offset, d_n_out, d_out_offset, n_seeds,
                        d_out, out_cap);
     return (int)hipGetLastError();
@@ -1386,69 +1454,6 @@ __global__ void __launch_bounds__(256) vr_next_kernel(const DevVrAnchor* __restr
     if (!m) return;
     u32 const wmin = (u32)~wave_max_u32(~rows);
     if (lane_id() == 0) { atomicAdd(&scalars[VR_N_CLIMBING], (u32)__popcll(m)); atomicMin(&scalars[VR_SMALLEST], wmin); }
-}
-
-// Inclusive scans (sum / max) of the rounds' flag arrays in two launches without any waiting between blocks: every block reduces
-// its tile, then every block scans its tile again behind the reduction of the tiles before it (a few hundred words it adds up
-// itself). The library scans are single-pass with decoupled look-back: their blocks spin on their predecessors' results, which on a
-// GPU filled with other lanes' kernels made a 1.2 M-element scan take a millisecond and burn issue slots meanwhile (11 % of the
-// kernel time of a run went into them); an onesweep radix sort in place of rocprim's merge sort for the same reason cost 10 % of the
-// throughput.
-constexpr u32 SCAN_ITEMS = 8, SCAN_TILE = 256 * SCAN_ITEMS;
-template <bool MAX> __device__ __forceinline__ u32 scan_op(u32 a, u32 b) { return MAX ? max(a, b) : a + b; }
-template <bool MAX>
-__device__ __forceinline__ u32 block_reduce_256(u32 v, u32* __restrict__ lds4) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v = scan_op<MAX>(v, (u32)__shfl_xor((int)v, off));
-    if (lane_id() == 0) lds4[threadIdx.x >> 6] = v;
-    __syncthreads();
-    u32 const r = scan_op<MAX>(scan_op<MAX>(lds4[0], lds4[1]), scan_op<MAX>(lds4[2], lds4[3]));
-    __syncthreads();
-    return r;
-}
-template <bool MAX>
-__global__ void __launch_bounds__(256) vr_scan_reduce_kernel(const u32* __restrict__ in, u32 n, u32* __restrict__ tile_total) {
-    __shared__ u32 lds4[4];
-    u32 const base = blockIdx.x * SCAN_TILE + threadIdx.x * SCAN_ITEMS;
-    u32 v = 0;
-#pragma unroll
-    for (u32 j = 0; j < SCAN_ITEMS; ++j) if (base + j < n) v = scan_op<MAX>(v, in[base + j]);
-    u32 const total = block_reduce_256<MAX>(v, lds4);
-    if (threadIdx.x == 0) tile_total[blockIdx.x] = total;
-}
-template <bool MAX>
-__global__ void __launch_bounds__(256) vr_scan_apply_kernel(const u32* __restrict__ in, u32 n, const u32* __restrict__ tile_total, u32* __restrict__ out) {
-    __shared__ u32 lds4[4];
-    __shared__ u32 wave_total[4];
-    u32 before = 0;                                       // the tiles before this one
-    for (u32 t = threadIdx.x; t < blockIdx.x; t += 256u) before = scan_op<MAX>(before, tile_total[t]);
-    before = block_reduce_256<MAX>(before, lds4);
-    u32 const base = blockIdx.x * SCAN_TILE + threadIdx.x * SCAN_ITEMS;
-    u32 item[SCAN_ITEMS];
-    u32 run = 0;
-#pragma unroll
-    for (u32 j = 0; j < SCAN_ITEMS; ++j) { run = scan_op<MAX>(run, base + j < n ? in[base + j] : 0u); item[j] = run; }
-    // exclusive scan of the threads' totals: within the wave by shuffles, across the four waves through LDS
-    u32 incl = run;
-#pragma unroll
-    for (u32 off = 1; off < 64u; off <<= 1) {
-        u32 const up = (u32)__shfl_up((int)incl, off);
-        if (lane_id() >= off) incl = scan_op<MAX>(incl, up);
-    }
-    if (lane_id() == 63u) wave_total[threadIdx.x >> 6] = incl;
-    __syncthreads();
-    u32 prefix = before;
-    for (u32 w = 0; w < (threadIdx.x >> 6); ++w) prefix = scan_op<MAX>(prefix, wave_total[w]);
-    u32 const excl = (u32)__shfl_up((int)incl, 1);
-    if (lane_id() > 0) prefix = scan_op<MAX>(prefix, excl);
-#pragma unroll
-    for (u32 j = 0; j < SCAN_ITEMS; ++j) if (base + j < n) out[base + j] = scan_op<MAX>(prefix, item[j]);
-}
-template <bool MAX>
-static void vr_inclusive_scan(hipStream_t s, const u32* in, u32* out, u32 n, u32* tile_total) {
-    unsigned const tiles = (n + SCAN_TILE - 1) / SCAN_TILE;
-    hipLaunchKernelGGL((vr_scan_reduce_kernel<MAX>), dim3(tiles), dim3(256), 0, s, in, n, tile_total);
-    hipLaunchKernelGGL((vr_scan_apply_kernel<MAX>), dim3(tiles), dim3(256), 0, s, in, n, tile_total, out);
 }
 
 size_t DeviceApi::vr_tmp_bytes(u32 n) {
