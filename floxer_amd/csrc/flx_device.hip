@@ -1456,35 +1456,6 @@ __global__ void __launch_bounds__(256) vr_next_kernel(const DevVrAnchor* __restr
     if (lane_id() == 0) { atomicAdd(&scalars[VR_N_CLIMBING], (u32)__popcll(m)); atomicMin(&scalars[VR_SMALLEST], wmin); }
 }
 
-// The anchors of a chunk come query by query, and a request's sort key starts with its query: sorting the keys of every query on
-// their own (one block per query, in LDS) orders the whole list, except that the keys of anchors outside the round (~0) end up
-// behind their own query's requests instead of behind everyone's, which none of the kernels after the sort minds. One launch
-// instead of the twenty of a merge sort of a million keys. VR_SEGMENT = the most anchors of one query a block takes.
-constexpr u32 VR_SEG_ITEMS = 8, VR_SEGMENT = 256 * VR_SEG_ITEMS;
-__global__ void __launch_bounds__(256) vr_segment_sort_kernel(const u64* __restrict__ keys_in, const u32* __restrict__ idx_in, const u32* __restrict__ query_first,
-                                                              u32 end_bit, u64* __restrict__ keys_out, u32* __restrict__ idx_out) {
-    using Sort = hipcub::BlockRadixSort<u64, 256, VR_SEG_ITEMS, u32>;
-    __shared__ typename Sort::TempStorage tmp;
-    u32 const first = query_first[blockIdx.x], count = query_first[blockIdx.x + 1] - first;
-    if (count == 0) return;
-    u64 k[VR_SEG_ITEMS];
-    u32 v[VR_SEG_ITEMS];
-#pragma unroll
-    for (u32 j = 0; j < VR_SEG_ITEMS; ++j) {
-        u32 const at = threadIdx.x * VR_SEG_ITEMS + j;
-        k[j] = at < count ? keys_in[first + at] : ~0ull;
-        v[j] = at < count ? idx_in[first + at] : 0xFFFFFFFFu;
-    }
-    Sort(tmp).Sort(k, v, 0, (int)end_bit);
-#pragma unroll
-    for (u32 j = 0; j < VR_SEG_ITEMS; ++j) {
-        u32 const at = threadIdx.x * VR_SEG_ITEMS + j;
-        if (at < count) { keys_out[first + at] = k[j]; idx_out[first + at] = v[j]; }
-    }
-}
-
-u32 DeviceApi::vr_segment_capacity() { return VR_SEGMENT; }
-
 size_t DeviceApi::vr_tmp_bytes(u32 n) {
     size_t a = 0, b = 0, c = 0;
     (void)rocprim::radix_sort_pairs(nullptr, a, (u64*)nullptr, (u64*)nullptr, (u32*)nullptr, (u32*)nullptr, (size_t)n, 0u, 64u, (hipStream_t)nullptr);
@@ -1502,14 +1473,8 @@ int DeviceApi::vr_round_requests(void* stream, VrBuffers const& B, u32 n, u32 li
     hipLaunchKernelGGL(vr_select_kernel, dim3(blocks), dim3(256), 0, s, B.anchors, B.nodes, B.node, B.status, n, limit, node_bits, B.key1, B.key2, B.key_mid, B.idx,
                        B.scalars, B.plan);
     // order by (node, window start): one sort over the bits in use; the anchor index rides along
-    if (B.query_first && !getenv("FLX_ROUND_GLOBAL_SORT")) {
-        // (padding keys are ~0 like the keys of anchors outside the round: both sort behind every request over the bits compared)
-        hipLaunchKernelGGL(vr_segment_sort_kernel, dim3(B.n_queries), dim3(256), 0, s, B.key_mid, B.idx, B.query_first, std::min(64u, 32u + node_bits),
-                           B.key1s, B.idxs);
-    } else {
-        size_t tb = B.tmp_bytes;
-        if ((e = rocprim::radix_sort_pairs(B.tmp, tb, B.key_mid, B.key1s, B.idx, B.idxs, (size_t)n, 0u, std::min(64u, 32u + node_bits + query_bits), s)) != hipSuccess) return (int)e;
-    }
+    size_t tb = B.tmp_bytes;
+    if ((e = rocprim::radix_sort_pairs(B.tmp, tb, B.key_mid, B.key1s, B.idx, B.idxs, (size_t)n, 0u, std::min(64u, 32u + node_bits + query_bits), s)) != hipSuccess) return (int)e;
     hipLaunchKernelGGL(vr_flag_requests_kernel, dim3(blocks), dim3(256), 0, s, B.key1s, n, B.flag_u, B.scalars);
     vr_inclusive_scan<false>(s, B.flag_u, B.uid, n, (u32*)B.tmp);
     hipLaunchKernelGGL(vr_scatter_unique_kernel, dim3(blocks), dim3(256), 0, s, B.key1, B.key2, B.idxs, B.flag_u, B.uid, n, B.ukey1, B.ukey2, B.urep, B.scalars);

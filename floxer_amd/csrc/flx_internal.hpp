@@ -177,8 +177,6 @@ struct VrBuffers {
     u64 *key1, *key2;                            // per anchor: the request {query offset << 20 | rows, reference offset << 20 | window length}
     u64 *key_mid, *key1s;                        // per anchor: sort key (node name << 32 | window start; ~0: not in this round), unsorted / sorted
     u32 *idx, *idxs;                             // per anchor: anchor index, unsorted / in sorted order
-    const u32* query_first;                      // first anchor of every query (anchors come query by query), n_queries + 1 entries; null:
-    u32 n_queries;                               //   some query has more anchors than a block sorts: the whole chunk is sorted at once
     u32 *flag_u, *uid, *flag_c, *cid, *run_first;// per sorted request / per distinct request
     u64 *ukey1, *ukey2; u32* urep;               // per distinct request: keys and one anchor that asked for it
     u32* cstart;                                 // per cluster: its first distinct request (n_clusters + 1 entries)
@@ -261,7 +259,6 @@ struct DeviceApi {
     // (scalar VR_N_UNDECIDED); apply: B.state = one decision per cluster (1 pass, 2 fail, 0: look at d_override, one per distinct
     // request, may be null), then scalars VR_N_CLIMBING / VR_SMALLEST for the next round
     static size_t vr_tmp_bytes(u32 n_anchors);
-    static u32 vr_segment_capacity();            // most anchors of one query the per-query sort of a round takes (VrBuffers::query_first)
     static int vr_round_requests(void* stream, VrBuffers const& B, u32 n_anchors, u32 limit, u32 query_bits, u32 node_bits);
     static int vr_round_decide(void* stream, VrBuffers const& B, u32 n_anchors);
     // undecided clusters: members: one job per distinct request of such a cluster replaces the round's job list (B.jobs, slot = the

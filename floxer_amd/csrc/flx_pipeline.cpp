@@ -1811,13 +1811,6 @@ int align_slice(Lane* lane, const flx_params* P, const flx_reads* RD, u64 first_
             h_status[i] = climbs ? VR_CLIMBING : a.at_root ? VR_AT_ROOT : VR_DEAD;
             if (climbs) { ++n_climbing; smallest = std::min(smallest, nodes[tb + a.node].rows); }
         }
-        // first anchor of every query (the anchors are in seed order: read by read, forward then reverse complement)
-        u32 const n_queries = 2 * (u32)reads.size();
-        hvec<u32> query_first(n_queries + 1, 0);
-        for (u32 i = 0; i < n; ++i) query_first[da[i].query + 1]++;
-        u32 largest_query = 0;
-        for (u32 q = 0; q < n_queries; ++q) { largest_query = std::max(largest_query, query_first[q + 1]); query_first[q + 1] += query_first[q]; }
-        bool const per_query_sort = largest_query <= DeviceApi::vr_segment_capacity();
         // ---- one device buffer cut into the arrays of VrBuffers
         size_t const tmp_bytes = DeviceApi::vr_tmp_bytes(n);
         size_t off = 0;
@@ -1829,7 +1822,7 @@ int align_slice(Lane* lane, const flx_params* P, const flx_reads* RD, u64 first_
                      o_run = take((size_t)n * 4), o_ukey1 = take((size_t)n * 8), o_ukey2 = take((size_t)n * 8), o_urep = take((size_t)n * 4),
                      o_cstart = take(((size_t)n + 1) * 4), o_jobs = take((size_t)n * 2 * sizeof(DevVrJob)), o_scalars = take(64), o_tmp = take(tmp_bytes),
                      o_class = take((size_t)n * 2), o_ajobs = take((size_t)n * 2 * sizeof(DevAlignJob)), o_outs = take((size_t)n * 2 * sizeof(DevAlignOut)),
-                     o_state = take(n), o_plan = take(sizeof(DevVrPlan)), o_qfirst = take(((size_t)n_queries + 1) * 4);
+                     o_state = take(n), o_plan = take(sizeof(DevVrPlan));
         vprof.mark("anchor-table");
         if ((rc = lane->vr.ensure(off))) return rc;
         char* const base = (char*)lane->vr.ptr;
@@ -1842,12 +1835,10 @@ int align_slice(Lane* lane, const flx_params* P, const flx_reads* RD, u64 first_
         B.jobs = (DevVrJob*)(base + o_jobs); B.scalars = (u32*)(base + o_scalars); B.tmp = base + o_tmp; B.tmp_bytes = tmp_bytes;
         B.job_class = (u8*)(base + o_class); B.align_jobs = (DevAlignJob*)(base + o_ajobs); B.outs = (DevAlignOut*)(base + o_outs);
         B.state = (u8*)(base + o_state); B.plan = (DevVrPlan*)(base + o_plan);
-        B.query_first = per_query_sort ? (const u32*)(base + o_qfirst) : nullptr; B.n_queries = n_queries;
         FLX_HIP(hipMemcpyAsync(base + o_anchors, da.data(), (size_t)n * sizeof(DevVrAnchor), hipMemcpyHostToDevice, lane->stream));
         FLX_HIP(hipMemcpyAsync(base + o_nodes, nodes.data(), nodes.size() * sizeof(DevVrNode), hipMemcpyHostToDevice, lane->stream));
         FLX_HIP(hipMemcpyAsync(base + o_node, h_node.data(), (size_t)n * 4, hipMemcpyHostToDevice, lane->stream));
         FLX_HIP(hipMemcpyAsync(base + o_status, h_status.data(), n, hipMemcpyHostToDevice, lane->stream));
-        FLX_HIP(hipMemcpyAsync(base + o_qfirst, query_first.data(), ((size_t)n_queries + 1) * 4, hipMemcpyHostToDevice, lane->stream));
         if ((rc = lane->vr_override.ensure(n + 64))) return rc;
         DevVrPlan plan;
         vprof.mark("upload");
