@@ -1426,13 +1426,13 @@ __global__ void __launch_bounds__(256) vr_decide_kernel(const DevVrJob* __restri
     u64 const m = __ballot(undecided);
     if (m && lane_id() == 0) atomicAdd(&scalars[VR_N_UNDECIDED], (u32)__popcll(m));
 }
-__global__ void __launch_bounds__(256) vr_apply_kernel(const u64* __restrict__ key1s, const u32* __restrict__ idxs, const u32* __restrict__ uid,
+__global__ void __launch_bounds__(256) vr_apply_kernel(const u64* __restrict__ sorted_key, const u32* __restrict__ idxs, const u32* __restrict__ uid,
                                                        const u32* __restrict__ cid, const u8* __restrict__ state, const u8* __restrict__ override_,
                                                        const DevVrAnchor* __restrict__ anchors, const DevVrNode* __restrict__ nodes, u32 n,
                                                        u32* __restrict__ node, u8* __restrict__ status, u32* __restrict__ scalars) {
     u32 const i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i == 0) { scalars[VR_N_CLIMBING] = 0u; scalars[VR_SMALLEST] = 0xFFFFFFFFu; }      // vr_next_kernel, the next launch, counts into them
-    if (i >= n || key1s[i] == ~0ull) return;
+    if (i >= n || sorted_key[i] == ~0ull) return;
     u32 const u = uid[i] - 1u;
     u8 dec = override_ ? override_[u] : (u8)0;
     if (!dec) dec = state[cid[u] - 1u];
@@ -1470,12 +1470,12 @@ int DeviceApi::vr_round_requests(void* stream, VrBuffers const& B, u32 n, u32 li
     hipError_t e;
     unsigned const blocks = (n + 255) / 256;
     static_assert(sizeof(DevVrPlan) % 4 == 0, "the plan is zeroed word by word");
-    hipLaunchKernelGGL(vr_select_kernel, dim3(blocks), dim3(256), 0, s, B.anchors, B.nodes, B.node, B.status, n, limit, node_bits, B.key1, B.key2, B.key_mid, B.idx,
+    hipLaunchKernelGGL(vr_select_kernel, dim3(blocks), dim3(256), 0, s, B.anchors, B.nodes, B.node, B.status, n, limit, node_bits, B.key1, B.key2, B.sort_key, B.idx,
                        B.scalars, B.plan);
     // order by (node, window start): one sort over the bits in use; the anchor index rides along
     size_t tb = B.tmp_bytes;
-    if ((e = rocprim::radix_sort_pairs(B.tmp, tb, B.key_mid, B.key1s, B.idx, B.idxs, (size_t)n, 0u, std::min(64u, 32u + node_bits + query_bits), s)) != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(vr_flag_requests_kernel, dim3(blocks), dim3(256), 0, s, B.key1s, n, B.flag_u, B.scalars);
+    if ((e = rocprim::radix_sort_pairs(B.tmp, tb, B.sort_key, B.sorted_key, B.idx, B.idxs, (size_t)n, 0u, std::min(64u, 32u + node_bits + query_bits), s)) != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(vr_flag_requests_kernel, dim3(blocks), dim3(256), 0, s, B.sorted_key, n, B.flag_u, B.scalars);
     vr_inclusive_scan<false>(s, B.flag_u, B.uid, n, (u32*)B.tmp);
     hipLaunchKernelGGL(vr_scatter_unique_kernel, dim3(blocks), dim3(256), 0, s, B.key1, B.key2, B.idxs, B.flag_u, B.uid, n, B.ukey1, B.ukey2, B.urep, B.scalars);
     // (the kernels below run over at most n distinct requests and stop at the device-side count)
@@ -1557,7 +1557,7 @@ int DeviceApi::vr_round_apply(void* stream, VrBuffers const& B, u32 n, const u8*
     if (n == 0) return 0;
     hipStream_t s = (hipStream_t)stream;
     unsigned const blocks = (n + 255) / 256;
-    hipLaunchKernelGGL(vr_apply_kernel, dim3(blocks), dim3(256), 0, s, B.key1s, B.idxs, B.uid, B.cid, B.state, d_override, B.anchors, B.nodes, n, B.node, B.status, B.scalars);
+    hipLaunchKernelGGL(vr_apply_kernel, dim3(blocks), dim3(256), 0, s, B.sorted_key, B.idxs, B.uid, B.cid, B.state, d_override, B.anchors, B.nodes, n, B.node, B.status, B.scalars);
     hipLaunchKernelGGL(vr_next_kernel, dim3(blocks), dim3(256), 0, s, B.anchors, B.nodes, B.node, B.status, n, B.scalars);
     return (int)hipGetLastError();
 }

@@ -175,7 +175,7 @@ struct VrBuffers {
     const DevVrAnchor* anchors; const DevVrNode* nodes;
     u32* node; u8* status;                       // per anchor, mutable
     u64 *key1, *key2;                            // per anchor: the request {query offset << 20 | rows, reference offset << 20 | window length}
-    u64 *key_mid, *key1s;                        // per anchor: sort key (node name << 32 | window start; ~0: not in this round), unsorted / sorted
+    u64 *sort_key, *sorted_key;                        // per anchor: sort key (node name << 32 | window start; ~0: not in this round), unsorted / sorted
     u32 *idx, *idxs;                             // per anchor: anchor index, unsorted / in sorted order
     u32 *flag_u, *uid, *flag_c, *cid, *run_first;// per sorted request / per distinct request
     u64 *ukey1, *ukey2; u32* urep;               // per distinct request: keys and one anchor that asked for it

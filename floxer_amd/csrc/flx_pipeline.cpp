@@ -1816,8 +1816,8 @@ int align_slice(Lane* lane, const flx_params* P, const flx_reads* RD, u64 first_
         size_t off = 0;
         auto take = [&](size_t bytes) { size_t const at = off; off += (bytes + 255) & ~(size_t)255; return at; };
         size_t const o_anchors = take((size_t)n * sizeof(DevVrAnchor)), o_nodes = take(nodes.size() * sizeof(DevVrNode)), o_node = take((size_t)n * 4),
-                     o_status = take(n), o_key1 = take((size_t)n * 8), o_key2 = take((size_t)n * 8), o_key1s = take((size_t)n * 8),
-                     o_key_mid = take((size_t)n * 8), o_idx = take((size_t)n * 4), o_idxs = take((size_t)n * 4),
+                     o_status = take(n), o_key1 = take((size_t)n * 8), o_key2 = take((size_t)n * 8), o_sorted_key = take((size_t)n * 8),
+                     o_sort_key = take((size_t)n * 8), o_idx = take((size_t)n * 4), o_idxs = take((size_t)n * 4),
                      o_flag_u = take((size_t)n * 4), o_uid = take((size_t)n * 4), o_flag_c = take((size_t)n * 4), o_cid = take((size_t)n * 4),
                      o_run = take((size_t)n * 4), o_ukey1 = take((size_t)n * 8), o_ukey2 = take((size_t)n * 8), o_urep = take((size_t)n * 4),
                      o_cstart = take(((size_t)n + 1) * 4), o_jobs = take((size_t)n * 2 * sizeof(DevVrJob)), o_scalars = take(64), o_tmp = take(tmp_bytes),
@@ -1828,7 +1828,7 @@ int align_slice(Lane* lane, const flx_params* P, const flx_reads* RD, u64 first_
         char* const base = (char*)lane->vr.ptr;
         VrBuffers B{};
         B.anchors = (const DevVrAnchor*)(base + o_anchors); B.nodes = (const DevVrNode*)(base + o_nodes); B.node = (u32*)(base + o_node); B.status = (u8*)(base + o_status);
-        B.key1 = (u64*)(base + o_key1); B.key2 = (u64*)(base + o_key2); B.key1s = (u64*)(base + o_key1s); B.key_mid = (u64*)(base + o_key_mid);
+        B.key1 = (u64*)(base + o_key1); B.key2 = (u64*)(base + o_key2); B.sorted_key = (u64*)(base + o_sorted_key); B.sort_key = (u64*)(base + o_sort_key);
         B.idx = (u32*)(base + o_idx); B.idxs = (u32*)(base + o_idxs);
         B.flag_u = (u32*)(base + o_flag_u); B.uid = (u32*)(base + o_uid); B.flag_c = (u32*)(base + o_flag_c); B.cid = (u32*)(base + o_cid); B.run_first = (u32*)(base + o_run);
         B.ukey1 = (u64*)(base + o_ukey1); B.ukey2 = (u64*)(base + o_ukey2); B.urep = (u32*)(base + o_urep); B.cstart = (u32*)(base + o_cstart);
