@@ -9,6 +9,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <string>
 #include <thread>
 #include <vector>
@@ -40,18 +41,34 @@ int bgzf_level() {
     return v;
 }
 
+// A deflate stream per I/O thread, made once and reset per block: deflateInit2 allocates and clears a quarter of a megabyte, which
+// for 64-KB blocks at level 1 costs as much as the compression and, with all threads in the allocator at once, made eight threads
+// slower than one.
+struct BlockDeflater {
+    z_stream zs;
+    bool ready = false;
+    ~BlockDeflater() { if (ready) deflateEnd(&zs); }
+    z_stream* get() {
+        if (ready) return deflateReset(&zs) == Z_OK ? &zs : nullptr;
+        memset(&zs, 0, sizeof(zs));
+        if (deflateInit2(&zs, bgzf_level(), Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY) != Z_OK) return nullptr;
+        ready = true;
+        return &zs;
+    }
+};
+
 // one BGZF block (a gzip member with the BC extra field) for `len` <= BGZF_BLOCK bytes; returns its size, 0 on failure
 size_t bgzf_compress_block(const uint8_t* data, size_t len, uint8_t* out) {
-    z_stream zs;
-    memset(&zs, 0, sizeof(zs));
-    if (deflateInit2(&zs, bgzf_level(), Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY) != Z_OK) return 0;
+    thread_local BlockDeflater deflater;
+    z_stream* const zp = deflater.get();
+    if (!zp) return 0;
+    z_stream& zs = *zp;
     zs.next_in = const_cast<Bytef*>(data);
     zs.avail_in = (uInt)len;
     zs.next_out = out + 18;
     zs.avail_out = (uInt)(BGZF_MAX_OUT - 18 - 8);
     int const rc = deflate(&zs, Z_FINISH);
     size_t const clen = zs.total_out;
-    deflateEnd(&zs);
     if (rc != Z_STREAM_END) return 0;
     size_t const bsize = clen + 18 + 8;
     static const uint8_t hdr[16] = {31, 139, 8, 4, 0, 0, 0, 0, 0, 255, 6, 0, 'B', 'C', 2, 0};
@@ -80,14 +97,14 @@ bool bgzf_flush(flx_sam_writer* w, bool all) {
     size_t const n_full = w->pending.size() / BGZF_BLOCK, tail = w->pending.size() - n_full * BGZF_BLOCK;
     size_t const n_blocks = n_full + ((all && tail) ? 1 : 0);
     if (n_blocks == 0) return true;
-    std::vector<uint8_t> out(n_blocks * BGZF_MAX_OUT);
+    std::unique_ptr<uint8_t[]> const out(new uint8_t[n_blocks * BGZF_MAX_OUT]);      // (not cleared: every block is written before it is read)
     std::vector<size_t> sizes(n_blocks, 0);
     io_parallel(n_blocks, w->threads, [&](size_t b) {
         size_t const len = b < n_full ? BGZF_BLOCK : tail;
-        sizes[b] = bgzf_compress_block(w->pending.data() + b * BGZF_BLOCK, len, out.data() + b * BGZF_MAX_OUT);
+        sizes[b] = bgzf_compress_block(w->pending.data() + b * BGZF_BLOCK, len, out.get() + b * BGZF_MAX_OUT);
     });
     bool ok = true;
-    for (size_t b = 0; b < n_blocks && ok; ++b) ok = sizes[b] != 0 && fwrite(out.data() + b * BGZF_MAX_OUT, 1, sizes[b], w->f) == sizes[b];
+    for (size_t b = 0; b < n_blocks && ok; ++b) ok = sizes[b] != 0 && fwrite(out.get() + b * BGZF_MAX_OUT, 1, sizes[b], w->f) == sizes[b];
     size_t const used = all ? w->pending.size() : n_full * BGZF_BLOCK;
     w->pending.erase(w->pending.begin(), w->pending.begin() + (long)used);
     return ok;
@@ -262,10 +279,23 @@ extern "C" int flx_sam_write(flx_sam_writer* w, const char* const* read_ids, con
     std::vector<std::string> errs(n_parts);
     io_parallel(n_parts, w->threads, [&](size_t p) {
         uint64_t const r0 = n_records * p / n_parts, r1 = n_records * (p + 1) / n_parts;
+        {
+            // the part's size, roughly (BAM: 4 bytes per CIGAR operation, 1.5 per base of a record with SEQ / QUAL; SAM: about twice
+            // that), so that the buffer is allocated once instead of doubling its way up through copies
+            size_t guess = 0;
+            for (uint64_t i = r0; i < r1; ++i) {
+                flx_record const& r = records[i];
+                bool const with_seq = (r.flag & 4u) || !(r.flag & 256u);
+                size_t const slen = with_seq ? (size_t)(read_offsets[r.read_index + 1] - read_offsets[r.read_index]) : 0;
+                guess += 96 + 4 * (size_t)r.cigar_length + slen + slen / 2;
+            }
+            parts[p].reserve(w->bam ? guess : 2 * guess);
+        }
         for (uint64_t i = r0; i < r1 && errs[p].empty(); ++i)
             if (!format_record(w, records[i], read_ids, read_pool, read_offsets, quals, cigar_words, parts[p], errs[p])) break;
     });
     for (auto const& e : errs) if (!e.empty()) { set_error(e); return FLX_ERR_INVALID; }
+    if (w->bam) { size_t total = w->pending.size(); for (auto const& part : parts) total += part.size(); w->pending.reserve(total); }
     for (auto const& part : parts) {
         if (part.empty()) continue;
         if (!w->bam) { if (fwrite(part.data(), 1, part.size(), w->f) != part.size()) w->failed = true; }
