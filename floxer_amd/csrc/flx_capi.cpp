@@ -122,7 +122,7 @@ int make_context(int hip_device, const flx_index* index, void* const image[5], b
         uint64_t bytes[5];
         image_sizes(H, bytes);
         DeviceBuffer* bufs[5] = {&ctx->occ0, &ctx->occ1, &ctx->sa, &ctx->text, &ctx->kmer};
-        for (int i = 0; i < 5; ++i) { if ((rc = bufs[i]->ensure(bytes[i]))) return rc; img[i] = bufs[i]->ptr; }
+        for (int i = 0; i < 5; ++i) { if ((rc = bufs[i]->ensure(bytes[i], true))) return rc; img[i] = bufs[i]->ptr; }
         if ((rc = upload_image(H, img, s0))) return rc;
     } else for (int i = 0; i < 5; ++i) img[i] = image[i];
     if ((rc = ctx->seq_start.ensure(H.seq_start.size() * 8))) return rc;
@@ -135,6 +135,25 @@ int make_context(int hip_device, const flx_index* index, void* const image[5], b
     ctx->didx.kmer = reinterpret_cast<const u32*>(img[4]);
     for (int c = 0; c < 7; ++c) ctx->didx.C[c] = (u32)H.C[c];
     ctx->didx.n = (u32)H.n;
+    // The tables the seeding kernels use beyond the image: the inverse suffix array and the presence filter, made here from the
+    // text and the suffix array in HBM (hg38 size: 12.4 GB + 8.6 GB, a fraction of a second). FLX_NO_DERIVED=1: neither (the walk
+    // then uses rank queries only); a filter that does not fit is left out.
+    ctx->didx.isa = nullptr; ctx->didx.filter = nullptr; ctx->didx.filter_k = 0; ctx->didx.filter_tmin = 0;
+    if (!getenv("FLX_NO_DERIVED") && H.n > 0) {
+        u32 fk = 0;
+        (void)DeviceApi::derived_bytes(H.n, &fk);
+        if ((rc = ctx->isa.ensure(H.n * 4 + 64, true))) return rc;
+        bool have_filter = false;
+        if (fk) {
+            size_t free_f = 0, total_f = 0;
+            FLX_HIP(hipMemGetInfo(&free_f, &total_f));
+            size_t const want = (size_t)(((1ull << (2 * fk)) + 63) / 64) * 8;
+            have_filter = want < free_f / 2 && ctx->filter.ensure(want, true) == FLX_OK;
+        }
+        int const e = DeviceApi::derive_index(s0, ctx->didx, ctx->isa.as<u32>(), have_filter ? ctx->filter.as<u64>() : nullptr);
+        if (e) { set_error(std::string("derive_index: ") + hipGetErrorString((hipError_t)e)); return FLX_ERR_NO_DEVICE; }
+        FLX_HIP(hipStreamSynchronize(s0));
+    }
     // trace arena budget: FLX_TRACE_ARENA_MB (whole context), default 40% of the free HBM, at least 256 MB; split over the lanes
     size_t free_b = 0, total_b = 0;
     FLX_HIP(hipMemGetInfo(&free_b, &total_b));
@@ -178,7 +197,7 @@ int flx_index_image_upload(const flx_index* index, int hip_device, void* const d
 flx_ctx::~flx_ctx() {
     (void)hipSetDevice(device);
     for (auto& lane : lanes) { if (lane->stream) (void)hipStreamSynchronize(lane->stream); lane->release_all(); }
-    for (DeviceBuffer* b : {&occ0, &occ1, &sa, &text, &text_rev, &kmer, &seq_start}) b->release();
+    for (DeviceBuffer* b : {&occ0, &occ1, &sa, &text, &text_rev, &kmer, &seq_start, &isa, &filter}) b->release();
     if (upload_stream) (void)hipStreamDestroy(upload_stream);
 }
 

@@ -30,7 +30,7 @@ struct DeviceBuffer {
     DeviceBuffer(DeviceBuffer const&) = delete;
     DeviceBuffer& operator=(DeviceBuffer const&) = delete;
     ~DeviceBuffer() { release(); }   // (error paths drop half-made owners: nothing stays allocated)
-    int ensure(size_t bytes);      // grow-only; contents are NOT preserved
+    int ensure(size_t bytes, bool exact = false);      // grow-only; contents are NOT preserved; exact: no growth slack
     void release();
     template <class T> T* as() const { return reinterpret_cast<T*>(ptr); }
 };
@@ -50,7 +50,7 @@ struct Lane {
     flx_ctx* ctx = nullptr;
     int id = 0;
     hipStream_t own_stream = nullptr, stream = nullptr;
-    DeviceBuffer seq, seq_rev, peq, peq_rev, scheme, seeds, stack, hits, counters, rows, rows_out;
+    DeviceBuffer seq, seq_rev, peq, peq_rev, scheme, seeds, stack, hits, counters, rows, rows_out, qpack, items;
     DeviceBuffer jobs, job_out, trace, tjobs, tjob_out, cigar, user_text, user_text_rev, lastrow, row_windows, row_out,
         seed_cnt, hit_off, grouped, sel_stat, sel_n, sel_off, sel_out, sel_tmp, sel_rows, sel_row_off, sel_sparse, sel_lists, vr, vr_override;
     size_t trace_budget_bytes = 0;
@@ -73,6 +73,7 @@ struct flx_ctx {
     const flx::HostIndex* hidx = nullptr;
     flx::DevIndex didx{};
     flx::DeviceBuffer occ0, occ1, sa, text, text_rev, kmer, seq_start;
+    flx::DeviceBuffer isa, filter;   // derived from text and suffix array when the context is made (flx_search.hip)
     bool text_rev_ready = false;
     std::mutex mu;                   // guards text_rev upload and the statistics
     std::vector<std::unique_ptr<flx::Lane>> lanes;
@@ -136,8 +137,10 @@ int timed_launch(Lane* lane, const char* name, u64 bytes, u64 units, F&& launch)
 struct HostAnchor { u32 seed_index, leaf, ref_id, errors; u64 pos; };
 struct SeedStats { u32 useful, raw, excluded_soft, fully_excluded; };
 
+// d_seq_pool_or_null: the pool is resident (then d_qpack_or_null may be its 2-bit form); seed_flags (per seed, SEED_* of
+// flx_fm_core.hpp) may be null when the host pool is given (they are read off it)
 int search_seeds_device(Lane* lane, const u8* d_seq_pool_or_null, const u8* h_seq_pool, u64 pool_len, const flx_seed* seeds,
                         u64 n_seeds, const flx_search_config& cfg, hvec<HostAnchor>& anchors, hvec<SeedStats>& stats,
-                        hvec<DevHit>* raw_hits, u64 raw_max_hits);
+                        hvec<DevHit>* raw_hits, u64 raw_max_hits, const u32* d_qpack_or_null = nullptr, const u8* seed_flags = nullptr);
 
 }  // namespace flx

@@ -389,11 +389,11 @@ constexpr u32 FM_KEY_MAX_X = 0x3FFFu;
 
 // start of search `srch` of the seed: the root cursor, or the cursor of the seed's first KMER_Q characters when the search begins
 // with an exact, rightward part that long and free of N. false: the search finds nothing.
-__device__ __forceinline__ bool fm_begin_search(DevIndex const& idx, const u32* __restrict__ ex, const u8* __restrict__ q, u32 len,
+__device__ __forceinline__ bool fm_begin_search(DevIndex const& idx, const u64* __restrict__ ex, const u8* __restrict__ q, u32 len,
                                                 u32& nlb, u32& nlbr, u32& nlen, u32& nx) {
     nlb = 0; nlbr = 0; nlen = idx.n; nx = 0;
     if (len >= KMER_Q && ((ex[KMER_Q - 1] >> 27) & 1u)) {
-        u32 const p0 = ex[0] & SCH_POS_MASK;
+        u32 const p0 = (u32)ex[0] & SCH_POS_MASK;
         u32 w[2];
         __builtin_memcpy(w, q + p0, 8);                                  // eight ranks, first character in the low byte
         u32 const t0 = w[0] - 0x01010101u, t1 = w[1] - 0x01010101u;      // A,C,G,T -> 0..3; anything else leaves bits 2..7 set
@@ -425,7 +425,7 @@ __device__ __forceinline__ u32 fm_child_mask(const u32 cl[6], u32 next_sym, bool
     return mask;
 }
 
-__global__ void __launch_bounds__(64) fm_search_kernel(DevIndex idx, const u8* __restrict__ seq, const u32* __restrict__ scheme,
+__global__ void __launch_bounds__(64) fm_search_kernel(DevIndex idx, const u8* __restrict__ seq, const u64* __restrict__ scheme,
                                                        const DevSeed* __restrict__ seeds, u32 n_seeds, u32 max_hits, u32 levels,
                                                        DevHit* __restrict__ hits, u32 hit_cap, u32* __restrict__ counters,
                                                        u32* __restrict__ seed_cnt, u32 prio) {
@@ -442,12 +442,13 @@ __global__ void __launch_bounds__(64) fm_search_kernel(DevIndex idx, const u8* _
     auto fr = [&](u32 level, u32 word) -> u32& { return lds[(level * FM_FRAME_WORDS + word) * 64u + lane]; };
 
     u32 n_ext = 0, n_iter = 0, n_busy_iter = 0, n_tail_iter = 0, n_single = 0;
+    u32 n_cls[6] = {0, 0, 0, 0, 0, 0};
     bool busy = false, exhausted = false;
     u32 sid = 0, srch = 0, num_searches = 0, len = 0, ct = 0;
     const u8* __restrict__ q = seq;
-    const u32* __restrict__ ex_base = scheme;
+    const u64* __restrict__ ex_base = scheme;
     bool in_search = false;
-    const u32* __restrict__ ex = scheme;
+    const u64* __restrict__ ex = scheme;
     u32 l_last = 0, u_last = 0;
     u32 nlb = 0, nlbr = 0, nlen = 0, nx = 0, ne = 0, nli = INFO_M, nri = INFO_M;
     u64 nkey = 0;                               // key of the node under inspection
@@ -487,7 +488,7 @@ __global__ void __launch_bounds__(64) fm_search_kernel(DevIndex idx, const u8* _
         if (!in_search) {
             if (srch >= num_searches) { busy = false; continue; }
             ex = ex_base + (u64)srch * len;
-            u32 const last_entry = ex[len - 1];
+            u32 const last_entry = (u32)ex[len - 1];
             l_last = (last_entry >> 20) & 7u;
             u_last = (last_entry >> 23) & 7u;
             ne = 0; nli = INFO_M; nri = INFO_M;
@@ -548,7 +549,7 @@ __global__ void __launch_bounds__(64) fm_search_kernel(DevIndex idx, const u8* _
             need_child = true;
             continue;
         }
-        u32 const sch = ex[nx];
+        u32 const sch = (u32)ex[nx];
         u32 const lower = (sch >> 20) & 7u, upper = (sch >> 23) & 7u, right = (sch >> 26) & 1u;
         if (ne > upper) { need_child = true; continue; }
         bool const mismatch_allowed = lower <= ne + 1 && ne + 1 <= upper;
@@ -561,6 +562,7 @@ __global__ void __launch_bounds__(64) fm_search_kernel(DevIndex idx, const u8* _
         extend_all(idx, idx.occ[right], lo, nlen, ab, cl);
         ++n_ext;
         n_single += nlen == 1u ? 1u : 0u;
+        { u32 const c = (nlen == 1u ? 0u : nlen <= 4u ? 1u : 2u) + (mismatch_allowed ? 0u : 3u); n_cls[c]++; }
 
         if (mismatch_allowed) {
             // this node branches: its frame goes on top of the frames of the error edges taken so far (at most `ne` of them)
@@ -602,6 +604,8 @@ __global__ void __launch_bounds__(64) fm_search_kernel(DevIndex idx, const u8* _
     n_ext = wave_sum_u32(n_ext);
     n_busy_iter = wave_sum_u32(n_busy_iter);
     n_single = wave_sum_u32(n_single);
+#pragma unroll
+    for (u32 c = 0; c < 6; ++c) { u32 const v = wave_sum_u32(n_cls[c]); if (lane == 0) atomicAdd(&counters[10 + c], v); }
     if (lane == 0) {
         atomicAdd(&counters[2], n_ext); atomicAdd(&counters[6], n_busy_iter); atomicAdd(&counters[3], n_single);
         atomicAdd(&counters[4], n_iter); atomicMax(&counters[5], n_iter); atomicAdd(&counters[8], n_tail_iter); atomicMax(&counters[9], n_tail_iter);
@@ -610,7 +614,7 @@ __global__ void __launch_bounds__(64) fm_search_kernel(DevIndex idx, const u8* _
 
 // The DFS in the reference's own order (match child first): frames are written to the seed's stack in HBM when they are made
 // (64 B = four 16-byte stores) and read back when the DFS returns to them; the children of the top frame are in LDS.
-__global__ void __launch_bounds__(64) fm_search_ordered_kernel(DevIndex idx, const u8* __restrict__ seq, const u32* __restrict__ scheme,
+__global__ void __launch_bounds__(64) fm_search_ordered_kernel(DevIndex idx, const u8* __restrict__ seq, const u64* __restrict__ scheme,
                                                                const DevSeed* __restrict__ seeds, u32 n_seeds, u32 max_hits,
                                                                DevFrame* __restrict__ stack, DevHit* __restrict__ hits, u32 hit_cap,
                                                                u32* __restrict__ counters, u32* __restrict__ seed_cnt) {
@@ -626,9 +630,9 @@ __global__ void __launch_bounds__(64) fm_search_ordered_kernel(DevIndex idx, con
     u32 sid = 0, srch = 0, num_searches = 0, len = 0, ct = 0, stack_frames = 0;
     const u8* __restrict__ q = seq;
     uint4* __restrict__ stk = reinterpret_cast<uint4*>(stack);
-    const u32* __restrict__ ex_base = scheme;
+    const u64* __restrict__ ex_base = scheme;
     bool in_search = false;
-    const u32* __restrict__ ex = scheme;
+    const u64* __restrict__ ex = scheme;
     u32 l_last = 0, u_last = 0;
     u32 nlb = 0, nlbr = 0, nlen = 0, nx = 0, ne = 0, nli = INFO_M, nri = INFO_M;
     // top frame (frame depth-1 of the stack): its node and the mask of children not taken yet
@@ -671,7 +675,7 @@ __global__ void __launch_bounds__(64) fm_search_ordered_kernel(DevIndex idx, con
         if (!in_search) {
             if (srch >= num_searches) { busy = false; continue; }
             ex = ex_base + (u64)srch * len;
-            u32 const last_entry = ex[len - 1];
+            u32 const last_entry = (u32)ex[len - 1];
             l_last = (last_entry >> 20) & 7u;
             u_last = (last_entry >> 23) & 7u;
             ne = 0; nli = INFO_M; nri = INFO_M;
@@ -741,7 +745,7 @@ __global__ void __launch_bounds__(64) fm_search_ordered_kernel(DevIndex idx, con
             need_child = true;
             continue;
         }
-        u32 const sch = ex[nx];
+        u32 const sch = (u32)ex[nx];
         u32 const lower = (sch >> 20) & 7u, upper = (sch >> 23) & 7u, right = (sch >> 26) & 1u;
         if (ne > upper) { need_child = true; continue; }
         bool const mismatch_allowed = lower <= ne + 1 && ne + 1 <= upper;
@@ -827,7 +831,7 @@ static u32 fm_max_waves(u32 concurrent_launches) {
 
 u32 fm_search_max_keyed_length() { return FM_KEY_MAX_X; }
 
-int DeviceApi::search(void* stream, const DevIndex& idx, const u8* d_seq, const u32* d_scheme, const DevSeed* d_seeds, u32 n_seeds,
+int DeviceApi::search(void* stream, const DevIndex& idx, const u8* d_seq, const u64* d_scheme, const DevSeed* d_seeds, u32 n_seeds,
                       u32 max_hits_per_seed, u32 frame_levels, DevFrame* d_stack, DevHit* d_hits, u32 hit_cap, u32* d_counters, u32* d_seed_cnt,
                       u32 concurrent_launches) {
     if (n_seeds == 0) return 0;

@@ -1,6 +1,7 @@
 // Host-side integer/double arithmetic of the path that defines seeds and windows: must be bit-identical to the reference,
 // so it stays on the host in IEEE double. math.hpp, input.cpp, pex.cpp, search-scheme expansion.
 #include <cmath>
+#include <algorithm>
 #include <cstdlib>
 #include <new>
 #include <vector>
@@ -173,9 +174,9 @@ const std::vector<SearchDef>& optimum_scheme(u32 k) {
     switch (k) { case 0: return s0; case 1: return s1; case 2: return s2; case 3: return s3; default: return none; }
 }
 
-std::vector<u32> expanded_scheme(u32 k, u32 len) {
+std::vector<u64> expanded_scheme(u32 k, u32 len) {
     auto const& scheme = optimum_scheme(k);
-    std::vector<u32> out;
+    std::vector<u64> out;
     if (scheme.empty()) return out;
     u32 const P = (u32)scheme[0].pi.size();
     if (len < P) return out;
@@ -185,6 +186,7 @@ std::vector<u32> expanded_scheme(u32 k, u32 len) {
     for (u32 p = 1; p < P; ++p) starts[p] = starts[p - 1] + counts[p - 1];
     out.reserve((size_t)scheme.size() * len);
     for (auto const& s : scheme) {
+        size_t const first = out.size();
         for (u32 i = 0; i < P; ++i) {
             u32 const part = s.pi[i];
             bool const right = i == 0 || s.pi[i - 1] < s.pi[i];
@@ -195,6 +197,16 @@ std::vector<u32> expanded_scheme(u32 k, u32 len) {
                 bool const exact_prefix = i == 0 && s.u[0] == 0 && s.l[0] == 0;       // first part of every optimum search
                 out.push_back(sch_pack(pos, last ? s.l[i] : lower_before_end, s.u[i], right, exact_prefix));
             }
+        }
+        // high word (flx_fm_core.hpp): end of the run of entries that share this one's upper bound and direction | lowest seed
+        // position among the entries before this one (the walk's string is seed[lo, lo + x) at entry x while it has no indel)
+        u64* const e = out.data() + first;
+        u32 run_end = len, lo = (u32)e[0] & SCH_POS_MASK;
+        std::vector<u32> lo_before(len);
+        for (u32 x = 0; x < len; ++x) { lo_before[x] = lo; lo = std::min(lo, (u32)e[x] & SCH_POS_MASK); }
+        for (u32 x = len; x-- > 0;) {
+            if (x + 1 < len && ((((u32)e[x] ^ (u32)e[x + 1]) >> 23) & 0xFu) != 0u) run_end = x + 1;      // upper bound (3 bits) or direction differs
+            e[x] |= ((u64)(run_end & 0x7FFFu) << 32) | ((u64)(lo_before[x] & 0x3FFFu) << 47);
         }
     }
     return out;

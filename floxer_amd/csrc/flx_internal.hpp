@@ -76,6 +76,10 @@ struct DevIndex {
     const u32* sa;
     const u8* text;        // points at text[0]; TEXT_PAD readable bytes on both sides
     const u32* kmer;       // KMER_Q-mer cursor table, 3 words per entry
+    // derived from text and sa on the device when a context is made (flx_search.hip): not part of the index file or image
+    const u32* isa;        // inverse suffix array: row of the suffix that starts at a text position
+    const u64* filter;     // presence bits of the text's filter_k-mers (flx_fm_core.hpp); null: no filter
+    u32 filter_k, filter_tmin;   // strings of filter_tmin .. filter_k symbols can be asked for
     u32 C[7];
     u32 n;
 };
@@ -96,6 +100,8 @@ struct DevSeed {
     u32 scheme_off;     // first entry of this (length, errors) expanded scheme; searches are consecutive, `length` entries each
     u32 frames_searches;// frames reserved for the DFS stack (bits 0..23) | number of searches (bits 24..)
     u32 id;             // index of the seed in the caller's list (the launch order is by expected cost, see search_seeds_device)
+    u32 flags;          // SEED_HAS_DELIM | SEED_NOT_ACGT (flx_fm_core.hpp): what the seed's read may hold
+    u32 pad;
 };
 
 struct DevFrame {       // 64 bytes: one branching node of the DFS, written when the node is made (four 16-byte stores of one lane)
@@ -237,9 +243,20 @@ struct DeviceApi {
     // hits carry keys that restore the emission order; every seed shorter than fm_search_max_keyed_length()); else the DFS in the
     // reference's order with DevSeed::stack_off / frames into d_stack. concurrent_launches: searches the caller keeps in flight at a
     // time on other streams (the launch takes a share of the waves).
-    static int search(void* stream, const DevIndex& idx, const u8* d_seq, const u32* d_scheme, const DevSeed* d_seeds,
+    static int search(void* stream, const DevIndex& idx, const u8* d_seq, const u64* d_scheme, const DevSeed* d_seeds,
                       u32 n_seeds, u32 max_hits_per_seed, u32 frame_levels, DevFrame* d_stack, DevHit* d_hits, u32 hit_cap,
                       u32* d_counters, u32* d_seed_cnt = nullptr, u32 concurrent_launches = 1);
+    // flx_search.hip: the walk with its stack in LDS plus the presence filter (d_qpack: 2-bit form of d_seq, null: no filter) and the
+    // text walk of one-row subtrees (d_items: room for item_cap queued subtrees, null: none are queued). d_counters: 32 zeroed words.
+    static int search_filtered(void* stream, const DevIndex& idx, const u8* d_seq, const u32* d_qpack, const u64* d_scheme, const DevSeed* d_seeds,
+                               u32 n_seeds, u32 max_hits_per_seed, u32 frame_levels, DevHit* d_hits, u32 hit_cap, DevHit* d_items, u32 item_cap,
+                               u32* d_counters, u32* d_seed_cnt, u32 concurrent_launches);
+    // the tables a context derives from text and suffix array: bytes of isa + filter for a text of n symbols; derive_index fills
+    // d_isa (n words) and d_filter (null: no filter) and sets idx.isa / filter / filter_k / filter_tmin
+    static size_t derived_bytes(u64 n, u32* filter_k_out);
+    static int derive_index(void* stream, DevIndex& idx, u32* d_isa, u64* d_filter);
+    // 2-bit form of a sequence pool (pack_words_for(len) words, flx_fm_core.hpp)
+    static int pack_pool(void* stream, const u8* d_seq, u64 len, u32* d_qpack);
     // anchor selection on the device (see seed_select_kernel). d_seed_cnt, d_hit_offset, d_n_out, d_out_offset: n_seeds + 1 entries
     // (the caller zeroes the last entry of d_seed_cnt and d_n_out); d_stat: one DevSelStat per seed;
     // d_grouped: as many entries as d_hits; d_out: one entry per selected anchor (at most the number of rows of the handled seeds);
@@ -289,9 +306,9 @@ PexTree build_pex_tree(u64 len, u64 k, u64 s, bool bottom_up);
 
 struct SearchDef { std::vector<u32> pi, l, u; };
 const std::vector<SearchDef>& optimum_scheme(u32 k);
-// expanded + packed (sch_pack) entries for all searches of optimum(0,k) at this length, `len` entries per search; empty if
-// the scheme cannot be expanded (len < number of parts)
-std::vector<u32> expanded_scheme(u32 k, u32 len);
+// expanded + packed entries (low word sch_pack, high word see flx_fm_core.hpp) for all searches of optimum(0,k) at this length,
+// `len` entries per search; empty if the scheme cannot be expanded (len < number of parts)
+std::vector<u64> expanded_scheme(u32 k, u32 len);
 
 // hip_device >= 0: the two suffix arrays are built on that device (prefix doubling), else on the host (SA-IS)
 HostIndex* build_host_index(const u8* concat, const u64* lens, u32 n_refs, int hip_device = -1);

@@ -17,17 +17,18 @@
 #include <unordered_map>
 
 #include "flx_context.hpp"
+#include "flx_fm_core.hpp"
 #include "flx_stats.hpp"
 
 namespace flx {
 
 // ================================================================================================ buffers / context
-int DeviceBuffer::ensure(size_t bytes) {
+int DeviceBuffer::ensure(size_t bytes, bool exact) {
     if (bytes <= cap && ptr) return FLX_OK;
     static int const debug = getenv("FLX_ALLOC_DEBUG") ? 1 : 0;
     if (debug) fprintf(stderr, "[flx alloc] %.3f device buffer grows %zu -> %zu bytes\n", std::chrono::duration<double>(std::chrono::system_clock::now().time_since_epoch()).count(), cap, bytes);
     release();
-    size_t const want = std::max<size_t>(bytes + bytes / 2, 4096);       // 50 % slack: batches of a run differ by a few per cent
+    size_t const want = exact ? std::max<size_t>(bytes, 4096) : std::max<size_t>(bytes + bytes / 2, 4096);       // 50 % slack: batches of a run differ by a few per cent
     void* p = nullptr;
     hipError_t e = hipMalloc(&p, want);
     size_t got = want;
@@ -92,7 +93,8 @@ hipEvent_t Lane::get_event() {
 hvec<DeviceBuffer*> lane_workspaces(Lane& l) {
     return {&l.seq, &l.seq_rev, &l.peq, &l.peq_rev, &l.scheme, &l.seeds, &l.stack, &l.hits, &l.counters, &l.rows, &l.rows_out, &l.jobs,
             &l.job_out, &l.trace, &l.tjobs, &l.tjob_out, &l.cigar, &l.user_text, &l.user_text_rev, &l.lastrow, &l.row_windows, &l.row_out,
-            &l.seed_cnt, &l.hit_off, &l.grouped, &l.sel_stat, &l.sel_n, &l.sel_off, &l.sel_out, &l.sel_tmp, &l.sel_rows, &l.sel_row_off, &l.sel_sparse, &l.sel_lists, &l.vr, &l.vr_override};
+            &l.seed_cnt, &l.hit_off, &l.grouped, &l.sel_stat, &l.sel_n, &l.sel_off, &l.sel_out, &l.sel_tmp, &l.sel_rows, &l.sel_row_off, &l.sel_sparse, &l.sel_lists, &l.vr, &l.vr_override,
+            &l.qpack, &l.items};
 }
 std::vector<DeviceBuffer*> Lane::workspaces() { auto v = lane_workspaces(*this); return std::vector<DeviceBuffer*>(v.begin(), v.end()); }
 int Lane::size_like(Lane& other) {
@@ -278,7 +280,7 @@ void erase_useless(hvec<RefAnchor>& v) {
 
 int search_seeds_device(Lane* ctx, const u8* d_seq_pool_or_null, const u8* h_seq_pool, u64 pool_len, const flx_seed* seeds,
                         u64 n_seeds, const flx_search_config& cfg, hvec<HostAnchor>& anchors, hvec<SeedStats>& stats,
-                        hvec<DevHit>* raw_hits, u64 raw_max_hits) {
+                        hvec<DevHit>* raw_hits, u64 raw_max_hits, const u32* d_qpack_or_null, const u8* seed_flags) {
     anchors.clear();
     stats.assign(n_seeds, SeedStats{0, 0, 0, 0});
     if (n_seeds == 0) return FLX_OK;
@@ -288,10 +290,19 @@ int search_seeds_device(Lane* ctx, const u8* d_seq_pool_or_null, const u8* h_seq
 
     // ---- expanded schemes (search_scheme_cache, search.cpp:328-350) and DFS stack reservations
     std::map<std::pair<u32, u32>, std::pair<u32, u32>> scheme_of;      // (len, k) -> (offset, searches)
-    hvec<u32> scheme_table;
+    hvec<u64> scheme_table;
     hvec<DevSeed> dseeds(n_seeds);
     u64 frames = 0;
     u32 max_errors = 0, max_length = 0;
+    // what a seed's symbols may be (SEED_* of flx_fm_core.hpp): given by the caller per seed, or read off the host pool
+    auto flags_of = [&](u64 i) -> u32 {
+        if (seed_flags) return seed_flags[i];
+        if (!h_seq_pool) return SEED_HAS_DELIM | SEED_NOT_ACGT;
+        u32 f = 0;
+        const u8* p = h_seq_pool + seeds[i].seq_offset;
+        for (u32 j = 0; j < seeds[i].length; ++j) { if (p[j] == 0) f |= SEED_HAS_DELIM; if (p[j] - 1u > 3u) f |= SEED_NOT_ACGT; }
+        return f;
+    };
     for (u64 i = 0; i < n_seeds; ++i) {
         flx_seed const& s = seeds[i];
         max_errors = std::max(max_errors, s.num_errors);
@@ -305,6 +316,7 @@ int search_seeds_device(Lane* ctx, const u8* d_seq_pool_or_null, const u8* h_seq
             d.seq_off = s.seq_offset;
             d.stack_off = frames;
             d.id = (u32)i;
+            d.flags = flags_of(i);
             frames += d.frames_searches & 0xFFFFFFu;
             continue;
         }
@@ -322,6 +334,8 @@ int search_seeds_device(Lane* ctx, const u8* d_seq_pool_or_null, const u8* h_seq
         d.frames_searches = (s.length + s.num_errors + 3) | (it->second.second << 24);
         d.stack_off = frames;
         d.id = (u32)i;
+        d.flags = flags_of(i);
+        d.pad = 0;
         frames += s.length + s.num_errors + 3;
     }
     // Launch order = expected cost, heaviest class first (more errors, then shorter): the work of a seed grows steeply with its
@@ -360,15 +374,27 @@ int search_seeds_device(Lane* ctx, const u8* d_seq_pool_or_null, const u8* h_seq
         if ((rc = h2d(ctx, ctx->seq, h_seq_pool, pool_len, 64))) return rc;
         d_seq = ctx->seq.as<u8>();
     }
-    if ((rc = h2d(ctx, ctx->scheme, scheme_table.data(), scheme_table.size() * 4))) return rc;
+    if ((rc = h2d(ctx, ctx->scheme, scheme_table.data(), scheme_table.size() * 8))) return rc;
     if ((rc = h2d(ctx, ctx->seeds, dseeds.data(), dseeds.size() * sizeof(DevSeed)))) return rc;
     // The DFS in the reference's order (frames on a per-seed stack in HBM) where the order of discovery matters: the raw-emission
     // hook and first_reported, which want the first n rows; everywhere else the walk with its stack in LDS, whose hits carry keys
     // that restore the emission order.
-    bool const ordered = raw_hits || cfg.anchor_choice_strategy == FLX_CHOICE_FIRST_REPORTED || max_length > fm_search_max_keyed_length() ||
+    bool const ordered = (raw_hits && !getenv("FLX_FM_KEYED_RAW")) || cfg.anchor_choice_strategy == FLX_CHOICE_FIRST_REPORTED || max_length > fm_search_max_keyed_length() ||
                          max_errors > 3 || getenv("FLX_FM_ORDERED");
     if (ordered && (rc = ctx->stack.ensure(frames * sizeof(DevFrame)))) return rc;
-    if ((rc = ctx->counters.ensure(64))) return rc;
+    if ((rc = ctx->counters.ensure(128))) return rc;
+    // the walk of flx_search.hip (presence filter, one-row subtrees against the text) unless the order of discovery matters;
+    // FLX_FM_V1=1: the round-2 kernel (rank queries all the way)
+    static int const fm_v1 = getenv("FLX_FM_V1") ? 1 : 0;
+    bool const filtered = !ordered && !fm_v1;
+    const u32* d_qpack = d_qpack_or_null;
+    if (filtered && !d_qpack && ctx->ctx->didx.filter) {
+        if ((rc = ctx->qpack.ensure(pack_words_for(pool_len) * 4 + 64))) return rc;
+        int const e = DeviceApi::pack_pool(ctx->stream, d_seq, pool_len, ctx->qpack.as<u32>());
+        if (e) { set_error(std::string("pack_pool: ") + hipGetErrorString((hipError_t)e)); return FLX_ERR_NO_DEVICE; }
+        d_qpack = ctx->qpack.as<u32>();
+    }
+    u64 item_cap = filtered && ctx->ctx->didx.isa ? n_seeds * 8 + 4096 * 64 : 0;      // (10-kb reads at 8 %: 6.3 one-row subtrees per seed)
 
     u32 const max_hits = raw_hits ? (u32)std::min<u64>(raw_max_hits, 0xFFFFFFF0u)
                                   : (cfg.anchor_choice_strategy == FLX_CHOICE_FIRST_REPORTED
@@ -395,14 +421,15 @@ int search_seeds_device(Lane* ctx, const u8* d_seq_pool_or_null, const u8* h_seq
         if ((rc = ctx->sel_lists.ensure((2 * n_seeds + 2) * 4))) return rc;
         sel_stat.resize(n_seeds);
     }
-    u32 counters[16];
+    u32 counters[32];
     u64 sel_cap = 0;                          // entries of the selected-anchor list
     struct K1Token { flx_ctx* c; explicit K1Token(flx_ctx* c_) : c(c_) { c->k1_acquire(); } ~K1Token() { c->k1_release(); } };
     for (int attempt = 0;; ++attempt) {
         K1Token const token(ctx->ctx);           // (held until this attempt's kernels have finished)
         sel_cap = std::max(sel_cap, hit_cap);
         if ((rc = ctx->hits.ensure(hit_cap * sizeof(DevHit)))) return rc;
-        FLX_HIP(hipMemsetAsync(ctx->counters.ptr, 0, 64, ctx->stream));
+        if (item_cap && (rc = ctx->items.ensure(item_cap * sizeof(DevHit)))) return rc;
+        FLX_HIP(hipMemsetAsync(ctx->counters.ptr, 0, 128, ctx->stream));
         if (device_select) {
             // one selected anchor per hit row at most; rows <= hits * SEL_MAX would be the hard bound, the seeds the device
             // handles have at most soft-cap rows each and nearly all hits have one row: hit_cap entries, checked after the run
@@ -414,10 +441,15 @@ int search_seeds_device(Lane* ctx, const u8* d_seq_pool_or_null, const u8* h_seq
             FLX_HIP(hipMemsetAsync((char*)ctx->sel_n.ptr + n_seeds * 4, 0, 4, ctx->stream));
         }
         rc = timed_launch(ctx, "fm_search", 0, n_seeds, [&] {
-            return DeviceApi::search(ctx->stream, ctx->ctx->didx, d_seq, ctx->scheme.as<u32>(), ctx->seeds.as<DevSeed>(), (u32)n_seeds,
+            u32 const concurrent = ctx->ctx->external_stream ? 1u : (u32)ctx->ctx->lanes.size();
+            if (filtered)
+                return DeviceApi::search_filtered(ctx->stream, ctx->ctx->didx, d_seq, d_qpack, ctx->scheme.as<u64>(), ctx->seeds.as<DevSeed>(), (u32)n_seeds,
+                                                  max_hits, max_errors, ctx->hits.as<DevHit>(), (u32)std::min<u64>(hit_cap, 0xFFFFFFFFu),
+                                                  item_cap ? ctx->items.as<DevHit>() : nullptr, (u32)std::min<u64>(item_cap, 0xFFFFFFFFu),
+                                                  ctx->counters.as<u32>(), device_select ? ctx->seed_cnt.as<u32>() : nullptr, concurrent);
+            return DeviceApi::search(ctx->stream, ctx->ctx->didx, d_seq, ctx->scheme.as<u64>(), ctx->seeds.as<DevSeed>(), (u32)n_seeds,
                                      max_hits, max_errors, ordered ? ctx->stack.as<DevFrame>() : nullptr, ctx->hits.as<DevHit>(), (u32)std::min<u64>(hit_cap, 0xFFFFFFFFu),
-                                     ctx->counters.as<u32>(), device_select ? ctx->seed_cnt.as<u32>() : nullptr,
-                                     ctx->ctx->external_stream ? 1u : (u32)ctx->ctx->lanes.size());
+                                     ctx->counters.as<u32>(), device_select ? ctx->seed_cnt.as<u32>() : nullptr, concurrent);
         });
         if (rc) return rc;
         if (device_select) {
@@ -432,7 +464,7 @@ int search_seeds_device(Lane* ctx, const u8* d_seq_pool_or_null, const u8* h_seq
             });
             if (rc) return rc;
         }
-        if ((rc = d2h(ctx, counters, ctx->counters.ptr, 64))) return rc;
+        if ((rc = d2h(ctx, counters, ctx->counters.ptr, 128))) return rc;
         if (device_select) {
             if ((rc = d2h(ctx, &sel_total, (char*)ctx->sel_off.ptr + n_seeds * 4, 4))) return rc;
             if ((rc = d2h(ctx, &sel_rows_total, (char*)ctx->sel_row_off.ptr + n_seeds * 4, 4))) return rc;
@@ -440,10 +472,14 @@ int search_seeds_device(Lane* ctx, const u8* d_seq_pool_or_null, const u8* h_seq
         }
         if ((rc = ctx->sync())) return rc;
         if (getenv("FLX_SEARCH_DEBUG")) fprintf(stderr, "[fm_search] seeds %llu ext %u (of single-row intervals %u) wave-iterations %u (max per wave %u) busy pair-iterations %u, after the queue ran dry %u (max %u)\n", (unsigned long long)n_seeds, counters[2], counters[3], counters[4], counters[5], counters[6], counters[8], counters[9]);
+        if (getenv("FLX_SEARCH_DEBUG")) fprintf(stderr, "[fm_search classes] branching: rows=1 %u, rows 2-4 %u, rows>4 %u; forced: rows=1 %u, rows 2-4 %u, rows>4 %u\n", counters[10], counters[11], counters[12], counters[13], counters[14], counters[15]);
+        if (getenv("FLX_SEARCH_DEBUG") && filtered) fprintf(stderr, "[fm_search filtered] subtrees queued %u (slots %u of %llu), filter lookups %u, children dropped %u, searches ended by the prefix lookup %u; text walk: lane-steps %u, wave-iterations %u\n", counters[3], counters[16], (unsigned long long)item_cap, counters[10], counters[11], counters[12], counters[18], counters[19]);
         if (counters[1]) { set_error("fm_search: DFS stack reservation exceeded"); return FLX_ERR_INTERNAL; }
-        if (counters[0] <= hit_cap && (!device_select || sel_rows_total <= sel_cap)) break;      // (selected anchors <= rows)
-        if (attempt >= 2) { set_error("fm_search: hit buffer could not be sized"); return FLX_ERR_INTERNAL; }
-        if (counters[0] > hit_cap) hit_cap = (u64)counters[0] + hit_slack;      // the number of hits is known now; run again
+        bool const items_fit = !item_cap || counters[16] <= item_cap;
+        if (items_fit && counters[0] <= hit_cap && (!device_select || sel_rows_total <= sel_cap)) break;      // (selected anchors <= rows)
+        if (attempt >= 3) { set_error("fm_search: hit buffer could not be sized"); return FLX_ERR_INTERNAL; }
+        if (!items_fit) item_cap = (u64)counters[16] + hit_slack;             // queued subtrees were dropped: run again with room for all
+        else if (counters[0] > hit_cap) hit_cap = (u64)counters[0] + hit_slack;      // the number of hits is known now; run again
         else sel_cap = (u64)sel_rows_total + 1024;
     }
     // fold the extension count into the kernel's accounting: SURVEY.md 8(d) prices a cursor extension at 2 x 64 B (rank data at both
@@ -1556,7 +1592,9 @@ struct flx_reads {
     hvec<u64> lens;            // per read
     hvec<u64> pool_off;        // per read: offset of the forward sequence; reverse complement follows at +len
     hvec<u8> pool;             // host copy (forward + reverse complement per read)
+    hvec<u8> flags;            // per read: SEED_HAS_DELIM | SEED_NOT_ACGT (flx_fm_core.hpp) when it holds such symbols
     flx::DeviceBuffer d_pool;         // HBM-resident copy
+    mutable flx::DeviceBuffer d_pack; // its 2-bit form (K1's presence filter), built with the Peq planes
     // Peq planes of the whole pool (K0), built by the first flx_align_reads_resident call on these reads and shared by all
     // lanes and later calls (they depend on the pool only)
     mutable std::mutex peq_mu;
@@ -1578,6 +1616,7 @@ extern "C" int flx_reads_upload(flx_ctx* ctx, const uint8_t* read_pool, const ui
     rd->n_reads = n_reads;
     rd->lens.resize(n_reads);
     rd->pool_off.resize(n_reads);
+    rd->flags.assign(n_reads, 0);
     u64 total = 0;
     for (u64 i = 0; i < n_reads; ++i) {
         if (read_offsets[i + 1] < read_offsets[i]) { set_error("read offsets must be non-decreasing"); return FLX_ERR_INVALID; }
@@ -1589,7 +1628,10 @@ extern "C" int flx_reads_upload(flx_ctx* ctx, const uint8_t* read_pool, const ui
     for (u64 i = 0; i < n_reads; ++i) {
         u64 const len = rd->lens[i];
         const u8* src = read_pool + read_offsets[i];
-        for (u64 b = 0; b < len; ++b) if (src[b] > 5) { set_error("read rank > 5"); return FLX_ERR_INVALID; }
+        u8 seen = 0;                                   // bit r: rank r occurs
+        for (u64 b = 0; b < len; ++b) seen |= (u8)(1u << (src[b] < 6 ? src[b] : 7));
+        if (seen & 0x80) { set_error("read rank > 5"); return FLX_ERR_INVALID; }
+        rd->flags[i] = (u8)(((seen & 1) ? SEED_HAS_DELIM : 0) | ((seen & 0x21) ? SEED_NOT_ACGT : 0));
         rd->pool_off[i] = off;
         memcpy(rd->pool.data() + off, src, len);
         reverse_complement(src, len, rd->pool.data() + off + len);
@@ -1609,6 +1651,7 @@ extern "C" void flx_reads_free(flx_reads* reads) {
     if (!reads) return;
     if (reads->ctx) (void)hipSetDevice(reads->ctx->device);
     reads->d_pool.release();
+    reads->d_pack.release();
     reads->d_peq.release();
     reads->d_pool_rev.release();
     reads->d_peq_rev.release();
@@ -1642,6 +1685,7 @@ int align_slice(Lane* lane, const flx_params* P, const flx_reads* RD, u64 first_
     hvec<flx_seed> seeds;
     struct SeedOwner { u32 read; u8 orientation; };
     hvec<SeedOwner> seed_owner;
+    hvec<u8> seed_flags;
     std::map<std::pair<u64, u64>, std::unique_ptr<PexTree>> tree_cache;      // (length, errors) -> tree
     {
         // (the lists below grow to a seed per ~40 read bases: sized once instead of doubling their way up)
@@ -1650,6 +1694,7 @@ int align_slice(Lane* lane, const flx_params* P, const flx_reads* RD, u64 first_
         u64 const guess = 2 * (bases / 32 + (end_read - first_read)) / std::max<u64>(1, P->seed_sampling_step_size) + 64;
         seeds.reserve(guess);
         seed_owner.reserve(guess);
+        seed_flags.reserve(guess);
         reads.reserve(end_read - first_read);
     }
     for (u64 i = first_read; i < end_read; ++i) {
@@ -1675,6 +1720,7 @@ int align_slice(Lane* lane, const flx_params* P, const flx_reads* RD, u64 first_
                 flx_pex_node const& leaf = rs.tree_ref().leaves[l];
                 seeds.push_back(flx_seed{rs.pool_off[o] + leaf.from, leaf.to - leaf.from + 1, leaf.num_errors, (u32)l, 0});
                 seed_owner.push_back(SeedOwner{(u32)reads.size(), (u8)o});
+                seed_flags.push_back(RD->flags[i]);
             }
         reads.push_back(std::move(rs));
     }
@@ -1691,7 +1737,10 @@ int align_slice(Lane* lane, const flx_params* P, const flx_reads* RD, u64 first_
     // ---- seeding
     hvec<HostAnchor> anchors;
     hvec<SeedStats> sstats;
-    if ((rc = search_seeds_device(lane, d_pool, pool.data(), pool.size(), seeds.data(), seeds.size(), P->search, anchors, sstats, nullptr, 0))) return rc;
+    // (K1 starts behind K0 and the pool's 2-bit form: the event is recorded when the first call on these reads has queued both)
+    FLX_HIP(hipStreamWaitEvent(lane->stream, RD->peq_event, 0));
+    if ((rc = search_seeds_device(lane, d_pool, pool.data(), pool.size(), seeds.data(), seeds.size(), P->search, anchors, sstats, nullptr, 0,
+                                  RD->d_pack.ptr ? RD->d_pack.as<u32>() : nullptr, seed_flags.data()))) return rc;
 
     prof.mark("search");
     double const search_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_slice).count();
@@ -2123,6 +2172,12 @@ extern "C" int flx_align_reads_resident(flx_ctx* ctx, const flx_params* P, const
             LaneLease lease(ctx, ctx->external_stream ? 0 : -1);
             int const rc = build_peq(lease.lane, RD->d_pool.as<u8>(), RD->pool.size(), RD->d_peq);
             if (rc) return rc;
+            if (ctx->didx.filter) {
+                int const rc2 = RD->d_pack.ensure(pack_words_for(RD->pool.size()) * 4 + 64);
+                if (rc2) return rc2;
+                int const e = DeviceApi::pack_pool(lease.lane->stream, RD->d_pool.as<u8>(), RD->pool.size(), RD->d_pack.as<u32>());
+                if (e) { set_error(std::string("pack_pool: ") + hipGetErrorString((hipError_t)e)); return FLX_ERR_NO_DEVICE; }
+            }
             if (!RD->peq_event) FLX_HIP(hipEventCreateWithFlags(&RD->peq_event, hipEventDisableTiming));
             FLX_HIP(hipEventRecord(RD->peq_event, lease.lane->stream));
             RD->peq_built = true;

@@ -66,6 +66,26 @@ def test_search_groups_match_oracle(small_genome):
             assert mine.tolist() == exp.tolist(), (cap, i, ln, k)
 
 
+def test_search_groups_of_the_filtered_walk_match_oracle(small_genome, monkeypatch):
+    """the default search path (stack in LDS, presence filter, one-row subtrees against the text; hits put back into emission order by
+    their keys) asked for its raw groups: every group of every seed, in the oracle's order; also with the filter or the text walk off"""
+    refs, idx, ctx, oidx = small_genome
+    rng = np.random.default_rng(23)
+    pool, seeds = _make_seeds(rng, refs, 400)
+    # (no cap: this walk finds the groups in another order than the oracle, so a cap would cut another group short)
+    exp = [oidx.search_groups(pool[off:off + ln], k, n=2 ** 40)[0].tolist() for off, ln, k, _ in seeds]
+    sr = F.searcher(ctx)
+    monkeypatch.setenv("FLX_FM_KEYED_RAW", "1")
+    for env in ({}, {"FLX_FM_NO_FILTER": "1"}, {"FLX_FM_NO_TEXT": "1"}):
+        for k_, v in env.items():
+            monkeypatch.setenv(k_, v)
+        got = sr.search_groups(pool, seeds, max_hits=2 ** 31)
+        for i in range(len(seeds)):
+            assert got[got[:, 0] == i][:, 1:].tolist() == exp[i], (env, i, seeds[i])
+        for k_ in env:
+            monkeypatch.delenv(k_)
+
+
 def test_search_short_and_degenerate_seeds(small_genome):
     refs, idx, ctx, oidx = small_genome
     sr = F.searcher(ctx)

@@ -181,6 +181,20 @@ def test_std_sort_emulation_matches_std_sort(tmp_path):
     assert out.returncode == 0 and out.stdout.startswith("ok "), out.stdout + out.stderr
 
 
+def test_fm_core_matches_oracle(tmp_path):
+    """K1's lane logic (flx_fm_core.hpp: the walk with LDS frames and keys, the presence filter, the text walk of one-row subtrees) is
+    plain code the HIP kernels and this check share: compiled for the host it is run seed by seed over the product's host-built index
+    and must give the oracle's search_n emission, order and duplicates included, in every mode (rank queries only / filter / text /
+    both, four filter sizes), on a repeat-rich reference with special seeds and on read-shaped seeds over a 1 Mb reference"""
+    import subprocess
+    exe = str(tmp_path / "fm_core_check")
+    src = [os.path.join(ROOT, "tests", "fm_core_check.cpp"), os.path.join(ROOT, "floxer_amd", "csrc", "flx_host.cpp"),
+           os.path.join(ROOT, "floxer_amd", "csrc", "flx_index.cpp"), os.path.join(ROOT, "oracle", "floxer_oracle.cpp")]
+    subprocess.run(["g++", "-O2", "-std=c++17", "-Wno-unknown-pragmas", "-pthread", "-o", exe] + src, check=True)
+    out = subprocess.run([exe, "250", "5"], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "fm_core_check ok" in out.stdout, out.stdout[-3000:] + out.stderr[-3000:]
+
+
 def test_writer_threads_long_cigar_and_name_limit(tmp_path):
     """flx_sam_set_threads: output bytes do not depend on the thread count; a CIGAR of more than 65535 operations goes into the
     CG:B,I tag behind a kSmN placeholder (SAM spec 4.2.2); a read name of 255 characters or more is refused for BAM"""
