@@ -89,7 +89,7 @@ EXPORTED = [
     "flx_search_groups", "flx_align_batch", "flx_params_default", "flx_align_reads", "flx_reads_upload", "flx_reads_free",
     "flx_align_reads_resident", "flx_run_num_records",
     "flx_run_num_cigar_words", "flx_run_copy", "flx_run_free", "flx_ctx_enable_kernel_timing", "flx_ctx_reset_kernel_stats",
-    "flx_ctx_get_kernel_stats", "flx_sam_open", "flx_sam_write", "flx_sam_close", "flx_sim_genome", "flx_sim_reads", "flx_ctx_get_path_counters",
+    "flx_ctx_get_kernel_stats", "flx_sam_open", "flx_sam_write", "flx_sam_close", "flx_sim_genome", "flx_sim_genome_repeats", "flx_sim_reads", "flx_ctx_get_path_counters",
     "flx_ctx_reset_path_counters", "flx_stats_create", "flx_stats_free", "flx_stats_merge", "flx_stats_num_queries", "flx_stats_format",
     "flx_ctx_set_stats", "flx_device_count", "flx_index_matches_reference", "flx_sam_set_threads", "flx_index_image_layout",
     "flx_index_image_upload", "flx_index_meta_export", "flx_index_meta_import", "flx_ctx_create_on_image",
@@ -174,6 +174,7 @@ def lib():
     L.flx_ctx_get_path_counters.argtypes = [C.c_void_p, C.POINTER(PathCounters)]
     L.flx_ctx_reset_path_counters.argtypes = [C.c_void_p]
     L.flx_sim_genome.argtypes = [C.c_uint64, C.c_uint64, u8p]
+    L.flx_sim_genome_repeats.argtypes = [C.c_uint64, C.c_uint64, u8p]
     L.flx_sim_reads.argtypes = [u8p, u64p, C.c_uint32, C.c_uint64, C.c_uint32, C.c_double, C.c_double, C.c_uint64, u8p, C.c_uint64,
                                 u64p, u32p, u64p, u8p]
     _lib = L

@@ -154,6 +154,9 @@ int make_context(int hip_device, const flx_index* index, void* const image[5], b
         if (e) { set_error(std::string("derive_index: ") + hipGetErrorString((hipError_t)e)); return FLX_ERR_NO_DEVICE; }
         FLX_HIP(hipStreamSynchronize(s0));
     }
+    if (getenv("FLX_ALLOC_DEBUG"))
+        fprintf(stderr, "[flx alloc] context: occ0 %p occ1 %p sa %p text %p kmer %p (n %llu) isa %p filter %p (K %u, tmin %u) seq_start %p\n", img[0], img[1], img[2], img[3],
+                img[4], (unsigned long long)H.n, ctx->isa.ptr, ctx->filter.ptr, ctx->didx.filter_k, ctx->didx.filter_tmin, ctx->seq_start.ptr);
     // trace arena budget: FLX_TRACE_ARENA_MB (whole context), default 40% of the free HBM, at least 256 MB; split over the lanes
     size_t free_b = 0, total_b = 0;
     FLX_HIP(hipMemGetInfo(&free_b, &total_b));

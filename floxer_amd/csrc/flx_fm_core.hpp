@@ -246,64 +246,100 @@ FLX_HD inline void fm_take_seed(FmConst const& C, FmLane& L, DevSeed const& seed
     L.in_search = false;
 }
 
+// what the filter needs from memory besides the table itself, asked for before the rank queries of the node so that both are in
+// flight together: the scheme entry behind the node's and the seed's symbols on both sides of the junction (32 each)
+struct FmFilterPre { u64 e1, xs, xf; };
+FLX_HD inline FmFilterPre fm_filter_prefetch(FmConst const& C, FmLane const& L, u32 x, u64 e64, u32 right) {
+    FmFilterPre P;
+    P.e1 = x + 1u < L.len ? L.ex[x + 1u] : 0ull;
+    u32 const a = sch_lo(e64);
+    i64 const g0 = (i64)L.qoff;
+    //   right: xs = seed[b-31 .. b] with b = a + x - 1 the string's last position, xf = seed[b+1 ...]
+    //   left:  xs = seed[a ...], xf = seed[a-32 .. a-1]
+    P.xs = pack_extract(C.qpack, right ? g0 + (i64)(a + x) - 32 : g0 + (i64)a);
+    P.xf = pack_extract(C.qpack, right ? g0 + (i64)(a + x) : g0 + (i64)a - 32);
+    return P;
+}
+// one kind of child (0 substitution, 1 deletion, 2 insertion): the code of its string without the junction symbol, where that symbol
+// goes, how far the code is shifted up (unknown symbols in front of a string shorter than K), and the symbols to ask for
+struct FmFilterKind { u64 base; u32 csh, ush, want; };
+// wide: the window with as many symbols of the string as fit (second look at a child that passed the first, whose window holds as
+// many forced symbols as fit: the two share about half of their symbols)
+FLX_HD inline FmFilterKind fm_filter_kind(u32 kind, u32 K, u32 tmin, u32 x, u32 right, u32 F, u32 want, u64 xs, u64 xf, bool wide) {
+    FmFilterKind Q{0ull, 0u, 0u, 0u};
+    u32 const jn = kind == 2u ? 0u : 1u;                             // a junction symbol c (the insertion has none: the position is skipped)
+    u32 h, r;
+    if (!wide) {
+        u32 const keep = x < 2u ? x : 2u;                           // string symbols a window always holds
+        h = F < K - jn - keep ? F : K - jn - keep;
+        r = x < K - jn - h ? x : K - jn - h;
+    } else {
+        r = x < K - jn - 1u ? x : K - jn - 1u;
+        h = F < K - jn - r ? F : K - jn - r;
+    }
+    u32 const t = h + jn + r;
+    if (h < 1u || t < tmin || K - t > 3u || (kind == 2u && r < 1u)) return Q;
+    u32 const skip = kind == 1u ? 0u : 2u;                           // the forced symbols of a deletion child start at the position itself
+    u64 str, forced;
+    if (right) { str = r ? xs >> (2u * (32u - r)) : 0ull; forced = low_syms(xf >> skip, h); }
+    else { str = low_syms(xs, r); forced = (xf << skip) >> (2u * (32u - h)); }
+    // codes: leftmost symbol lowest. right: string | c | forced; left: forced | c | string
+    Q.base = right ? str | (forced << (2u * (r + jn))) : forced | (str << (2u * (h + jn)));
+    Q.csh = 2u * (right ? r : h);
+    Q.ush = 2u * (K - t);
+    Q.want = want;
+    return Q;
+}
 // The presence filter at a branching node without errors so far: the node's string is seed[a, a + x). Children that have no error
 // left at the positions that follow are dropped from the mask when the string they are bound to reach does not occur in the text.
-FLX_HD inline u32 fm_filter_children(FmConst const& C, FmLane& L, u32 x, u64 e64, u32 right, u32 mask) {
+// Two looks: one window of K symbols around the junction per child, then a second, shifted window for the children that passed
+// (a K-mer drawn at random is present with probability n / 4^K, 4.5 % at hg38 size: two windows leave 0.2 % of the wrong children).
+FLX_HD inline u32 fm_filter_children(FmConst const& C, FmLane& L, u32 x, u64 e64, u32 right, u32 mask, FmFilterPre const& P) {
     u32 const K = C.idx.filter_k, tmin = C.idx.filter_tmin;
-    u32 const sch = (u32)e64;
     // forced positions behind the children: F1 for the children that move on to entry x + 1 (substitution, insertion), F0 for
     // the deletion children, which stay at entry x
     u32 F1 = 0, F0 = 0;
-    if (x + 1u < L.len) {
-        u64 const e1 = L.ex[x + 1u];
-        if (sch_upper((u32)e1) == 1u && sch_right((u32)e1) == right) F1 = sch_run_end(e1) - (x + 1u);
-    }
-    if (sch_upper(sch) == 1u) F0 = sch_run_end(e64) - x;
+    if (x + 1u < L.len && sch_upper((u32)P.e1) == 1u && sch_right((u32)P.e1) == right) F1 = sch_run_end(P.e1) - (x + 1u);
+    if (sch_upper((u32)e64) == 1u) F0 = sch_run_end(e64) - x;
     if ((F1 | F0) == 0u) return mask;
-    u32 const a = sch_lo(e64);
-    i64 const g0 = (i64)L.qoff;
-    // the string's symbols next to the junction (xs) and the seed's symbols beyond it (xf), 32 each:
-    //   right: xs = seed[b-31 .. b] with b = a + x - 1 the string's last position, xf = seed[b+1 ...]
-    //   left:  xs = seed[a ...], xf = seed[a-32 .. a-1]
-    u64 const xs = pack_extract(C.qpack, right ? g0 + (i64)(a + x) - 32 : g0 + (i64)a);
-    u64 const xf = pack_extract(C.qpack, right ? g0 + (i64)(a + x) : g0 + (i64)a - 32);
     const u64* __restrict__ bits = C.idx.filter;
-    u32 const keep = x < 2u ? x : 2u;                               // string symbols a window always holds
-    u32 drop = 0, nq = 0;
-    // kind 0: substitution (junction symbol c, the forced symbols follow the replaced position), 1: deletion (junction symbol c, the
-    // forced symbols start at the position itself), 2: insertion (no junction symbol, the position is skipped)
+    // symbols asked for per kind, bit 2(c-1): symbol c
+    u32 want_s = (mask >> 2) & 0x55u, want_d = (mask >> 1) & 0x55u, want_i = (mask >> 11) & 1u;
 #pragma unroll 1
-    for (u32 kind = 0; kind < 3u; ++kind) {
-        u32 const F = kind == 1u ? F0 : F1, jn = kind == 2u ? 0u : 1u;
-        // as many forced symbols as there are (they are the ones not looked at yet), the rest of the K from the string
-        u32 const h = F < K - jn - keep ? F : K - jn - keep;
-        u32 const r = x < K - jn - h ? x : K - jn - h;
-        u32 const t = h + jn + r;
-        if (h < 1u || t < tmin || K - t > 3u) continue;
-        u32 const want = kind == 0u ? (mask >> 2) & 0x55u : kind == 1u ? (mask >> 1) & 0x55u : (r >= 1u ? (mask >> 11) & 1u : 0u);   // bit 2(c-1): symbol c
-        if (!want) continue;
-        u32 const skip = kind == 1u ? 0u : 2u;                       // bits of xf the forced symbols start behind (the position itself)
-        u64 str, forced;
-        if (right) { str = r ? xs >> (2u * (32u - r)) : 0ull; forced = low_syms(xf >> skip, h); }
-        else { str = low_syms(xs, r); forced = (xf << skip) >> (2u * (32u - h)); }
-        // codes: leftmost symbol lowest. right: string | c | forced; left: forced | c | string
-        u64 const base = right ? str | (forced << (2u * (r + jn))) : forced | (str << (2u * (h + jn)));
-        u32 const csh = 2u * (right ? r : h), ush = 2u * (K - t);
-        // a lookup is the 64-bit word that holds the string's bit, or the 4 / 16 / 64 bits of its left extensions
-        u64 const span = ush >= 6u ? ~0ull : (1ull << (1u << ush)) - 1ull;
-        u64 w[4];
-#pragma unroll
-        for (u32 c = 0; c < 4u; ++c) w[c] = ((want >> (2u * c)) & 1u) ? bits[((base | ((u64)c << csh)) << ush) >> 6] : ~0ull;
+    for (u32 look = 0; look < 2u; ++look) {
+        FmFilterKind const qs = fm_filter_kind(0u, K, tmin, x, right, F1, want_s, P.xs, P.xf, look != 0u);
+        FmFilterKind const qd = fm_filter_kind(1u, K, tmin, x, right, F0, want_d, P.xs, P.xf, look != 0u);
+        FmFilterKind const qi = fm_filter_kind(2u, K, tmin, x, right, F1, want_i, P.xs, P.xf, look != 0u);
+        if ((qs.want | qd.want | qi.want) == 0u) break;
+        // a lookup is the 64-bit word that holds the string's bit, or the 4 / 16 / 64 bits of its left extensions; all of them are
+        // asked for before the first is looked at
+        u64 ws[4], wd[4];
 #pragma unroll
         for (u32 c = 0; c < 4u; ++c) {
-            u32 const at = (u32)((base | ((u64)c << csh)) << ush) & 63u;
-            if (((w[c] >> at) & span) == 0ull) drop |= kind == 0u ? 4u << (2u * c) : kind == 1u ? 2u << (2u * c) : 1u << 11;
+            ws[c] = ((qs.want >> (2u * c)) & 1u) ? bits[((qs.base | ((u64)c << qs.csh)) << qs.ush) >> 6] : ~0ull;
+            wd[c] = ((qd.want >> (2u * c)) & 1u) ? bits[((qd.base | ((u64)c << qd.csh)) << qd.ush) >> 6] : ~0ull;
         }
-        nq += fm_popc(want);
+        u64 const wi = qi.want ? bits[(qi.base << qi.ush) >> 6] : ~0ull;
+        u64 const span_s = qs.ush >= 6u ? ~0ull : (1ull << (1u << qs.ush)) - 1ull;
+        u64 const span_d = qd.ush >= 6u ? ~0ull : (1ull << (1u << qd.ush)) - 1ull;
+        u64 const span_i = qi.ush >= 6u ? ~0ull : (1ull << (1u << qi.ush)) - 1ull;
+        u32 drop_s = 0, drop_d = 0, drop_i = 0;
+#pragma unroll
+        for (u32 c = 0; c < 4u; ++c) {
+            u32 const at_s = (u32)((qs.base | ((u64)c << qs.csh)) << qs.ush) & 63u;
+            u32 const at_d = (u32)((qd.base | ((u64)c << qd.csh)) << qd.ush) & 63u;
+            if (((ws[c] >> at_s) & span_s) == 0ull) drop_s |= 1u << (2u * c);
+            if (((wd[c] >> at_d) & span_d) == 0ull) drop_d |= 1u << (2u * c);
+        }
+        if (((wi >> ((u32)(qi.base << qi.ush) & 63u)) & span_i) == 0ull) drop_i = 1u;
+        L.n_lookup += fm_popc(qs.want) + fm_popc(qd.want) + qi.want;
+        L.n_pruned += fm_popc(drop_s) + fm_popc(drop_d) + drop_i;
+        mask &= ~((drop_s << 2) | (drop_d << 1) | (drop_i << 11));
+        // the second look: only the children the first one was asked about and let pass
+        want_s = qs.want & ~drop_s; want_d = qd.want & ~drop_d; want_i = qi.want & ~drop_i;
+        if ((want_s | want_d | want_i) == 0u) break;
     }
-    L.n_lookup += nq;
-    L.n_pruned += fm_popc(drop);
-    return mask & ~drop;
+    return mask;
 }
 
 // start of search `srch` of the seed: the root cursor, or the cursor of the seed's first KMER_Q symbols when the search begins
@@ -424,6 +460,9 @@ FLX_HD inline void fm_step(FmConst const& C, FmLane& L, FR&& fr) {
         return;
     }
 
+    bool const filtered = mismatch_allowed && C.use_filter && L.ne == 0u && L.nx >= 1u && !(L.flags & SEED_NOT_ACGT);
+    FmFilterPre pre{0ull, 0ull, 0ull};
+    if (filtered) pre = fm_filter_prefetch(C, L, L.nx, e64, right);
     u32 const next_sym = C.seq[L.qoff + (sch & SCH_POS_MASK)];
     u32 const lo = right ? L.nlbr : L.nlb, other = right ? L.nlb : L.nlbr;
     u32 ab[6], cl[6];
@@ -435,8 +474,8 @@ FLX_HD inline void fm_step(FmConst const& C, FmLane& L, FR&& fr) {
         u32 const tinfo = right ? L.nri : L.nli;
         u32 mask = fm_child_mask6(cl, next_sym, match_allowed, tinfo == FM_INFO_M || tinfo == FM_INFO_D, tinfo == FM_INFO_M || tinfo == FM_INFO_I);
         if (mask == 0u) { L.need_child = true; return; }
-        if (C.use_filter && L.ne == 0u && L.nx >= 1u && !(L.flags & SEED_NOT_ACGT) && (mask & ~1u)) {
-            mask = fm_filter_children(C, L, L.nx, e64, right, mask);
+        if (filtered && (mask & ~1u)) {
+            mask = fm_filter_children(C, L, L.nx, e64, right, mask, pre);
             if (mask == 0u) { L.need_child = true; return; }
         }
         if (L.depth >= C.levels) { L.overflow = true; L.busy = false; return; }
@@ -474,10 +513,9 @@ FLX_HD inline void fm_step(FmConst const& C, FmLane& L, FR&& fr) {
 // ------------------------------------------------------------------------------------------------ text mode
 // A lane walks the subtree below a one-row node: its string occupies text[pL, pR]; every extension reads the text symbol next to it.
 struct TxLane {
-    u32 sid = 0, len = 0, ct = 0;
+    u32 sid = 0, len = 0;
     u64 qoff = 0;
     const u64* ex = nullptr;
-    u32 l_last = 0, u_last = 0;
     bool busy = false, need_child = false;
     u32 pL = 0, pR = 0, nx = 0, ne = 0, nli = 0, nri = 0;
     u64 nkey = 0;
@@ -490,15 +528,12 @@ struct TxLane {
 
 FLX_HD inline void tx_take_item(FmConst const& C, TxLane& L, DevHit const& item, DevSeed const& seed) {
     u32 const st = item.len;
+    L.pL = C.idx.sa[item.lb];
     L.sid = seed.id;
     L.len = seed.length;
     L.qoff = seed.seq_off;
     L.ex = C.scheme + seed.scheme_off + (u64)item_srch(st) * seed.length;
-    u32 const last_entry = (u32)L.ex[L.len - 1];
-    L.l_last = sch_lower(last_entry);
-    L.u_last = sch_upper(last_entry);
     L.nx = fst_x(st); L.ne = fst_e(st); L.nli = fst_li(st); L.nri = fst_ri(st);
-    L.pL = C.idx.sa[item.lb];
     L.pR = L.pL + L.nx + fst_dl(st) - 4u - 1u;          // the string has nx + (deletions - insertions) text symbols
     L.nkey = item.key;
     L.depth = 0;
@@ -542,8 +577,11 @@ FLX_HD inline void tx_step(FmConst const& C, TxLane& L, FR&& fr) {
     }
     if (L.nx == L.len) {
         bool const ok_l = L.nli == FM_INFO_M || L.nli == FM_INFO_I, ok_r = L.nri == FM_INFO_M || L.nri == FM_INFO_I;
-        if (ok_l && ok_r && L.l_last <= L.ne && L.ne <= L.u_last) {
-            L.out = FM_OUT_HIT; L.out_lb = C.idx.isa[L.pL]; L.out_e = L.ne; L.out_key = L.nkey;
+        if (ok_l && ok_r) {
+            u32 const last_entry = (u32)L.ex[L.len - 1];              // (read here: few nodes get this far)
+            if (sch_lower(last_entry) <= L.ne && L.ne <= sch_upper(last_entry)) {
+                L.out = FM_OUT_HIT; L.out_lb = C.idx.isa[L.pL]; L.out_e = L.ne; L.out_key = L.nkey;
+            }
         }
         L.need_child = true;
         return;

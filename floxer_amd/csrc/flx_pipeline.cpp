@@ -36,6 +36,7 @@ int DeviceBuffer::ensure(size_t bytes, bool exact) {
     if (e != hipSuccess) { set_error(std::string("hipMalloc of ") + std::to_string(bytes) + " bytes failed: " + hipGetErrorString(e)); return FLX_ERR_NO_DEVICE; }
     ptr = p;
     cap = got;
+    if (debug) fprintf(stderr, "[flx alloc] buffer %p .. %p (%zu bytes, asked %zu)\n", p, (void*)((char*)p + got), got, bytes);
     return FLX_OK;
 }
 void DeviceBuffer::release() {
@@ -95,6 +96,15 @@ hvec<DeviceBuffer*> lane_workspaces(Lane& l) {
             &l.job_out, &l.trace, &l.tjobs, &l.tjob_out, &l.cigar, &l.user_text, &l.user_text_rev, &l.lastrow, &l.row_windows, &l.row_out,
             &l.seed_cnt, &l.hit_off, &l.grouped, &l.sel_stat, &l.sel_n, &l.sel_off, &l.sel_out, &l.sel_tmp, &l.sel_rows, &l.sel_row_off, &l.sel_sparse, &l.sel_lists, &l.vr, &l.vr_override,
             &l.qpack, &l.items};
+}
+// FLX_ALLOC_DEBUG: the address ranges of a lane's workspaces (a GPU memory fault reports an address)
+static void dump_lane_buffers(Lane& l, const char* when) {
+    static const char* const names[] = {"seq", "seq_rev", "peq", "peq_rev", "scheme", "seeds", "stack", "hits", "counters", "rows", "rows_out", "jobs", "job_out",
+        "trace", "tjobs", "tjob_out", "cigar", "user_text", "user_text_rev", "lastrow", "row_windows", "row_out", "seed_cnt", "hit_off", "grouped", "sel_stat",
+        "sel_n", "sel_off", "sel_out", "sel_tmp", "sel_rows", "sel_row_off", "sel_sparse", "sel_lists", "vr", "vr_override", "qpack", "items"};
+    auto const ws = lane_workspaces(l);
+    for (size_t i = 0; i < ws.size(); ++i)
+        if (ws[i]->ptr) fprintf(stderr, "[flx alloc] lane %d %s %s %p .. %p\n", l.id, when, names[i], ws[i]->ptr, (void*)((char*)ws[i]->ptr + ws[i]->cap));
 }
 std::vector<DeviceBuffer*> Lane::workspaces() { auto v = lane_workspaces(*this); return std::vector<DeviceBuffer*>(v.begin(), v.end()); }
 int Lane::size_like(Lane& other) {
@@ -426,6 +436,7 @@ int search_seeds_device(Lane* ctx, const u8* d_seq_pool_or_null, const u8* h_seq
     struct K1Token { flx_ctx* c; explicit K1Token(flx_ctx* c_) : c(c_) { c->k1_acquire(); } ~K1Token() { c->k1_release(); } };
     for (int attempt = 0;; ++attempt) {
         K1Token const token(ctx->ctx);           // (held until this attempt's kernels have finished)
+        static int const alloc_debug = getenv("FLX_ALLOC_DEBUG") ? 1 : 0;
         sel_cap = std::max(sel_cap, hit_cap);
         if ((rc = ctx->hits.ensure(hit_cap * sizeof(DevHit)))) return rc;
         if (item_cap && (rc = ctx->items.ensure(item_cap * sizeof(DevHit)))) return rc;
@@ -440,6 +451,7 @@ int search_seeds_device(Lane* ctx, const u8* d_seq_pool_or_null, const u8* h_seq
             FLX_HIP(hipMemsetAsync(ctx->seed_cnt.ptr, 0, (n_seeds + 1) * 4, ctx->stream));
             FLX_HIP(hipMemsetAsync((char*)ctx->sel_n.ptr + n_seeds * 4, 0, 4, ctx->stream));
         }
+        if (alloc_debug) { dump_lane_buffers(*ctx, "search"); fprintf(stderr, "[flx alloc] lane %d search: seeds %llu hit_cap %llu item_cap %llu pool %p qpack %p\n", ctx->id, (unsigned long long)n_seeds, (unsigned long long)hit_cap, (unsigned long long)item_cap, (const void*)d_seq, (const void*)d_qpack); }
         rc = timed_launch(ctx, "fm_search", 0, n_seeds, [&] {
             u32 const concurrent = ctx->ctx->external_stream ? 1u : (u32)ctx->ctx->lanes.size();
             if (filtered)

@@ -155,7 +155,7 @@ __device__ __forceinline__ u32 wave_slots_take(WaveSlots& S, DevHit* __restrict_
 }
 }  // namespace
 
-__global__ void __launch_bounds__(64) fm_search_filter_kernel(FmConst C, const DevSeed* __restrict__ seeds, u32 n_seeds, DevHit* __restrict__ hits,
+__global__ void __launch_bounds__(64, 4) fm_search_filter_kernel(FmConst C, const DevSeed* __restrict__ seeds, u32 n_seeds, DevHit* __restrict__ hits,
                                                               u32 hit_cap, DevHit* __restrict__ items, u32 item_cap, u32* __restrict__ counters,
                                                               u32* __restrict__ seed_cnt) {
     extern __shared__ u32 lds[];                // frames: [level][FM_FRAME_WORDS][64 lanes]
@@ -291,8 +291,11 @@ int DeviceApi::search_filtered(void* stream, const DevIndex& idx, const u8* d_se
     hipLaunchKernelGGL(fm_search_filter_kernel, grid, dim3(64), (size_t)C.levels * FM_FRAME_WORDS * 64 * sizeof(u32), s, C, d_seeds, n_seeds, d_hits, hit_cap,
                        d_items, item_cap, d_counters, d_seed_cnt);
     if (C.text_min_remain) {
-        // (the number of queued subtrees is only known on the device: a fixed grid, waves without work leave at once)
-        hipLaunchKernelGGL(fm_search_text_kernel, dim3(std::min<u32>(grid.x, max_waves)), dim3(64), (size_t)C.levels * TX_FRAME_WORDS * 64 * sizeof(u32), s, C,
+        // (the number of queued subtrees is only known on the device: a fixed grid, waves without work leave at once; the walk is a
+        // chain of dependent loads from the L2, so it wants every wave slot: 8 per SIMD)
+        static u32 const text_waves = env_u32("FLX_FM_TEXT_WAVES", 8192);
+        u32 const tw = std::max(1u, text_waves / std::max(1u, std::min(concurrent_launches, 8u)));
+        hipLaunchKernelGGL(fm_search_text_kernel, dim3(std::min<u32>(std::max<u32>(grid.x * 4u, 64u), tw)), dim3(64), (size_t)C.levels * TX_FRAME_WORDS * 64 * sizeof(u32), s, C,
                            d_seeds, d_items, item_cap, d_hits, hit_cap, d_counters, d_seed_cnt);
     }
     return (int)hipGetLastError();

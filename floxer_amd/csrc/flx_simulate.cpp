@@ -10,6 +10,7 @@
 // across standard libraries; this generator is xoshiro256** seeded per read (splitmix64 of seed and read index), so its output
 // does not depend on the number of threads.
 #include <algorithm>
+#include <cmath>
 #include <cstdlib>
 #include <cstring>
 #include <thread>
@@ -128,6 +129,119 @@ extern "C" int flx_sim_genome(uint64_t length, uint64_t seed, uint8_t* out) {
             }
         }
     });
+    return FLX_OK;
+}
+
+// A repeat-rich reference at genome scale: what a uniform random text lacks and a human genome has. Per 256-kb block (its own
+// generator stream, so the result does not depend on the thread count) stretches of unique sequence alternate with elements drawn
+// by their share of the bases:
+//   interspersed families (the consensus sequences are a function of the seed alone): one of 300 bp with copies 2-15 % diverged
+//   (Alu-like, 11 % of the bases), one of 6 kb whose copies are 5'-truncated to 200 bp .. 6 kb and 2-20 % diverged (L1-like,
+//   18 %), six more of 250 .. 1500 bp (12 %); a copy is the consensus or its reverse complement with substitutions (80 % of the
+//   edits), deletions and insertions;
+//   tandem repeats: units of 1-6 bp in arrays of 20 .. 300 bp and units of 10-60 bp in arrays of 5 .. 100 copies (3 %);
+//   two-letter low-complexity stretches of 100 .. 1500 bp (1 %);
+//   runs of N of 100 .. 20000 bp (0.3 %).
+// A second pass copies segments of 5 .. 50 kb to other places with 1-3 % divergence (segmental duplications, 5 % of the bases).
+// About half of the bases stay unique. floxer's caps (-M 500 / -m 50, search.cpp:190-272) exist because of such sequence.
+extern "C" int flx_sim_genome_repeats(uint64_t length, uint64_t seed, uint8_t* out) {
+    if (!out && length) { set_error("flx_sim_genome_repeats: null output"); return FLX_ERR_INVALID; }
+    static const u8 comp[6] = {0, 4, 3, 2, 1, 5};
+    struct Family { std::vector<u8> cons; double share; u32 min_len; double div_lo, div_hi; bool truncate; };
+    std::vector<Family> fams;
+    {
+        Rng rng(seed, 0xFA111E5ull);
+        auto make = [&](u32 len, double share, u32 min_len, double lo, double hi, bool trunc) {
+            Family f{std::vector<u8>(len), share, min_len, lo, hi, trunc};
+            for (auto& c : f.cons) c = (u8)(1 + rng.below(4));
+            fams.push_back(std::move(f));
+        };
+        make(300, 0.11, 300, 0.02, 0.15, false);
+        make(6000, 0.18, 200, 0.02, 0.20, true);
+        for (u32 i = 0; i < 6; ++i) make((u32)(250 + rng.below(1251)), 0.02, 100, 0.03, 0.25, true);
+    }
+    double const share_tandem = 0.03, share_low = 0.01, share_n = 0.003;
+    // elements per base of each kind = share / mean length; the unique stretch between two elements has the mean length that
+    // leaves the unique share
+    std::vector<double> rate;
+    for (auto const& f : fams) rate.push_back(f.share / (f.truncate ? 0.5 * (f.min_len + f.cons.size()) : (double)f.cons.size()));
+    rate.push_back(share_tandem / 400.0);
+    rate.push_back(share_low / 800.0);
+    rate.push_back(share_n / 10050.0);
+    double rate_sum = 0, repeat_share = share_tandem + share_low + share_n;
+    for (double r : rate) rate_sum += r;
+    for (auto const& f : fams) repeat_share += f.share;
+    double const mean_unique = (1.0 - repeat_share) / rate_sum;
+    constexpr u64 BLOCK = 256 << 10;
+    u64 const n_blocks = (length + BLOCK - 1) / BLOCK;
+    parallel_ranges(n_blocks, [&](u64 b0, u64 b1) {
+        std::vector<u8> piece;
+        for (u64 b = b0; b < b1; ++b) {
+            Rng rng(seed, b + 1);
+            u64 at = b * BLOCK;
+            u64 const last = std::min(length, at + BLOCK);
+            auto put = [&](u8 c) { if (at < last) out[at++] = c; };
+            while (at < last) {
+                // unique stretch: geometric with the mean above (at least 20)
+                u64 const ulen = 20 + (u64)(-std::log(1.0 - rng.unit()) * mean_unique);
+                for (u64 i = 0; i < ulen && at < last; ++i) put((u8)(1 + (rng.next() >> 62)));
+                if (at >= last) break;
+                double pick = rng.unit() * rate_sum;
+                size_t kind = 0;
+                while (kind + 1 < rate.size() && pick >= rate[kind]) { pick -= rate[kind]; ++kind; }
+                if (kind < fams.size()) {
+                    Family const& f = fams[kind];
+                    u32 const clen = f.truncate ? (u32)(f.min_len + rng.below(f.cons.size() - f.min_len + 1)) : (u32)f.cons.size();
+                    u32 const first = (u32)f.cons.size() - clen;                      // 5'-truncated: the copy keeps the consensus' end
+                    double const div = f.div_lo + rng.unit() * (f.div_hi - f.div_lo);
+                    bool const rc = rng.next() & 1;
+                    piece.clear();
+                    for (u32 i = 0; i < clen; ++i) {
+                        u8 const c = f.cons[first + i];
+                        if (rng.unit() < div) {
+                            u64 const t = rng.below(10);
+                            if (t < 8) piece.push_back((u8)(1 + (c - 1 + 1 + rng.below(3)) % 4));
+                            else if (t == 8) continue;
+                            else { piece.push_back(c); piece.push_back((u8)(1 + rng.below(4))); }
+                        } else piece.push_back(c);
+                    }
+                    if (rc) for (size_t i = piece.size(); i-- > 0;) put(comp[piece[i]]);
+                    else for (u8 c : piece) put(c);
+                } else if (kind == fams.size()) {                                   // tandem repeat
+                    bool const micro = rng.next() & 1;
+                    u32 const ulen = micro ? (u32)(1 + rng.below(6)) : (u32)(10 + rng.below(51));
+                    u64 const total = micro ? 20 + rng.below(281) : (u64)ulen * (5 + rng.below(96));
+                    u8 unit[64];
+                    for (u32 i = 0; i < ulen; ++i) unit[i] = (u8)(1 + rng.below(4));
+                    for (u64 i = 0; i < total; ++i) put(rng.unit() < 0.01 ? (u8)(1 + rng.below(4)) : unit[i % ulen]);
+                } else if (kind == fams.size() + 1) {                               // two-letter low complexity
+                    u8 const x = (u8)(1 + rng.below(4)), y = (u8)(1 + rng.below(4));
+                    u64 const total = 100 + rng.below(1401);
+                    for (u64 i = 0; i < total; ++i) put((rng.next() & 1) ? x : y);
+                } else {                                                            // run of N
+                    u64 const total = 100 + rng.below(19901);
+                    for (u64 i = 0; i < total; ++i) put(5);
+                }
+            }
+        }
+    });
+    // segmental duplications, one after the other (a copy may be copied again)
+    if (length > 200000) {
+        Rng rng(seed, 0x5E6D09ull);
+        u64 copied = 0;
+        while (copied < length / 20) {
+            u64 const len = 5000 + rng.below(45001);
+            u64 const from = rng.below(length - len), to = rng.below(length - len);
+            if (from + len > to && to + len > from) continue;                        // overlapping: draw again
+            double const div = 0.01 + rng.unit() * 0.02;
+            for (u64 i = 0; i < len; ++i) {
+                u8 c = out[from + i];
+                if (c >= 1 && c <= 4 && rng.unit() < div) c = (u8)(1 + (c - 1 + 1 + rng.below(3)) % 4);
+                out[to + i] = c;
+            }
+            copied += len;
+        }
+    }
     return FLX_OK;
 }
 

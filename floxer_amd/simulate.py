@@ -82,12 +82,15 @@ def write_fastq(path, reads, names):
 # ------------------------------------------------------------------------------------------------ the same, at benchmark scale
 # flx_sim_genome / flx_sim_reads (floxer_amd/csrc/flx_simulate.cpp): same semantics, multi-threaded, own portable generator
 # (a different stream of random numbers than make_genome / make_reads above).
-def make_genome_fast(chromosome_length, num_chromosomes=1, seed=DEFAULT_SEED):
-    """one contiguous uint8 rank array of num_chromosomes * chromosome_length symbols + the list of per-chromosome views"""
+def make_genome_fast(chromosome_length, num_chromosomes=1, seed=DEFAULT_SEED, repeat_rich=False):
+    """one contiguous uint8 rank array of num_chromosomes * chromosome_length symbols + the list of per-chromosome views.
+    repeat_rich: interspersed repeat families, tandem repeats, low complexity, runs of N and segmental duplications over about half
+    of the bases (flx_sim_genome_repeats) instead of uniform random sequence"""
     import ctypes as C
     from . import capi
     pool = np.empty(chromosome_length * num_chromosomes, dtype=np.uint8)
-    capi.check(capi.lib().flx_sim_genome(len(pool), seed, capi.ptr(pool, capi.u8p)))
+    gen = capi.lib().flx_sim_genome_repeats if repeat_rich else capi.lib().flx_sim_genome
+    capi.check(gen(len(pool), seed, capi.ptr(pool, capi.u8p)))
     return pool, [pool[i * chromosome_length:(i + 1) * chromosome_length] for i in range(num_chromosomes)]
 
 

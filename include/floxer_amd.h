@@ -271,6 +271,9 @@ int flx_sam_set_threads(flx_sam_writer* w, uint32_t n_threads);
  * (mismatch / insertion / deletion uniformly), reverse-complemented with probability revcomp_fraction. Read r depends on
  * (seed, r) only. out_offsets has n_reads + 1 entries; out_chrom / out_pos / out_reverse (may be NULL) receive the truth. */
 int flx_sim_genome(uint64_t length, uint64_t seed, uint8_t* out_ranks);
+/* the same length of repeat-rich sequence (interspersed repeat families, tandem repeats, low complexity, runs of N, segmental
+ * duplications: about half of the bases unique, as in a human genome): the workload floxer's caps -M / -m (search.cpp:190-272) exist for */
+int flx_sim_genome_repeats(uint64_t length, uint64_t seed, uint8_t* out_ranks);
 int flx_sim_reads(const uint8_t* genome_concat, const uint64_t* chrom_lens, uint32_t n_chrom, uint64_t n_reads, uint32_t base_len,
                   double error_rate, double revcomp_fraction, uint64_t seed, uint8_t* out_pool, uint64_t pool_capacity,
                   uint64_t* out_offsets, uint32_t* out_chrom, uint64_t* out_pos, uint8_t* out_reverse);
