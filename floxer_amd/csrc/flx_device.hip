@@ -1026,12 +1026,12 @@ __device__ __forceinline__ bool select_seed(const DevHit* __restrict__ groups, u
 }
 
 // Every seed's class: nothing to select (no hit / over the hard cap / left to the host: its statistics are final here), light (at
-// most SEL_LIGHT groups and rows: the common case, one group of one row) or heavy (up to SEL_MAX groups, any number of rows up to
-// the hard cap of which the soft cap's worth is kept). rows[sid] = the slots the seed
-// gets in the sparse anchor list. Light and heavy seeds go on two lists (wave-aggregated appends; the order of a list does not
-// matter, every seed writes to its own slots): the few heavy seeds, whose threads run a hundred times longer on scratch arrays,
-// then do not sit in the waves of the light ones.
+// most SEL_LIGHT groups and rows: one thread per seed, seed_select_kernel) or heavy (up to SELW_MAX_GROUPS groups, any number of
+// rows up to the hard cap of which the soft cap's worth, at most SEL_MAX, is kept: one wave per seed, seed_select_wave_kernel).
+// rows[sid] = the slots the seed gets in the sparse anchor list. Light and heavy seeds go on two lists (wave-aggregated appends;
+// the order of a list does not matter, every seed writes to its own slots).
 constexpr u32 SEL_LIGHT = 8;
+constexpr u32 SELW_MAX_GROUPS = 512;
 __global__ void __launch_bounds__(256) seed_rows_kernel(const DevHit* __restrict__ grouped, const u32* __restrict__ hit_offset, u32 n_seeds,
                                                         u32 hard_cap, u32 soft_cap, u32* __restrict__ rows, SelStat* __restrict__ stat,
                                                         u32* __restrict__ n_out, u32* __restrict__ lists, u32* __restrict__ list_counts) {
@@ -1041,7 +1041,8 @@ __global__ void __launch_bounds__(256) seed_rows_kernel(const DevHit* __restrict
         u32 const g0 = hit_offset[sid], cnt = hit_offset[sid + 1] - g0;
         SelStat st{0, 0, 0, 0, 0};
         u32 total = 0;
-        if (cnt > SEL_MAX) st.flag = 1;                     // more groups than the sort arrays hold: the host
+        if (cnt > hard_cap) st.excluded = 1;                // every group has at least one row: over the hard cap whatever the rows are
+        else if (cnt > SELW_MAX_GROUPS) st.flag = 1;        // more groups than the wave kernel's arrays hold: the host
         else if (cnt > 0) {
             u32 all = 0;
             for (u32 i = 0; i < cnt; ++i) all += min(grouped[g0 + i].len, 0x1000000u);
@@ -1088,6 +1089,138 @@ __global__ void __launch_bounds__(64) seed_select_kernel(const u32* __restrict__
     }
 }
 
+// One wave per heavy seed: what select_seed does, with the parts that parallelise spread over the lanes - the emission order and
+// the stable orders as ranks (element i goes to the number of elements in front of it), the rows' round robin as one ballot per
+// round, SA and reference lookups one per lane - and the parts that are std::sort's own (more than 16 elements: introsort, whose
+// order of equal elements has to be reproduced step by step) and the erase sweep on one lane over LDS arrays. A round-2 profile had
+// the thread-per-seed form of this at 3 ms per launch on 2.3 KB of scratch per thread (profiles/r03_k1v2_kernel_stats.csv).
+__global__ void __launch_bounds__(64) seed_select_wave_kernel(const u32* __restrict__ list, const u32* __restrict__ list_count,
+                                                              const DevHit* __restrict__ grouped, const u32* __restrict__ hit_offset,
+                                                              const u32* __restrict__ sa, u32 n_text, const u64* __restrict__ seq_start, u32 n_ref,
+                                                              u32 erase, SelStat* __restrict__ stat, u32* __restrict__ n_out,
+                                                              const u32* __restrict__ row_offset, const u32* __restrict__ rows,
+                                                              DevOutAnchor* __restrict__ sparse, u32 sparse_cap) {
+    __shared__ u64 s_key[SELW_MAX_GROUPS];
+    __shared__ SelGroup s_a[SELW_MAX_GROUPS], s_b[SELW_MAX_GROUPS];
+    __shared__ u32 s_row[SEL_MAX], s_err[SEL_MAX];
+    __shared__ SelAnchor s_an[SEL_MAX];
+    __shared__ u32 s_flag[4];                 // [0] a sort gave up (host), [1..2] erased anchors (bits)
+    u32 const lane = lane_id();
+    u64 const below = (1ull << lane) - 1ull;
+    u32 const n = *list_count;
+    for (u32 li = blockIdx.x; li < n; li += gridDim.x) {
+        u32 const sid = list[li];
+        u32 const g0 = hit_offset[sid], cnt = hit_offset[sid + 1] - g0, total = rows[sid];
+        __syncthreads();
+        for (u32 i = lane; i < cnt; i += 64u) { DevHit const h = grouped[g0 + i]; s_key[i] = h.key; s_a[i] = SelGroup{h.lb, h.len, h.errors}; }
+        if (lane < 4u) s_flag[lane] = 0u;
+        __syncthreads();
+        // ---- emission order (the keys of fm_search; equal keys keep their order), then std::sort by (count, errors): up to 16
+        //      elements that is an insertion sort, i.e. stable
+        for (u32 i = lane; i < cnt; i += 64u) {
+            u64 const k = s_key[i];
+            u32 r = 0;
+            for (u32 j = 0; j < cnt; ++j) { u64 const kj = s_key[j]; r += (kj < k || (kj == k && j < i)) ? 1u : 0u; }
+            s_b[r] = s_a[i];
+        }
+        __syncthreads();
+        auto less_g = [](SelGroup const& x, SelGroup const& y) { return x.len != y.len ? x.len < y.len : x.errors < y.errors; };
+        if (cnt <= 16u) {
+            if (lane < cnt) {
+                SelGroup const me = s_b[lane];
+                u32 r = 0;
+                for (u32 j = 0; j < cnt; ++j) { SelGroup const o = s_b[j]; r += (less_g(o, me) || (!less_g(me, o) && j < lane)) ? 1u : 0u; }
+                s_a[r] = me;
+            }
+        } else {
+            if (lane == 0u && !std_sort_emulated(s_b, (int)cnt, less_g)) s_flag[0] = 1u;
+            __syncthreads();
+            for (u32 i = lane; i < cnt; i += 64u) s_a[i] = s_b[i];
+        }
+        __syncthreads();
+        // ---- rows round robin over the groups (search.cpp:239-272): row lb + round of every group that still has one, until
+        //      `total` are kept
+        u32 kept = 0;
+        for (u32 round = 0; kept < total; ++round) {
+            bool any = false;
+            for (u32 base = 0; base < cnt && kept < total; base += 64u) {
+                u32 const i = base + lane;
+                bool const alive = i < cnt && s_a[i].len > round;
+                u64 const m = __ballot(alive);
+                if (!m) continue;
+                any = true;
+                u32 const slot = kept + (u32)__popcll(m & below);
+                if (alive && slot < total) { s_row[slot] = s_a[i].lb + round; s_err[slot] = s_a[i].errors; }
+                kept = min(total, kept + (u32)__popcll(m));
+            }
+            if (!any) break;
+        }
+        __syncthreads();
+        // ---- locate, reference, position; buckets per reference in id order, each keeping the order of selection
+        bool const mine = lane < kept;
+        u64 p = 0;
+        u32 ref = 0, err = 0;
+        bool bad = false;
+        if (mine) {
+            u32 const row = s_row[lane];
+            err = s_err[lane];
+            p = row < n_text ? sa[row] : 0xFFFFFFFFull;
+            bad = p >= n_text;
+            if (!bad && n_ref > 1) {
+                u32 lo = 0, hi = n_ref;
+                while (hi - lo > 1) { u32 const mid = (lo + hi) >> 1; if (seq_start[mid] <= p) lo = mid; else hi = mid; }
+                ref = lo;
+            }
+        }
+        if (__any(bad)) s_flag[0] = 1u;
+        u32 r3 = 0;
+        for (u32 j = 0; j < kept; ++j) { u32 const rj = (u32)__shfl((int)ref, (int)j); r3 += (rj < ref || (rj == ref && j < lane)) ? 1u : 0u; }
+        if (mine && !bad) s_an[r3] = SelAnchor{p - seq_start[ref], ref, err};
+        __syncthreads();
+        // ---- erase_useless_anchors (search.cpp:352-389) bucket by bucket: std::sort by position, then the sweep
+        if (erase && lane == 0u && s_flag[0] == 0u) {
+            u64 gone = 0;
+            u32 b0 = 0;
+            while (b0 < kept) {
+                u32 b1 = b0;
+                while (b1 < kept && s_an[b1].ref == s_an[b0].ref) ++b1;
+                if (!std_sort_emulated(s_an + b0, (int)(b1 - b0), [](SelAnchor const& x, SelAnchor const& y) { return x.pos < y.pos; })) { s_flag[0] = 1u; break; }
+                auto better = [&](u32 a, u32 b) {          // an erased anchor compares with "infinitely many" errors
+                    u64 const ea = (gone >> a) & 1 ? ~0ull : (u64)s_an[a].errors, eb = (gone >> b) & 1 ? ~0ull : (u64)s_an[b].errors;
+                    u64 const d = s_an[a].pos < s_an[b].pos ? s_an[b].pos - s_an[a].pos : s_an[a].pos - s_an[b].pos;
+                    return ea <= eb && d <= eb - ea;
+                };
+                for (u32 cur = b0; cur + 1 < b1;) {
+                    u32 other = cur + 1;
+                    while (other < b1 && better(cur, other)) { gone |= 1ull << other; ++other; }
+                    if (other < b1 && better(other, cur)) gone |= 1ull << cur;
+                    cur = other;
+                }
+                b0 = b1;
+            }
+            s_flag[1] = (u32)gone;
+            s_flag[2] = (u32)(gone >> 32);
+        }
+        __syncthreads();
+        bool const to_host = s_flag[0] != 0u;
+        u64 const gone = (u64)s_flag[1] | ((u64)s_flag[2] << 32);
+        bool const keep = mine && !to_host && !((gone >> lane) & 1ull);
+        u64 const km = __ballot(keep);
+        u32 const produced = (u32)__popcll(km);
+        if (keep) {
+            u32 const at = row_offset[sid] + (u32)__popcll(km & below);
+            SelAnchor const a = s_an[lane];
+            if (at < sparse_cap) sparse[at] = DevOutAnchor{sid, 0u, a.ref, a.errors, a.pos};
+        }
+        if (lane == 0u) {
+            SelStat st{(u8)produced, (u8)kept, 0, 0, stat[sid].excluded_soft};
+            if (to_host) st = SelStat{0, 0, 1, 0, 0};
+            stat[sid] = st;
+            n_out[sid] = to_host ? 0u : produced;
+        }
+    }
+}
+
 __global__ void __launch_bounds__(256) seed_compact_kernel(const DevOutAnchor* __restrict__ sparse, const u32* __restrict__ row_offset,
                                                            const u32* __restrict__ n_out, const u32* __restrict__ out_offset, u32 n_seeds,
                                                            DevOutAnchor* __restrict__ out, u32 out_cap) {
@@ -1121,8 +1254,14 @@ int DeviceApi::select(void* stream, const DevHit* d_hits, const u32* d_counters,
     // grids sized for the usual shares (a quarter of the seeds light, a per cent heavy); the kernels loop over their lists
     hipLaunchKernelGGL((seed_select_kernel<SEL_LIGHT>), dim3(std::max(1u, (n_seeds / 4 + 63) / 64)), dim3(64), 0, s, d_lists, list_counts, d_grouped, d_hit_offset,
                        idx.sa, idx.n, d_seq_start, n_ref, erase ? 1u : 0u, stat, d_n_out, d_row_offset, d_rows, d_sparse, sparse_cap);
-    hipLaunchKernelGGL((seed_select_kernel<SEL_MAX>), dim3(std::max(1u, (n_seeds / 64 + 63) / 64)), dim3(64), 0, s, d_lists + n_seeds, list_counts + 1, d_grouped,
-                       d_hit_offset, idx.sa, idx.n, d_seq_start, n_ref, erase ? 1u : 0u, stat, d_n_out, d_row_offset, d_rows, d_sparse, sparse_cap);
+    // (one wave per heavy seed; FLX_SELECT_THREADS=1: the thread-per-seed form, for seeds of at most SEL_MAX groups)
+    static int const thread_form = getenv("FLX_SELECT_THREADS") ? 1 : 0;
+    if (thread_form)
+        hipLaunchKernelGGL((seed_select_kernel<SEL_MAX>), dim3(std::max(1u, (n_seeds / 64 + 63) / 64)), dim3(64), 0, s, d_lists + n_seeds, list_counts + 1, d_grouped,
+                           d_hit_offset, idx.sa, idx.n, d_seq_start, n_ref, erase ? 1u : 0u, stat, d_n_out, d_row_offset, d_rows, d_sparse, sparse_cap);
+    else
+        hipLaunchKernelGGL(seed_select_wave_kernel, dim3(std::max(1u, std::min(n_seeds / 8u + 1u, 16384u))), dim3(64), 0, s, d_lists + n_seeds, list_counts + 1, d_grouped,
+                           d_hit_offset, idx.sa, idx.n, d_seq_start, n_ref, erase ? 1u : 0u, stat, d_n_out, d_row_offset, d_rows, d_sparse, sparse_cap);
     if ((e = hipGetLastError()) != hipSuccess) return (int)e;
     exclusive_sum(s, d_n_out, d_out_offset, n_seeds + 1, (u32*)d_scan_tmp);
     hipLaunchKernelGGL(seed_compact_kernel, dim3((n_seeds + 255) / 256), dim3(256), 0, s, d_sparse, d_row_offset, d_n_out, d_out_offset, n_seeds,

@@ -205,7 +205,7 @@ struct FmConst {                            // the same for every lane of a laun
     u32 max_hits;
     u32 levels;                             // frames a lane may hold
     u32 text_min_remain;                    // a one-row node is queued when at least this many scheme entries remain (0: never)
-    u32 use_filter;
+    u32 use_filter;                         // 0: no filter; 1: one look per child; 2: a second, shifted look at the children that pass
 };
 
 constexpr u32 FM_FRAME_WORDS = 18;          // oth[1..5], end, abs[1..5], lb, lb_rev, state, mask, key lo, key hi, abs[0]
@@ -306,7 +306,7 @@ FLX_HD inline u32 fm_filter_children(FmConst const& C, FmLane& L, u32 x, u64 e64
     // symbols asked for per kind, bit 2(c-1): symbol c
     u32 want_s = (mask >> 2) & 0x55u, want_d = (mask >> 1) & 0x55u, want_i = (mask >> 11) & 1u;
 #pragma unroll 1
-    for (u32 look = 0; look < 2u; ++look) {
+    for (u32 look = 0; look < C.use_filter; ++look) {
         FmFilterKind const qs = fm_filter_kind(0u, K, tmin, x, right, F1, want_s, P.xs, P.xf, look != 0u);
         FmFilterKind const qd = fm_filter_kind(1u, K, tmin, x, right, F0, want_d, P.xs, P.xf, look != 0u);
         FmFilterKind const qi = fm_filter_kind(2u, K, tmin, x, right, F1, want_i, P.xs, P.xf, look != 0u);

@@ -284,7 +284,8 @@ int DeviceApi::search_filtered(void* stream, const DevIndex& idx, const u8* d_se
     C.scheme = d_scheme;
     C.max_hits = max_hits_per_seed;
     C.levels = std::max(1u, frame_levels);
-    C.use_filter = (idx.filter && d_qpack && !no_filter) ? 1u : 0u;
+    static u32 const looks = env_u32("FLX_FM_LOOKS", 2);
+    C.use_filter = (idx.filter && d_qpack && !no_filter) ? std::max(1u, std::min(2u, looks)) : 0u;
     C.text_min_remain = (d_items && item_cap && idx.isa && !no_text) ? std::max(1u, text_min) : 0u;
     hipStream_t s = (hipStream_t)stream;
     dim3 const grid(std::min<u32>((n_seeds + spw - 1) / spw, max_waves));

@@ -81,7 +81,7 @@ struct Harness {
         C.scheme = scheme.data();
         C.max_hits = (u32)std::min<u64>(max_hits, 0xFFFFFFF0u);
         C.levels = std::max(1u, k);
-        C.use_filter = mode.filter ? 1u : 0u;
+        C.use_filter = mode.filter ? 2u : 0u;
         C.text_min_remain = mode.text ? 2u : 0u;
         std::vector<u32> frames((size_t)C.levels * FM_FRAME_WORDS);
         auto fr = [&](u32 level, u32 word) -> u32& { return frames[level * FM_FRAME_WORDS + word]; };
