@@ -2054,13 +2054,23 @@ __global__ void __launch_bounds__(64) ed_band_kernel(const u8* __restrict__ text
 template <int W>
 __global__ void __launch_bounds__(64) ed_exists_block_kernel(const u8* __restrict__ text, const u64* __restrict__ peq,
                                                              const DevAlignJob* __restrict__ jobs, u32 n_jobs, u32 log2_r,
-                                                             DevAlignOut* __restrict__ out) {
+                                                             DevAlignOut* __restrict__ out, const u32* __restrict__ n_jobs_dev, u32 gate_r,
+                                                             u32 gate_lo, u32 gate_hi) {
     // LDS: [7 symbols][64 lanes][W words] equality masks; symbol 6 (columns past the end of the window) matches nothing
     extern __shared__ __attribute__((aligned(16))) u64 lds_eq[];
     u32 const lane = lane_id();
     u32 const R = 1u << log2_r;
     u32 const p = lane & (R - 1u);
     u32 const jobs_per_wave = 64u >> log2_r;
+    if (n_jobs_dev) {
+        // the job count is on the device (verification rounds, flx_rounds.hip): the grid is an upper bound, and of the two shapes
+        // launched for a round the one runs whose range of waves (jobs x gate_r lanes / 64) holds the count
+        u32 const nj = *n_jobs_dev;
+        u64 const waves = (u64)nj * gate_r / 64u;
+        if (waves < gate_lo || waves >= gate_hi) return;
+        n_jobs = min(n_jobs, nj);
+    }
+    if (blockIdx.x * jobs_per_wave >= n_jobs) return;
     u32 const job_id = blockIdx.x * jobs_per_wave + (lane >> log2_r);
     bool valid = job_id < n_jobs;
     DevAlignJob job;
@@ -2263,7 +2273,7 @@ static int launch_align(hipStream_t s, const u8* d_text, const u64* d_peq, const
     if (banded && !trace && !d_lastrow && exists_block_form()) {
         size_t const lds_b = (size_t)7 * 64 * W * sizeof(u64);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ed_exists_block_kernel<W>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_b);
-        hipLaunchKernelGGL((ed_exists_block_kernel<W>), dim3(blocks), dim3(64), lds_b, s, d_text, d_peq, d_jobs, n_jobs, log2_g, d_out);
+        hipLaunchKernelGGL((ed_exists_block_kernel<W>), dim3(blocks), dim3(64), lds_b, s, d_text, d_peq, d_jobs, n_jobs, log2_g, d_out, (const u32*)nullptr, 0u, 0u, 0u);
         return (int)hipGetLastError();
     }
     if (banded) { if (trace) FLX_LAUNCH((ed_band_kernel<W, true>)); else FLX_LAUNCH((ed_band_kernel<W, false>)); }
@@ -2271,6 +2281,40 @@ static int launch_align(hipStream_t s, const u8* d_text, const u64* d_peq, const
 #undef FLX_LAUNCH
     return (int)hipGetLastError();
 }
+
+// existence tests whose number is on the device: a grid for max_jobs, blocks beyond *d_n_jobs leave at once; the launch only runs when
+// *d_n_jobs x gate_r / 64 lies in [gate_lo, gate_hi) (see ed_exists_block_kernel)
+template <int W>
+static int launch_exists_gated(hipStream_t s, const u8* d_text, const u64* d_peq, const DevAlignJob* d_jobs, u32 max_jobs, u32 log2_g, DevAlignOut* d_out,
+                               const u32* d_n_jobs, u32 gate_r, u32 gate_lo, u32 gate_hi) {
+    u32 const jobs_per_wave = 64u >> log2_g;
+    u32 const blocks = (max_jobs + jobs_per_wave - 1) / jobs_per_wave;
+    size_t const lds_b = (size_t)7 * 64 * W * sizeof(u64);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ed_exists_block_kernel<W>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_b);
+    hipLaunchKernelGGL((ed_exists_block_kernel<W>), dim3(blocks), dim3(64), lds_b, s, d_text, d_peq, d_jobs, max_jobs, log2_g, d_out, d_n_jobs, gate_r, gate_lo, gate_hi);
+    return (int)hipGetLastError();
+}
+int DeviceApi::align_exists_gated(void* stream, const u8* d_text, const u64* d_peq, const DevAlignJob* d_jobs, u32 max_jobs, const u32* d_n_jobs,
+                                  AlignShape shape, u32 gate_r, u32 gate_lo, u32 gate_hi, DevAlignOut* d_out) {
+    if (max_jobs == 0) return 0;
+    u32 log2_g = 0;
+    while ((1u << log2_g) < shape.lanes_per_job) ++log2_g;
+    hipStream_t s = (hipStream_t)stream;
+    switch (shape.words_per_lane) {
+        case 1: return launch_exists_gated<1>(s, d_text, d_peq, d_jobs, max_jobs, log2_g, d_out, d_n_jobs, gate_r, gate_lo, gate_hi);
+        case 2: return launch_exists_gated<2>(s, d_text, d_peq, d_jobs, max_jobs, log2_g, d_out, d_n_jobs, gate_r, gate_lo, gate_hi);
+        case 3: return launch_exists_gated<3>(s, d_text, d_peq, d_jobs, max_jobs, log2_g, d_out, d_n_jobs, gate_r, gate_lo, gate_hi);
+        case 4: return launch_exists_gated<4>(s, d_text, d_peq, d_jobs, max_jobs, log2_g, d_out, d_n_jobs, gate_r, gate_lo, gate_hi);
+        case 5: return launch_exists_gated<5>(s, d_text, d_peq, d_jobs, max_jobs, log2_g, d_out, d_n_jobs, gate_r, gate_lo, gate_hi);
+        case 6: return launch_exists_gated<6>(s, d_text, d_peq, d_jobs, max_jobs, log2_g, d_out, d_n_jobs, gate_r, gate_lo, gate_hi);
+        case 8: return launch_exists_gated<8>(s, d_text, d_peq, d_jobs, max_jobs, log2_g, d_out, d_n_jobs, gate_r, gate_lo, gate_hi);
+        case 13: return launch_exists_gated<13>(s, d_text, d_peq, d_jobs, max_jobs, log2_g, d_out, d_n_jobs, gate_r, gate_lo, gate_hi);
+        case 25: return launch_exists_gated<25>(s, d_text, d_peq, d_jobs, max_jobs, log2_g, d_out, d_n_jobs, gate_r, gate_lo, gate_hi);
+        default: return (int)hipErrorInvalidValue;
+    }
+}
+// the cheapest shape (parallel: the one with the fewest words per lane) that holds every job of at most nw query words and `width` diagonals
+AlignShape DeviceApi::shape_holding(u32 nw, i64 width, bool parallel) { return choose_align_shape_uncached(nw, width, use_band(), parallel); }
 
 int DeviceApi::align(void* stream, const u8* d_text, const u64* d_peq, const DevAlignJob* d_jobs, u32 n_jobs, AlignShape shape, bool trace,
                      u64* d_trace, DevAlignOut* d_out, u16* d_lastrow) {

@@ -159,7 +159,7 @@ struct DevVrAnchor {            // 48 bytes
 };
 struct DevVrNode { u32 parent, from, rows, errors; };          // parent = index within the tree, 0xFFFFFFFF for the root
 struct DevVrJob { u64 ref_off, q_off; u32 n, m, k, pad; };     // n == 0: unused slot
-enum : u8 { VR_CLIMBING = 0, VR_DEAD = 1, VR_AT_ROOT = 2 };
+enum : u8 { VR_CLIMBING = 0, VR_DEAD = 1, VR_AT_ROOT = 2, VR_SOLO = 3 };      // VR_SOLO: climbing, its next test alone (flx_rounds.hip)
 enum : u32 { VR_N_REQ = 0, VR_N_UNIQ = 1, VR_N_CLUSTERS = 2, VR_N_CLIMBING = 3, VR_SMALLEST = 4, VR_N_UNDECIDED = 5 };
 // The launch plan of a round's job list. A shape class is (index into the words-per-lane table) * 7 + log2(lanes per job); the
 // jobs are stored class by class, `count` of them from `start` on. `lanes`, `par_w`, `par_r` describe the one-launch form the host
@@ -194,6 +194,19 @@ struct VrBuffers {
     DevVrPlan* plan;
     u32* scalars;                                // VR_*
     void* tmp; size_t tmp_bytes;
+};
+
+// ---- the rounds as three launches each (flx_rounds.hip)
+// scalars (u32 words): jobs of the round, requests (anchors in the round), anchors left to climb and their smallest node after the
+// round, then two 64-bit sums for the accounting: word-steps and sequence bytes of the round's jobs
+enum : u32 { VR2_N_JOBS = 0, VR2_N_REQ = 1, VR2_N_CLIMBING = 2, VR2_SMALLEST = 3, VR2_WORD_STEPS = 4, VR2_BYTES = 6, VR2_SCALARS = 16 };
+struct Vr2Buffers {
+    const DevVrAnchor* anchors; const DevVrNode* nodes;
+    const u32* q_first;                          // per query (read x orientation): its first anchor; n_queries + 1 entries
+    u32* node; u8* status;                       // per anchor, mutable
+    u32* a_slot;                                 // per anchor in the round: first job slot of its cluster << 2 | union job << 1 | own / intersection job; else ~0
+    DevAlignJob* jobs; DevAlignOut* outs;        // the round's job list (at most two per anchor in the round) and its results
+    u32* scalars;
 };
 
 // launch geometry for one alignment job shape
@@ -285,6 +298,12 @@ struct DeviceApi {
     static int vr_round_override(void* stream, VrBuffers const& B, u32 n_anchors, u8* d_override);
     static int vr_round_apply(void* stream, VrBuffers const& B, u32 n_anchors, const u8* d_override);
     static AlignShape vr_class_shape(u32 shape_class);
+    // flx_rounds.hip: a round = vr2_request (job list and count on the device), align_exists_gated on it, vr2_apply
+    static int vr2_request(void* stream, Vr2Buffers const& B, u32 n_queries, u32 limit, u32 acct_words);
+    static int vr2_apply(void* stream, Vr2Buffers const& B, u32 n_anchors);
+    static int align_exists_gated(void* stream, const u8* d_text, const u64* d_peq, const DevAlignJob* d_jobs, u32 max_jobs, const u32* d_n_jobs,
+                                  AlignShape shape, u32 gate_r, u32 gate_lo, u32 gate_hi, DevAlignOut* d_out);
+    static AlignShape shape_holding(u32 nw, i64 width, bool parallel);
     static int lastrow_min(void* stream, const u16* d_lastrow, const DevRowWindow* d_windows, u32 n_windows, DevAlignOut* d_out);
     static int traceback(void* stream, const u8* d_text, const u8* d_query, const u64* d_peq, const u64* d_trace,
                          const DevTraceJob* d_jobs, u32 n_jobs, bool checkpointed, u32* d_cigar, DevTraceOut* d_out);

@@ -1842,7 +1842,8 @@ int align_slice(Lane* lane, const flx_params* P, const flx_reads* RD, u64 first_
     if (!host_rounds && !st_local && !climbing.empty()) {
         u32 const n = (u32)A.size();
         PhaseTimer vprof("rounds");
-        // ---- node table of the chunk's trees, anchors
+        // ---- node table of the chunk's trees, anchors, the anchors of every query (read x orientation: contiguous, the anchors are in
+        //      seed order)
         std::map<const PexTree*, u32> tree_base;
         hvec<DevVrNode> nodes;
         for (auto const& kv : tree_cache) {
@@ -1851,11 +1852,8 @@ int align_slice(Lane* lane, const flx_params* P, const flx_reads* RD, u64 first_
             for (auto const& nd : t.inner) nodes.push_back(DevVrNode{nd.parent_id, nd.from, nd.to - nd.from + 1, nd.num_errors});
         }
         if (nodes.empty()) nodes.push_back(DevVrNode{0xFFFFFFFFu, 0, 1, 0});
-        auto bits_for = [](u64 count) { u32 b = 1; while ((1ull << b) < count) ++b; return b; };      // bits that hold 0 .. count - 1
-        size_t max_nodes = 1;
-        for (auto const& kv : tree_cache) max_nodes = std::max(max_nodes, kv.second->inner.size());
-        u32 const query_bits = bits_for(2 * reads.size()), node_bits = bits_for(max_nodes);
-        if (query_bits + node_bits > 32) { set_error("verification rounds: node names do not fit their sort key"); return FLX_ERR_INTERNAL; }
+        u32 const n_queries = (u32)(2 * reads.size());
+        hvec<u32> q_first(n_queries + 1, 0);
         hvec<DevVrAnchor> da(n);
         hvec<u32> h_node(n);
         hvec<u8> h_status(n);
@@ -1865,105 +1863,83 @@ int align_slice(Lane* lane, const flx_params* P, const flx_reads* RD, u64 first_
             ReadState const& rs = reads[a.read];
             flx_pex_node const& leaf = rs.tree_ref().leaves[a.leaf];
             u32 const tb = tree_base[rs.tree_ptr];
-            da[i] = DevVrAnchor{(i64)a.pos - (i64)leaf.from, H.seq_start[a.ref_id], H.seq_len[a.ref_id], rs.pool_off[a.orientation], tb,
-                                2u * a.read + a.orientation};
+            u32 const query = 2u * a.read + a.orientation;
+            q_first[query + 1]++;
+            da[i] = DevVrAnchor{(i64)a.pos - (i64)leaf.from, H.seq_start[a.ref_id], H.seq_len[a.ref_id], rs.pool_off[a.orientation], tb, query};
             bool const climbs = a.alive && !a.at_root;
             h_node[i] = climbs ? a.node : 0u;
             h_status[i] = climbs ? VR_CLIMBING : a.at_root ? VR_AT_ROOT : VR_DEAD;
             if (climbs) { ++n_climbing; smallest = std::min(smallest, nodes[tb + a.node].rows); }
+            if (i > 0 && 2u * A[i - 1].read + A[i - 1].orientation > query) { set_error("verification rounds: anchors out of query order"); return FLX_ERR_INTERNAL; }
         }
-        // ---- one device buffer cut into the arrays of VrBuffers
-        size_t const tmp_bytes = DeviceApi::vr_tmp_bytes(n);
+        for (u32 qi = 0; qi < n_queries; ++qi) q_first[qi + 1] += q_first[qi];
+        // ---- one device buffer cut into the arrays of Vr2Buffers
         size_t off = 0;
         auto take = [&](size_t bytes) { size_t const at = off; off += (bytes + 255) & ~(size_t)255; return at; };
-        size_t const o_anchors = take((size_t)n * sizeof(DevVrAnchor)), o_nodes = take(nodes.size() * sizeof(DevVrNode)), o_node = take((size_t)n * 4),
-                     o_status = take(n), o_key1 = take((size_t)n * 8), o_key2 = take((size_t)n * 8), o_sorted_key = take((size_t)n * 8),
-                     o_sort_key = take((size_t)n * 8), o_idx = take((size_t)n * 4), o_idxs = take((size_t)n * 4),
-                     o_flag_u = take((size_t)n * 4), o_uid = take((size_t)n * 4), o_flag_c = take((size_t)n * 4), o_cid = take((size_t)n * 4),
-                     o_run = take((size_t)n * 4), o_ukey1 = take((size_t)n * 8), o_ukey2 = take((size_t)n * 8), o_urep = take((size_t)n * 4),
-                     o_cstart = take(((size_t)n + 1) * 4), o_jobs = take((size_t)n * 2 * sizeof(DevVrJob)), o_scalars = take(64), o_tmp = take(tmp_bytes),
-                     o_class = take((size_t)n * 2), o_ajobs = take((size_t)n * 2 * sizeof(DevAlignJob)), o_outs = take((size_t)n * 2 * sizeof(DevAlignOut)),
-                     o_state = take(n), o_plan = take(sizeof(DevVrPlan));
+        size_t const o_anchors = take((size_t)n * sizeof(DevVrAnchor)), o_nodes = take(nodes.size() * sizeof(DevVrNode)), o_qfirst = take(((size_t)n_queries + 1) * 4),
+                     o_node = take((size_t)n * 4), o_status = take(n), o_slot = take((size_t)n * 4), o_jobs = take((size_t)n * 2 * sizeof(DevAlignJob)),
+                     o_outs = take((size_t)n * 2 * sizeof(DevAlignOut)), o_scalars = take(VR2_SCALARS * 4);
         vprof.mark("anchor-table");
         if ((rc = lane->vr.ensure(off))) return rc;
         char* const base = (char*)lane->vr.ptr;
-        VrBuffers B{};
-        B.anchors = (const DevVrAnchor*)(base + o_anchors); B.nodes = (const DevVrNode*)(base + o_nodes); B.node = (u32*)(base + o_node); B.status = (u8*)(base + o_status);
-        B.key1 = (u64*)(base + o_key1); B.key2 = (u64*)(base + o_key2); B.sorted_key = (u64*)(base + o_sorted_key); B.sort_key = (u64*)(base + o_sort_key);
-        B.idx = (u32*)(base + o_idx); B.idxs = (u32*)(base + o_idxs);
-        B.flag_u = (u32*)(base + o_flag_u); B.uid = (u32*)(base + o_uid); B.flag_c = (u32*)(base + o_flag_c); B.cid = (u32*)(base + o_cid); B.run_first = (u32*)(base + o_run);
-        B.ukey1 = (u64*)(base + o_ukey1); B.ukey2 = (u64*)(base + o_ukey2); B.urep = (u32*)(base + o_urep); B.cstart = (u32*)(base + o_cstart);
-        B.jobs = (DevVrJob*)(base + o_jobs); B.scalars = (u32*)(base + o_scalars); B.tmp = base + o_tmp; B.tmp_bytes = tmp_bytes;
-        B.job_class = (u8*)(base + o_class); B.align_jobs = (DevAlignJob*)(base + o_ajobs); B.outs = (DevAlignOut*)(base + o_outs);
-        B.state = (u8*)(base + o_state); B.plan = (DevVrPlan*)(base + o_plan);
+        Vr2Buffers B{};
+        B.anchors = (const DevVrAnchor*)(base + o_anchors); B.nodes = (const DevVrNode*)(base + o_nodes); B.q_first = (const u32*)(base + o_qfirst);
+        B.node = (u32*)(base + o_node); B.status = (u8*)(base + o_status); B.a_slot = (u32*)(base + o_slot);
+        B.jobs = (DevAlignJob*)(base + o_jobs); B.outs = (DevAlignOut*)(base + o_outs); B.scalars = (u32*)(base + o_scalars);
         FLX_HIP(hipMemcpyAsync(base + o_anchors, da.data(), (size_t)n * sizeof(DevVrAnchor), hipMemcpyHostToDevice, lane->stream));
         FLX_HIP(hipMemcpyAsync(base + o_nodes, nodes.data(), nodes.size() * sizeof(DevVrNode), hipMemcpyHostToDevice, lane->stream));
+        FLX_HIP(hipMemcpyAsync(base + o_qfirst, q_first.data(), ((size_t)n_queries + 1) * 4, hipMemcpyHostToDevice, lane->stream));
         FLX_HIP(hipMemcpyAsync(base + o_node, h_node.data(), (size_t)n * 4, hipMemcpyHostToDevice, lane->stream));
         FLX_HIP(hipMemcpyAsync(base + o_status, h_status.data(), n, hipMemcpyHostToDevice, lane->stream));
-        if ((rc = lane->vr_override.ensure(n + 64))) return rc;
-        DevVrPlan plan;
+        FLX_HIP(hipMemsetAsync(base + o_slot, 0xFF, (size_t)n * 4, lane->stream));
         vprof.mark("upload");
+        u64 const few_waves = align_few_waves();
         while (n_climbing > 0) {
             u64 const limit = (u64)smallest * round_span_percent() / 100;
-            int const e1 = DeviceApi::vr_round_requests(lane->stream, B, n, (u32)std::min<u64>(limit, 0xFFFFFFFFu), query_bits, node_bits);
-            if (e1) { set_error(std::string("verification round: ") + hipGetErrorString((hipError_t)e1)); return FLX_ERR_NO_DEVICE; }
-            u32 sc[3] = {0, 0, 0};
-            if ((rc = d2h(lane, sc, B.scalars, 12))) return rc;
-            if ((rc = d2h(lane, &plan, B.plan, sizeof(plan)))) return rc;
-            if ((rc = lane->sync())) return rc;
-            n_inner_requested += sc[VR_N_REQ];
-            vprof.mark("requests-wait");
-            // K3 on a job list where the device left it: one launch per shape class, or (few jobs: they would leave most SIMDs without
-            // a wave) one launch in the common shape with the fewest words per lane
-            auto launch_plan = [&]() -> int {
-                if (plan.unsupported) { set_error("query longer than the supported maximum"); return FLX_ERR_UNSUPPORTED; }
-                if (!plan.n_jobs) return FLX_OK;
-                auto launch = [&](u32 first, u32 count, AlignShape shape, u64 bytes, u64 word_steps) {
-                    return timed_launch(lane, "ed_align_exists", bytes, word_steps, [&] {
-                        return DeviceApi::align(lane->stream, d_text, d_peq, B.align_jobs + first, count, shape, false, nullptr, B.outs);
-                    });
-                };
-                if (plan.lanes / 64 >= align_few_waves()) {
-                    for (u32 c = 0; c < VR_CLASSES; ++c)
-                        if (plan.count[c])
-                            if (int const r = launch(plan.start[c], plan.count[c], DeviceApi::vr_class_shape(c), plan.bytes[c], plan.word_steps[c])) return r;
-                    return FLX_OK;
+            // One launch shape for the round: the cheapest that holds every job its node sizes can give (a union window is at most a
+            // cluster's bucket wider than a window), and the one with the fewest words per lane for rounds of few jobs (they would
+            // leave most SIMDs without a wave); which of the two runs is decided on the device, where the job count is
+            u32 nw_max = 0;
+            i64 width_max = 0;
+            for (auto const& nd : nodes)
+                if (nd.rows >= smallest && nd.rows <= limit) {
+                    nw_max = std::max(nw_max, (nd.rows + 63u) / 64u);
+                    width_max = std::max<i64>(width_max, 4 * (i64)nd.errors + 1 + (i64)std::max<u32>(8u, nd.rows / 8u));
                 }
-                u32 log2_r = 0;
-                while ((1u << log2_r) < plan.par_r) ++log2_r;
-                u64 bytes = 0;
-                for (u32 c = 0; c < VR_CLASSES; ++c) bytes += plan.bytes[c];
-                return launch(0, plan.n_jobs, DeviceApi::vr_class_shape(plan.par_w_index * 7u + log2_r), bytes, plan.common_word_steps);
-            };
-            if ((rc = launch_plan())) return rc;
-            int const e3 = DeviceApi::vr_round_decide(lane->stream, B, n);
-            if (e3) { set_error(std::string("verification round: ") + hipGetErrorString((hipError_t)e3)); return FLX_ERR_NO_DEVICE; }
-            u32 n_undecided = 0;
-            if ((rc = d2h(lane, &n_undecided, B.scalars + VR_N_UNDECIDED, 4))) return rc;
-            if ((rc = lane->sync())) return rc;
-            vprof.mark("score");
-            const u8* d_override = nullptr;
-            if (n_undecided) {
-                // the members of the undecided clusters one by one: a second job list, made, run and read on the device as well
-                int const e4 = DeviceApi::vr_round_members(lane->stream, B, n, B.flag_u);        // (flag_u: free since the distinct requests were scattered)
-                if (e4) { set_error(std::string("verification round: ") + hipGetErrorString((hipError_t)e4)); return FLX_ERR_NO_DEVICE; }
-                if ((rc = d2h(lane, &plan, B.plan, sizeof(plan)))) return rc;
-                if ((rc = lane->sync())) return rc;
-                if ((rc = launch_plan())) return rc;
-                int const e5 = DeviceApi::vr_round_override(lane->stream, B, n, lane->vr_override.as<u8>());
-                if (e5) { set_error(std::string("verification round: ") + hipGetErrorString((hipError_t)e5)); return FLX_ERR_NO_DEVICE; }
-                d_override = lane->vr_override.as<u8>();
-                vprof.mark("undecided");
-            }
-            int const e2 = DeviceApi::vr_round_apply(lane->stream, B, n, d_override);
+            AlignShape const shape_t = DeviceApi::shape_holding(nw_max, width_max, false), shape_p = DeviceApi::shape_holding(nw_max, width_max, true);
+            if (shape_t.words_per_lane == 0 || shape_p.words_per_lane == 0) { set_error("query longer than the supported maximum"); return FLX_ERR_UNSUPPORTED; }
+            FLX_HIP(hipMemsetAsync(B.scalars, 0, VR2_SCALARS * 4, lane->stream));
+            int const e1 = DeviceApi::vr2_request(lane->stream, B, n_queries, (u32)std::min<u64>(limit, 0xFFFFFFFFu), shape_t.words_per_lane);
+            if (e1) { set_error(std::string("verification round: ") + hipGetErrorString((hipError_t)e1)); return FLX_ERR_NO_DEVICE; }
+            u32 const max_jobs = (u32)std::min<u64>(2ull * n_climbing, 2ull * n);
+            bool const one_shape = shape_t.words_per_lane == shape_p.words_per_lane && shape_t.lanes_per_job == shape_p.lanes_per_job;
+            u32 const gate = (u32)std::min<u64>(few_waves, 0xFFFFFFFFu);
+            rc = timed_launch(lane, "ed_align_exists", 0, 0, [&] {
+                int e = DeviceApi::align_exists_gated(lane->stream, d_text, d_peq, B.jobs, max_jobs, B.scalars + VR2_N_JOBS, shape_t, shape_t.lanes_per_job,
+                                                      one_shape ? 0u : gate, 0xFFFFFFFFu, B.outs);
+                if (!e && !one_shape)
+                    e = DeviceApi::align_exists_gated(lane->stream, d_text, d_peq, B.jobs, max_jobs, B.scalars + VR2_N_JOBS, shape_p, shape_t.lanes_per_job, 0u, gate, B.outs);
+                return e;
+            });
+            if (rc) return rc;
+            int const e2 = DeviceApi::vr2_apply(lane->stream, B, n);
             if (e2) { set_error(std::string("verification round: ") + hipGetErrorString((hipError_t)e2)); return FLX_ERR_NO_DEVICE; }
-            u32 nx[2] = {0, 0};
-            if ((rc = d2h(lane, nx, B.scalars + VR_N_CLIMBING, 8))) return rc;
-            if ((rc = lane->sync())) return rc;                       // (also: state / override_ may be rewritten now)
-            if (sc[VR_N_REQ] == 0 && nx[0] >= n_climbing) { set_error("verification rounds do not advance"); return FLX_ERR_INTERNAL; }
-            n_climbing = nx[0];
-            smallest = nx[1];
-            vprof.mark("apply-wait");
+            u32 sc[VR2_SCALARS];
+            if ((rc = d2h(lane, sc, B.scalars, VR2_SCALARS * 4))) return rc;
+            if ((rc = lane->sync())) return rc;
+            n_inner_requested += sc[VR2_N_REQ];
+            if (ctx->timing) {        // the round's word-steps and sequence bytes were counted on the device: fold them into the kernel's accounting
+                u64 ws, by;
+                memcpy(&ws, &sc[VR2_WORD_STEPS], 8);
+                memcpy(&by, &sc[VR2_BYTES], 8);
+                std::lock_guard<std::mutex> g(ctx->mu);
+                auto it = ctx->stats.find("ed_align_exists");
+                if (it != ctx->stats.end()) { it->second.algorithmic_bytes += by; it->second.work_units += ws; }
+            }
+            if (sc[VR2_N_REQ] == 0 && sc[VR2_N_CLIMBING] >= n_climbing) { set_error("verification rounds do not advance"); return FLX_ERR_INTERNAL; }
+            n_climbing = sc[VR2_N_CLIMBING];
+            smallest = sc[VR2_SMALLEST];
+            vprof.mark("round");
         }
         if ((rc = d2h(lane, h_status.data(), B.status, n))) return rc;
         if ((rc = d2h(lane, h_node.data(), B.node, (size_t)n * 4))) return rc;
