@@ -286,7 +286,13 @@ struct FastqReader {
             int const got = gzread(f, raw.data() + at, (unsigned)want);
             if (got < 0) { err = "read error on the query file"; return false; }
             raw.resize(at + (size_t)got);
-            if ((size_t)got < want) eof = true;
+            if ((size_t)got < want) {
+                // a short read is the end of the data only when zlib agrees (a truncated .gz ends with Z_BUF_ERROR / Z_DATA_ERROR)
+                int zerr = Z_OK;
+                (void)gzerror(f, &zerr);
+                if (zerr != Z_OK && zerr != Z_STREAM_END) { err = "the query file is truncated or corrupt (gzip stream error)"; return false; }
+                eof = true;
+            }
             scan();
         }
         if (eof && !raw.empty() && raw.back() != '\n') { nl.push_back(raw.size()); raw.push_back('\n'); ++lines; }   // last line without a line end
@@ -301,7 +307,7 @@ struct FastqReader {
         // ---- records: id (up to the first blank, input.cpp:161-163), sequence, quality; terminated in place
         struct Rec { size_t id, seq, seq_len, qual; bool keep; };
         std::vector<Rec> recs(n_rec);
-        bool bad = false;
+        std::atomic<bool> bad{false}, bad_qual{false};
         parallel_for(n_rec, threads, [&](size_t r0, size_t r1) {
             for (size_t r = r0; r < r1; ++r) {
                 size_t const l0 = r ? nl[4 * r - 1] + 1 : 0, e0 = nl[4 * r], l1 = e0 + 1, e1 = nl[4 * r + 1], l3 = nl[4 * r + 2] + 1, e3 = nl[4 * r + 3];
@@ -314,10 +320,12 @@ struct FastqReader {
                 if (s_end > l1 && raw[s_end - 1] == '\r') --s_end;
                 if (q_end > l3 && raw[q_end - 1] == '\r') --q_end;
                 raw[q_end] = 0;
+                if (q_end - l3 != s_end - l1) { bad_qual = true; continue; }             // input.cpp:137 asserts qual.size() == seq.size()
                 recs[r] = Rec{l0 + 1, l1, s_end - l1, l3, true};
             }
         });
         if (bad) { err = "malformed FASTQ record in the query file"; return false; }
+        if (bad_qual) { err = "a FASTQ record's sequence and quality differ in length"; return false; }
         for (auto& rc : recs) {                 // the reference's filters on the way in (input.cpp:95-110)
             if (rc.seq_len == 0) { log_line("warning", "The record %s in the query file has an empty sequence and will be skipped.", raw.data() + rc.id); rc.keep = false; }
             else if (rc.seq_len > 100000) { log_line("warning", "skipping too large query: %s", raw.data() + rc.id); rc.keep = false; }

@@ -4,6 +4,7 @@
 #include <cstring>
 #include <malloc.h>
 #include <memory>
+#include <mutex>
 #include <thread>
 
 #include "flx_context.hpp"
@@ -47,7 +48,7 @@ void image_sizes(HostIndex const& H, uint64_t bytes[5]) {
     bytes[3] = H.n + 2 * TEXT_PAD + 16;
     bytes[4] = (((u64)1 << (2 * KMER_Q)) * 3) * 4;
 }
-bool has_arrays(HostIndex const& H) { return H.text.size() == H.n && H.sa.size() == H.n && !H.occ[0].empty() && !H.occ[1].empty() && !H.kmer_table.empty(); }
+bool has_arrays(HostIndex const& H) { return index_has_arrays(H); }
 int upload_image(HostIndex const& H, void* const buf[5], hipStream_t s) {
     FLX_HIP(hipMemcpyAsync(buf[0], H.occ[0].data(), H.occ[0].size() * sizeof(OccBlock), hipMemcpyHostToDevice, s));
     FLX_HIP(hipMemcpyAsync(buf[1], H.occ[1].data(), H.occ[1].size() * sizeof(OccBlock), hipMemcpyHostToDevice, s));
@@ -98,13 +99,17 @@ int make_context(int hip_device, const flx_index* index, void* const image[5], b
         ctx->lanes.push_back(std::move(lane));
         ctx->free_lanes.push_back((int)l);
     }
-    // the host lists' blocks page-locked for DMA (FLX_NO_PIN=1: pageable, the runtime stages every copy)
-    if (!getenv("FLX_NO_PIN"))
-        host_pool_pin_hook = [](void* p, size_t bytes, int pin) {
+    // the host lists' blocks page-locked for DMA (FLX_NO_PIN=1: pageable, the runtime stages every copy). Process-wide and installed
+    // once, by the first context: blocks the pool took before that stay pageable (the unregister of such a block fails quietly)
+    static std::once_flag pin_once;
+    std::call_once(pin_once, [] {
+        if (getenv("FLX_NO_PIN")) return;
+        host_pool_pin_hook.store([](void* p, size_t bytes, int pin) {
             if (pin) (void)hipHostRegister(p, bytes, hipHostRegisterPortable);
             else (void)hipHostUnregister(p);
             (void)hipGetLastError();      // (a block that could not be locked is simply pageable)
-        };
+        }, std::memory_order_release);
+    });
     // K1 launches in flight at a time: with every lane free to start its search the GPU swings between phases where K1's waves
     // (memory-bound, long-lived) hold most wave slots and phases where only the VALU-bound DP kernels run; about 3072 K1 waves at a
     // time keep the mix steady (16 lanes, 3.1 Gb / 10 kb: 74.7 k reads/s unlimited, 73-75 k with 4 x 512 waves, 78-79.5 k with 6 x 512,

@@ -12,6 +12,12 @@ const char* last_error_cstr();
 }
 using namespace flx;
 
+// an index made by flx_index_meta_import holds sizes and sequence bounds only (its arrays live in another rank's HBM image)
+#define FLX_NEED_ARRAYS(index, who)                                                                                                   \
+    do {                                                                                                                              \
+        if (!index_has_arrays(*(index)->host)) { set_error(std::string(who) + ": this index holds no arrays (flx_index_meta_import)"); return FLX_ERR_INVALID; } \
+    } while (0)
+
 extern "C" {
 
 const char* flx_last_error(void) { return last_error_cstr(); }
@@ -46,6 +52,7 @@ int flx_index_build(const uint8_t* concat, const uint64_t* lens, uint32_t n_refs
 }
 int flx_index_save(const flx_index* index, const char* path) {
     if (!index || !path) { set_error("flx_index_save: null argument"); return FLX_ERR_INVALID; }
+    FLX_NEED_ARRAYS(index, "flx_index_save");
     return save_host_index(*index->host, path);
 }
 int flx_index_load(const char* path, flx_index** out) {
@@ -65,10 +72,13 @@ uint32_t flx_index_num_references(const flx_index* index) { return index ? (uint
 uint64_t flx_index_device_bytes(const flx_index* index) {
     if (!index) return 0;
     HostIndex const& h = *index->host;
-    return (h.occ[0].size() + h.occ[1].size()) * sizeof(OccBlock) + h.sa.size() * 4 + h.text.size() + 2 * TEXT_PAD + h.kmer_table.size() * 4;
+    // (from the sizes, so that an index without arrays reports what its image takes as well)
+    u64 const nb = h.n / OCC_BLOCK_POS + 1;
+    return 2 * nb * sizeof(OccBlock) + h.n * 4 + h.n + 2 * TEXT_PAD + (((u64)1 << (2 * KMER_Q)) * 3) * 4;
 }
 int flx_index_matches_reference(const flx_index* index, const uint8_t* concat, const uint64_t* lens, uint32_t n_refs) {
     if (!index || !concat || !lens) { set_error("flx_index_matches_reference: null argument"); return FLX_ERR_INVALID; }
+    FLX_NEED_ARRAYS(index, "flx_index_matches_reference");
     HostIndex const& h = *index->host;
     if (h.seq_len.size() != n_refs) { set_error("the index holds " + std::to_string(h.seq_len.size()) + " sequences, the reference " + std::to_string(n_refs)); return FLX_ERR_INVALID; }
     uint64_t off = 0;
@@ -81,17 +91,21 @@ int flx_index_matches_reference(const flx_index* index, const uint8_t* concat, c
 }
 int flx_index_copy_sa(const flx_index* index, uint64_t* out) {
     if (!index || !out) { set_error("null argument"); return FLX_ERR_INVALID; }
+    FLX_NEED_ARRAYS(index, "flx_index_copy_sa");
     for (size_t i = 0; i < index->host->sa.size(); ++i) out[i] = index->host->sa[i];
     return FLX_OK;
 }
 int flx_index_copy_sa_u32(const flx_index* index, uint32_t* out) {
     if (!index || !out) { set_error("null argument"); return FLX_ERR_INVALID; }
+    FLX_NEED_ARRAYS(index, "flx_index_copy_sa_u32");
     memcpy(out, index->host->sa.data(), index->host->sa.size() * 4);
     return FLX_OK;
 }
 int flx_index_copy_bwt(const flx_index* index, int reversed, uint8_t* out) {
     if (!index || !out) { set_error("null argument"); return FLX_ERR_INVALID; }
+    FLX_NEED_ARRAYS(index, "flx_index_copy_bwt");
     auto const& b = index->host->bwt[reversed ? 1 : 0];
+    if (b.size() != index->host->n) { set_error("flx_index_copy_bwt: this index was loaded without its BWTs"); return FLX_ERR_INVALID; }
     memcpy(out, b.data(), b.size());
     return FLX_OK;
 }
@@ -121,7 +135,7 @@ int flx_index_meta_import(const uint8_t* buf, uint64_t len, flx_index** out) {
     h->n = w[1];
     for (int c = 0; c < 7; ++c) h->C[c] = w[2 + c];
     u64 const n_refs = w[9];
-    if (h->n == 0 || h->n >= ((u64)1 << 32) || n_refs == 0 || len < 8 * (10 + 2 * n_refs)) { set_error("index meta block is corrupt"); return FLX_ERR_INVALID; }
+    if (h->n == 0 || h->n >= ((u64)1 << 32) || n_refs == 0 || n_refs > (len / 8 - 10) / 2) { set_error("index meta block is corrupt"); return FLX_ERR_INVALID; }
     h->seq_start.assign(w + 10, w + 10 + n_refs);
     h->seq_len.assign(w + 10 + n_refs, w + 10 + 2 * n_refs);
     *out = new flx_index{h.release()};

@@ -39,7 +39,7 @@ struct BlockPool {
 BlockPool& block_pool() { static BlockPool* p = new BlockPool(); return *p; }    // never destroyed: lists may outlive static teardown
 }  // namespace
 
-void (*host_pool_pin_hook)(void* p, size_t bytes, int pin) = nullptr;
+std::atomic<void (*)(void* p, size_t bytes, int pin)> host_pool_pin_hook{nullptr};
 
 void* host_pool_get(size_t bytes) {
     if (bytes < POOL_MIN) { void* p = malloc(bytes ? bytes : 1); if (!p) throw std::bad_alloc(); return p; }
@@ -57,7 +57,7 @@ void* host_pool_get(size_t bytes) {
     }
     void* p = malloc(cls);
     if (!p) throw std::bad_alloc();
-    if (host_pool_pin_hook) host_pool_pin_hook(p, cls, 1);
+    if (auto const hook = host_pool_pin_hook.load(std::memory_order_acquire)) hook(p, cls, 1);
     return p;
 }
 void host_pool_put(void* p, size_t bytes) {
@@ -69,7 +69,7 @@ void host_pool_put(void* p, size_t bytes) {
         std::lock_guard<std::mutex> g(bp.mu);
         if (bp.kept + cls <= bp.cap) { bp.free_blocks[cls].push_back(p); bp.kept += cls; return; }
     }
-    if (host_pool_pin_hook) host_pool_pin_hook(p, cls, 0);
+    if (auto const hook = host_pool_pin_hook.load(std::memory_order_acquire)) hook(p, cls, 0);
     free(p);
 }
 

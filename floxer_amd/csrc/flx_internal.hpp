@@ -1,6 +1,7 @@
 // floxer_amd internal declarations shared by the host sources and the HIP translation unit.
 #pragma once
 
+#include <atomic>
 #include <cstddef>
 #include <cstdint>
 #include <string>
@@ -29,7 +30,8 @@ void host_pool_put(void* p, size_t bytes);
 // Called for every block the pool takes from / returns to the C library (pin = 1 / 0). The device side of the library sets it to
 // page-lock the blocks (hipHostRegister): the lists then go to and come from the GPU by DMA instead of through the runtime's
 // staging copies. Null in the HIP-free builds.
-extern void (*host_pool_pin_hook)(void* p, size_t bytes, int pin);
+// (process-wide, installed once: the first context decides; FLX_NO_PIN is read then)
+extern std::atomic<void (*)(void* p, size_t bytes, int pin)> host_pool_pin_hook;
 template <class T>
 struct PoolAlloc {
     using value_type = T;
@@ -69,6 +71,7 @@ struct HostIndex {
     std::vector<u32> kmer_table;
 };
 constexpr u32 KMER_Q = 8;
+inline bool index_has_arrays(HostIndex const& H) { return H.text.size() == H.n && H.sa.size() == H.n && !H.occ[0].empty() && !H.occ[1].empty() && !H.kmer_table.empty(); }
 
 // Device-side view handed to kernels (plain pointers into HBM)
 struct DevIndex {
@@ -299,7 +302,7 @@ struct DeviceApi {
     static int vr_round_apply(void* stream, VrBuffers const& B, u32 n_anchors, const u8* d_override);
     static AlignShape vr_class_shape(u32 shape_class);
     // flx_rounds.hip: a round = vr2_request (job list and count on the device), align_exists_gated on it, vr2_apply
-    static int vr2_request(void* stream, Vr2Buffers const& B, u32 n_queries, u32 limit, u32 acct_words);
+    static int vr2_request(void* stream, Vr2Buffers const& B, u32 n_queries, u32 limit, u32 acct_words, u32 width_cap);
     static int vr2_apply(void* stream, Vr2Buffers const& B, u32 n_anchors);
     static int align_exists_gated(void* stream, const u8* d_text, const u64* d_peq, const DevAlignJob* d_jobs, u32 max_jobs, const u32* d_n_jobs,
                                   AlignShape shape, u32 gate_r, u32 gate_lo, u32 gate_hi, DevAlignOut* d_out);

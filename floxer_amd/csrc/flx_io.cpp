@@ -213,11 +213,10 @@ bool format_record(flx_sam_writer const* w, flx_record const& r, const char* con
     }
     size_t const l_name = strlen(id) + 1;
     if (l_name > 255) { err = std::string("read name longer than 254 characters cannot be written to BAM: ") + id; return false; }
-    int64_t ref_span = 0, query_span = 0;
+    int64_t ref_span = 0;
     for (uint32_t c = 0; c < r.cigar_length; ++c) {
         uint32_t const op = cig[c] & 15, len = cig[c] >> 4;
         if (op == 0 || op == 2 || op == 3 || op == 7 || op == 8) ref_span += len;
-        if (op == 0 || op == 1 || op == 4 || op == 7 || op == 8) query_span += len;
     }
     // more than 65535 operations do not fit n_cigar_op: the record carries kSmN and the real CIGAR in the CG:B,I tag (SAM spec 4.2.2)
     bool const long_cigar = r.cigar_length > 65535u;
@@ -238,7 +237,9 @@ bool format_record(flx_sam_writer const* w, flx_record const& r, const char* con
     put32(-1);
     put32(0);
     out.insert(out.end(), id, id + l_name);
-    if (long_cigar) { put32((int32_t)(((uint32_t)query_span << 4) | 4u)); put32((int32_t)(((uint32_t)ref_span << 4) | 3u)); }
+    // (the placeholder's S length is the stored SEQ length, 0 for a secondary record written without SEQ: that is what htslib's
+    // bam_tag2cigar and seqan3 compare it with)
+    if (long_cigar) { put32((int32_t)(((uint32_t)slen << 4) | 4u)); put32((int32_t)(((uint32_t)ref_span << 4) | 3u)); }
     else { size_t const at = out.size(); out.resize(at + 4 * (size_t)r.cigar_length); memcpy(out.data() + at, cig, 4 * (size_t)r.cigar_length); }
     static const uint8_t nib[6] = {15, 1, 2, 4, 8, 15};       // =ACMGRSVTWYHKDBN codes for $ACGTN
     for (uint64_t b = 0; b < slen; b += 2) {

@@ -1896,20 +1896,27 @@ int align_slice(Lane* lane, const flx_params* P, const flx_reads* RD, u64 first_
         u64 const few_waves = align_few_waves();
         while (n_climbing > 0) {
             u64 const limit = (u64)smallest * round_span_percent() / 100;
-            // One launch shape for the round: the cheapest that holds every job its node sizes can give (a union window is at most a
-            // cluster's bucket wider than a window), and the one with the fewest words per lane for rounds of few jobs (they would
-            // leave most SIMDs without a wave); which of the two runs is decided on the device, where the job count is
+            // One launch shape for the round: the cheapest that holds the window of every node in the round's size class, and the one
+            // with the fewest words per lane for rounds of few jobs (they would leave most SIMDs without a wave); which of the two
+            // runs is decided on the device, where the job count is
             u32 nw_max = 0;
             i64 width_max = 0;
             for (auto const& nd : nodes)
                 if (nd.rows >= smallest && nd.rows <= limit) {
                     nw_max = std::max(nw_max, (nd.rows + 63u) / 64u);
-                    width_max = std::max<i64>(width_max, 4 * (i64)nd.errors + 1 + (i64)std::max<u32>(8u, nd.rows / 8u));
+                    width_max = std::max<i64>(width_max, 4 * (i64)nd.errors + 1);            // a window of its own: n - m + 2k = (2e + 1) + 2e
                 }
             AlignShape const shape_t = DeviceApi::shape_holding(nw_max, width_max, false), shape_p = DeviceApi::shape_holding(nw_max, width_max, true);
             if (shape_t.words_per_lane == 0 || shape_p.words_per_lane == 0) { set_error("query longer than the supported maximum"); return FLX_ERR_UNSUPPORTED; }
+            // what the shapes hold beyond that goes to the clusters' union windows (a shape holds a job when every word group has a lane of
+            // its own, or when the ring's lanes are free again before their next group starts: 64 W (R - 1) + R + 1 > diagonals)
+            auto cap_of = [&](AlignShape const& sh) -> u64 {
+                if ((nw_max + sh.words_per_lane - 1) / sh.words_per_lane <= sh.lanes_per_job) return 0xFFFFFFFFull;
+                return 64ull * sh.words_per_lane * (sh.lanes_per_job - 1) + sh.lanes_per_job;
+            };
+            u32 const width_cap = (u32)std::min<u64>(std::min(cap_of(shape_t), cap_of(shape_p)), 0xFFFFFFFFull);
             FLX_HIP(hipMemsetAsync(B.scalars, 0, VR2_SCALARS * 4, lane->stream));
-            int const e1 = DeviceApi::vr2_request(lane->stream, B, n_queries, (u32)std::min<u64>(limit, 0xFFFFFFFFu), shape_t.words_per_lane);
+            int const e1 = DeviceApi::vr2_request(lane->stream, B, n_queries, (u32)std::min<u64>(limit, 0xFFFFFFFFu), shape_t.words_per_lane, width_cap);
             if (e1) { set_error(std::string("verification round: ") + hipGetErrorString((hipError_t)e1)); return FLX_ERR_NO_DEVICE; }
             u32 const max_jobs = (u32)std::min<u64>(2ull * n_climbing, 2ull * n);
             bool const one_shape = shape_t.words_per_lane == shape_p.words_per_lane && shape_t.lanes_per_job == shape_p.lanes_per_job;

@@ -49,7 +49,7 @@ __device__ __forceinline__ u64 vr2_key(u32 node, u64 start, u32 solo) { return (
 
 }  // namespace
 
-__global__ void __launch_bounds__(VR2_THREADS) vr2_request_kernel(Vr2Buffers B, u32 limit, u32 acct_words) {
+__global__ void __launch_bounds__(VR2_THREADS) vr2_request_kernel(Vr2Buffers B, u32 limit, u32 acct_words, u32 width_cap) {
     __shared__ u64 s_key[VR2_TILE];
     __shared__ u16 s_val[VR2_TILE];
     __shared__ u8 s_flag[VR2_TILE];           // bit 0: first of its distinct window, bit 1: first of its cluster
@@ -107,25 +107,33 @@ __global__ void __launch_bounds__(VR2_THREADS) vr2_request_kernel(Vr2Buffers B, 
                 __syncthreads();
             }
         // ---- one thread per node run: distinct windows and clusters. A cluster = the distinct windows of a node whose starts fall
-        //      into the same bucket of max(8, rows / 8) columns counted from the node's first window.
-        DevVrAnchor const a_first = B.anchors[tile];                  // (tree, reference sequence pool offsets are per anchor; the tree is the query's)
+        //      into the same bucket of max(8, rows / 8) columns counted from the node's first window - as long as their union stays
+        //      within the diagonals the round's launch shape holds (width_cap; the host chose the shape for single windows)
+        DevVrAnchor const a_first = B.anchors[tile];                  // (the tree is the query's)
         for (u32 t = tid; t < cnt; t += VR2_THREADS) {
             u64 const key = s_key[t];
             u32 const node = (u32)(key >> 33);
             if (t > 0 && (u32)(s_key[t - 1] >> 33) == node) continue;          // not the head of a run
             DevVrNode const nd = B.nodes[a_first.tree_base + node];
             u64 const d = max((u64)8, (u64)nd.rows / 8ull);
+            u64 const base = (u64)nd.rows + 2ull * nd.errors + 1ull;
             u64 const first = (key >> 1) & 0xFFFFFFFFull;
-            u64 prev_key = VR2_NO_KEY, prev_bucket = ~0ull;
+            u64 prev_key = VR2_NO_KEY, prev_bucket = ~0ull, c_lo = 0, c_hi = 0;
             bool prev_solo = false;
             for (u32 j = t; j < cnt && (u32)(s_key[j] >> 33) == node; ++j) {
                 u64 const kj = s_key[j];
                 bool const solo = kj & 1ull;
-                u64 const bucket = (((kj >> 1) & 0xFFFFFFFFull) - first) / d;
+                u64 const st = (kj >> 1) & 0xFFFFFFFFull;
+                u64 const bucket = (st - first) / d;
                 u8 f = 0;
                 if (kj != prev_key) {
+                    DevVrAnchor const a = B.anchors[tile + s_val[j]];
+                    u64 const en = st + min(base, a.seq_start + a.seq_len - st);
                     f = 1;
-                    if (j == t || solo || prev_solo || bucket != prev_bucket) f = 3;
+                    u64 const u_hi = max(c_hi, en);
+                    bool const too_wide = (u_hi - c_lo) + 2ull * nd.errors > (u64)nd.rows + width_cap;      // union width = n - m + 2k
+                    if (j == t || solo || prev_solo || bucket != prev_bucket || too_wide) { f = 3; c_lo = st; c_hi = en; }
+                    else c_hi = u_hi;
                 }
                 s_flag[j] = f;
                 prev_key = kj; prev_bucket = bucket; prev_solo = solo;
@@ -273,10 +281,11 @@ __global__ void __launch_bounds__(256) vr2_apply_kernel(Vr2Buffers B, u32 n) {
     }
 }
 
-// everything up to the round's job list (B.jobs, B.scalars[VR2_N_JOBS]); acct_words: words per lane of the launch shape (accounting)
-int DeviceApi::vr2_request(void* stream, Vr2Buffers const& B, u32 n_queries, u32 limit, u32 acct_words) {
+// everything up to the round's job list (B.jobs, B.scalars[VR2_N_JOBS]); acct_words: words per lane of the launch shape (accounting);
+// width_cap: most diagonals (n - m + 2k) a job of the round may have (what the launch shapes hold)
+int DeviceApi::vr2_request(void* stream, Vr2Buffers const& B, u32 n_queries, u32 limit, u32 acct_words, u32 width_cap) {
     if (n_queries == 0) return 0;
-    hipLaunchKernelGGL(vr2_request_kernel, dim3(n_queries), dim3(VR2_THREADS), 0, (hipStream_t)stream, B, limit, std::max(1u, acct_words));
+    hipLaunchKernelGGL(vr2_request_kernel, dim3(n_queries), dim3(VR2_THREADS), 0, (hipStream_t)stream, B, limit, std::max(1u, acct_words), width_cap);
     return (int)hipGetLastError();
 }
 int DeviceApi::vr2_apply(void* stream, Vr2Buffers const& B, u32 n_anchors) {

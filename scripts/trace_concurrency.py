@@ -6,14 +6,15 @@ import csv, sys, collections
 rows = list(csv.DictReader(open(sys.argv[1])))
 n_last = int(sys.argv[2]) if len(sys.argv) > 2 else 64          # window = from the start of the n-th last search launch to the end of the last
 ev = [(int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]) for r in rows]
-fm = sorted((s, e) for s, e, k in ev if "fm_search" in k)
+fm = sorted((s, e) for s, e, k in ev if "fm_search_filter" in k or "fm_search_kernel" in k)
 t0 = fm[-min(n_last, len(fm))][0]
 t_end = max(e for _, e in fm)
 ev = [(s, min(e, t_end), k) for s, e, k in ev if s < t_end]
 ev = [(max(s, t0), e, k) for s, e, k in ev if e > t0]
 span = t_end - t0
 def family(k):
-    for f in ("fm_search", "ed_band_kernel", "ed_exists_block", "ed_align_kernel", "ed_traceback", "seed_select", "seed_rows", "hit_scatter", "vr_", "lastrow", "rocprim", "hipcub"):
+    for f in ("fm_search_filter", "fm_search_text", "fm_search", "ed_band_kernel", "ed_exists_block", "ed_align_kernel", "ed_traceback", "seed_select", "seed_rows", "hit_scatter",
+              "vr2_request", "vr2_apply", "vr_", "lastrow", "rocprim", "hipcub", "fillBuffer", "copyBuffer", "peq_build", "pack_pool", "seed_compact"):
         if f in k: return f
     return "other"
 def union(iv):
@@ -29,10 +30,10 @@ for s, e, k in ev: fam[family(k)].append((s, e))
 print(f"window {span / 1e6:.1f} ms, {len(ev)} launches")
 print(f"any kernel running: {union([(s, e) for s, e, _ in ev]) / span:.3f} of the time")
 for f, iv in sorted(fam.items(), key=lambda kv: -sum(e - s for s, e in kv[1])):
-    print(f"  {f:18s} launches {len(iv):6d}  sum {sum(e - s for s, e in iv) / 1e6:9.1f} ms  union {union(list(iv)) / span:.3f} of the time")
+    print(f"  {f:18s} launches {len(iv):6d}  sum {sum(e - s for s, e in iv) / 1e6:9.1f} ms  avg {sum(e - s for s, e in iv) / 1e3 / len(iv):9.1f} us  union {union(list(iv)) / span:.3f} of the time")
 # distribution of concurrent search launches
 pts = []
-for s, e in fam["fm_search"]: pts += [(s, 1), (e, -1)]
+for s, e in fam["fm_search_filter"] + fam["fm_search"]: pts += [(s, 1), (e, -1)]
 pts.sort(); cur = 0; last = t0; hist = collections.Counter()
 for t, d in pts:
     hist[cur] += t - last; last = t; cur += d
