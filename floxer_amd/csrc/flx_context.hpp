@@ -57,6 +57,7 @@ struct Lane {
     std::vector<PendingTiming> pending;
     std::vector<hipEvent_t> event_pool;
     hipEvent_t sync_event = nullptr;
+    u32* vr_host_scalars = nullptr;  // page-locked, mapped: a round's scalars, written by the device (flx_rounds.hip)
     bool has_run = false;            // a chunk has run here (its workspaces have their working sizes)
     int wait_idle();                 // the stream has drained (the thread sleeps on a blocking event unless FLX_SPIN_SYNC is set)
     int sync();                      // wait_idle + fold pending timings into the context's statistics

@@ -2051,27 +2051,15 @@ __global__ void __launch_bounds__(64) ed_band_kernel(const u8* __restrict__ text
 // the band may be computed, from exact or over-estimated inputs: both are over-estimates there, as in ed_band_kernel); a group
 // keeps going for the block in which the next group starts, whose start value D[last row of this group][column before that
 // block] travels with the carries.
+// (the jobs of one wave: group `blk` of 64 >> log2_r jobs)
 template <int W>
-__global__ void __launch_bounds__(64) ed_exists_block_kernel(const u8* __restrict__ text, const u64* __restrict__ peq,
-                                                             const DevAlignJob* __restrict__ jobs, u32 n_jobs, u32 log2_r,
-                                                             DevAlignOut* __restrict__ out, const u32* __restrict__ n_jobs_dev, u32 gate_r,
-                                                             u32 gate_lo, u32 gate_hi) {
-    // LDS: [7 symbols][64 lanes][W words] equality masks; symbol 6 (columns past the end of the window) matches nothing
-    extern __shared__ __attribute__((aligned(16))) u64 lds_eq[];
+__device__ __forceinline__ void ed_exists_block_body(const u8* __restrict__ text, const u64* __restrict__ peq, const DevAlignJob* __restrict__ jobs, u32 n_jobs,
+                                                     u32 log2_r, DevAlignOut* __restrict__ out, u32 blk, u64* __restrict__ lds_eq) {
     u32 const lane = lane_id();
     u32 const R = 1u << log2_r;
     u32 const p = lane & (R - 1u);
     u32 const jobs_per_wave = 64u >> log2_r;
-    if (n_jobs_dev) {
-        // the job count is on the device (verification rounds, flx_rounds.hip): the grid is an upper bound, and of the two shapes
-        // launched for a round the one runs whose range of waves (jobs x gate_r lanes / 64) holds the count
-        u32 const nj = *n_jobs_dev;
-        u64 const waves = (u64)nj * gate_r / 64u;
-        if (waves < gate_lo || waves >= gate_hi) return;
-        n_jobs = min(n_jobs, nj);
-    }
-    if (blockIdx.x * jobs_per_wave >= n_jobs) return;
-    u32 const job_id = blockIdx.x * jobs_per_wave + (lane >> log2_r);
+    u32 const job_id = blk * jobs_per_wave + (lane >> log2_r);
     bool valid = job_id < n_jobs;
     DevAlignJob job;
     if (valid) job = jobs[job_id];
@@ -2205,6 +2193,19 @@ __global__ void __launch_bounds__(64) ed_exists_block_kernel(const u8* __restric
 }
 
 
+// A launch is a grid over the groups of jobs, or (n_jobs_dev: the job count is on the device, verification rounds of flx_rounds.hip)
+// a fixed grid whose waves take the groups in turn until the count is reached.
+template <int W>
+__global__ void __launch_bounds__(64) ed_exists_block_kernel(const u8* __restrict__ text, const u64* __restrict__ peq,
+                                                             const DevAlignJob* __restrict__ jobs, u32 n_jobs, u32 log2_r,
+                                                             DevAlignOut* __restrict__ out, const u32* __restrict__ n_jobs_dev) {
+    // LDS: [7 symbols][64 lanes][W words] equality masks; symbol 6 (columns past the end of the window) matches nothing
+    extern __shared__ __attribute__((aligned(16))) u64 lds_eq[];
+    if (n_jobs_dev) n_jobs = min(n_jobs, *n_jobs_dev);
+    u32 const jobs_per_wave = 64u >> log2_r;
+    for (u32 blk = blockIdx.x; blk * jobs_per_wave < n_jobs; blk += gridDim.x) ed_exists_block_body<W>(text, peq, jobs, n_jobs, log2_r, out, blk, lds_eq);
+}
+
 static AlignShape choose_align_shape_uncached(u32 nw, i64 width, bool band, bool parallel) {
     AlignShape best{0, 0, 0};
     u64 best_cost = ~0ull;
@@ -2273,7 +2274,7 @@ static int launch_align(hipStream_t s, const u8* d_text, const u64* d_peq, const
     if (banded && !trace && !d_lastrow && exists_block_form()) {
         size_t const lds_b = (size_t)7 * 64 * W * sizeof(u64);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ed_exists_block_kernel<W>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_b);
-        hipLaunchKernelGGL((ed_exists_block_kernel<W>), dim3(blocks), dim3(64), lds_b, s, d_text, d_peq, d_jobs, n_jobs, log2_g, d_out, (const u32*)nullptr, 0u, 0u, 0u);
+        hipLaunchKernelGGL((ed_exists_block_kernel<W>), dim3(blocks), dim3(64), lds_b, s, d_text, d_peq, d_jobs, n_jobs, log2_g, d_out, (const u32*)nullptr);
         return (int)hipGetLastError();
     }
     if (banded) { if (trace) FLX_LAUNCH((ed_band_kernel<W, true>)); else FLX_LAUNCH((ed_band_kernel<W, false>)); }
@@ -2282,34 +2283,34 @@ static int launch_align(hipStream_t s, const u8* d_text, const u64* d_peq, const
     return (int)hipGetLastError();
 }
 
-// existence tests whose number is on the device: a grid for max_jobs, blocks beyond *d_n_jobs leave at once; the launch only runs when
-// *d_n_jobs x gate_r / 64 lies in [gate_lo, gate_hi) (see ed_exists_block_kernel)
+// existence tests whose number is on the device (*d_n_jobs, at most max_jobs): a grid of at most `max_waves` waves that take the
+// groups of jobs in turn
 template <int W>
-static int launch_exists_gated(hipStream_t s, const u8* d_text, const u64* d_peq, const DevAlignJob* d_jobs, u32 max_jobs, u32 log2_g, DevAlignOut* d_out,
-                               const u32* d_n_jobs, u32 gate_r, u32 gate_lo, u32 gate_hi) {
+static int launch_exists_counted(hipStream_t s, const u8* d_text, const u64* d_peq, const DevAlignJob* d_jobs, u32 max_jobs, u32 log2_g, DevAlignOut* d_out,
+                                 const u32* d_n_jobs, u32 max_waves) {
     u32 const jobs_per_wave = 64u >> log2_g;
-    u32 const blocks = (max_jobs + jobs_per_wave - 1) / jobs_per_wave;
+    u32 const blocks = std::max(1u, std::min((max_jobs + jobs_per_wave - 1) / jobs_per_wave, max_waves));
     size_t const lds_b = (size_t)7 * 64 * W * sizeof(u64);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ed_exists_block_kernel<W>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_b);
-    hipLaunchKernelGGL((ed_exists_block_kernel<W>), dim3(blocks), dim3(64), lds_b, s, d_text, d_peq, d_jobs, max_jobs, log2_g, d_out, d_n_jobs, gate_r, gate_lo, gate_hi);
+    hipLaunchKernelGGL((ed_exists_block_kernel<W>), dim3(blocks), dim3(64), lds_b, s, d_text, d_peq, d_jobs, max_jobs, log2_g, d_out, d_n_jobs);
     return (int)hipGetLastError();
 }
-int DeviceApi::align_exists_gated(void* stream, const u8* d_text, const u64* d_peq, const DevAlignJob* d_jobs, u32 max_jobs, const u32* d_n_jobs,
-                                  AlignShape shape, u32 gate_r, u32 gate_lo, u32 gate_hi, DevAlignOut* d_out) {
+int DeviceApi::align_exists_counted(void* stream, const u8* d_text, const u64* d_peq, const DevAlignJob* d_jobs, u32 max_jobs, const u32* d_n_jobs,
+                                    AlignShape shape, u32 max_waves, DevAlignOut* d_out) {
     if (max_jobs == 0) return 0;
     u32 log2_g = 0;
     while ((1u << log2_g) < shape.lanes_per_job) ++log2_g;
     hipStream_t s = (hipStream_t)stream;
     switch (shape.words_per_lane) {
-        case 1: return launch_exists_gated<1>(s, d_text, d_peq, d_jobs, max_jobs, log2_g, d_out, d_n_jobs, gate_r, gate_lo, gate_hi);
-        case 2: return launch_exists_gated<2>(s, d_text, d_peq, d_jobs, max_jobs, log2_g, d_out, d_n_jobs, gate_r, gate_lo, gate_hi);
-        case 3: return launch_exists_gated<3>(s, d_text, d_peq, d_jobs, max_jobs, log2_g, d_out, d_n_jobs, gate_r, gate_lo, gate_hi);
-        case 4: return launch_exists_gated<4>(s, d_text, d_peq, d_jobs, max_jobs, log2_g, d_out, d_n_jobs, gate_r, gate_lo, gate_hi);
-        case 5: return launch_exists_gated<5>(s, d_text, d_peq, d_jobs, max_jobs, log2_g, d_out, d_n_jobs, gate_r, gate_lo, gate_hi);
-        case 6: return launch_exists_gated<6>(s, d_text, d_peq, d_jobs, max_jobs, log2_g, d_out, d_n_jobs, gate_r, gate_lo, gate_hi);
-        case 8: return launch_exists_gated<8>(s, d_text, d_peq, d_jobs, max_jobs, log2_g, d_out, d_n_jobs, gate_r, gate_lo, gate_hi);
-        case 13: return launch_exists_gated<13>(s, d_text, d_peq, d_jobs, max_jobs, log2_g, d_out, d_n_jobs, gate_r, gate_lo, gate_hi);
-        case 25: return launch_exists_gated<25>(s, d_text, d_peq, d_jobs, max_jobs, log2_g, d_out, d_n_jobs, gate_r, gate_lo, gate_hi);
+        case 1: return launch_exists_counted<1>(s, d_text, d_peq, d_jobs, max_jobs, log2_g, d_out, d_n_jobs, max_waves);
+        case 2: return launch_exists_counted<2>(s, d_text, d_peq, d_jobs, max_jobs, log2_g, d_out, d_n_jobs, max_waves);
+        case 3: return launch_exists_counted<3>(s, d_text, d_peq, d_jobs, max_jobs, log2_g, d_out, d_n_jobs, max_waves);
+        case 4: return launch_exists_counted<4>(s, d_text, d_peq, d_jobs, max_jobs, log2_g, d_out, d_n_jobs, max_waves);
+        case 5: return launch_exists_counted<5>(s, d_text, d_peq, d_jobs, max_jobs, log2_g, d_out, d_n_jobs, max_waves);
+        case 6: return launch_exists_counted<6>(s, d_text, d_peq, d_jobs, max_jobs, log2_g, d_out, d_n_jobs, max_waves);
+        case 8: return launch_exists_counted<8>(s, d_text, d_peq, d_jobs, max_jobs, log2_g, d_out, d_n_jobs, max_waves);
+        case 13: return launch_exists_counted<13>(s, d_text, d_peq, d_jobs, max_jobs, log2_g, d_out, d_n_jobs, max_waves);
+        case 25: return launch_exists_counted<25>(s, d_text, d_peq, d_jobs, max_jobs, log2_g, d_out, d_n_jobs, max_waves);
         default: return (int)hipErrorInvalidValue;
     }
 }

@@ -200,9 +200,11 @@ struct VrBuffers {
 };
 
 // ---- the rounds as three launches each (flx_rounds.hip)
-// scalars (u32 words): jobs of the round, requests (anchors in the round), anchors left to climb and their smallest node after the
-// round, then two 64-bit sums for the accounting: word-steps and sequence bytes of the round's jobs
-enum : u32 { VR2_N_JOBS = 0, VR2_N_REQ = 1, VR2_N_CLIMBING = 2, VR2_SMALLEST = 3, VR2_WORD_STEPS = 4, VR2_BYTES = 6, VR2_SCALARS = 16 };
+// scalars (u32 words): jobs of the round (two counters, taken in turn), anchors left to climb and their smallest node after the round,
+// two 64-bit running sums for the accounting (word-steps and sequence bytes of the jobs so far), requests so far (anchors in rounds),
+// blocks of vr2_apply that have finished
+enum : u32 { VR2_N_JOBS = 0 /* and 1: by the round's parity */, VR2_N_CLIMBING = 2, VR2_SMALLEST = 3, VR2_WORD_STEPS = 4, VR2_BYTES = 6, VR2_N_REQ = 8, VR2_DONE = 9,
+             VR2_SCALARS = 16 };
 struct Vr2Buffers {
     const DevVrAnchor* anchors; const DevVrNode* nodes;
     const u32* q_first;                          // per query (read x orientation): its first anchor; n_queries + 1 entries
@@ -301,11 +303,11 @@ struct DeviceApi {
     static int vr_round_override(void* stream, VrBuffers const& B, u32 n_anchors, u8* d_override);
     static int vr_round_apply(void* stream, VrBuffers const& B, u32 n_anchors, const u8* d_override);
     static AlignShape vr_class_shape(u32 shape_class);
-    // flx_rounds.hip: a round = vr2_request (job list and count on the device), align_exists_gated on it, vr2_apply
-    static int vr2_request(void* stream, Vr2Buffers const& B, u32 n_queries, u32 limit, u32 acct_words, u32 width_cap);
-    static int vr2_apply(void* stream, Vr2Buffers const& B, u32 n_anchors);
-    static int align_exists_gated(void* stream, const u8* d_text, const u64* d_peq, const DevAlignJob* d_jobs, u32 max_jobs, const u32* d_n_jobs,
-                                  AlignShape shape, u32 gate_r, u32 gate_lo, u32 gate_hi, DevAlignOut* d_out);
+    // flx_rounds.hip: a round = vr2_request (job list and count on the device), align_exists_counted on it, vr2_apply
+    static int vr2_request(void* stream, Vr2Buffers const& B, u32 n_queries, u32 limit, u32 acct_words, u32 width_cap, u32 parity);
+    static int vr2_apply(void* stream, Vr2Buffers const& B, u32 n_anchors, u32* host_scalars);
+    static int align_exists_counted(void* stream, const u8* d_text, const u64* d_peq, const DevAlignJob* d_jobs, u32 max_jobs, const u32* d_n_jobs,
+                                    AlignShape shape, u32 max_waves, DevAlignOut* d_out);
     static AlignShape shape_holding(u32 nw, i64 width, bool parallel);
     static int lastrow_min(void* stream, const u16* d_lastrow, const DevRowWindow* d_windows, u32 n_windows, DevAlignOut* d_out);
     static int traceback(void* stream, const u8* d_text, const u8* d_query, const u64* d_peq, const u64* d_trace,

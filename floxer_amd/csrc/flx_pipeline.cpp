@@ -128,6 +128,7 @@ void Lane::release_all() {
     event_pool.clear();
     if (own_stream) (void)hipStreamDestroy(own_stream);
     own_stream = stream = nullptr;
+    if (vr_host_scalars) { (void)hipHostFree(vr_host_scalars); vr_host_scalars = nullptr; }
 }
 void flx_ctx::account(const char* name, u64 bytes, u64 units, hipEvent_t start, hipEvent_t stop) {
     float ms = 0.f;
@@ -1892,13 +1893,16 @@ int align_slice(Lane* lane, const flx_params* P, const flx_reads* RD, u64 first_
         FLX_HIP(hipMemcpyAsync(base + o_node, h_node.data(), (size_t)n * 4, hipMemcpyHostToDevice, lane->stream));
         FLX_HIP(hipMemcpyAsync(base + o_status, h_status.data(), n, hipMemcpyHostToDevice, lane->stream));
         FLX_HIP(hipMemsetAsync(base + o_slot, 0xFF, (size_t)n * 4, lane->stream));
+        FLX_HIP(hipMemsetAsync(B.scalars, 0, VR2_SCALARS * 4, lane->stream));
+        if (!lane->vr_host_scalars) FLX_HIP(hipHostMalloc((void**)&lane->vr_host_scalars, VR2_SCALARS * 4, hipHostMallocMapped));
         vprof.mark("upload");
         u64 const few_waves = align_few_waves();
-        while (n_climbing > 0) {
+        u64 prev_jobs = n_climbing / 2, acc_steps = 0, acc_bytes = 0, acc_req = 0;
+        for (u32 round = 0; n_climbing > 0; ++round) {
             u64 const limit = (u64)smallest * round_span_percent() / 100;
-            // One launch shape for the round: the cheapest that holds the window of every node in the round's size class, and the one
-            // with the fewest words per lane for rounds of few jobs (they would leave most SIMDs without a wave); which of the two
-            // runs is decided on the device, where the job count is
+            // One launch shape for the round: the cheapest that holds the window of every node in the round's size class, or the one
+            // with the fewest words per lane when the round has few jobs (they would leave most SIMDs without a wave; the last round's
+            // job count is the estimate: either shape holds every job)
             u32 nw_max = 0;
             i64 width_max = 0;
             for (auto const& nd : nodes)
@@ -1908,42 +1912,37 @@ int align_slice(Lane* lane, const flx_params* P, const flx_reads* RD, u64 first_
                 }
             AlignShape const shape_t = DeviceApi::shape_holding(nw_max, width_max, false), shape_p = DeviceApi::shape_holding(nw_max, width_max, true);
             if (shape_t.words_per_lane == 0 || shape_p.words_per_lane == 0) { set_error("query longer than the supported maximum"); return FLX_ERR_UNSUPPORTED; }
-            // what the shapes hold beyond that goes to the clusters' union windows (a shape holds a job when every word group has a lane of
+            AlignShape const shape = prev_jobs * shape_t.lanes_per_job / 64 >= few_waves ? shape_t : shape_p;
+            // what the shape holds beyond that goes to the clusters' union windows (a shape holds a job when every word group has a lane of
             // its own, or when the ring's lanes are free again before their next group starts: 64 W (R - 1) + R + 1 > diagonals)
-            auto cap_of = [&](AlignShape const& sh) -> u64 {
-                if ((nw_max + sh.words_per_lane - 1) / sh.words_per_lane <= sh.lanes_per_job) return 0xFFFFFFFFull;
-                return 64ull * sh.words_per_lane * (sh.lanes_per_job - 1) + sh.lanes_per_job;
-            };
-            u32 const width_cap = (u32)std::min<u64>(std::min(cap_of(shape_t), cap_of(shape_p)), 0xFFFFFFFFull);
-            FLX_HIP(hipMemsetAsync(B.scalars, 0, VR2_SCALARS * 4, lane->stream));
-            int const e1 = DeviceApi::vr2_request(lane->stream, B, n_queries, (u32)std::min<u64>(limit, 0xFFFFFFFFu), shape_t.words_per_lane, width_cap);
+            u64 const cap = (nw_max + shape.words_per_lane - 1) / shape.words_per_lane <= shape.lanes_per_job
+                                ? 0xFFFFFFFFull : 64ull * shape.words_per_lane * (shape.lanes_per_job - 1) + shape.lanes_per_job;
+            int const e1 = DeviceApi::vr2_request(lane->stream, B, n_queries, (u32)std::min<u64>(limit, 0xFFFFFFFFu), shape.words_per_lane,
+                                                  (u32)std::min<u64>(cap, 0xFFFFFFFFull), round);
             if (e1) { set_error(std::string("verification round: ") + hipGetErrorString((hipError_t)e1)); return FLX_ERR_NO_DEVICE; }
             u32 const max_jobs = (u32)std::min<u64>(2ull * n_climbing, 2ull * n);
-            bool const one_shape = shape_t.words_per_lane == shape_p.words_per_lane && shape_t.lanes_per_job == shape_p.lanes_per_job;
-            u32 const gate = (u32)std::min<u64>(few_waves, 0xFFFFFFFFu);
             rc = timed_launch(lane, "ed_align_exists", 0, 0, [&] {
-                int e = DeviceApi::align_exists_gated(lane->stream, d_text, d_peq, B.jobs, max_jobs, B.scalars + VR2_N_JOBS, shape_t, shape_t.lanes_per_job,
-                                                      one_shape ? 0u : gate, 0xFFFFFFFFu, B.outs);
-                if (!e && !one_shape)
-                    e = DeviceApi::align_exists_gated(lane->stream, d_text, d_peq, B.jobs, max_jobs, B.scalars + VR2_N_JOBS, shape_p, shape_t.lanes_per_job, 0u, gate, B.outs);
-                return e;
+                return DeviceApi::align_exists_counted(lane->stream, d_text, d_peq, B.jobs, max_jobs, B.scalars + VR2_N_JOBS + (round & 1u), shape, 8192u, B.outs);
             });
             if (rc) return rc;
-            int const e2 = DeviceApi::vr2_apply(lane->stream, B, n);
+            int const e2 = DeviceApi::vr2_apply(lane->stream, B, n, lane->vr_host_scalars);
             if (e2) { set_error(std::string("verification round: ") + hipGetErrorString((hipError_t)e2)); return FLX_ERR_NO_DEVICE; }
-            u32 sc[VR2_SCALARS];
-            if ((rc = d2h(lane, sc, B.scalars, VR2_SCALARS * 4))) return rc;
             if ((rc = lane->sync())) return rc;
-            n_inner_requested += sc[VR2_N_REQ];
+            u32 sc[VR2_SCALARS];
+            memcpy(sc, lane->vr_host_scalars, sizeof(sc));            // (left there by the last block of vr2_apply)
+            u64 ws, by;
+            memcpy(&ws, &sc[VR2_WORD_STEPS], 8);
+            memcpy(&by, &sc[VR2_BYTES], 8);
             if (ctx->timing) {        // the round's word-steps and sequence bytes were counted on the device: fold them into the kernel's accounting
-                u64 ws, by;
-                memcpy(&ws, &sc[VR2_WORD_STEPS], 8);
-                memcpy(&by, &sc[VR2_BYTES], 8);
                 std::lock_guard<std::mutex> g(ctx->mu);
                 auto it = ctx->stats.find("ed_align_exists");
-                if (it != ctx->stats.end()) { it->second.algorithmic_bytes += by; it->second.work_units += ws; }
+                if (it != ctx->stats.end()) { it->second.algorithmic_bytes += by - acc_bytes; it->second.work_units += ws - acc_steps; }
             }
-            if (sc[VR2_N_REQ] == 0 && sc[VR2_N_CLIMBING] >= n_climbing) { set_error("verification rounds do not advance"); return FLX_ERR_INTERNAL; }
+            u64 const round_req = sc[VR2_N_REQ] - acc_req;
+            acc_steps = ws; acc_bytes = by; acc_req = sc[VR2_N_REQ];
+            n_inner_requested += round_req;
+            if (round_req == 0 && sc[VR2_N_CLIMBING] >= n_climbing) { set_error("verification rounds do not advance"); return FLX_ERR_INTERNAL; }
+            prev_jobs = sc[VR2_N_JOBS + (round & 1u)];
             n_climbing = sc[VR2_N_CLIMBING];
             smallest = sc[VR2_SMALLEST];
             vprof.mark("round");

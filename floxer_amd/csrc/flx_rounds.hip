@@ -28,7 +28,7 @@ namespace flx {
 namespace {
 
 constexpr u32 VR2_TILE = 1024;          // anchors of a query looked at per pass of its block
-constexpr u32 VR2_THREADS = 256;
+constexpr u32 VR2_THREADS = 64;
 constexpr u64 VR2_NO_KEY = ~0ull;
 
 __device__ __forceinline__ u64 vr2_word_steps(u32 n, u32 m, u32 k, u32 W) {          // job_word_steps of flx_pipeline.cpp, banded
@@ -49,17 +49,23 @@ __device__ __forceinline__ u64 vr2_key(u32 node, u64 start, u32 solo) { return (
 
 }  // namespace
 
-__global__ void __launch_bounds__(VR2_THREADS) vr2_request_kernel(Vr2Buffers B, u32 limit, u32 acct_words, u32 width_cap) {
+// One wave per query: a block of 64 threads finds a free wave slot on a GPU full of other lanes' kernels far sooner than four waves
+// and their LDS at once, and the steps below are short (a query has a few hundred anchors).
+__global__ void __launch_bounds__(VR2_THREADS) vr2_request_kernel(Vr2Buffers B, u32 limit, u32 acct_words, u32 width_cap, u32 parity) {
     __shared__ u64 s_key[VR2_TILE];
+    __shared__ u32 s_len[VR2_TILE];           // window length of the tile's anchor (by its place in the tile)
     __shared__ u16 s_val[VR2_TILE];
     __shared__ u8 s_flag[VR2_TILE];           // bit 0: first of its distinct window, bit 1: first of its cluster
     __shared__ u32 s_jobs[VR2_TILE];          // jobs of the cluster that starts here (0 elsewhere); then their exclusive sums
-    __shared__ u32 s_wave[VR2_THREADS / 64 + 1];
     __shared__ u32 s_count, s_base;
     u32 const tid = threadIdx.x;
     u32 const q = blockIdx.x;
-    if (q == 0 && tid == 0) { B.scalars[VR2_N_CLIMBING] = 0u; B.scalars[VR2_SMALLEST] = 0xFFFFFFFFu; }      // vr2_apply counts into them
+    if (q == 0 && tid == 0) {
+        B.scalars[VR2_N_CLIMBING] = 0u; B.scalars[VR2_SMALLEST] = 0xFFFFFFFFu; B.scalars[VR2_DONE] = 0u;      // vr2_apply counts into them
+        B.scalars[VR2_N_JOBS + (parity ^ 1u)] = 0u;                                                         // the next round's job counter
+    }
     u32 const a0 = B.q_first[q], a1 = B.q_first[q + 1];
+    u32* const n_jobs = &B.scalars[VR2_N_JOBS + parity];
     for (u32 tile = a0; tile < a1; tile += VR2_TILE) {
         u32 const n_here = min(VR2_TILE, a1 - tile);
         u32 size = 64;
@@ -69,6 +75,7 @@ __global__ void __launch_bounds__(VR2_THREADS) vr2_request_kernel(Vr2Buffers B, 
         __syncthreads();
         // ---- the requests of this tile's anchors that are in the round
         u32 mine = 0;
+        u32 tree_base = 0;
         for (u32 t = tid; t < size; t += VR2_THREADS) {
             u64 key = VR2_NO_KEY;
             if (t < n_here) {
@@ -81,7 +88,9 @@ __global__ void __launch_bounds__(VR2_THREADS) vr2_request_kernel(Vr2Buffers B, 
                     if (nd.rows <= limit) {
                         i64 const start_signed = a.diag_rel + (i64)nd.from - (i64)nd.errors;
                         u64 const start = start_signed > 0 ? (u64)start_signed : 0ull;
+                        u64 const base = (u64)nd.rows + 2ull * nd.errors + 1ull;
                         key = vr2_key(nd_i, a.seq_start + start, st == VR_SOLO ? 1u : 0u);
+                        s_len[t] = (u32)min(base, a.seq_len - start);
                         ++mine;
                     }
                 }
@@ -93,6 +102,8 @@ __global__ void __launch_bounds__(VR2_THREADS) vr2_request_kernel(Vr2Buffers B, 
         __syncthreads();
         u32 const cnt = s_count;
         if (cnt == 0) continue;
+        DevVrAnchor const a_first = B.anchors[tile];                  // (the tree and the read are the query's)
+        tree_base = a_first.tree_base;
         // ---- bitonic sort of (key, anchor) over `size` slots; slots without a request sort to the end
         for (u32 k = 2; k <= size; k <<= 1)
             for (u32 j = k >> 1; j > 0; j >>= 1) {
@@ -109,14 +120,12 @@ __global__ void __launch_bounds__(VR2_THREADS) vr2_request_kernel(Vr2Buffers B, 
         // ---- one thread per node run: distinct windows and clusters. A cluster = the distinct windows of a node whose starts fall
         //      into the same bucket of max(8, rows / 8) columns counted from the node's first window - as long as their union stays
         //      within the diagonals the round's launch shape holds (width_cap; the host chose the shape for single windows)
-        DevVrAnchor const a_first = B.anchors[tile];                  // (the tree is the query's)
         for (u32 t = tid; t < cnt; t += VR2_THREADS) {
             u64 const key = s_key[t];
             u32 const node = (u32)(key >> 33);
             if (t > 0 && (u32)(s_key[t - 1] >> 33) == node) continue;          // not the head of a run
-            DevVrNode const nd = B.nodes[a_first.tree_base + node];
+            DevVrNode const nd = B.nodes[tree_base + node];
             u64 const d = max((u64)8, (u64)nd.rows / 8ull);
-            u64 const base = (u64)nd.rows + 2ull * nd.errors + 1ull;
             u64 const first = (key >> 1) & 0xFFFFFFFFull;
             u64 prev_key = VR2_NO_KEY, prev_bucket = ~0ull, c_lo = 0, c_hi = 0;
             bool prev_solo = false;
@@ -127,8 +136,7 @@ __global__ void __launch_bounds__(VR2_THREADS) vr2_request_kernel(Vr2Buffers B, 
                 u64 const bucket = (st - first) / d;
                 u8 f = 0;
                 if (kj != prev_key) {
-                    DevVrAnchor const a = B.anchors[tile + s_val[j]];
-                    u64 const en = st + min(base, a.seq_start + a.seq_len - st);
+                    u64 const en = st + s_len[s_val[j]];
                     f = 1;
                     u64 const u_hi = max(c_hi, en);
                     bool const too_wide = (u_hi - c_lo) + 2ull * nd.errors > (u64)nd.rows + width_cap;      // union width = n - m + 2k
@@ -140,22 +148,16 @@ __global__ void __launch_bounds__(VR2_THREADS) vr2_request_kernel(Vr2Buffers B, 
             }
         }
         __syncthreads();
-        // ---- one thread per cluster: its windows' intersection and union -> one or two jobs
+        // ---- one thread per cluster: one job, or two when it has several windows that share columns (intersection and union)
         for (u32 t = tid; t < size; t += VR2_THREADS) {
             u32 nj = 0;
             if (t < cnt && (s_flag[t] & 2u)) {
                 u32 distinct = 0;
-                u64 lo_start = 0, hi_start = 0, lo_end = 0, hi_end = 0;
+                u64 hi_start = 0, lo_end = 0;
                 for (u32 j = t; j < cnt && (j == t || !(s_flag[j] & 2u)); ++j) {
                     if (!(s_flag[j] & 1u)) continue;
-                    u32 const i = tile + s_val[j];
-                    DevVrAnchor const a = B.anchors[i];
-                    DevVrNode const nd = B.nodes[a.tree_base + B.node[i]];
-                    u64 const st = (s_key[j] >> 1) & 0xFFFFFFFFull;
-                    u64 const base = (u64)nd.rows + 2ull * nd.errors + 1ull;
-                    u64 const len = min(base, a.seq_start + a.seq_len - st);
-                    if (distinct == 0) { lo_start = hi_start = st; lo_end = hi_end = st + len; }
-                    else { hi_start = max(hi_start, st); lo_start = min(lo_start, st); lo_end = min(lo_end, st + len); hi_end = max(hi_end, st + len); }
+                    u64 const st = (s_key[j] >> 1) & 0xFFFFFFFFull, en = st + s_len[s_val[j]];
+                    if (distinct == 0) { hi_start = st; lo_end = en; } else { hi_start = max(hi_start, st); lo_end = min(lo_end, en); }
                     ++distinct;
                 }
                 nj = distinct > 1 && lo_end > hi_start ? 2u : 1u;
@@ -163,25 +165,19 @@ __global__ void __launch_bounds__(VR2_THREADS) vr2_request_kernel(Vr2Buffers B, 
             s_jobs[t] = nj;
         }
         __syncthreads();
-        // ---- exclusive sums of the clusters' job counts (thread: its consecutive slots; wave: shuffles; block: LDS), one slot range
-        //      of the round's job list for the block
+        // ---- exclusive sums of the clusters' job counts (a thread's consecutive slots, then the wave by shuffles), one slot range of
+        //      the round's job list for the query
         {
-            u32 const per = size / VR2_THREADS ? size / VR2_THREADS : 1u;          // size >= 64: 1 .. 4 slots per thread when size >= 256
+            u32 const per = size / VR2_THREADS;                                   // size >= 64: 1 .. 16 slots per thread
             u32 const first = tid * per;
-            u32 local[VR2_TILE / VR2_THREADS];
             u32 run = 0;
-            for (u32 x = 0; x < per; ++x) { u32 const v = first + x < size ? s_jobs[first + x] : 0u; local[x] = run; run += v; }
+            for (u32 x = 0; x < per; ++x) run += s_jobs[first + x];
             u32 incl = run;
 #pragma unroll
-            for (u32 off = 1; off < 64u; off <<= 1) { u32 const up = (u32)__shfl_up((int)incl, off); if ((tid & 63u) >= off) incl += up; }
-            if ((tid & 63u) == 63u) s_wave[tid >> 6] = incl;
-            __syncthreads();
-            u32 before = 0;
-            for (u32 w = 0; w < (tid >> 6); ++w) before += s_wave[w];
-            u32 const excl = before + incl - run;
-            __syncthreads();
-            for (u32 x = 0; x < per; ++x) if (first + x < size) s_jobs[first + x] = excl + local[x];
-            if (tid == VR2_THREADS - 1u) { u32 const total = before + incl; s_base = total ? atomicAdd(&B.scalars[VR2_N_JOBS], total) : 0u; }
+            for (u32 off = 1; off < 64u; off <<= 1) { u32 const up = (u32)__shfl_up((int)incl, off); if (tid >= off) incl += up; }
+            u32 at = incl - run;
+            for (u32 x = 0; x < per; ++x) { u32 const v = s_jobs[first + x]; s_jobs[first + x] = at; at += v; }
+            if (tid == VR2_THREADS - 1u) s_base = incl ? atomicAdd(n_jobs, incl) : 0u;
             __syncthreads();
         }
         u32 const base_slot = s_base;
@@ -197,20 +193,13 @@ __global__ void __launch_bounds__(VR2_THREADS) vr2_request_kernel(Vr2Buffers B, 
             for (u32 j = t; j < cnt && (j == t || !(s_flag[j] & 2u)); ++j) {
                 last = j;
                 if (!(s_flag[j] & 1u)) continue;
-                u32 const i = tile + s_val[j];
-                DevVrAnchor const a = B.anchors[i];
-                DevVrNode const nd = B.nodes[a.tree_base + B.node[i]];
-                u64 const st = (s_key[j] >> 1) & 0xFFFFFFFFull;
-                u64 const base = (u64)nd.rows + 2ull * nd.errors + 1ull;
-                u64 const len = min(base, a.seq_start + a.seq_len - st);
-                if (distinct == 0) { lo_start = hi_start = st; lo_end = hi_end = st + len; }
-                else { hi_start = max(hi_start, st); lo_start = min(lo_start, st); lo_end = min(lo_end, st + len); hi_end = max(hi_end, st + len); }
+                u64 const st = (s_key[j] >> 1) & 0xFFFFFFFFull, en = st + s_len[s_val[j]];
+                if (distinct == 0) { lo_start = hi_start = st; lo_end = hi_end = en; }
+                else { hi_start = max(hi_start, st); lo_start = min(lo_start, st); lo_end = min(lo_end, en); hi_end = max(hi_end, en); }
                 ++distinct;
             }
-            u32 const i0 = tile + s_val[t];
-            DevVrAnchor const a = B.anchors[i0];
-            DevVrNode const nd = B.nodes[a.tree_base + B.node[i0]];
-            u64 const q_off = a.q_base + nd.from;
+            DevVrNode const nd = B.nodes[tree_base + (u32)(s_key[t] >> 33)];
+            u64 const q_off = a_first.q_base + nd.from;
             u32 code;
             if (distinct == 1) {
                 B.jobs[slot] = DevAlignJob{lo_start, q_off, 0, (u32)(hi_end - lo_start), nd.rows, nd.errors, slot, 0};
@@ -233,7 +222,7 @@ __global__ void __launch_bounds__(VR2_THREADS) vr2_request_kernel(Vr2Buffers B, 
         // accounting (one atomic per wave)
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) { steps += __shfl_xor(steps, off); bytes += __shfl_xor(bytes, off); n_req += (u32)__shfl_xor((int)n_req, off); }
-        if ((tid & 63u) == 0u && n_req) {
+        if (tid == 0u && n_req) {
             atomicAdd(&B.scalars[VR2_N_REQ], n_req);
             atomicAdd((unsigned long long*)&B.scalars[VR2_WORD_STEPS], (unsigned long long)steps);
             atomicAdd((unsigned long long*)&B.scalars[VR2_BYTES], (unsigned long long)bytes);
@@ -241,7 +230,9 @@ __global__ void __launch_bounds__(VR2_THREADS) vr2_request_kernel(Vr2Buffers B, 
     }
 }
 
-__global__ void __launch_bounds__(256) vr2_apply_kernel(Vr2Buffers B, u32 n) {
+// host_scalars (page-locked, mapped): where the last block to finish leaves the round's scalars, so that the host reads them behind
+// an event without a copy of its own
+__global__ void __launch_bounds__(256) vr2_apply_kernel(Vr2Buffers B, u32 n, u32* __restrict__ host_scalars) {
     __shared__ u32 s_cnt[4], s_min[4];
     u32 count = 0, smallest = 0xFFFFFFFFu;
     for (u32 i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
@@ -278,19 +269,25 @@ __global__ void __launch_bounds__(256) vr2_apply_kernel(Vr2Buffers B, u32 n) {
     if (threadIdx.x == 0) {
         u32 const c = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3], m = min(min(s_min[0], s_min[1]), min(s_min[2], s_min[3]));
         if (c) { atomicAdd(&B.scalars[VR2_N_CLIMBING], c); atomicMin(&B.scalars[VR2_SMALLEST], m); }
+        __threadfence();
+        if (atomicAdd(&B.scalars[VR2_DONE], 1u) == gridDim.x - 1u && host_scalars) {
+            __threadfence();
+            for (u32 w = 0; w < VR2_SCALARS; ++w) host_scalars[w] = __hip_atomic_load(&B.scalars[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __threadfence_system();
+        }
     }
 }
 
-// everything up to the round's job list (B.jobs, B.scalars[VR2_N_JOBS]); acct_words: words per lane of the launch shape (accounting);
+// everything up to the round's job list (B.jobs, B.scalars[VR2_N_JOBS + parity]; the other parity's counter is zeroed for the next round); acct_words: words per lane of the launch shape (accounting);
 // width_cap: most diagonals (n - m + 2k) a job of the round may have (what the launch shapes hold)
-int DeviceApi::vr2_request(void* stream, Vr2Buffers const& B, u32 n_queries, u32 limit, u32 acct_words, u32 width_cap) {
+int DeviceApi::vr2_request(void* stream, Vr2Buffers const& B, u32 n_queries, u32 limit, u32 acct_words, u32 width_cap, u32 parity) {
     if (n_queries == 0) return 0;
-    hipLaunchKernelGGL(vr2_request_kernel, dim3(n_queries), dim3(VR2_THREADS), 0, (hipStream_t)stream, B, limit, std::max(1u, acct_words), width_cap);
+    hipLaunchKernelGGL(vr2_request_kernel, dim3(n_queries), dim3(VR2_THREADS), 0, (hipStream_t)stream, B, limit, std::max(1u, acct_words), width_cap, parity & 1u);
     return (int)hipGetLastError();
 }
-int DeviceApi::vr2_apply(void* stream, Vr2Buffers const& B, u32 n_anchors) {
+int DeviceApi::vr2_apply(void* stream, Vr2Buffers const& B, u32 n_anchors, u32* host_scalars) {
     if (n_anchors == 0) return 0;
-    hipLaunchKernelGGL(vr2_apply_kernel, dim3(std::min<u32>((n_anchors + 255) / 256, 1024u)), dim3(256), 0, (hipStream_t)stream, B, n_anchors);
+    hipLaunchKernelGGL(vr2_apply_kernel, dim3(std::min<u32>((n_anchors + 255) / 256, 1024u)), dim3(256), 0, (hipStream_t)stream, B, n_anchors, host_scalars);
     return (int)hipGetLastError();
 }
 
