@@ -241,32 +241,12 @@ done:
     return (int)e;
 }
 
-// ================================================================================================ K1: FM search
-static u32 fm_priority() {              // FLX_FM_PRIO=0: the search waves at the default issue priority (measurements)
-    static u32 const v = getenv("FLX_FM_PRIO") ? (u32)atoi(getenv("FLX_FM_PRIO")) : 0u;
-    return v;
-}
-// One lane serves one seed. A rank query reads one 32-byte block (32 BWT positions: five absolute counters + three bit-planes)
-// with two 16-byte loads and pop-counts the positions below the offset (v_bcnt accumulates onto the counters); the count of
-// symbol 5 is what is left of the interval. A cursor extension is two rank queries (both ends of the interval, usually in the same
-// 128-byte line). The roofline accounting stays the one of SURVEY.md section 8(d): 2 x 64 B per extension.
-//
-// fm_search_kernel (the default path) walks the DFS of search_ng21 in a different order than the reference: at a branching node
-// the children that cost an error are visited first and the match child last, as a tail call. A frame (the node and its child
-// cursors) is then only alive while one of its error children is explored, so at most `errors` frames exist at a time: the whole
-// stack lives in LDS ([level][word][lane], conflict-free b32 accesses), nothing of the DFS is written to HBM and no stack has to be
-// reserved per seed. Every hit carries a key that puts the hits of a seed back into the reference's emission order (which decides
-// ties of the unstable sorts downstream): the DFS order is the lexicographic order of the child indices taken along the path,
-// match = 0 first; a path is determined by its <= 3 error edges, so key = search << 54 | three 18-bit components, one per
-// error edge in path order: (MAX_X - x of the node the edge leaves) << 4 | child index, 0 when there is no such edge (between two
-// error edges the depth grows with x, so comparing x is comparing depths). This only works when all hits of a seed are wanted
-// (round_robin / full_groups: a seed with more rows than the hard cap is excluded whatever the rows are).
-// fm_search_ordered_kernel walks the DFS in the reference's order with an explicit stack in HBM: for first_reported (the first n
-// rows in emission order) and the raw-emission test hook.
-//
-// (Round 1 served a seed with a DPP pair of lanes on 128-byte blocks and was bound by VALU issue, every control instruction being
-// issued twice per seed; one lane per seed on 64-byte blocks with the stack in HBM was bound by the vector memory path: 18 vector
-// memory instructions per DFS step, three loads per block, TA busy 82 %, profiles/r02_k1_pmc_1gb_64B_blocks.txt.)
+// ================================================================================================ K1: FM search, the reference's order
+// The default walk (error children first, stack in LDS, presence filter, one-row subtrees against the text) is in flx_fm_core.hpp /
+// flx_search.hip. fm_search_ordered_kernel below walks the DFS of search_ng21 in the reference's own order with an explicit stack in
+// HBM: for first_reported (the first n rows in emission order) and the raw-emission test hook, where the order of discovery itself
+// is the result. One lane serves one seed; a rank query reads one 32-byte block (32 BWT positions: five absolute counters + three
+// bit-planes) with two 16-byte loads and pop-counts the positions below the offset.
 
 // r[c] = number of symbol c in bwt[0, pos) for c = 0..4
 __device__ __forceinline__ void rank5(const OccBlock* __restrict__ tab, u32 pos, u32 r[5]) {
@@ -328,8 +308,6 @@ constexpr u32 FM_GRAB = 64;
 constexpr u32 FM_HIT_GRAB = 64;
 constexpr u32 FM_MAX_WAVES = 4096;
 constexpr u32 FM_SEEDS_PER_WAVE = 256;      // a launch has at most n_seeds / this many waves, so that every wave gets several ranges
-constexpr u32 FM_FRAME_WORDS = 18;          // LDS frame: oth[1..5], end, abs[1..5], lb, lb_rev, state, mask, key lo, key hi, abs[0]
-constexpr u32 FM_KEY_BITS = 18;             // per error edge: (0x3FFF - x) << 4 | child index
 constexpr u32 FM_KEY_MAX_X = 0x3FFFu;
 
 // hit slots for the hits the lanes found in the last iteration. Slots are reserved FM_HIT_GRAB at a time per wave (one global
@@ -423,193 +401,6 @@ __device__ __forceinline__ u32 fm_child_mask(const u32 cl[6], u32 next_sym, bool
     if (next_sym == 0u && match_allowed && cl[0] > 0u) mask |= 1u;      // a '$' of the query matches a sequence delimiter
     if (insertion) mask |= 1u << 11;
     return mask;
-}
-
-__global__ void __launch_bounds__(64) fm_search_kernel(DevIndex idx, const u8* __restrict__ seq, const u64* __restrict__ scheme,
-                                                       const DevSeed* __restrict__ seeds, u32 n_seeds, u32 max_hits, u32 levels,
-                                                       DevHit* __restrict__ hits, u32 hit_cap, u32* __restrict__ counters,
-                                                       u32* __restrict__ seed_cnt, u32 prio) {
-    extern __shared__ u32 lds[];                // frames: [level][FM_FRAME_WORDS][64 lanes]
-    // This kernel issues few instructions and lives on memory requests in flight; the DP kernels it shares the CUs with issue
-    // VALU work back to back. Ahead of them in the issue arbitration, its waves keep their requests flowing and cost the DP waves
-    // next to nothing.
-    if (prio) __builtin_amdgcn_s_setprio(3);
-    u32 q_next = 0, q_end = 0;                  // wave-uniform: the unserved rest of the last grabbed seed range
-    bool queue_done = false;
-    u32 h_next = 0, h_end = 0;                  // wave-uniform: the unwritten rest of the last reserved range of hit slots
-    u32 const lane = threadIdx.x & 63u;
-    u64 const lanes_below = (1ull << lane) - 1ull;
-    auto fr = [&](u32 level, u32 word) -> u32& { return lds[(level * FM_FRAME_WORDS + word) * 64u + lane]; };
-
-    u32 n_ext = 0, n_iter = 0, n_busy_iter = 0, n_tail_iter = 0, n_single = 0;
-    u32 n_cls[6] = {0, 0, 0, 0, 0, 0};
-    bool busy = false, exhausted = false;
-    u32 sid = 0, srch = 0, num_searches = 0, len = 0, ct = 0;
-    const u8* __restrict__ q = seq;
-    const u64* __restrict__ ex_base = scheme;
-    bool in_search = false;
-    const u64* __restrict__ ex = scheme;
-    u32 l_last = 0, u_last = 0;
-    u32 nlb = 0, nlbr = 0, nlen = 0, nx = 0, ne = 0, nli = INFO_M, nri = INFO_M;
-    u64 nkey = 0;                               // key of the node under inspection
-    u32 depth = 0;                              // frames alive
-    bool need_child = false;
-    bool hit_pending = false;                   // a hit of this lane (sid, nlb, hit_rep, ne, hit_key) waits for its slot
-    u32 hit_rep = 0, hit_idx = 0;
-    u64 hit_key = 0;
-
-    while (true) {
-        FM_EMIT_HITS();
-        bool const want = !busy && !exhausted;
-        u64 const idle = __ballot(want);
-        if (idle) {                                                     // wave-uniform
-            u32 k = 0xFFFFFFFFu;
-            FM_ASSIGN_SEEDS(k);
-            if (want) {
-                if (k != 0xFFFFFFFFu) {
-                    DevSeed const seed = seeds[k];
-                    sid = seed.id;
-                    q = seq + seed.seq_off;
-                    len = seed.length;
-                    num_searches = seed.frames_searches >> 24;
-                    ex_base = scheme + seed.scheme_off;
-                    srch = 0; ct = 0; hit_idx = 0;
-                    busy = true;
-                    in_search = false;
-                } else exhausted = true;
-            }
-        }
-        if (__all(exhausted && !busy)) break;
-        ++n_iter;
-        if (queue_done && q_next == q_end) ++n_tail_iter;
-        if (!busy) continue;
-        ++n_busy_iter;
-
-        if (!in_search) {
-            if (srch >= num_searches) { busy = false; continue; }
-            ex = ex_base + (u64)srch * len;
-            u32 const last_entry = (u32)ex[len - 1];
-            l_last = (last_entry >> 20) & 7u;
-            u_last = (last_entry >> 23) & 7u;
-            ne = 0; nli = INFO_M; nri = INFO_M;
-            nkey = (u64)srch << (3u * FM_KEY_BITS);
-            depth = 0;
-            need_child = false;
-            in_search = true;
-            if (!fm_begin_search(idx, ex, q, len, nlb, nlbr, nlen, nx)) { in_search = false; ++srch; continue; }
-        }
-
-        // ---- the next child of the top frame becomes the node: children that cost an error first, the match child last
-        if (need_child) {
-            if (depth == 0u) { in_search = false; ++srch; continue; }        // search exhausted
-            u32 const lv = depth - 1u;
-            u32 const mask = fr(lv, 14);
-            u32 const st = fr(lv, 13);
-            u32 const costly = mask & ~1u;
-            u32 const ci = costly ? (u32)__ffs((int)costly) - 1u : 0u;
-            u32 const rest = mask & ~(1u << ci);
-            if (rest) fr(lv, 14) = rest;
-            else --depth;                                                   // the last child of a frame is a tail call: the frame is gone
-            u32 const right = ST_RIGHT(st);
-            u32 const px = ST_X(st), pe = ST_E(st);
-            u32 info, sym;
-            if (ci == 0) { sym = ST_SYM(st); nx = px + 1; ne = pe; info = INFO_M; }
-            else if (ci == 11) { sym = 1; nx = px + 1; ne = pe + 1; info = INFO_I; }
-            else {
-                sym = (ci + 1) >> 1;
-                bool const del = ci & 1u;
-                nx = del ? px : px + 1;
-                ne = pe + 1;
-                info = del ? INFO_D : INFO_S;
-            }
-            // sym is 1..5 for every child but the match of a '$' (symbol 0: its cursor starts where the node's does)
-            u32 const p_lb = fr(lv, 11), p_lbr = fr(lv, 12);
-            u32 const c_oth = sym ? fr(lv, sym - 1u) : (right ? p_lb : p_lbr), c_end = fr(lv, sym), c_abs = fr(lv, sym ? 5u + sym : 17u);
-            u64 const pkey = (u64)fr(lv, 15) | ((u64)fr(lv, 16) << 32);
-            if (ci == 11) { nlb = p_lb; nlbr = p_lbr; nlen = fr(lv, 5) - (right ? p_lb : p_lbr); }
-            else { nlen = c_end - c_oth; nlb = right ? c_oth : c_abs; nlbr = right ? c_abs : c_oth; }
-            nli = right ? ST_LI(st) : info;
-            nri = right ? info : ST_RI(st);
-            nkey = ci ? pkey | ((u64)(((FM_KEY_MAX_X - px) << 4) | ci) << (FM_KEY_BITS * (2u - pe))) : pkey;
-            need_child = false;
-        }
-
-        // ---- inspect node (nlb, nlbr, nlen, nx, ne, nli, nri); nlen > 0 by construction
-        if (nx == len) {
-            bool const ok_l = nli == INFO_M || nli == INFO_I, ok_r = nri == INFO_M || nri == INFO_I;
-            if (ok_l && ok_r && l_last <= ne && ne <= u_last) {
-                u32 rep = nlen;
-                if (ct + rep > max_hits) rep = max_hits - ct;        // more rows than the caller wants to know of
-                ct += rep;
-                hit_pending = true;                                  // written at the top of the next iteration
-                hit_rep = rep;
-                hit_key = nkey;
-                if (ct == max_hits) { busy = false; continue; }      // the seed has too many rows: its other hits do not matter
-            }
-            need_child = true;
-            continue;
-        }
-        u32 const sch = (u32)ex[nx];
-        u32 const lower = (sch >> 20) & 7u, upper = (sch >> 23) & 7u, right = (sch >> 26) & 1u;
-        if (ne > upper) { need_child = true; continue; }
-        bool const mismatch_allowed = lower <= ne + 1 && ne + 1 <= upper;
-        bool const match_allowed = lower <= ne && ne <= upper;
-        if (!mismatch_allowed && !match_allowed) { need_child = true; continue; }
-
-        u32 const next_sym = q[sch & SCH_POS_MASK];
-        u32 const lo = right ? nlbr : nlb, other = right ? nlb : nlbr;
-        u32 ab[6], cl[6];
-        extend_all(idx, idx.occ[right], lo, nlen, ab, cl);
-        ++n_ext;
-        n_single += nlen == 1u ? 1u : 0u;
-        { u32 const c = (nlen == 1u ? 0u : nlen <= 4u ? 1u : 2u) + (mismatch_allowed ? 0u : 3u); n_cls[c]++; }
-
-        if (mismatch_allowed) {
-            // this node branches: its frame goes on top of the frames of the error edges taken so far (at most `ne` of them)
-            u32 const tinfo = right ? nri : nli;
-            u32 const mask = fm_child_mask(cl, next_sym, match_allowed, tinfo == INFO_M || tinfo == INFO_D, tinfo == INFO_M || tinfo == INFO_I);
-            if (mask == 0u) { need_child = true; continue; }
-            if (depth >= levels) { atomicOr(&counters[1], 1u); busy = false; continue; }
-            u32 const lv = depth;
-            u32 const o1 = other + cl[0], o2 = o1 + cl[1], o3 = o2 + cl[2], o4 = o3 + cl[3], o5 = o4 + cl[4];
-            fr(lv, 0) = o1; fr(lv, 1) = o2; fr(lv, 2) = o3; fr(lv, 3) = o4; fr(lv, 4) = o5; fr(lv, 5) = o5 + cl[5];
-            fr(lv, 6) = ab[1]; fr(lv, 7) = ab[2]; fr(lv, 8) = ab[3]; fr(lv, 9) = ab[4]; fr(lv, 10) = ab[5];
-            fr(lv, 11) = nlb; fr(lv, 12) = nlbr;
-            fr(lv, 13) = st_pack(nx, ne, nli, nri, next_sym, right);
-            fr(lv, 14) = mask;
-            fr(lv, 15) = (u32)nkey; fr(lv, 16) = (u32)(nkey >> 32);
-            fr(lv, 17) = ab[0];
-            ++depth;
-            need_child = true;
-        } else {
-            // only an exact extension is possible: continue in place (no frame)
-            if (next_sym > 5u) { need_child = true; continue; }
-            u32 clen = cl[0], cabs = ab[0], coth = other;
-#pragma unroll
-            for (u32 c = 1; c < 6; ++c) {
-                coth += c <= next_sym ? cl[c - 1u] : 0u;
-                bool const take = c == next_sym;
-                clen = take ? cl[c] : clen;
-                cabs = take ? ab[c] : cabs;
-            }
-            if (clen == 0) { need_child = true; continue; }
-            nlb = right ? coth : cabs;
-            nlbr = right ? cabs : coth;
-            if (right) nri = INFO_M; else nli = INFO_M;
-            nlen = clen;
-            nx = nx + 1;
-        }
-    }
-    { u32 const at = h_next + lane; if (at < h_end && at < hit_cap) hits[at] = DevHit{0xFFFFFFFFu, 0u, 0u, 0u, 0ull}; }
-    n_ext = wave_sum_u32(n_ext);
-    n_busy_iter = wave_sum_u32(n_busy_iter);
-    n_single = wave_sum_u32(n_single);
-#pragma unroll
-    for (u32 c = 0; c < 6; ++c) { u32 const v = wave_sum_u32(n_cls[c]); if (lane == 0) atomicAdd(&counters[10 + c], v); }
-    if (lane == 0) {
-        atomicAdd(&counters[2], n_ext); atomicAdd(&counters[6], n_busy_iter); atomicAdd(&counters[3], n_single);
-        atomicAdd(&counters[4], n_iter); atomicMax(&counters[5], n_iter); atomicAdd(&counters[8], n_tail_iter); atomicMax(&counters[9], n_tail_iter);
-    }
 }
 
 // The DFS in the reference's own order (match child first): frames are written to the seed's stack in HBM when they are made
@@ -819,37 +610,21 @@ static u32 fm_seeds_per_wave() {
     return v;
 }
 
-// K1 is bound by the memory system's request rate, the DP kernels by VALU issue: they overlap well on one CU, but only while K1's
-// waves leave registers and wave slots free. A context with several lanes (several K1 launches in flight at a time) therefore caps
-// each launch at a share of the 4096 waves one launch needs to saturate the memory system alone (FLX_FM_MAX_WAVES overrides;
-// 16 lanes, 3.1 Gb / 10 kb: 63.5 k reads/s at 4096 waves per launch, 69.5 k at 1024, 70.6 k at 512).
-static u32 fm_max_waves(u32 concurrent_launches) {
-    static u32 const v = [] { const char* e = getenv("FLX_FM_MAX_WAVES"); return e ? (u32)strtoul(e, nullptr, 10) : 0u; }();
-    if (v) return v;
-    return FM_MAX_WAVES / std::max(1u, std::min(concurrent_launches, 8u));
-}
-
 u32 fm_search_max_keyed_length() { return FM_KEY_MAX_X; }
 
+// the walk in the reference's order (fm_search_ordered_kernel); the default walk is DeviceApi::search_filtered (flx_search.hip)
 int DeviceApi::search(void* stream, const DevIndex& idx, const u8* d_seq, const u64* d_scheme, const DevSeed* d_seeds, u32 n_seeds,
-                      u32 max_hits_per_seed, u32 frame_levels, DevFrame* d_stack, DevHit* d_hits, u32 hit_cap, u32* d_counters, u32* d_seed_cnt,
-                      u32 concurrent_launches) {
+                      u32 max_hits_per_seed, DevFrame* d_stack, DevHit* d_hits, u32 hit_cap, u32* d_counters, u32* d_seed_cnt) {
     if (n_seeds == 0) return 0;
+    if (!d_stack) return (int)hipErrorInvalidValue;
     u32 const spw = fm_seeds_per_wave();
-    dim3 const grid(std::min<u32>((n_seeds + spw - 1) / spw, fm_max_waves(concurrent_launches)));
-    if (d_stack)      // the reference's DFS order, stack in HBM
-        hipLaunchKernelGGL(fm_search_ordered_kernel, grid, dim3(64), 0, (hipStream_t)stream, idx, d_seq, d_scheme, d_seeds, n_seeds,
-                           max_hits_per_seed, d_stack, d_hits, hit_cap, d_counters, d_seed_cnt);
-    else {
-        u32 const levels = std::max(1u, frame_levels);
-        size_t const lds = (size_t)levels * FM_FRAME_WORDS * 64 * sizeof(u32);
-        hipLaunchKernelGGL(fm_search_kernel, grid, dim3(64), lds, (hipStream_t)stream, idx, d_seq, d_scheme, d_seeds, n_seeds,
-                           max_hits_per_seed, levels, d_hits, hit_cap, d_counters, d_seed_cnt, fm_priority());
-    }
+    dim3 const grid(std::min<u32>((n_seeds + spw - 1) / spw, FM_MAX_WAVES));
+    hipLaunchKernelGGL(fm_search_ordered_kernel, grid, dim3(64), 0, (hipStream_t)stream, idx, d_seq, d_scheme, d_seeds, n_seeds,
+                       max_hits_per_seed, d_stack, d_hits, hit_cap, d_counters, d_seed_cnt);
     return (int)hipGetLastError();
 }
 
-// Scans (sum / max, inclusive / exclusive) of the pipeline's flag and count arrays in two launches without any waiting between blocks: every block reduces
+// Scans (exclusive sums) of the anchor selection's count arrays in two launches without any waiting between blocks: every block reduces
 // its tile, then every block scans its tile again behind the reduction of the tiles before it (a few hundred words it adds up
 // itself). The library scans are single-pass with decoupled look-back: their blocks spin on their predecessors' results, which on a
 // GPU filled with other lanes' kernels made a 1.2 M-element scan take a millisecond and burn issue slots meanwhile (11 % of the
@@ -908,12 +683,6 @@ __global__ void __launch_bounds__(256) vr_scan_apply_kernel(const u32* __restric
     if (lane_id() > 0) prefix = scan_op<MAX>(prefix, excl);
 #pragma unroll
     for (u32 j = 0; j < SCAN_ITEMS; ++j) if (base + j < n) out[base + j] = scan_op<MAX>(prefix, item[j]);
-}
-template <bool MAX>
-static void vr_inclusive_scan(hipStream_t s, const u32* in, u32* out, u32 n, u32* tile_total) {
-    unsigned const tiles = (n + SCAN_TILE - 1) / SCAN_TILE;
-    hipLaunchKernelGGL((vr_scan_reduce_kernel<MAX>), dim3(tiles), dim3(256), 0, s, in, n, tile_total);
-    hipLaunchKernelGGL((vr_scan_apply_kernel<MAX, false>), dim3(tiles), dim3(256), 0, s, in, n, tile_total, out);
 }
 static void exclusive_sum(hipStream_t s, const u32* in, u32* out, u32 n, u32* tile_total) {
     unsigned const tiles = (n + SCAN_TILE - 1) / SCAN_TILE;
@@ -1031,12 +800,12 @@ __device__ __forceinline__ bool select_seed(const DevHit* __restrict__ groups, u
 // rows[sid] = the slots the seed gets in the sparse anchor list. Light and heavy seeds go on two lists (wave-aggregated appends;
 // the order of a list does not matter, every seed writes to its own slots).
 constexpr u32 SEL_LIGHT = 8;
-constexpr u32 SELW_MAX_GROUPS = 512;
+constexpr u32 SELW_MAX_GROUPS = 512, SELW_FEW_GROUPS = 64;
 __global__ void __launch_bounds__(256) seed_rows_kernel(const DevHit* __restrict__ grouped, const u32* __restrict__ hit_offset, u32 n_seeds,
                                                         u32 hard_cap, u32 soft_cap, u32* __restrict__ rows, SelStat* __restrict__ stat,
                                                         u32* __restrict__ n_out, u32* __restrict__ lists, u32* __restrict__ list_counts) {
     u32 const sid = blockIdx.x * blockDim.x + threadIdx.x;
-    u32 cls = 0;                                             // 1 light, 2 heavy
+    u32 cls = 0;                                             // 1 light, 2 heavy (a wave, up to SELW_FEW_GROUPS groups), 3 heavy with more groups
     if (sid < n_seeds) {
         u32 const g0 = hit_offset[sid], cnt = hit_offset[sid + 1] - g0;
         SelStat st{0, 0, 0, 0, 0};
@@ -1049,14 +818,14 @@ __global__ void __launch_bounds__(256) seed_rows_kernel(const DevHit* __restrict
             total = min(all, soft_cap);                      // rows kept (search.cpp:239-272 stops at the soft cap)
             if (all > hard_cap) st.excluded = 1;
             else if (total > SEL_MAX) st.flag = 1;           // a soft cap beyond the anchor arrays: the host
-            else { cls = (cnt <= SEL_LIGHT && total <= SEL_LIGHT) ? 1u : 2u; st.excluded_soft = all - total; }
+            else { cls = (cnt <= SEL_LIGHT && total <= SEL_LIGHT) ? 1u : cnt <= SELW_FEW_GROUPS ? 2u : 3u; st.excluded_soft = all - total; }
         }
         rows[sid] = cls ? total : 0u;
         if (!cls) { stat[sid] = st; n_out[sid] = 0; }
         else stat[sid].excluded_soft = st.excluded_soft;     // (the select kernels fill in the rest)
     }
 #pragma unroll
-    for (u32 c = 1; c <= 2; ++c) {
+    for (u32 c = 1; c <= 3; ++c) {
         u64 const m = __ballot(cls == c);
         if (!m) continue;
         u32 base = 0;
@@ -1094,14 +863,17 @@ __global__ void __launch_bounds__(64) seed_select_kernel(const u32* __restrict__
 // round, SA and reference lookups one per lane - and the parts that are std::sort's own (more than 16 elements: introsort, whose
 // order of equal elements has to be reproduced step by step) and the erase sweep on one lane over LDS arrays. A round-2 profile had
 // the thread-per-seed form of this at 3 ms per launch on 2.3 KB of scratch per thread (profiles/r03_k1v2_kernel_stats.csv).
+// (MAXG: groups a seed of the list may have; 64 groups keep the block at 2.7 KB of LDS, which finds room on a CU next to the DP
+// kernels of other lanes; the few seeds with up to 512 groups take the 17-KB form)
+template <u32 MAXG>
 __global__ void __launch_bounds__(64) seed_select_wave_kernel(const u32* __restrict__ list, const u32* __restrict__ list_count,
                                                               const DevHit* __restrict__ grouped, const u32* __restrict__ hit_offset,
                                                               const u32* __restrict__ sa, u32 n_text, const u64* __restrict__ seq_start, u32 n_ref,
                                                               u32 erase, SelStat* __restrict__ stat, u32* __restrict__ n_out,
                                                               const u32* __restrict__ row_offset, const u32* __restrict__ rows,
                                                               DevOutAnchor* __restrict__ sparse, u32 sparse_cap) {
-    __shared__ u64 s_key[SELW_MAX_GROUPS];
-    __shared__ SelGroup s_a[SELW_MAX_GROUPS], s_b[SELW_MAX_GROUPS];
+    __shared__ u64 s_key[MAXG];
+    __shared__ SelGroup s_a[MAXG], s_b[MAXG];
     __shared__ u32 s_row[SEL_MAX], s_err[SEL_MAX];
     __shared__ SelAnchor s_an[SEL_MAX];
     __shared__ u32 s_flag[4];                 // [0] a sort gave up (host), [1..2] erased anchors (bits)
@@ -1245,8 +1017,8 @@ int DeviceApi::select(void* stream, const DevHit* d_hits, const u32* d_counters,
     exclusive_sum(s, d_seed_cnt, d_hit_offset, n_seeds + 1, (u32*)d_scan_tmp);
     hipLaunchKernelGGL(hit_scatter_kernel, dim3(2048), dim3(256), 0, s, d_hits, d_counters, hit_cap, d_hit_offset, d_grouped);
     SelStat* const stat = reinterpret_cast<SelStat*>(d_stat);
-    u32* const list_counts = d_lists + 2 * (size_t)n_seeds;
-    if ((e = hipMemsetAsync(list_counts, 0, 8, s)) != hipSuccess) return (int)e;
+    u32* const list_counts = d_lists + 3 * (size_t)n_seeds;
+    if ((e = hipMemsetAsync(list_counts, 0, 12, s)) != hipSuccess) return (int)e;
     hipLaunchKernelGGL(seed_rows_kernel, dim3((n_seeds + 255) / 256), dim3(256), 0, s, d_grouped, d_hit_offset, n_seeds, hard_cap, soft_cap, d_rows,
                        stat, d_n_out, d_lists, list_counts);
     if ((e = hipGetLastError()) != hipSuccess) return (int)e;
@@ -1260,8 +1032,10 @@ int DeviceApi::select(void* stream, const DevHit* d_hits, const u32* d_counters,
         hipLaunchKernelGGL((seed_select_kernel<SEL_MAX>), dim3(std::max(1u, (n_seeds / 64 + 63) / 64)), dim3(64), 0, s, d_lists + n_seeds, list_counts + 1, d_grouped,
                            d_hit_offset, idx.sa, idx.n, d_seq_start, n_ref, erase ? 1u : 0u, stat, d_n_out, d_row_offset, d_rows, d_sparse, sparse_cap);
     else
-        hipLaunchKernelGGL(seed_select_wave_kernel, dim3(std::max(1u, std::min(n_seeds / 8u + 1u, 16384u))), dim3(64), 0, s, d_lists + n_seeds, list_counts + 1, d_grouped,
+        hipLaunchKernelGGL((seed_select_wave_kernel<SELW_FEW_GROUPS>), dim3(std::max(1u, std::min(n_seeds / 8u + 1u, 16384u))), dim3(64), 0, s, d_lists + n_seeds, list_counts + 1, d_grouped,
                            d_hit_offset, idx.sa, idx.n, d_seq_start, n_ref, erase ? 1u : 0u, stat, d_n_out, d_row_offset, d_rows, d_sparse, sparse_cap);
+    hipLaunchKernelGGL((seed_select_wave_kernel<SELW_MAX_GROUPS>), dim3(std::max(1u, std::min(n_seeds / 256u + 1u, 2048u))), dim3(64), 0, s, d_lists + 2 * (size_t)n_seeds, list_counts + 2, d_grouped,
+                       d_hit_offset, idx.sa, idx.n, d_seq_start, n_ref, erase ? 1u : 0u, stat, d_n_out, d_row_offset, d_rows, d_sparse, sparse_cap);
     if ((e = hipGetLastError()) != hipSuccess) return (int)e;
     exclusive_sum(s, d_n_out, d_out_offset, n_seeds + 1, (u32*)d_scan_tmp);
     hipLaunchKernelGGL(seed_compact_kernel, dim3((n_seeds + 255) / 256), dim3(256), 0, s, d_sparse, d_row_offset, d_n_out, d_out_offset, n_seeds,
@@ -1290,419 +1064,6 @@ static const u32 kWordsPerLane[] = {1, 2, 3, 4, 5, 6, 8, 13, 25};
 static bool use_band() {
     static int const v = getenv("FLX_NO_BAND") ? 0 : 1;
     return v != 0;
-}
-
-// ================================================================================================ verification rounds on the device
-// (see VrBuffers in flx_internal.hpp) The request of an anchor at an inner node: verification.cpp:157-184 with ratio 0, i.e.
-// base = m + 2e + 1, start = max(0, pos - (leaf_from - node_from) - e), length = min(base, reflen - start).
-// key1 = query offset << 20 | rows (identifies (read, orientation, node)), key2 = reference offset << 20 | window length.
-// The requests are ordered by one radix sort on (node name, window start): the node's name = (query ordinal << node_bits | node
-// index), the start a 32-bit text offset; a node and a start determine the window's length (same sequence, same clip), so equal
-// sort keys are equal requests, and the distinct windows of a node come out by start.
-constexpr u32 VR_SHIFT = 20;
-
-__global__ void __launch_bounds__(256) vr_select_kernel(const DevVrAnchor* __restrict__ anchors, const DevVrNode* __restrict__ nodes,
-                                                        const u32* __restrict__ node, const u8* __restrict__ status, u32 n_anchors, u32 limit,
-                                                        u32 node_bits, u64* __restrict__ key1, u64* __restrict__ key2, u64* __restrict__ sort_key,
-                                                        u32* __restrict__ idx, u32* __restrict__ scalars, DevVrPlan* __restrict__ plan) {
-    u32 const i = blockIdx.x * blockDim.x + threadIdx.x;
-    // (first kernel of a round: the counters and the plan the later kernels of the round add to start from zero)
-    if (blockIdx.x == 0) {
-        if (threadIdx.x < 3u) scalars[threadIdx.x] = 0u;
-        if (threadIdx.x == 3u) scalars[VR_N_UNDECIDED] = 0u;
-        u32* const words = reinterpret_cast<u32*>(plan);
-        for (u32 w = threadIdx.x; w < (u32)(sizeof(DevVrPlan) / 4); w += blockDim.x) words[w] = 0u;
-    }
-    if (i >= n_anchors) return;
-    u64 k1 = ~0ull, k2 = ~0ull, ks = ~0ull;
-    if (status[i] == VR_CLIMBING) {
-        DevVrAnchor const a = anchors[i];
-        DevVrNode const nd = nodes[a.tree_base + node[i]];
-        if (nd.rows <= limit) {
-            i64 const start_signed = a.diag_rel + (i64)nd.from - (i64)nd.errors;
-            u64 const start = start_signed > 0 ? (u64)start_signed : 0ull;
-            u64 const base = (u64)nd.rows + 2ull * nd.errors + 1ull;
-            u64 const len = min(base, a.seq_len - start);
-            k1 = ((a.q_base + nd.from) << VR_SHIFT) | nd.rows;
-            k2 = ((a.seq_start + start) << VR_SHIFT) | len;
-            ks = ((((u64)a.query << node_bits) | node[i]) << 32) | ((a.seq_start + start) & 0xFFFFFFFFull);
-        }
-    }
-    key1[i] = k1;
-    key2[i] = k2;
-    sort_key[i] = ks;
-    idx[i] = i;
-}
-// sorted requests: head of a distinct request, head of a run of one node's requests; the count of real requests
-__global__ void __launch_bounds__(256) vr_flag_requests_kernel(const u64* __restrict__ keys, u32 n, u32* __restrict__ flag_u, u32* __restrict__ scalars) {
-    u32 const i = blockIdx.x * blockDim.x + threadIdx.x;
-    bool real = false;
-    if (i < n) {
-        real = keys[i] != ~0ull;
-        flag_u[i] = real && (i == 0 || keys[i] != keys[i - 1]) ? 1u : 0u;
-    }
-    u64 const m = __ballot(real);
-    if (m && lane_id() == 0) atomicAdd(&scalars[VR_N_REQ], (u32)__popcll(m));
-}
-// the distinct requests: their keys, one anchor that asked, and the first reference offset of their node's run
-__global__ void __launch_bounds__(256) vr_scatter_unique_kernel(const u64* __restrict__ key1, const u64* __restrict__ key2, const u32* __restrict__ idxs,
-                                                                const u32* __restrict__ flag_u, const u32* __restrict__ uid, u32 n,
-                                                                u64* __restrict__ ukey1, u64* __restrict__ ukey2, u32* __restrict__ urep,
-                                                                u32* __restrict__ scalars) {
-    u32 const i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    if (flag_u[i]) { u32 const u = uid[i] - 1u, a = idxs[i]; ukey1[u] = key1[a]; ukey2[u] = key2[a]; urep[u] = a; }
-    if (i == n - 1) scalars[VR_N_UNIQ] = uid[i];                         // inclusive scan: the last entry is the number of distinct requests
-}
-// run_first[u] = index of the first distinct request of u's node (filled in two steps: heads write themselves, a max-scan spreads)
-__global__ void __launch_bounds__(256) vr_run_heads_kernel(const u64* __restrict__ ukey1, const u32* __restrict__ scalars, u32* __restrict__ run_first) {
-    u32 const u = blockIdx.x * blockDim.x + threadIdx.x;
-    if (u >= scalars[VR_N_UNIQ]) return;
-    run_first[u] = (u == 0 || ukey1[u] != ukey1[u - 1]) ? u : 0u;
-}
-// Clusters: the distinct windows of one node whose starts fall into the same bucket of max(8, rows / 8) columns counted from the
-// node's first window (a cluster then spans at most that much: its union window stays a small multiple of the node's own)
-__global__ void __launch_bounds__(256) vr_flag_clusters_kernel(const u64* __restrict__ ukey1, const u64* __restrict__ ukey2, const u32* __restrict__ run_first,
-                                                               const u32* __restrict__ scalars, u32* __restrict__ flag_c) {
-    u32 const u = blockIdx.x * blockDim.x + threadIdx.x;
-    if (u >= scalars[VR_N_UNIQ]) return;
-    u32 f = 1;
-    if (u > 0 && run_first[u] == run_first[u - 1]) {
-        u64 const first = ukey2[run_first[u]] >> VR_SHIFT;
-        u64 const d = max((u64)8, (ukey1[u] & ((1ull << VR_SHIFT) - 1ull)) / 8ull);
-        f = ((ukey2[u] >> VR_SHIFT) - first) / d != ((ukey2[u - 1] >> VR_SHIFT) - first) / d ? 1u : 0u;
-    }
-    flag_c[u] = f;
-}
-__global__ void __launch_bounds__(256) vr_cluster_starts_kernel(const u32* __restrict__ flag_c, const u32* __restrict__ cid, u32* __restrict__ scalars,
-                                                                u32* __restrict__ cstart) {
-    u32 const u = blockIdx.x * blockDim.x + threadIdx.x;
-    u32 const n = scalars[VR_N_UNIQ];
-    if (u >= n) return;
-    if (flag_c[u]) cstart[cid[u] - 1u] = u;
-    if (u == n - 1) { scalars[VR_N_CLUSTERS] = cid[u]; cstart[cid[u]] = n; }
-}
-// a cluster's jobs: the window itself (one member), or the intersection of its windows (if not empty) and their union
-__global__ void __launch_bounds__(256) vr_jobs_kernel(const u64* __restrict__ ukey1, const u64* __restrict__ ukey2, const u32* __restrict__ urep,
-                                                      const u32* __restrict__ cstart, const DevVrAnchor* __restrict__ anchors,
-                                                      const DevVrNode* __restrict__ nodes, const u32* __restrict__ node, const u32* __restrict__ scalars,
-                                                      DevVrJob* __restrict__ jobs) {
-    u32 const c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= scalars[VR_N_CLUSTERS]) return;
-    u32 const u0 = cstart[c], u1 = cstart[c + 1];
-    u64 const mask = (1ull << VR_SHIFT) - 1ull;
-    u64 const k1 = ukey1[u0];
-    u32 const rep = urep[u0];
-    u32 const k = nodes[anchors[rep].tree_base + node[rep]].errors;
-    u64 lo_start = ukey2[u0] >> VR_SHIFT, hi_start = lo_start, lo_end = lo_start + (ukey2[u0] & mask), hi_end = lo_end;
-    for (u32 u = u0 + 1; u < u1; ++u) {
-        u64 const st = ukey2[u] >> VR_SHIFT, en = st + (ukey2[u] & mask);
-        hi_start = max(hi_start, st);
-        lo_end = min(lo_end, en);
-        hi_end = max(hi_end, en);
-    }
-    DevVrJob a{0, k1 >> VR_SHIFT, 0, (u32)(k1 & mask), k, 0}, b = a;
-    if (u1 - u0 == 1) { a.ref_off = lo_start; a.n = (u32)(hi_end - lo_start); }
-    else {
-        if (lo_end > hi_start) { a.ref_off = hi_start; a.n = (u32)(lo_end - hi_start); }
-        b.ref_off = lo_start;
-        b.n = (u32)(hi_end - lo_start);
-    }
-    jobs[2 * c] = a;
-    jobs[2 * c + 1] = b;
-}
-// ---- the round's job list grouped by launch shape (the rules of choose_align_shape / choose_shapes, evaluated per job here)
-__device__ __constant__ u32 kVrWords[9] = {1, 2, 3, 4, 5, 6, 8, 13, 25};
-constexpr u32 VR_LOG2R = 7;             // lanes per job 1 .. 64
-
-__device__ __forceinline__ bool vr_shape_holds(u32 nw, i64 width, u32 w, u32 r, bool band) {
-    return (nw + w - 1u) / w <= r || (band && (i64)64 * w * (r - 1u) + r + 1 > width);
-}
-// cheapest class of a job; `parallel`: fewest words per lane first (see choose_align_shape_uncached)
-__device__ u32 vr_shape_class(u32 nw, i64 width, bool band, bool parallel) {
-    u32 best = VR_NO_CLASS;
-    u64 best_cost = ~0ull;
-    for (u32 wi = 0; wi < 9u; ++wi)
-        for (u32 lr = 0; lr < VR_LOG2R; ++lr) {
-            u32 const w = kVrWords[wi], r = 1u << lr;
-            if (!vr_shape_holds(nw, width, w, r, band)) continue;
-            u64 const cost = parallel ? (u64)w * 1000ull + r : (u64)w * r * 1000ull + w;
-            if (cost < best_cost) { best_cost = cost; best = wi * VR_LOG2R + lr; }
-        }
-    return best;
-}
-__device__ u64 vr_word_steps(u32 n, u32 m, u32 k, u32 W, bool band) {          // job_word_steps of flx_pipeline.cpp
-    u64 const nw = (m + 63u) / 64u;
-    if (!band) return (u64)n * nw;
-    i64 const band_hi = (i64)n - (i64)m + (i64)k;
-    u64 total = 0;
-    for (i64 g = 0; g * W < (i64)nw; ++g) {
-        i64 const r0 = 64 * (i64)W * g, r1 = min((i64)m, r0 + 64 * (i64)W);
-        i64 const lo = max((i64)0, r0 - (i64)k), hi = min((i64)n - 1, r1 - 1 + band_hi);
-        if (hi >= lo) total += (u64)(hi - lo + 1) * (u64)min((i64)W, (i64)nw - g * W);
-    }
-    return total;
-}
-__device__ __forceinline__ u64 wave_sum_u64(u64 v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
-    return v;
-}
-// Adds, for every class present in the wave, the members' count (and optionally two 64-bit sums) with one atomic per class and wave.
-// `cls` = VR_NO_CLASS: the lane takes no part.
-__device__ __forceinline__ void vr_class_add(u32 cls, u32* __restrict__ count, u64* __restrict__ sum_a, u64 a, u64* __restrict__ sum_b, u64 b) {
-    u64 todo = __ballot(cls != VR_NO_CLASS);
-    while (todo) {
-        u32 const leader = (u32)__ffsll((long long)todo) - 1u;
-        u32 const c = (u32)__shfl((int)cls, (int)leader);
-        bool const mine = cls == c;
-        u64 const members = __ballot(mine);
-        u64 const sa = sum_a ? wave_sum_u64(mine ? a : 0ull) : 0ull;
-        u64 const sb = sum_b ? wave_sum_u64(mine ? b : 0ull) : 0ull;
-        if (lane_id() == leader) {
-            atomicAdd(&count[c], (u32)__popcll(members));
-            if (sum_a) atomicAdd((unsigned long long*)&sum_a[c], (unsigned long long)sa);
-            if (sum_b) atomicAdd((unsigned long long*)&sum_b[c], (unsigned long long)sb);
-        }
-        todo &= ~members;
-    }
-}
-// (job slots of the kernels below: [0, per_count * *count), e.g. two per cluster, one per distinct request)
-__global__ void __launch_bounds__(256) vr_shape_kernel(const DevVrJob* __restrict__ jobs, const u32* __restrict__ count, u32 per_count, u32 band,
-                                                       u8* __restrict__ job_class, DevVrPlan* __restrict__ plan) {
-    u32 const j = blockIdx.x * blockDim.x + threadIdx.x;
-    u32 cls = VR_NO_CLASS, par = 0, lanes = 0;
-    if (j < per_count * *count) {
-        DevVrJob const job = jobs[j];
-        if (job.n != 0) {
-            u32 const nw = (job.m + 63u) / 64u;
-            i64 const width = (i64)job.n - (i64)job.m + 2 * (i64)job.k;
-            cls = vr_shape_class(nw, width, band != 0, false);
-            if (cls == VR_NO_CLASS) plan->unsupported = 1;
-            else {
-                lanes = 1u << (cls % VR_LOG2R);
-                par = vr_shape_class(nw, width, band != 0, true) / VR_LOG2R;
-            }
-        }
-        job_class[j] = (u8)cls;
-    }
-    vr_class_add(cls, plan->count_first, nullptr, 0, nullptr, 0);
-    u32 const wl = wave_sum_u32(lanes), wp = wave_max_u32(par);
-    if (lane_id() == 0 && wl) { atomicAdd((unsigned long long*)&plan->lanes, (unsigned long long)wl); atomicMax(&plan->par_w_index, wp); }
-}
-// A launch lasts at least as long as its longest job: the jobs of a class with fewer than 64 members join the most frequent class
-// of at least 64 that can hold them (choose_shapes). Then the per-class totals and the lanes per job of the one-launch form.
-__global__ void __launch_bounds__(256) vr_regroup_kernel(const DevVrJob* __restrict__ jobs, const u32* __restrict__ count, u32 per_count, u32 band,
-                                                         u8* __restrict__ job_class, DevVrPlan* __restrict__ plan) {
-    u32 const j = blockIdx.x * blockDim.x + threadIdx.x;
-    u32 cls = VR_NO_CLASS, par_r = 0;
-    u64 steps = 0, bytes = 0, common_steps = 0;
-    if (j < per_count * *count) {
-        cls = job_class[j];
-        if (cls != VR_NO_CLASS) {
-            DevVrJob const job = jobs[j];
-            u32 const nw = (job.m + 63u) / 64u;
-            i64 const width = (i64)job.n - (i64)job.m + 2 * (i64)job.k;
-            if (plan->count_first[cls] < 64u) {
-                u32 best_n = 0, best = cls;
-                for (u32 c = 0; c < 9u * VR_LOG2R; ++c) {
-                    u32 const cnt = plan->count_first[c];
-                    if (cnt >= 64u && cnt > best_n && vr_shape_holds(nw, width, kVrWords[c / VR_LOG2R], 1u << (c % VR_LOG2R), band != 0)) { best_n = cnt; best = c; }
-                }
-                cls = best;
-                job_class[j] = (u8)cls;
-            }
-            steps = vr_word_steps(job.n, job.m, job.k, kVrWords[cls / VR_LOG2R], band != 0);
-            bytes = (u64)job.n + job.m;
-            u32 const W = kVrWords[plan->par_w_index];
-            common_steps = vr_word_steps(job.n, job.m, job.k, W, band != 0);
-            par_r = 1;
-            while (par_r < 64u && !vr_shape_holds(nw, width, W, par_r, band != 0)) par_r *= 2u;
-        }
-    }
-    vr_class_add(cls, plan->count, plan->word_steps, steps, plan->bytes, bytes);
-    u64 const cs = wave_sum_u64(common_steps);
-    u32 const pr = wave_max_u32(par_r);
-    if (lane_id() == 0 && pr) { atomicAdd((unsigned long long*)&plan->common_word_steps, (unsigned long long)cs); atomicMax(&plan->par_r, pr); }
-}
-__global__ void __launch_bounds__(64) vr_plan_kernel(DevVrPlan* __restrict__ plan) {
-    if (threadIdx.x != 0) return;
-    u32 at = 0;
-    for (u32 c = 0; c < VR_CLASSES; ++c) { plan->start[c] = at; plan->cursor[c] = at; at += plan->count[c]; }
-    plan->n_jobs = at;
-}
-__global__ void __launch_bounds__(256) vr_emit_kernel(const DevVrJob* __restrict__ jobs, const u32* __restrict__ count, u32 per_count, const u8* __restrict__ job_class,
-                                                      DevVrPlan* __restrict__ plan, DevAlignJob* __restrict__ out) {
-    u32 const j = blockIdx.x * blockDim.x + threadIdx.x;
-    u32 const cls = j < per_count * *count ? (u32)job_class[j] : VR_NO_CLASS;
-    // one cursor grab per class and wave; the members keep their order within the wave
-    u64 todo = __ballot(cls != VR_NO_CLASS);
-    u32 pos = 0;
-    while (todo) {
-        u32 const leader = (u32)__ffsll((long long)todo) - 1u;
-        u32 const c = (u32)__shfl((int)cls, (int)leader);
-        u64 const members = __ballot(cls == c);
-        u32 base = 0;
-        if (lane_id() == leader) base = atomicAdd(&plan->cursor[c], (u32)__popcll(members));
-        base = (u32)__shfl((int)base, (int)leader);
-        if (cls == c) pos = base + (u32)__popcll(members & ((1ull << lane_id()) - 1ull));
-        todo &= ~members;
-    }
-    if (cls == VR_NO_CLASS) return;
-    DevVrJob const job = jobs[j];
-    out[pos] = DevAlignJob{job.ref_off, job.q_off, 0, job.n, job.m, job.k, j, 0};
-}
-// a cluster's decision: its own window / the intersection holds an alignment -> all members pass; the union holds none -> all
-// fail; else (rare) the members one by one (state 0)
-__global__ void __launch_bounds__(256) vr_decide_kernel(const DevVrJob* __restrict__ jobs, const DevAlignOut* __restrict__ outs, u32* __restrict__ scalars,
-                                                        u8* __restrict__ state) {
-    u32 const c = blockIdx.x * blockDim.x + threadIdx.x;
-    bool undecided = false;
-    if (c < scalars[VR_N_CLUSTERS]) {
-        bool const has_a = jobs[2 * c].n != 0, has_b = jobs[2 * c + 1].n != 0;
-        u8 st = 0;
-        if (has_a) { if (outs[2 * c].score != 0xFFFFFFFFu) st = 1; else if (!has_b) st = 2; }
-        if (st == 0 && has_b && outs[2 * c + 1].score == 0xFFFFFFFFu) st = 2;
-        state[c] = st;
-        undecided = st == 0;
-    }
-    u64 const m = __ballot(undecided);
-    if (m && lane_id() == 0) atomicAdd(&scalars[VR_N_UNDECIDED], (u32)__popcll(m));
-}
-__global__ void __launch_bounds__(256) vr_apply_kernel(const u64* __restrict__ sorted_key, const u32* __restrict__ idxs, const u32* __restrict__ uid,
-                                                       const u32* __restrict__ cid, const u8* __restrict__ state, const u8* __restrict__ override_,
-                                                       const DevVrAnchor* __restrict__ anchors, const DevVrNode* __restrict__ nodes, u32 n,
-                                                       u32* __restrict__ node, u8* __restrict__ status, u32* __restrict__ scalars) {
-    u32 const i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i == 0) { scalars[VR_N_CLIMBING] = 0u; scalars[VR_SMALLEST] = 0xFFFFFFFFu; }      // vr_next_kernel, the next launch, counts into them
-    if (i >= n || sorted_key[i] == ~0ull) return;
-    u32 const u = uid[i] - 1u;
-    u8 dec = override_ ? override_[u] : (u8)0;
-    if (!dec) dec = state[cid[u] - 1u];
-    u32 const a = idxs[i];
-    if (dec == 1) {
-        u32 const tb = anchors[a].tree_base;
-        u32 const parent = nodes[tb + node[a]].parent;
-        node[a] = parent;
-        if (nodes[tb + parent].parent == 0xFFFFFFFFu) status[a] = VR_AT_ROOT;
-    } else status[a] = VR_DEAD;
-}
-__global__ void __launch_bounds__(256) vr_next_kernel(const DevVrAnchor* __restrict__ anchors, const DevVrNode* __restrict__ nodes, const u32* __restrict__ node,
-                                                      const u8* __restrict__ status, u32 n, u32* __restrict__ scalars) {
-    u32 const i = blockIdx.x * blockDim.x + threadIdx.x;
-    bool const climbing = i < n && status[i] == VR_CLIMBING;
-    u32 rows = 0xFFFFFFFFu;
-    if (climbing) rows = nodes[anchors[i].tree_base + node[i]].rows;
-    u64 const m = __ballot(climbing);
-    if (!m) return;
-    u32 const wmin = (u32)~wave_max_u32(~rows);
-    if (lane_id() == 0) { atomicAdd(&scalars[VR_N_CLIMBING], (u32)__popcll(m)); atomicMin(&scalars[VR_SMALLEST], wmin); }
-}
-
-size_t DeviceApi::vr_tmp_bytes(u32 n) {
-    size_t a = 0, b = 0, c = 0;
-    (void)rocprim::radix_sort_pairs(nullptr, a, (u64*)nullptr, (u64*)nullptr, (u32*)nullptr, (u32*)nullptr, (size_t)n, 0u, 64u, (hipStream_t)nullptr);
-    b = ((size_t)n / SCAN_TILE + 1) * sizeof(u32);       // tile totals of vr_inclusive_scan
-    c = 0;
-    return std::max(a, std::max(b, c)) + 256;
-}
-
-int DeviceApi::vr_round_requests(void* stream, VrBuffers const& B, u32 n, u32 limit, u32 query_bits, u32 node_bits) {
-    if (n == 0) return 0;
-    hipStream_t s = (hipStream_t)stream;
-    hipError_t e;
-    unsigned const blocks = (n + 255) / 256;
-    static_assert(sizeof(DevVrPlan) % 4 == 0, "the plan is zeroed word by word");
-    hipLaunchKernelGGL(vr_select_kernel, dim3(blocks), dim3(256), 0, s, B.anchors, B.nodes, B.node, B.status, n, limit, node_bits, B.key1, B.key2, B.sort_key, B.idx,
-                       B.scalars, B.plan);
-    // order by (node, window start): one sort over the bits in use; the anchor index rides along
-    size_t tb = B.tmp_bytes;
-    if ((e = rocprim::radix_sort_pairs(B.tmp, tb, B.sort_key, B.sorted_key, B.idx, B.idxs, (size_t)n, 0u, std::min(64u, 32u + node_bits + query_bits), s)) != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(vr_flag_requests_kernel, dim3(blocks), dim3(256), 0, s, B.sorted_key, n, B.flag_u, B.scalars);
-    vr_inclusive_scan<false>(s, B.flag_u, B.uid, n, (u32*)B.tmp);
-    hipLaunchKernelGGL(vr_scatter_unique_kernel, dim3(blocks), dim3(256), 0, s, B.key1, B.key2, B.idxs, B.flag_u, B.uid, n, B.ukey1, B.ukey2, B.urep, B.scalars);
-    // (the kernels below run over at most n distinct requests and stop at the device-side count)
-    hipLaunchKernelGGL(vr_run_heads_kernel, dim3(blocks), dim3(256), 0, s, B.ukey1, B.scalars, B.run_first);
-    vr_inclusive_scan<true>(s, B.run_first, B.run_first, n, (u32*)B.tmp);
-    hipLaunchKernelGGL(vr_flag_clusters_kernel, dim3(blocks), dim3(256), 0, s, B.ukey1, B.ukey2, B.run_first, B.scalars, B.flag_c);
-    vr_inclusive_scan<false>(s, B.flag_c, B.cid, n, (u32*)B.tmp);
-    hipLaunchKernelGGL(vr_cluster_starts_kernel, dim3(blocks), dim3(256), 0, s, B.flag_c, B.cid, B.scalars, B.cstart);
-    hipLaunchKernelGGL(vr_jobs_kernel, dim3(blocks), dim3(256), 0, s, B.ukey1, B.ukey2, B.urep, B.cstart, B.anchors, B.nodes, B.node, B.scalars, B.jobs);
-    // the job list by launch shape (two slots per cluster, at most n clusters)
-    unsigned const job_blocks = (2 * n + 255) / 256;
-    u32 const band = use_band() ? 1u : 0u;
-    hipLaunchKernelGGL(vr_shape_kernel, dim3(job_blocks), dim3(256), 0, s, B.jobs, B.scalars + VR_N_CLUSTERS, 2u, band, B.job_class, B.plan);
-    hipLaunchKernelGGL(vr_regroup_kernel, dim3(job_blocks), dim3(256), 0, s, B.jobs, B.scalars + VR_N_CLUSTERS, 2u, band, B.job_class, B.plan);
-    hipLaunchKernelGGL(vr_plan_kernel, dim3(1), dim3(64), 0, s, B.plan);
-    hipLaunchKernelGGL(vr_emit_kernel, dim3(job_blocks), dim3(256), 0, s, B.jobs, B.scalars + VR_N_CLUSTERS, 2u, B.job_class, B.plan, B.align_jobs);
-    return (int)hipGetLastError();
-}
-
-// The members of the undecided clusters one by one: a job per distinct request of such a cluster (slot = the request's index),
-// grouped by launch shape like the round's first list (the plan is rewritten); B.jobs is reused for the member jobs.
-__global__ void __launch_bounds__(256) vr_member_jobs_kernel(const u64* __restrict__ ukey1, const u64* __restrict__ ukey2, const u32* __restrict__ cid,
-                                                             const u8* __restrict__ state, const u32* __restrict__ scalars, DevVrJob* __restrict__ jobs,
-                                                             u32* __restrict__ member_k, DevVrPlan* __restrict__ plan) {
-    u32 const u = blockIdx.x * blockDim.x + threadIdx.x;
-    if (blockIdx.x == 0) {
-        u32* const words = reinterpret_cast<u32*>(plan);
-        for (u32 w = threadIdx.x; w < (u32)(sizeof(DevVrPlan) / 4); w += blockDim.x) words[w] = 0u;
-    }
-    if (u >= scalars[VR_N_UNIQ]) return;
-    u64 const mask = (1ull << VR_SHIFT) - 1ull;
-    DevVrJob j{ukey2[u] >> VR_SHIFT, ukey1[u] >> VR_SHIFT, 0u, (u32)(ukey1[u] & mask), member_k[u], 0u};
-    if (state[cid[u] - 1u] == 0) j.n = (u32)(ukey2[u] & mask);
-    jobs[u] = j;
-}
-// (before the round's job list is overwritten: the error bound of every distinct request = that of its cluster's jobs)
-__global__ void __launch_bounds__(256) vr_member_k_kernel(const DevVrJob* __restrict__ jobs, const u32* __restrict__ cid, const u32* __restrict__ scalars,
-                                                          u32* __restrict__ member_k) {
-    u32 const u = blockIdx.x * blockDim.x + threadIdx.x;
-    if (u < scalars[VR_N_UNIQ]) member_k[u] = jobs[2u * (cid[u] - 1u) + 1u].k;
-}
-__global__ void __launch_bounds__(256) vr_override_kernel(const DevVrJob* __restrict__ jobs, const DevAlignOut* __restrict__ outs, const u32* __restrict__ scalars,
-                                                          u8* __restrict__ override_) {
-    u32 const u = blockIdx.x * blockDim.x + threadIdx.x;
-    if (u >= scalars[VR_N_UNIQ]) return;
-    override_[u] = jobs[u].n == 0 ? (u8)0 : outs[u].score != 0xFFFFFFFFu ? (u8)1 : (u8)2;
-}
-
-int DeviceApi::vr_round_members(void* stream, VrBuffers const& B, u32 n, u32* d_member_k) {
-    if (n == 0) return 0;
-    hipStream_t s = (hipStream_t)stream;
-    unsigned const blocks = (n + 255) / 256;
-    u32 const band = use_band() ? 1u : 0u;
-    hipLaunchKernelGGL(vr_member_k_kernel, dim3(blocks), dim3(256), 0, s, B.jobs, B.cid, B.scalars, d_member_k);
-    hipLaunchKernelGGL(vr_member_jobs_kernel, dim3(blocks), dim3(256), 0, s, B.ukey1, B.ukey2, B.cid, B.state, B.scalars, B.jobs, d_member_k, B.plan);
-    hipLaunchKernelGGL(vr_shape_kernel, dim3(blocks), dim3(256), 0, s, B.jobs, B.scalars + VR_N_UNIQ, 1u, band, B.job_class, B.plan);
-    hipLaunchKernelGGL(vr_regroup_kernel, dim3(blocks), dim3(256), 0, s, B.jobs, B.scalars + VR_N_UNIQ, 1u, band, B.job_class, B.plan);
-    hipLaunchKernelGGL(vr_plan_kernel, dim3(1), dim3(64), 0, s, B.plan);
-    hipLaunchKernelGGL(vr_emit_kernel, dim3(blocks), dim3(256), 0, s, B.jobs, B.scalars + VR_N_UNIQ, 1u, B.job_class, B.plan, B.align_jobs);
-    return (int)hipGetLastError();
-}
-int DeviceApi::vr_round_override(void* stream, VrBuffers const& B, u32 n, u8* d_override) {
-    if (n == 0) return 0;
-    hipLaunchKernelGGL(vr_override_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, B.jobs, B.outs, B.scalars, d_override);
-    return (int)hipGetLastError();
-}
-
-AlignShape DeviceApi::vr_class_shape(u32 shape_class) {
-    return AlignShape{kWordsPerLane[shape_class / 7u], 1u << (shape_class % 7u), use_band() ? 1u : 0u};
-}
-
-int DeviceApi::vr_round_decide(void* stream, VrBuffers const& B, u32 n) {
-    if (n == 0) return 0;
-    hipLaunchKernelGGL(vr_decide_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, B.jobs, B.outs, B.scalars, B.state);
-    return (int)hipGetLastError();
-}
-
-int DeviceApi::vr_round_apply(void* stream, VrBuffers const& B, u32 n, const u8* d_override) {
-    if (n == 0) return 0;
-    hipStream_t s = (hipStream_t)stream;
-    unsigned const blocks = (n + 255) / 256;
-    hipLaunchKernelGGL(vr_apply_kernel, dim3(blocks), dim3(256), 0, s, B.sorted_key, B.idxs, B.uid, B.cid, B.state, d_override, B.anchors, B.nodes, n, B.node, B.status, B.scalars);
-    hipLaunchKernelGGL(vr_next_kernel, dim3(blocks), dim3(256), 0, s, B.anchors, B.nodes, B.node, B.status, n, B.scalars);
-    return (int)hipGetLastError();
 }
 
 // ================================================================================================ K3/K4: edit-distance DP

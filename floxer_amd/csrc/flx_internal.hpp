@@ -147,57 +147,16 @@ struct DevTraceJob {
 struct DevTraceOut { u32 begin; u32 cigar_start; u32 cigar_len; u32 pad; };   // cigar_start relative to the slab
 
 // ------------------------------------------------------------------------------------------------ verification rounds on the device
-// The inner PEX levels as device-resident state: every anchor of a chunk with the node it is about to test; a round builds the
-// requests of the anchors in the current node-size class, sorts them, finds the distinct ones and the clusters of windows of one
-// locus, and writes the job list (one or two existence tests per cluster) grouped by launch shape, with the counts the host needs
-// to launch K3 on it (DevVrPlan); a decide step turns the K3 results into one decision per cluster; an apply step moves the
-// anchors up their trees (the members of undecided clusters go through a second job list first). Per round the host reads a plan
-// or two and three scalars, nothing per anchor or per job.
+// The inner PEX levels as device-resident state: every anchor of a chunk with the node it is about to test (flx_rounds.hip).
 struct DevVrAnchor {            // 48 bytes
     i64 diag_rel;               // anchor position minus the leaf's first query row (relative to its reference sequence, may be < 0)
     u64 seq_start, seq_len;     // the reference sequence in the padded text
     u64 q_base;                 // pool offset of the read in the anchor's orientation
     u32 tree_base;              // first node of the read's tree in the node table
-    u32 query;                  // ordinal of (read, orientation) in the chunk: with the node's index it names the node in a sort key
+    u32 query;                  // ordinal of (read, orientation) in the chunk
 };
 struct DevVrNode { u32 parent, from, rows, errors; };          // parent = index within the tree, 0xFFFFFFFF for the root
-struct DevVrJob { u64 ref_off, q_off; u32 n, m, k, pad; };     // n == 0: unused slot
-enum : u8 { VR_CLIMBING = 0, VR_DEAD = 1, VR_AT_ROOT = 2, VR_SOLO = 3 };      // VR_SOLO: climbing, its next test alone (flx_rounds.hip)
-enum : u32 { VR_N_REQ = 0, VR_N_UNIQ = 1, VR_N_CLUSTERS = 2, VR_N_CLIMBING = 3, VR_SMALLEST = 4, VR_N_UNDECIDED = 5 };
-// The launch plan of a round's job list. A shape class is (index into the words-per-lane table) * 7 + log2(lanes per job); the
-// jobs are stored class by class, `count` of them from `start` on. `lanes`, `par_w`, `par_r` describe the one-launch form the host
-// uses when the round has few jobs (choose_shapes in flx_pipeline.cpp is the host form of the same rules).
-constexpr u32 VR_CLASSES = 64, VR_NO_CLASS = 0xFF;
-struct DevVrPlan {
-    u32 count_first[VR_CLASSES];     // jobs whose own cheapest shape is this class
-    u32 count[VR_CLASSES];           // after the jobs of rare classes joined a common one that can hold them
-    u32 start[VR_CLASSES];
-    u32 cursor[VR_CLASSES];
-    u64 word_steps[VR_CLASSES];      // accounting: DP word-steps and sequence bytes of the class's launch
-    u64 bytes[VR_CLASSES];
-    u64 lanes;                       // lanes the jobs occupy in their own cheapest shapes
-    u64 common_word_steps;           // word-steps of the one-launch form (words per lane = par_w)
-    u32 par_w_index, par_r;          // one-launch form: words-per-lane table index and lanes per job that hold every job
-    u32 n_jobs, unsupported;         // unsupported != 0: a query longer than any shape holds
-};
-struct VrBuffers {
-    const DevVrAnchor* anchors; const DevVrNode* nodes;
-    u32* node; u8* status;                       // per anchor, mutable
-    u64 *key1, *key2;                            // per anchor: the request {query offset << 20 | rows, reference offset << 20 | window length}
-    u64 *sort_key, *sorted_key;                        // per anchor: sort key (node name << 32 | window start; ~0: not in this round), unsorted / sorted
-    u32 *idx, *idxs;                             // per anchor: anchor index, unsorted / in sorted order
-    u32 *flag_u, *uid, *flag_c, *cid, *run_first;// per sorted request / per distinct request
-    u64 *ukey1, *ukey2; u32* urep;               // per distinct request: keys and one anchor that asked for it
-    u32* cstart;                                 // per cluster: its first distinct request (n_clusters + 1 entries)
-    DevVrJob* jobs;                              // two slots per cluster: {the window itself | the intersection}, {the union}
-    u8* job_class;                               // per slot: its shape class (VR_NO_CLASS: unused slot)
-    DevAlignJob* align_jobs;                     // the used slots as K3 jobs, class by class; out_index = the slot
-    DevAlignOut* outs;                           // K3 results per slot
-    u8* state;                                   // per cluster: 1 pass, 2 fail, 0 undecided (its members one by one)
-    DevVrPlan* plan;
-    u32* scalars;                                // VR_*
-    void* tmp; size_t tmp_bytes;
-};
+enum : u8 { VR_CLIMBING = 0, VR_DEAD = 1, VR_AT_ROOT = 2, VR_SOLO = 3 };      // VR_SOLO: climbing, its next test alone
 
 // ---- the rounds as three launches each (flx_rounds.hip)
 // scalars (u32 words): jobs of the round (two counters, taken in turn), anchors left to climb and their smallest node after the round,
@@ -256,14 +215,12 @@ struct DeviceApi {
     // device; all outputs on the host
     static int index_arrays(int hip_device, const u8* text, u64 n, u32* out_sa, u8* out_bwt0, u8* out_bwt1, OccBlock* out_occ0, OccBlock* out_occ1);
     static int build_peq(void* stream, const u8* d_seq, u64 len, u64* d_peq);
-    // d_seed_cnt (may be null): number of hits of every seed; each hit then carries its ordinal within its seed in errors >> 8.
-    // d_stack == nullptr: the DFS with error children first and its frames in LDS (frame_levels = largest error count of a seed;
-    // hits carry keys that restore the emission order; every seed shorter than fm_search_max_keyed_length()); else the DFS in the
-    // reference's order with DevSeed::stack_off / frames into d_stack. concurrent_launches: searches the caller keeps in flight at a
-    // time on other streams (the launch takes a share of the waves).
+    // The DFS in the reference's order, frames on per-seed stacks in HBM (DevSeed::stack_off / frames into d_stack): for first_reported
+    // (the first n rows in emission order) and the raw-emission hook. d_seed_cnt (may be null): number of hits of every seed; each hit
+    // then carries its ordinal within its seed in errors >> 8.
     static int search(void* stream, const DevIndex& idx, const u8* d_seq, const u64* d_scheme, const DevSeed* d_seeds,
-                      u32 n_seeds, u32 max_hits_per_seed, u32 frame_levels, DevFrame* d_stack, DevHit* d_hits, u32 hit_cap,
-                      u32* d_counters, u32* d_seed_cnt = nullptr, u32 concurrent_launches = 1);
+                      u32 n_seeds, u32 max_hits_per_seed, DevFrame* d_stack, DevHit* d_hits, u32 hit_cap,
+                      u32* d_counters, u32* d_seed_cnt = nullptr);
     // flx_search.hip: the walk with its stack in LDS plus the presence filter (d_qpack: 2-bit form of d_seq, null: no filter) and the
     // text walk of one-row subtrees (d_items: room for item_cap queued subtrees, null: none are queued). d_counters: 32 zeroed words.
     static int search_filtered(void* stream, const DevIndex& idx, const u8* d_seq, const u32* d_qpack, const u64* d_scheme, const DevSeed* d_seeds,
@@ -278,7 +235,7 @@ struct DeviceApi {
     // anchor selection on the device (see seed_select_kernel). d_seed_cnt, d_hit_offset, d_n_out, d_out_offset: n_seeds + 1 entries
     // (the caller zeroes the last entry of d_seed_cnt and d_n_out); d_stat: one DevSelStat per seed;
     // d_grouped: as many entries as d_hits; d_out: one entry per selected anchor (at most the number of rows of the handled seeds);
-    // d_lists: 2 * n_seeds + 2 entries (the lists of light and heavy seeds and their lengths)
+    // d_lists: 3 * n_seeds + 3 entries (the lists of light, heavy and many-group seeds and their lengths)
     static size_t select_scan_bytes(u32 n_seeds);
     static int select(void* stream, const DevHit* d_hits, const u32* d_counters, u32 hit_cap, u32* d_seed_cnt, u32* d_hit_offset,
                       DevHit* d_grouped, u32 n_seeds, const DevIndex& idx, const u64* d_seq_start, u32 n_ref, u32 hard_cap, u32 soft_cap,
@@ -288,21 +245,6 @@ struct DeviceApi {
     // d_lastrow (banded TRACE launches only, may be null): D[m][c] of every computed column c, 0xFFFF elsewhere (pre-filled by the caller)
     static int align(void* stream, const u8* d_text, const u64* d_peq, const DevAlignJob* d_jobs, u32 n_jobs, AlignShape shape,
                      bool trace, u64* d_trace, DevAlignOut* d_out, u16* d_lastrow = nullptr);
-    // verification rounds (see VrBuffers). query_bits / node_bits: bits that hold every DevVrAnchor::query / node index of the chunk.
-    // requests: everything up to the job list of the round whose node-size limit is `limit`,
-    // grouped by launch shape (scalars VR_N_REQ / VR_N_UNIQ / VR_N_CLUSTERS and the plan are set); decide: B.state from B.outs
-    // (scalar VR_N_UNDECIDED); apply: B.state = one decision per cluster (1 pass, 2 fail, 0: look at d_override, one per distinct
-    // request, may be null), then scalars VR_N_CLIMBING / VR_SMALLEST for the next round
-    static size_t vr_tmp_bytes(u32 n_anchors);
-    static int vr_round_requests(void* stream, VrBuffers const& B, u32 n_anchors, u32 limit, u32 query_bits, u32 node_bits);
-    static int vr_round_decide(void* stream, VrBuffers const& B, u32 n_anchors);
-    // undecided clusters: members: one job per distinct request of such a cluster replaces the round's job list (B.jobs, slot = the
-    // request's index; B.plan rewritten; d_member_k: one word per anchor of scratch); override: d_override[request] = 1 pass, 2 fail,
-    // 0 not a member, from B.outs
-    static int vr_round_members(void* stream, VrBuffers const& B, u32 n_anchors, u32* d_member_k);
-    static int vr_round_override(void* stream, VrBuffers const& B, u32 n_anchors, u8* d_override);
-    static int vr_round_apply(void* stream, VrBuffers const& B, u32 n_anchors, const u8* d_override);
-    static AlignShape vr_class_shape(u32 shape_class);
     // flx_rounds.hip: a round = vr2_request (job list and count on the device), align_exists_counted on it, vr2_apply
     static int vr2_request(void* stream, Vr2Buffers const& B, u32 n_queries, u32 limit, u32 acct_words, u32 width_cap, u32 parity);
     static int vr2_apply(void* stream, Vr2Buffers const& B, u32 n_anchors, u32* host_scalars);

@@ -391,13 +391,11 @@ int search_seeds_device(Lane* ctx, const u8* d_seq_pool_or_null, const u8* h_seq
     // hook and first_reported, which want the first n rows; everywhere else the walk with its stack in LDS, whose hits carry keys
     // that restore the emission order.
     bool const ordered = (raw_hits && !getenv("FLX_FM_KEYED_RAW")) || cfg.anchor_choice_strategy == FLX_CHOICE_FIRST_REPORTED || max_length > fm_search_max_keyed_length() ||
-                         max_errors > 3 || getenv("FLX_FM_ORDERED");
+                         max_errors > 3 || getenv("FLX_FM_ORDERED");      // (FLX_FM_ORDERED=1: the ordered walk for everything, for comparisons)
     if (ordered && (rc = ctx->stack.ensure(frames * sizeof(DevFrame)))) return rc;
     if ((rc = ctx->counters.ensure(128))) return rc;
-    // the walk of flx_search.hip (presence filter, one-row subtrees against the text) unless the order of discovery matters;
-    // FLX_FM_V1=1: the round-2 kernel (rank queries all the way)
-    static int const fm_v1 = getenv("FLX_FM_V1") ? 1 : 0;
-    bool const filtered = !ordered && !fm_v1;
+    // the walk of flx_search.hip (presence filter, one-row subtrees against the text) unless the order of discovery matters
+    bool const filtered = !ordered;
     const u32* d_qpack = d_qpack_or_null;
     if (filtered && !d_qpack && ctx->ctx->didx.filter) {
         if ((rc = ctx->qpack.ensure(pack_words_for(pool_len) * 4 + 64))) return rc;
@@ -429,7 +427,7 @@ int search_seeds_device(Lane* ctx, const u8* d_seq_pool_or_null, const u8* h_seq
         if ((rc = ctx->sel_rows.ensure((n_seeds + 1) * 4))) return rc;
         if ((rc = ctx->sel_row_off.ensure((n_seeds + 1) * 4))) return rc;
         if ((rc = ctx->sel_tmp.ensure(scan_bytes + 64))) return rc;
-        if ((rc = ctx->sel_lists.ensure((2 * n_seeds + 2) * 4))) return rc;
+        if ((rc = ctx->sel_lists.ensure((3 * n_seeds + 3) * 4))) return rc;
         sel_stat.resize(n_seeds);
     }
     u32 counters[32];
@@ -461,8 +459,8 @@ int search_seeds_device(Lane* ctx, const u8* d_seq_pool_or_null, const u8* h_seq
                                                   item_cap ? ctx->items.as<DevHit>() : nullptr, (u32)std::min<u64>(item_cap, 0xFFFFFFFFu),
                                                   ctx->counters.as<u32>(), device_select ? ctx->seed_cnt.as<u32>() : nullptr, concurrent);
             return DeviceApi::search(ctx->stream, ctx->ctx->didx, d_seq, ctx->scheme.as<u64>(), ctx->seeds.as<DevSeed>(), (u32)n_seeds,
-                                     max_hits, max_errors, ordered ? ctx->stack.as<DevFrame>() : nullptr, ctx->hits.as<DevHit>(), (u32)std::min<u64>(hit_cap, 0xFFFFFFFFu),
-                                     ctx->counters.as<u32>(), device_select ? ctx->seed_cnt.as<u32>() : nullptr, concurrent);
+                                     max_hits, ctx->stack.as<DevFrame>(), ctx->hits.as<DevHit>(), (u32)std::min<u64>(hit_cap, 0xFFFFFFFFu),
+                                     ctx->counters.as<u32>(), device_select ? ctx->seed_cnt.as<u32>() : nullptr);
         });
         if (rc) return rc;
         if (device_select) {
@@ -485,7 +483,6 @@ int search_seeds_device(Lane* ctx, const u8* d_seq_pool_or_null, const u8* h_seq
         }
         if ((rc = ctx->sync())) return rc;
         if (getenv("FLX_SEARCH_DEBUG")) fprintf(stderr, "[fm_search] seeds %llu ext %u (of single-row intervals %u) wave-iterations %u (max per wave %u) busy pair-iterations %u, after the queue ran dry %u (max %u)\n", (unsigned long long)n_seeds, counters[2], counters[3], counters[4], counters[5], counters[6], counters[8], counters[9]);
-        if (getenv("FLX_SEARCH_DEBUG")) fprintf(stderr, "[fm_search classes] branching: rows=1 %u, rows 2-4 %u, rows>4 %u; forced: rows=1 %u, rows 2-4 %u, rows>4 %u\n", counters[10], counters[11], counters[12], counters[13], counters[14], counters[15]);
         if (getenv("FLX_SEARCH_DEBUG") && filtered) fprintf(stderr, "[fm_search filtered] subtrees queued %u (slots %u of %llu), filter lookups %u, children dropped %u, searches ended by the prefix lookup %u; text walk: lane-steps %u, wave-iterations %u\n", counters[3], counters[16], (unsigned long long)item_cap, counters[10], counters[11], counters[12], counters[18], counters[19]);
         if (counters[1]) { set_error("fm_search: DFS stack reservation exceeded"); return FLX_ERR_INTERNAL; }
         bool const items_fit = !item_cap || counters[16] <= item_cap;

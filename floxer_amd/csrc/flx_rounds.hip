@@ -27,7 +27,10 @@ namespace flx {
 
 namespace {
 
-constexpr u32 VR2_TILE = 1024;          // anchors of a query looked at per pass of its block
+// anchors of a query looked at per pass of its block. 256: 4.75 KB of LDS per block, so that the block finds room on a CU whose LDS the DP
+// kernels of other lanes have taken (at 1024, 19 KB, a launch waited 3 ms for its blocks to be placed); a query with more anchors is
+// handled tile by tile (the anchors of a node's subtree are contiguous, few nodes are cut; windows cut apart are simply tested twice)
+constexpr u32 VR2_TILE = 256;
 constexpr u32 VR2_THREADS = 64;
 constexpr u64 VR2_NO_KEY = ~0ull;
 
