@@ -1581,7 +1581,11 @@ static AlignShape choose_align_shape_uncached(u32 nw, i64 width, bool band, bool
             // (A cost by instructions issued, r * (35 + 25 w), which prefers four words per lane over one at the same w * r, made
             // the existence tests a third slower: more distinct shapes per round = more launches, and fewer resident waves per CU
             // with the larger LDS tables; measured in round 2, gpurun_out r02u.)
-            u64 const cost = parallel ? (u64)w * 1000 + r : (u64)w * r * 1000 + w;
+            // (FLX_SHAPE_MODEL=a,b: throughput form by instructions issued instead, r * (a + b * w): per column a lane pays `a` whatever its
+            // words and `b` per word)
+            static int const model_a = [] { const char* e = getenv("FLX_SHAPE_MODEL"); int a = 0, b = 0; return e && sscanf(e, "%d,%d", &a, &b) == 2 ? a : 0; }();
+            static int const model_b = [] { const char* e = getenv("FLX_SHAPE_MODEL"); int a = 0, b = 0; return e && sscanf(e, "%d,%d", &a, &b) == 2 ? b : 0; }();
+            u64 const cost = parallel ? (u64)w * 1000 + r : model_b ? (u64)r * (u64)(model_a + model_b * (int)w) * 16 + w : (u64)w * r * 1000 + w;
             if (cost < best_cost) { best_cost = cost; best = AlignShape{w, r, band ? 1u : 0u}; }
         }
     return best;

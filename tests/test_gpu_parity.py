@@ -670,6 +670,135 @@ def test_index_built_on_the_device_is_the_host_index(tmp_path):
     assert open(p1, "rb").read() == open(p2, "rb").read()
 
 
+def _padded_text(refs):
+    """the text the index is over: every sequence followed by 4 - (len % 4) delimiters (BiFMIndex's layout, floxer.cpp:93-97)"""
+    parts = []
+    for r in refs:
+        parts.append(np.asarray(r, dtype=np.uint8))
+        parts.append(np.zeros(4 - len(r) % 4, np.uint8))
+    return np.concatenate(parts)
+
+
+def test_index_at_scale_checked_without_the_products_arrays():
+    """250 Mb in 5 sequences, index built on the device. Nothing of the product checks it here: the suffix array is a permutation,
+    2 M sampled neighbouring rows are in suffix order (texts compared with numpy, the end of the text sorting first), the BWT is the
+    symbol in front of every suffix (all rows), and the BWT of the reversed text has the text's symbol counts and every sampled LF walk
+    over it spells a string that occurs in the text (found with the suffix array just checked)."""
+    chrom = 50_000_000
+    pool, genome = S.make_genome_fast(chrom, 5, seed=4242)
+    idx = F.fmindex(genome, device=0)
+    text = _padded_text(genome)
+    n = len(text)
+    assert idx.text_length == n
+    sa = idx.suffix_array_u32()
+    seen = np.zeros(n, dtype=bool)
+    seen[sa] = True
+    assert seen.all()                                                         # a permutation of 0 .. n-1
+    del seen
+    rng = np.random.default_rng(99)
+
+    def suffix_cmp(a, b):
+        """-1 / 0 / +1 per pair: text[a:] against text[b:], a suffix that ends first being the smaller one"""
+        res = np.zeros(len(a), dtype=np.int8)
+        todo = np.arange(len(a))
+        a, b = a.astype(np.int64), b.astype(np.int64)
+        for d in range(0, 1 << 20):
+            if len(todo) == 0:
+                break
+            pa, pb = a[todo] + d, b[todo] + d
+            ea, eb = pa >= n, pb >= n
+            ca = np.where(ea, -1, text[np.minimum(pa, n - 1)].astype(np.int16))
+            cb = np.where(eb, -1, text[np.minimum(pb, n - 1)].astype(np.int16))
+            diff = ca != cb
+            res[todo[diff]] = np.where(ca[diff] < cb[diff], -1, 1)
+            todo = todo[~diff & ~(ea & eb)]
+        return res
+
+    rows = rng.integers(0, n - 1, size=2_000_000)
+    assert (suffix_cmp(sa[rows], sa[rows + 1]) < 0).all()
+    # rows around the delimiters too (suffixes that start with runs of the delimiter sort first)
+    assert (suffix_cmp(sa[:5000], sa[1:5001]) < 0).all()
+    bwt = idx.bwt(False)
+    assert (bwt == text[(sa.astype(np.int64) - 1) % n]).all()
+    del bwt
+    # ---- the BWT of the reversed text
+    bwt_r = idx.bwt(True)
+    counts = np.bincount(text, minlength=6)
+    assert (np.bincount(bwt_r, minlength=6) == counts).all()
+    C = np.concatenate([[0], np.cumsum(counts)])[:6]
+    step = 256
+    ck = np.zeros((n // step + 1, 6), dtype=np.int64)                       # symbol counts in front of every 256th row
+    for c in range(6):
+        ck[1:, c] = np.cumsum(np.add.reduceat((bwt_r == c).astype(np.int32), np.arange(0, n, step)))[: n // step]
+
+    def rank(c, i):                                                          # occurrences of c[k] in bwt_r[0, i[k])
+        base = ck[i // step, c]
+        out = base.copy()
+        for d in range(step):
+            at = (i // step) * step + d
+            live = at < i
+            out += (live & (bwt_r[np.minimum(at, n - 1)] == c)).astype(np.int64)
+        return out
+
+    walkers = rng.integers(0, n, size=400)
+    spelled = []
+    for _ in range(24):
+        c = bwt_r[walkers]
+        spelled.append(c)
+        walkers = C[c] + rank(c.astype(np.int64), walkers)
+    # an LF step on the reversed text's BWT prepends a symbol of the reversed text = appends one of the text: the walk spells text forwards
+    strings = np.stack(spelled, axis=1)
+    sa64 = sa.astype(np.int64)
+    for s_ in strings:
+        if (s_ == 0).any():
+            continue                                                         # (walks through a delimiter wrap around the text's end)
+        lo, hi = 0, n
+        for d, c in enumerate(s_):                                           # narrow [lo, hi) by the d-th symbol with binary searches on the suffix array
+            def sym(row):
+                p = sa64[row] + d
+                return -1 if p >= n else int(text[p])
+            l, h = lo, hi
+            while l < h:
+                m = (l + h) // 2
+                if sym(m) < c: l = m + 1
+                else: h = m
+            first = l
+            h = hi
+            while l < h:
+                m = (l + h) // 2
+                if sym(m) <= c: l = m + 1
+                else: h = m
+            lo, hi = first, l
+            assert lo < hi, "an LF walk over the reverse BWT spelled a string the text does not hold"
+
+
+def test_hifi_shape_at_grch38_size_properties():
+    """BASELINE.json configs[4]'s shape at full size: 20 kb reads @ 2 % against the 3.1 Gb reference (25 sequences), floxer defaults.
+    Every read has one primary at its simulated sequence, place and strand; the CIGARs of a sample are consistent with both texts and
+    their NM; batch invariance; -I keeps every primary."""
+    chrom = 124_000_000
+    pool, genome = S.make_genome_fast(chrom, 25, seed=S.DEFAULT_SEED)
+    idx = F.fmindex(genome, device=0)
+    ctx = F.context(idx)
+    (rpool, offs), (tc, tp, tr) = S.make_reads_fast(pool, [chrom] * 25, 192, 20000, 0.02, seed=77)
+    reads = [rpool[int(offs[i]):int(offs[i + 1])] for i in range(192)]
+    p = F.params(error_probability=0.02)
+    got = F.aligner(ctx, p).align_reads(reads)
+    recs = got.records()
+    prim = {r[0]: r for r in recs if not r[1] & 256 and not r[1] & 4}
+    assert len(prim) == 192
+    for i in range(192):
+        r = prim[i]
+        assert r[2] == int(tc[i]) and bool(r[1] & 16) == bool(tr[i]) and abs(r[3] - int(tp[i])) <= 2000, (i, r[:5], int(tc[i]), int(tp[i]))
+    _check_cigars(genome, reads, [r for r in recs if r[0] < 24], 0.02)
+    half = F.aligner(ctx, p).align_reads(reads[:96]).records()
+    assert half == [r for r in recs if r[0] < 96]
+    with_i = F.aligner(ctx, F.params(error_probability=0.02, interval_optimization=True)).align_reads(reads).records()
+    prim_i = {r[0]: r for r in with_i if not r[1] & 256 and not r[1] & 4}
+    assert {k: v[:5] for k, v in prim_i.items()} == {k: v[:5] for k, v in prim.items()}
+    ctx.close()
+
+
 # ---------------------------------------------------------------- '$' in a read, repeat-rich text, scale
 def test_dollar_in_reads_and_seeds_matches_oracle(small_genome):
     """input.cpp:165-176 maps '$' to rank 0, the rank of the sequence delimiters: search_ng21 extends a cursor with it like with any
