@@ -253,6 +253,12 @@ def main():
         stats = ctx.kernel_stats()
         path = ctx.path_counters()
         ctx.enable_kernel_timing(False)
+    # the timed region's context and its resident batches leave the GPU before the one-lane pass makes its own (a repeat-rich reference
+    # grows the lanes' workspaces: both contexts together ran out of HBM)
+    for rr in resident:
+        rr.close()
+    resident = []
+    ctx.close()
 
     # ---- isolated pass (rank 0): the first timed batch once more on ONE lane, so that no two kernels overlap and a launch's
     #      HIP-event time (on the launch stream) is its own duration. Outside the timed region; feeds "roofline".

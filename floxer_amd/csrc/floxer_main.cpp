@@ -460,16 +460,24 @@ int main(int argc, char** argv) {
     // Batches are independent: up to three are in a context at a time (their chunks share its lanes), the next one is parsed
     // while they run, and results are written in input order.
     struct Finished { std::unique_ptr<ReadBatch> batch; std::vector<flx_record> recs; std::vector<uint32_t> cig; std::vector<uint8_t> skipped; int rc = FLX_OK; std::string err; };
+    // FLX_CLI_PROFILE=1: seconds this run spent parsing (this thread), aligning (sum over the batches' tasks) and writing (the writer
+    // thread) on stderr at the end: which of the three stages bounds the end-to-end rate
+    std::atomic<uint64_t> us_parse{0}, us_align{0}, us_copy{0}, us_write{0};
+    auto const now_us = [] { return (uint64_t)std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     auto align_batch = [&](std::unique_ptr<ReadBatch> b, flx_ctx* ctx) {
         Finished f;
         flx_run* run = nullptr;
+        uint64_t const t0 = now_us();
         f.rc = flx_align_reads(ctx, &p, b->pool.data(), b->offsets.data(), b->ids.size(), &run);
+        us_align += now_us() - t0;
         if (f.rc != FLX_OK) { f.err = flx_last_error(); f.batch = std::move(b); return f; }
         f.recs.resize(flx_run_num_records(run));
         f.cig.resize(flx_run_num_cigar_words(run) + 1);
         f.skipped.resize(b->ids.size());
+        uint64_t const t1 = now_us();
         flx_run_copy(run, f.recs.data(), f.cig.data(), f.skipped.data());
         flx_run_free(run);
+        us_copy += now_us() - t1;
         f.batch = std::move(b);
         return f;
     };
@@ -492,7 +500,9 @@ int main(int argc, char** argv) {
         ReadBatch const& batch = *f.batch;
         for (size_t i = 0; i < f.skipped.size(); ++i)
             if (f.skipped[i]) log_line("warning", "skipping query: %s due to bad configuration regarding the number of errors.", batch.ids[i]);
+        uint64_t const t0 = now_us();
         if (flx_sam_write(out, batch.ids.data(), batch.pool.data(), batch.offsets.data(), batch.quals.data(), f.recs.data(), f.recs.size(), f.cig.data()) != FLX_OK) { log_line("error", "%s", flx_last_error()); failed.store(true); }
+        us_write += now_us() - t0;
         total_reads += batch.ids.size();
         total_records += f.recs.size();
         log_line("debug", "finished a batch: %llu queries, %llu records so far", (unsigned long long)total_reads, (unsigned long long)total_records);
@@ -520,7 +530,10 @@ int main(int argc, char** argv) {
             break;
         }
         auto batch = std::make_unique<ReadBatch>();
-        if (!qin.next(*batch, batch_reads, err)) {
+        uint64_t const t_parse = now_us();
+        bool const got = qin.next(*batch, batch_reads, err);
+        us_parse += now_us() - t_parse;
+        if (!got) {
             eof = true;
             if (!err.empty()) { log_line("error", "An error occured while trying to read the queries from the file %s.\n%s", o.queries.c_str(), err.c_str()); failed.store(true); }
             break;
@@ -543,6 +556,9 @@ int main(int argc, char** argv) {
     if (failed.load() || timed_out) return -1;
     double const secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_align).count();
     log_line("info", "finished aligning successfully in %.3f seconds (%llu queries, %llu records)", secs, (unsigned long long)total_reads, (unsigned long long)total_records);
+    if (getenv("FLX_CLI_PROFILE"))
+        fprintf(stderr, "[flx cli profile] wall %.2f s: parsing %.2f s (reader thread), aligning %.2f s summed over %llu batches (up to %zu in flight), copying results %.2f s, writing %.2f s (writer thread, %u I/O threads)\n",
+                secs, us_parse.load() / 1e6, us_align.load() / 1e6, (unsigned long long)n_batches, max_in_flight, us_copy.load() / 1e6, us_write.load() / 1e6, n_io);
     if (stats) {                                                                       // floxer.cpp:182-192
         uint64_t len = 0;
         flx_stats_format(stats, o.stats != "terminal", nullptr, &len);

@@ -162,10 +162,17 @@ int make_context(int hip_device, const flx_index* index, void* const image[5], b
     if (getenv("FLX_ALLOC_DEBUG"))
         fprintf(stderr, "[flx alloc] context: occ0 %p occ1 %p sa %p text %p kmer %p (n %llu) isa %p filter %p (K %u, tmin %u) seq_start %p\n", img[0], img[1], img[2], img[3],
                 img[4], (unsigned long long)H.n, ctx->isa.ptr, ctx->filter.ptr, ctx->didx.filter_k, ctx->didx.filter_tmin, ctx->seq_start.ptr);
-    // trace arena budget: FLX_TRACE_ARENA_MB (whole context), default 40% of the free HBM, at least 256 MB; split over the lanes
+    for (auto& lane : ctx->lanes) {
+        int const e = DeviceApi::warm_scratch(lane->stream);
+        if (e) { set_error(std::string("warm_scratch: ") + hipGetErrorString((hipError_t)e)); return FLX_ERR_NO_DEVICE; }
+    }
+    for (auto& lane : ctx->lanes) FLX_HIP(hipStreamSynchronize(lane->stream));
+    // trace arena budget: FLX_TRACE_ARENA_MB (whole context), default 40% of the free HBM but not more than 4 GB per lane (a 2048-read
+    // chunk of 10-kb reads needs 2-4 GB; what is not taken stays free for other contexts and processes on the GPU), at least 256 MB;
+    // split over the lanes
     size_t free_b = 0, total_b = 0;
     FLX_HIP(hipMemGetInfo(&free_b, &total_b));
-    size_t budget = free_b / 10 * 4;
+    size_t budget = std::min<size_t>(free_b / 10 * 4, n_lanes * ((size_t)4 << 30));
     if (const char* env = getenv("FLX_TRACE_ARENA_MB")) { size_t const mb = strtoull(env, nullptr, 10); if (mb) budget = mb << 20; }
     budget = std::max<size_t>(budget, (size_t)256 << 20);
     for (auto& lane : ctx->lanes) lane->trace_budget_bytes = std::max<size_t>(budget / n_lanes, (size_t)128 << 20);

@@ -1438,39 +1438,41 @@ __device__ __forceinline__ void ed_exists_block_body(const u8* __restrict__ text
 #pragma unroll
     for (int w = 0; w < W; ++w) lds_eq[(6u * 64u + lane) * W + w] = 0ull;
 
+    // The query is right-aligned in its Lg groups: `pad` rows in front of row 0 that match every symbol and start with vertical delta 0
+    // keep D = 0 (what row 0's boundary is) down to the first real row, and the last real row is bit 63 of every group's last word: the
+    // value that travels down (and the score in the last group) follows from the word's carries, no row has to be picked out of a word.
+    int const pad = Lg * 64 * W - m;                      // 0 <= pad < 64 W: only group 0 holds padding
     int g = (int)p;
     int b_lo = 0, b_hi = -1, rows_g = 0;
-    u32 keep_shift = 63u;                                 // bit of the group's last row in word keep_w (the bottom row of the matrix for the last group)
-    int keep_w = W - 1;
     u64 vp[W], vn[W];
     auto enter_group = [&]() {
-        int const r0 = 64 * W * g;
-        int const r1 = min(m, r0 + 64 * W);
+        int const r0 = max(0, 64 * W * g - pad);
+        int const r1 = 64 * W * (g + 1) - pad;
         rows_g = r1 - r0;
         b_lo = max(0, r0 - k) >> 4;
         b_hi = min(n - 1, r1 - 1 + band_hi) >> 4;
         if (g + 1 < Lg) b_hi = max(b_hi, max(0, r1 - k) >> 4);
-        bool const last = g == Lg - 1;
-        keep_w = last ? (nw - 1) - g * W : W - 1;
-        keep_shift = last ? (u32)(m - 1) & 63u : 63u;
-        u64 const a = job.q_off >> 6;
-        u32 const sh = (u32)(job.q_off & 63u);
 #pragma unroll
         for (int w = 0; w < W; ++w) {
-            int const gw = g * W + w;
+            int const rs = 64 * (g * W + w) - pad;        // real row of the word's bit 0 (negative: that many padding rows first)
+            u64 const padmask = rs <= -64 ? ~0ull : rs < 0 ? (1ull << (u32)(-rs)) - 1ull : 0ull;
+            i64 const off = (i64)job.q_off + rs;          // pool position of the word's bit 0
 #pragma unroll
             for (u32 s = 0; s < 6; ++s) {
                 u64 v = 0;
-                if (gw < nw) {
-                    u64 const lo = peq[(a + gw) * 6 + s];
-                    u64 const hi = peq[(a + gw + 1) * 6 + s];
-                    v = sh ? (lo >> sh) | (hi << (64 - sh)) : lo;
-                    int const rows_left = m - gw * 64;
-                    if (rows_left < 64) v &= (1ull << rows_left) - 1ull;
+                if (rs > -64) {
+                    if (off >= 0) {
+                        u64 const a = (u64)off >> 6;
+                        u32 const sh = (u32)off & 63u;
+                        u64 const lo = peq[a * 6 + s];
+                        u64 const hi = peq[(a + 1) * 6 + s];
+                        v = sh ? (lo >> sh) | (hi << (64 - sh)) : lo;
+                    } else v = peq[s] << (u32)(-off);     // (the pool starts inside the word: the bits in front of it are padding rows)
                 }
-                lds_eq[(s * 64u + lane) * W + w] = v;
+                lds_eq[(s * 64u + lane) * W + w] = v | padmask;
             }
-            vp[w] = ~0ull;
+            lds_eq[(6u * 64u + lane) * W + w] = padmask;  // symbol 6 (columns past the end of the window) matches nothing but the padding
+            vp[w] = ~padmask;
             vn[w] = 0ull;
         }
     };
@@ -1508,7 +1510,7 @@ __device__ __forceinline__ void ed_exists_block_body(const u8* __restrict__ text
             u32 cw = 0;
 #pragma unroll
             for (int qd = 0; qd < 4; ++qd) {
-#pragma unroll 1
+#pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     int const j = 4 * qd + i;
                     int const c = 16 * b + j;
@@ -1516,7 +1518,6 @@ __device__ __forceinline__ void ed_exists_block_body(const u8* __restrict__ text
                     sym = c < n ? sym : 6u;
                     u64 c_hp = (cw_in >> (2 * j)) & 1u, c_hn = (cw_in >> (2 * j + 1)) & 1u;
                     const u64* __restrict__ eqp = &lds_eq[(sym * 64u + lane) * W];
-                    u64 hp_keep = 0, hn_keep = 0;
 #pragma unroll
                     for (int w = 0; w < W; ++w) {
                         u64 const eq = eqp[w];
@@ -1531,10 +1532,9 @@ __device__ __forceinline__ void ed_exists_block_body(const u8* __restrict__ text
                         vp[w] = (hn << 1) | ~(xh | d0) | c_hn;
                         c_hp = hp >> 63;
                         c_hn = hn >> 63;
-                        if (w == keep_w) { hp_keep = hp; hn_keep = hn; }
                     }
                     cw |= ((u32)c_hp | ((u32)c_hn << 1)) << (2 * j);
-                    bot += (int)((u32)(hp_keep >> keep_shift) & 1u) - (int)((u32)(hn_keep >> keep_shift) & 1u);
+                    bot += (int)(u32)c_hp - (int)(u32)c_hn;       // the group's last row is its last word's bit 63
                     if (last && c < n && bot <= best) { best = bot; best_col = c + 1; }
                 }
             }

@@ -392,12 +392,12 @@ FLX_HD inline void fm_step(FmConst const& C, FmLane& L, FR&& fr) {
         L.depth = 0;
         L.need_child = false;
         L.in_search = true;
-        if (!fm_begin_search(C, L)) { L.in_search = false; ++L.srch; return; }
+        if (!fm_begin_search(C, L)) { L.in_search = false; ++L.srch; if (L.srch >= L.num_searches) L.busy = false; return; }
     }
 
     // ---- the next child of the top frame becomes the node: children that cost an error first, the match child last
     if (L.need_child) {
-        if (L.depth == 0u) { L.in_search = false; ++L.srch; return; }        // search exhausted
+        if (L.depth == 0u) { L.in_search = false; ++L.srch; if (L.srch >= L.num_searches) L.busy = false; return; }        // search exhausted
         u32 const lv = L.depth - 1u;
         u32 const mask = fr(lv, 14);
         u32 const st = fr(lv, 13);

@@ -230,6 +230,8 @@ struct DeviceApi {
     // d_isa (n words) and d_filter (null: no filter) and sets idx.isa / filter / filter_k / filter_tmin
     static size_t derived_bytes(u64 n, u32* filter_k_out);
     static int derive_index(void* stream, DevIndex& idx, u32* d_isa, u64* d_filter);
+    // reserves the hardware queue's scratch for the pipeline's kernels (see scratch_warm_kernel)
+    static int warm_scratch(void* stream);
     // 2-bit form of a sequence pool (pack_words_for(len) words, flx_fm_core.hpp)
     static int pack_pool(void* stream, const u8* d_seq, u64 len, u32* d_qpack);
     // anchor selection on the device (see seed_select_kernel). d_seed_cnt, d_hit_offset, d_n_out, d_out_offset: n_seeds + 1 entries

@@ -83,6 +83,20 @@ int DeviceApi::derive_index(void* stream, DevIndex& idx, u32* d_isa, u64* d_filt
     return (int)hipGetLastError();
 }
 
+// A kernel that needs scratch (private segment) makes the runtime reserve it for the kernel's hardware queue when it is first launched
+// there; when HBM is full by then the runtime aborts the process. Launched once per lane when the context is made, this reserves what
+// the largest scratch user of the pipeline needs (seed_select_kernel<8>: 400 B per lane) while memory is still free.
+__global__ void __launch_bounds__(64) scratch_warm_kernel(u32* __restrict__ sink) {
+    volatile u32 a[128];
+    a[threadIdx.x & 127u] = threadIdx.x;
+    a[(threadIdx.x * 5u + 1u) & 127u] = 1u;
+    if (sink) *sink = a[(threadIdx.x * 7u) & 127u];
+}
+int DeviceApi::warm_scratch(void* stream) {
+    hipLaunchKernelGGL(scratch_warm_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (u32*)nullptr);
+    return (int)hipGetLastError();
+}
+
 int DeviceApi::pack_pool(void* stream, const u8* d_seq, u64 len, u32* d_qpack) {
     u64 const n_words = pack_words_for(len);
     hipLaunchKernelGGL(pack_pool_kernel, dim3((unsigned)((n_words + 255) / 256)), dim3(256), 0, (hipStream_t)stream, d_seq, len, d_qpack, n_words);
@@ -157,7 +171,7 @@ __device__ __forceinline__ u32 wave_slots_take(WaveSlots& S, DevHit* __restrict_
 
 __global__ void __launch_bounds__(64, 4) fm_search_filter_kernel(FmConst C, const DevSeed* __restrict__ seeds, u32 n_seeds, DevHit* __restrict__ hits,
                                                               u32 hit_cap, DevHit* __restrict__ items, u32 item_cap, u32* __restrict__ counters,
-                                                              u32* __restrict__ seed_cnt) {
+                                                              u32* __restrict__ seed_cnt, u32 refill) {
     extern __shared__ u32 lds[];                // frames: [level][FM_FRAME_WORDS][64 lanes]
     u32 const lane = s_lane_id();
     u64 const lanes_below = (1ull << lane) - 1ull;
@@ -187,9 +201,15 @@ __global__ void __launch_bounds__(64, 4) fm_search_filter_kernel(FmConst C, cons
                 L.out = FM_OUT_NONE;
             }
         }
-        // ---- seeds for the idle lanes
+        // ---- seeds for the idle lanes, and the start of the next search for the lanes between two searches - in batches. Taking a seed
+        //      and starting a search are chains of dependent loads (seed record, scheme entries, packed symbols, filter word, k-mer
+        //      table: ~7 us) that every lane of the wave waits for; a lane gets there every dozen iterations, so with 64 lanes some lane
+        //      is there in every iteration. Lanes at that point therefore wait until `refill` of them are, or no lane is inside a search.
         bool const want = !L.busy && !exhausted;
-        u64 const idle = __ballot(want);
+        bool const boundary = want || (L.busy && !L.in_search);
+        u64 const at_boundary = __ballot(boundary);
+        bool const go = (u32)__popcll(at_boundary) >= refill || !__any(L.busy && L.in_search);
+        u64 const idle = go ? __ballot(want) : 0ull;
         if (idle) {                                                     // wave-uniform
             u32 const k = wave_queue_take(Q, &counters[7], n_seeds, want, idle, lane, lanes_below);
             if (want) {
@@ -200,7 +220,7 @@ __global__ void __launch_bounds__(64, 4) fm_search_filter_kernel(FmConst C, cons
         if (__all(exhausted && !L.busy)) break;
         ++n_iter;
         if (Q.done && Q.next == Q.end) ++n_tail_iter;
-        if (!L.busy) continue;
+        if (!L.busy || (!go && !L.in_search)) continue;
         ++n_busy_iter;
         fm_step(C, L, fr);
     }
@@ -217,7 +237,8 @@ __global__ void __launch_bounds__(64, 4) fm_search_filter_kernel(FmConst C, cons
 }
 
 __global__ void __launch_bounds__(64) fm_search_text_kernel(FmConst C, const DevSeed* __restrict__ seeds, const DevHit* __restrict__ items, u32 item_cap,
-                                                            DevHit* __restrict__ hits, u32 hit_cap, u32* __restrict__ counters, u32* __restrict__ seed_cnt) {
+                                                            DevHit* __restrict__ hits, u32 hit_cap, u32* __restrict__ counters, u32* __restrict__ seed_cnt,
+                                                            u32 refill) {
     extern __shared__ u32 lds[];                // frames: [level][TX_FRAME_WORDS][64 lanes]
     u32 const lane = s_lane_id();
     u64 const lanes_below = (1ull << lane) - 1ull;
@@ -239,8 +260,10 @@ __global__ void __launch_bounds__(64) fm_search_text_kernel(FmConst C, const Dev
                 L.out = FM_OUT_NONE;
             }
         }
+        // (subtrees are handed out in batches too: a hand-out is three dependent loads - item, seed record, suffix array - for the whole wave)
         bool const want = !L.busy && !exhausted;
-        u64 const idle = __ballot(want);
+        u64 const wanting = __ballot(want);
+        u64 const idle = ((u32)__popcll(wanting) >= refill || !__any(L.busy)) ? wanting : 0ull;
         if (idle) {
             u32 const k = wave_queue_take(Q, &counters[17], n_slots, want, idle, lane, lanes_below);
             if (want) {
@@ -276,6 +299,7 @@ int DeviceApi::search_filtered(void* stream, const DevIndex& idx, const u8* d_se
     static u32 const forced_waves = env_u32("FLX_FM_MAX_WAVES", 0);
     u32 const no_filter = env_u32("FLX_FM_NO_FILTER", 0), no_text = env_u32("FLX_FM_NO_TEXT", 0);      // (read per call: tests switch them)
     u32 const text_min = env_u32("FLX_FM_TEXT_MIN", 2);
+    static u32 const refill_a = std::max(1u, std::min(64u, env_u32("FLX_FM_REFILL", 16))), refill_t = std::max(1u, std::min(64u, env_u32("FLX_FM_TEXT_REFILL", 16)));
     u32 const max_waves = forced_waves ? forced_waves : 4096u / std::max(1u, std::min(concurrent_launches, 8u));
     FmConst C{};
     C.idx = idx;
@@ -290,14 +314,14 @@ int DeviceApi::search_filtered(void* stream, const DevIndex& idx, const u8* d_se
     hipStream_t s = (hipStream_t)stream;
     dim3 const grid(std::min<u32>((n_seeds + spw - 1) / spw, max_waves));
     hipLaunchKernelGGL(fm_search_filter_kernel, grid, dim3(64), (size_t)C.levels * FM_FRAME_WORDS * 64 * sizeof(u32), s, C, d_seeds, n_seeds, d_hits, hit_cap,
-                       d_items, item_cap, d_counters, d_seed_cnt);
+                       d_items, item_cap, d_counters, d_seed_cnt, refill_a);
     if (C.text_min_remain) {
         // (the number of queued subtrees is only known on the device: a fixed grid, waves without work leave at once; the walk is a
         // chain of dependent loads from the L2, so it wants every wave slot: 8 per SIMD)
         static u32 const text_waves = env_u32("FLX_FM_TEXT_WAVES", 8192);
         u32 const tw = std::max(1u, text_waves / std::max(1u, std::min(concurrent_launches, 8u)));
         hipLaunchKernelGGL(fm_search_text_kernel, dim3(std::min<u32>(std::max<u32>(grid.x * 4u, 64u), tw)), dim3(64), (size_t)C.levels * TX_FRAME_WORDS * 64 * sizeof(u32), s, C,
-                           d_seeds, d_items, item_cap, d_hits, hit_cap, d_counters, d_seed_cnt);
+                           d_seeds, d_items, item_cap, d_hits, hit_cap, d_counters, d_seed_cnt, refill_t);
     }
     return (int)hipGetLastError();
 }
