@@ -1208,7 +1208,7 @@ __global__ void __launch_bounds__(64) ed_align_kernel(const u8* __restrict__ tex
 // starts late starts from the all-(+1) column, a group whose predecessor has finished receives horizontal delta +1: both only
 // over-estimate cells outside the band, every cell on a valid path (and the trace bits of its predecessors) stays exact.
 // Each carry word also hands the predecessor's bottom-row value down so that the last group knows D[m][c] absolutely.
-template <int W, bool TRACE>
+template <int W>
 __global__ void __launch_bounds__(64) ed_band_kernel(const u8* __restrict__ text, const u64* __restrict__ peq,
                                                      const DevAlignJob* __restrict__ jobs, u32 n_jobs, u32 log2_r,
                                                      u64* __restrict__ trace, DevAlignOut* __restrict__ out, u16* __restrict__ lastrow) {
@@ -1304,15 +1304,6 @@ __global__ void __launch_bounds__(64) ed_band_kernel(const u8* __restrict__ text
     int best = m, best_col = 0;
     u32 const last_shift = (u32)(m - 1) & 63u;
     int const w_last_of_last = (nw - 1) - (Lg - 1) * W;   // word of the last group that holds row m-1
-    // TRACE: nothing of the trace itself is stored. Per step and word the two carry bits entering the word from above are
-    // collected (16 steps per u32) and every TRACE_CKPT steps the lane's {vp, vn} are written out; ed_traceback_ckpt_kernel
-    // recomputes the trace words it needs from those (see TraceLayout).
-    TraceLayout const tl = ckpt_trace_layout(job.n, job.m, (u32)W, R);
-    u32* __restrict__ carry_out = reinterpret_cast<u32*>(reinterpret_cast<ulonglong2*>(trace) + job.trace_off);
-    ulonglong2* __restrict__ ckpt_out = reinterpret_cast<ulonglong2*>(trace) + job.trace_off + tl.carry_slots;
-    u32 cbits[W];
-#pragma unroll
-    for (int w = 0; w < W; ++w) cbits[w] = 0;
 
     for (u32 t = 0; t < t_max; ++t) {
         if ((t & 15u) == 0u) {
@@ -1332,12 +1323,6 @@ __global__ void __launch_bounds__(64) ed_band_kernel(const u8* __restrict__ text
             started = false;
             c = (int)t - g;
         }
-        if (TRACE && (t % TRACE_CKPT) == 0u && valid && t < my_steps) {
-            // state of the group this lane holds, before step t
-            ulonglong2* __restrict__ dst = ckpt_out + ((u64)(t / TRACE_CKPT) * R + p) * W;
-#pragma unroll
-            for (int w = 0; w < W; ++w) { ulonglong2 v; v.x = vp[w]; v.y = vn[w]; dst[w] = v; }
-        }
         u32 const cin_raw = (u32)__shfl((int)cout, (int)src_lane);
         bool const active = has_group && c >= c_lo && c <= c_hi;
         if (active) {
@@ -1352,10 +1337,8 @@ __global__ void __launch_bounds__(64) ed_band_kernel(const u8* __restrict__ text
             }
             const u64* __restrict__ eqp = &lds_eq[(sym * 64u + lane) * W];
             u64 hp_keep = 0, hn_keep = 0;                 // horizontal deltas of the word that holds row m-1 (last group only)
-            u32 const cshift = 2u * (t % TRACE_CARRY_STEPS);
 #pragma unroll
             for (int w = 0; w < W; ++w) {
-                if (TRACE) cbits[w] |= ((u32)c_hp | ((u32)c_hn << 1)) << cshift;
                 u64 const eq = eqp[w];
                 u64 const pv = vp[w], mv = vn[w];
                 u64 const x = eq | mv;
@@ -1376,23 +1359,10 @@ __global__ void __launch_bounds__(64) ed_band_kernel(const u8* __restrict__ text
             else {
                 bot += (int)((hp_keep >> last_shift) & 1ull) - (int)((hn_keep >> last_shift) & 1ull);
                 if (bot <= best) { best = bot; best_col = c + 1; }
-                if (TRACE && lastrow) lastrow[job.lastrow_off + (u64)c] = (u16)min(bot, 0xFFFF);
             }
             cout = ((u32)c_hp << 1) | ((u32)c_hn << 2) | ((u32)bot << 3);
         } else {
             cout = 2u;
-        }
-        if (TRACE && ((t % TRACE_CARRY_STEPS) == TRACE_CARRY_STEPS - 1u || t + 1u == t_max)) {
-            if (valid && t < my_steps + TRACE_CARRY_STEPS) {
-                u64 const blk = t / TRACE_CARRY_STEPS;
-                if (blk * TRACE_CARRY_STEPS < my_steps) {
-                    u32* __restrict__ dst = carry_out + (blk * R + p) * W;
-#pragma unroll
-                    for (int w = 0; w < W; ++w) dst[w] = cbits[w];
-                }
-            }
-#pragma unroll
-            for (int w = 0; w < W; ++w) cbits[w] = 0;
         }
     }
     if (valid && has_group && g == Lg - 1) {
@@ -1413,9 +1383,13 @@ __global__ void __launch_bounds__(64) ed_band_kernel(const u8* __restrict__ text
 // keeps going for the block in which the next group starts, whose start value D[last row of this group][column before that
 // block] travels with the carries.
 // (the jobs of one wave: group `blk` of 64 >> log2_r jobs)
-template <int W>
-__device__ __forceinline__ void ed_exists_block_body(const u8* __restrict__ text, const u64* __restrict__ peq, const DevAlignJob* __restrict__ jobs, u32 n_jobs,
-                                                     u32 log2_r, DevAlignOut* __restrict__ out, u32 blk, u64* __restrict__ lds_eq) {
+// TRACE (K4): per block-step T = b + g, ring lane and word the block's 16 pairs of carry bits that enter the word from above (one
+// u32) and the word's {vp, vn} before the block (one 16-byte slot) are written out (TraceLayout; ed_traceback_wave_kernel recomputes
+// any word's trace bits over any block from those), and the last group stores D[m][c] of its columns.
+template <int W, bool TRACE>
+__device__ __forceinline__ void ed_block_body(const u8* __restrict__ text, const u64* __restrict__ peq, const DevAlignJob* __restrict__ jobs, u32 n_jobs,
+                                              u32 log2_r, DevAlignOut* __restrict__ out, u32 blk, u64* __restrict__ lds_eq,
+                                              u64* __restrict__ trace, u16* __restrict__ lastrow) {
     u32 const lane = lane_id();
     u32 const R = 1u << log2_r;
     u32 const p = lane & (R - 1u);
@@ -1485,6 +1459,13 @@ __device__ __forceinline__ void ed_exists_block_body(const u8* __restrict__ text
     u32 const my_steps = valid ? (u32)(((n - 1) >> 4) + Lg) : 0u;
     u32 const t_max = wave_max_u32(my_steps);
     const u8* __restrict__ ref = text + job.ref_off;
+    u32* __restrict__ carry_out = nullptr;
+    ulonglong2* __restrict__ ckpt_out = nullptr;
+    if (TRACE) {
+        TraceLayout const tl = ckpt_trace_layout(job.n, job.m, (u32)W, R);
+        carry_out = reinterpret_cast<u32*>(reinterpret_cast<ulonglong2*>(trace) + job.trace_off);
+        ckpt_out = reinterpret_cast<ulonglong2*>(trace) + job.trace_off + tl.carry_slots;
+    }
 
     u32 cw_out = 0x55555555u;                             // what an idle lane hands down: horizontal +1 in every column
     int botv_out = 0;
@@ -1508,6 +1489,21 @@ __device__ __forceinline__ void ed_exists_block_body(const u8* __restrict__ text
             __builtin_memcpy(&tq, ref + 16 * b, 16);
             u32 const quad[4] = {tq.x, tq.y, tq.z, tq.w};
             u32 cw = 0;
+            u64 const slot = ((u64)T * R + p) * W;        // this lane's words at this block-step
+            u32 cbits[W];
+            u32 rowv[8];                                  // TRACE, last group: D[m][c] of the block's columns, two per word
+            if (TRACE) {
+#pragma unroll
+                for (int w = 0; w < W; ++w) {
+                    ulonglong2 v;
+                    v.x = vp[w];
+                    v.y = vn[w];
+                    ckpt_out[slot + w] = v;
+                    cbits[w] = 0;
+                }
+#pragma unroll
+                for (int q = 0; q < 8; ++q) rowv[q] = 0xFFFFFFFFu;
+            }
 #pragma unroll
             for (int qd = 0; qd < 4; ++qd) {
 #pragma unroll
@@ -1520,6 +1516,7 @@ __device__ __forceinline__ void ed_exists_block_body(const u8* __restrict__ text
                     const u64* __restrict__ eqp = &lds_eq[(sym * 64u + lane) * W];
 #pragma unroll
                     for (int w = 0; w < W; ++w) {
+                        if (TRACE) cbits[w] |= ((u32)c_hp | ((u32)c_hn << 1)) << (2 * j);
                         u64 const eq = eqp[w];
                         u64 const pv = vp[w], mv = vn[w];
                         u64 const x = eq | mv;
@@ -1536,6 +1533,20 @@ __device__ __forceinline__ void ed_exists_block_body(const u8* __restrict__ text
                     cw |= ((u32)c_hp | ((u32)c_hn << 1)) << (2 * j);
                     bot += (int)(u32)c_hp - (int)(u32)c_hn;       // the group's last row is its last word's bit 63
                     if (last && c < n && bot <= best) { best = bot; best_col = c + 1; }
+                    if (TRACE && c < n) {
+                        u32 const v16 = (u32)min(bot, 0xFFFF);
+                        rowv[j >> 1] = (j & 1) ? (rowv[j >> 1] & 0xFFFFu) | (v16 << 16) : (rowv[j >> 1] & 0xFFFF0000u) | v16;
+                    }
+                }
+            }
+            if (TRACE) {
+#pragma unroll
+                for (int w = 0; w < W; ++w) carry_out[slot + w] = cbits[w];
+                if (last && lastrow) {
+                    // (a job's last-row region starts at a multiple of 16 entries and covers whole blocks: 0xFFFF past column n)
+                    uint4* __restrict__ dst = reinterpret_cast<uint4*>(lastrow + job.lastrow_off + 16 * (u64)b);
+                    dst[0] = make_uint4(rowv[0], rowv[1], rowv[2], rowv[3]);
+                    dst[1] = make_uint4(rowv[4], rowv[5], rowv[6], rowv[7]);
                 }
             }
             cw_out = cw;
@@ -1564,7 +1575,17 @@ __global__ void __launch_bounds__(64) ed_exists_block_kernel(const u8* __restric
     extern __shared__ __attribute__((aligned(16))) u64 lds_eq[];
     if (n_jobs_dev) n_jobs = min(n_jobs, *n_jobs_dev);
     u32 const jobs_per_wave = 64u >> log2_r;
-    for (u32 blk = blockIdx.x; blk * jobs_per_wave < n_jobs; blk += gridDim.x) ed_exists_block_body<W>(text, peq, jobs, n_jobs, log2_r, out, blk, lds_eq);
+    for (u32 blk = blockIdx.x; blk * jobs_per_wave < n_jobs; blk += gridDim.x)
+        ed_block_body<W, false>(text, peq, jobs, n_jobs, log2_r, out, blk, lds_eq, nullptr, nullptr);
+}
+
+// K4: the same body with the checkpointed trace and the last rows written out, one wave per group of jobs
+template <int W>
+__global__ void __launch_bounds__(64) ed_trace_block_kernel(const u8* __restrict__ text, const u64* __restrict__ peq,
+                                                            const DevAlignJob* __restrict__ jobs, u32 n_jobs, u32 log2_r,
+                                                            u64* __restrict__ trace, DevAlignOut* __restrict__ out, u16* __restrict__ lastrow) {
+    extern __shared__ __attribute__((aligned(16))) u64 lds_eq[];
+    ed_block_body<W, true>(text, peq, jobs, n_jobs, log2_r, out, blockIdx.x, lds_eq, trace, lastrow);
 }
 
 static AlignShape choose_align_shape_uncached(u32 nw, i64 width, bool band, bool parallel) {
@@ -1642,7 +1663,13 @@ static int launch_align(hipStream_t s, const u8* d_text, const u64* d_peq, const
         hipLaunchKernelGGL((ed_exists_block_kernel<W>), dim3(blocks), dim3(64), lds_b, s, d_text, d_peq, d_jobs, n_jobs, log2_g, d_out, (const u32*)nullptr);
         return (int)hipGetLastError();
     }
-    if (banded) { if (trace) FLX_LAUNCH((ed_band_kernel<W, true>)); else FLX_LAUNCH((ed_band_kernel<W, false>)); }
+    if (banded && trace) {
+        size_t const lds_b = (size_t)7 * 64 * W * sizeof(u64);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ed_trace_block_kernel<W>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_b);
+        hipLaunchKernelGGL((ed_trace_block_kernel<W>), dim3(blocks), dim3(64), lds_b, s, d_text, d_peq, d_jobs, n_jobs, log2_g, d_trace, d_out, d_lastrow);
+        return (int)hipGetLastError();
+    }
+    if (banded) FLX_LAUNCH((ed_band_kernel<W>));
     else { if (trace) FLX_LAUNCH((ed_align_kernel<W, true>)); else FLX_LAUNCH((ed_align_kernel<W, false>)); }
 #undef FLX_LAUNCH
     return (int)hipGetLastError();
@@ -1827,22 +1854,21 @@ __global__ void __launch_bounds__(64) ed_traceback_kernel(const u8* __restrict__
 
 // ------------------------------------------------------------------------------------------------ K5: traceback over a checkpointed trace, one wave per job
 // The walk is serial, the recomputation of the trace is not: a path moves up its diagonal and drifts from it by one column per
-// indel only, so the (word, 16-step block) windows it is going to cross are known in advance. A round therefore recomputes 64
-// windows at once, one per lane: for each of the 8 words at and above the walker the 8 blocks around the steps the path's
-// current diagonal crosses in that word (exactly one checkpoint + one carry word + 16 steps each; the old form recomputed up to
-// 31 steps per window with one lane per job and all lanes of a wave waiting for each other). Then the wave walks: lane l looks at
-// cell (i - l, j - l), ballots give the stretch of diagonal moves up to the first indel, and the walk goes on until it needs a
-// window the round does not hold (the path drifted further than foreseen, or left the 8 words), which starts the next round from
-// where the walker stands. ~20 rounds for a 10-kb path instead of ~700 dependent window recomputations.
+// indel only, so the (word, 16-column block) windows it is going to cross are known in advance. A round therefore recomputes 64
+// windows at once, one per lane: for each of the 8 words at and above the walker the 8 blocks around the columns the path's
+// current diagonal crosses in that word (exactly one checkpoint + one carry word + 16 columns each). Then the wave walks: lane l
+// looks at cell (i - l, j - l), ballots give the stretch of diagonal moves up to the first indel, and the walk goes on until it
+// needs a window the round does not hold (the path drifted further than foreseen, or left the 8 words), which starts the next round
+// from where the walker stands. ~20 rounds for a 10-kb path.
+// Rows are in K4's coordinates: the query right-aligned in its groups, `pad` rows in front of row 1 (ed_block_body).
 constexpr u32 TBW_WORDS = 8, TBW_BLOCKS = 8;     // windows of a round: words x blocks = 64 lanes
 constexpr u32 TBW_REF = 1024;                    // reference symbols cached per round (columns)
 
 __global__ void __launch_bounds__(64) ed_traceback_wave_kernel(const u8* __restrict__ text, const u64* __restrict__ peq,
                                                                const u64* __restrict__ trace, const DevTraceJob* __restrict__ jobs,
                                                                u32 n_jobs, u32* __restrict__ cigar, DevTraceOut* __restrict__ out) {
-    static_assert(TRACE_CKPT == 16 && TRACE_CARRY_STEPS == 16, "a window is one checkpoint block");
-    __shared__ ulonglong2 win[64 * 17];              // [window * 17 + step % 16] = {hp, vp} of the window's word after that step (17: no bank conflicts)
-    __shared__ u32 win_valid[64];                    // bit s: step s of the window was computed
+    __shared__ ulonglong2 win[64 * 17];              // [window * 17 + column % 16] = {hp, vp} of the window's word after that column (17: no bank conflicts)
+    __shared__ u32 win_valid[64];                    // non-zero: the window was computed
     __shared__ u64 eqm[TBW_WORDS][6];                // equality masks of the round's words
     __shared__ u8 refs[TBW_REF];                     // reference symbols of columns [ref_base, ref_base + TBW_REF)
     u32 const id = blockIdx.x;
@@ -1854,6 +1880,9 @@ __global__ void __launch_bounds__(64) ed_traceback_wave_kernel(const u8* __restr
     int const W = (int)job.words_per_lane, R = (int)job.lanes;
     int const n = (int)job.n, m = (int)job.m, k = (int)job.k;
     int const band_hi = n - m + k;
+    int const nw = (max(m, 1) + 63) >> 6;
+    int const Lg = (nw + W - 1) / W;
+    int const pad = Lg * 64 * W - max(m, 1);
     TraceLayout const tl = ckpt_trace_layout(job.n, job.m ? job.m : 1u, (u32)W, (u32)R);
     const u32* __restrict__ carry = reinterpret_cast<const u32*>(reinterpret_cast<const ulonglong2*>(trace) + job.trace_off);
     const ulonglong2* __restrict__ ckpt = reinterpret_cast<const ulonglong2*>(trace) + job.trace_off + tl.carry_slots;
@@ -1872,21 +1901,20 @@ __global__ void __launch_bounds__(64) ed_traceback_wave_kernel(const u8* __restr
         cur_op = op;
         cur_len = len;
     };
-    // first block of word w's windows in a round that started on diagonal `diag` (column - row): the path crosses the word's rows
-    // 64w+1 .. 64w+64 at columns row + diag, i.e. steps 64w + diag + g .. 64w + 63 + diag + g
+    // first block of (padded) word w's windows in a round that started on diagonal `diag` (column - row): the path crosses the word's
+    // rows at columns 64w - pad + diag .. 64w - pad + 63 + diag (0-based)
     auto first_block = [&](int w, int diag) {
-        int const g = w / W;
-        int const t_lo = 64 * w + diag + g;
-        return (t_lo >= 0 ? t_lo / 16 : -((-t_lo + 15) / 16)) - 1;
+        int const c_lo = 64 * w - pad + diag;
+        return (c_lo >= 0 ? c_lo / 16 : -((-c_lo + 15) / 16)) - 1;
     };
 
     while (i > 0 && !overflow) {
         if (j == 0) { emit(1u, (u32)i); i = 0; break; }                 // only insertions remain
         // ---- a round: windows of words gw_top, gw_top-1, ... around the walker's diagonal
-        int const gw_top = (i - 1) >> 6;
+        int const gw_top = (i - 1 + pad) >> 6;
         int const diag = j - i;
         // columns the round can touch: from 64 * TBW_WORDS + 32 below the walker's to 16 * TBW_BLOCKS above it
-        int const ref_base = max(0, j - 640);
+        int const ref_base = max(0, j - 640) & ~15;
         __syncthreads();                                                // (one wave: orders this round's LDS writes after the last round's reads)
         for (u32 x = lane; x < TBW_REF; x += 64u) { int const c = ref_base + (int)x; refs[x] = c < n ? r[c] : (u8)7; }
         __syncthreads();
@@ -1895,46 +1923,49 @@ __global__ void __launch_bounds__(64) ed_traceback_wave_kernel(const u8* __restr
             u32 valid = 0;
             if (w >= 0) {
                 int const g = w / W, ww = w - g * W, p = g % R;
-                int const B = first_block(w, diag) + (int)(lane % TBW_BLOCKS);
-                int const r0 = 64 * W * g, r1 = min(m, r0 + 64 * W);
-                int const c_lo = max(0, r0 - k), c_hi = min(n - 1, r1 - 1 + band_hi);
-                int const t_first = c_lo + g, t_last = c_hi + g;
-                // equality masks of the word (the lane of the word's first window also keeps them for the walk)
+                int const b = first_block(w, diag) + (int)(lane % TBW_BLOCKS);
+                // the blocks group g is computed for (ed_block_body's enter_group)
+                int const r0 = max(0, 64 * W * g - pad), r1 = 64 * W * (g + 1) - pad;
+                int const b_lo = max(0, r0 - k) >> 4;
+                int b_hi = min(n - 1, r1 - 1 + band_hi) >> 4;
+                if (g + 1 < Lg) b_hi = max(b_hi, max(0, r1 - k) >> 4);
+                // equality masks of the word, padding rows included (the lane of the word's first window also keeps them for the walk)
                 u64 eq[6];
+                int const rs = 64 * w - pad;
+                u64 const padmask = rs <= -64 ? ~0ull : rs < 0 ? (1ull << (u32)(-rs)) - 1ull : 0ull;
                 {
-                    u64 const a = job.q_off >> 6;
-                    u32 const sh = (u32)(job.q_off & 63u);
-                    int const rows_left = m - w * 64;
+                    i64 const off = (i64)job.q_off + rs;
 #pragma unroll
                     for (u32 sy = 0; sy < 6; ++sy) {
-                        u64 const lo = peq[(a + (u64)w) * 6 + sy];
-                        u64 const hi = peq[(a + (u64)w + 1) * 6 + sy];
-                        u64 v = sh ? (lo >> sh) | (hi << (64 - sh)) : lo;
-                        if (rows_left < 64) v &= (1ull << rows_left) - 1ull;
-                        eq[sy] = v;
+                        u64 v = 0;
+                        if (rs > -64) {
+                            if (off >= 0) {
+                                u64 const a = (u64)off >> 6;
+                                u32 const sh = (u32)off & 63u;
+                                u64 const lo = peq[a * 6 + sy];
+                                u64 const hi = peq[(a + 1) * 6 + sy];
+                                v = sh ? (lo >> sh) | (hi << (64 - sh)) : lo;
+                            } else v = peq[sy] << (u32)(-off);
+                        }
+                        eq[sy] = v | padmask;
                     }
                     if (lane % TBW_BLOCKS == 0) {
 #pragma unroll
                         for (u32 sy = 0; sy < 6; ++sy) eqm[lane / TBW_BLOCKS][sy] = eq[sy];
                     }
                 }
-                // the steps of the block the group is active in; all of their columns must be in the symbol cache (a step left
-                // out in the middle would spoil the ones after it)
-                int const s_lo = max(16 * B, t_first), s_hi = min(16 * B + 15, t_last);
-                if (B >= 0 && s_lo <= s_hi && (u64)B * 16 < tl.steps && s_lo - g >= ref_base && s_hi - g < ref_base + (int)TBW_REF) {
-                    u64 pv = ~0ull, mv = 0ull;
-                    if (t_first <= 16 * B) {                            // the group was running before the block: its checkpoint
-                        ulonglong2 const v = ckpt[((u64)B * R + p) * W + ww];
-                        pv = v.x;
-                        mv = v.y;
-                    }
-                    u32 const cw = carry[((u64)B * R + p) * W + ww];
-                    for (int t = s_lo; t <= s_hi; ++t) {
-                        u32 const sidx = (u32)t & 15u;
+                // all 16 columns of the block must be in the symbol cache
+                if (b >= b_lo && b <= b_hi && 16 * b >= ref_base && 16 * b + 16 <= ref_base + (int)TBW_REF) {
+                    u64 const slot = ((u64)(b + g) * R + p) * W + ww;
+                    ulonglong2 const v = ckpt[slot];
+                    u64 pv = v.x, mv = v.y;
+                    u32 const cw = carry[slot];
+#pragma unroll 4
+                    for (u32 sidx = 0; sidx < 16u; ++sidx) {
                         u32 const cb = (cw >> (2u * sidx)) & 3u;
                         u64 const c_hp = cb & 1u, c_hn = cb >> 1;
-                        u32 const rsym = refs[t - g - ref_base] & 7u;
-                        u64 const e = rsym == 0 ? eq[0] : rsym == 1 ? eq[1] : rsym == 2 ? eq[2] : rsym == 3 ? eq[3] : rsym == 4 ? eq[4] : rsym == 5 ? eq[5] : 0ull;
+                        u32 const rsym = refs[16 * b + (int)sidx - ref_base] & 7u;
+                        u64 const e = rsym == 0 ? eq[0] : rsym == 1 ? eq[1] : rsym == 2 ? eq[2] : rsym == 3 ? eq[3] : rsym == 4 ? eq[4] : rsym == 5 ? eq[5] : padmask;
                         u64 const x_ = e | mv;
                         u64 const sum = pv + (x_ & pv) + c_hn;
                         u64 const d0 = (sum ^ pv) | x_;
@@ -1947,8 +1978,8 @@ __global__ void __launch_bounds__(64) ed_traceback_wave_kernel(const u8* __restr
                         o.x = hp;
                         o.y = pv;
                         win[lane * 17u + sidx] = o;
-                        valid |= 1u << sidx;
                     }
+                    valid = 1u;
                 }
             }
             win_valid[lane] = valid;
@@ -1963,18 +1994,17 @@ __global__ void __launch_bounds__(64) ed_traceback_wave_kernel(const u8* __restr
             bool have = false, up = false, left = false, same = false;
             if (in_range) {
                 int const ci = i - (int)lane, cj = j - (int)lane;
-                int const w = (ci - 1) >> 6;
-                u32 const bit = (u32)(ci - 1) & 63u;
-                int const g = w / W;
-                int const t = (cj - 1) + g;
+                int const w = (ci - 1 + pad) >> 6;
+                u32 const bit = (u32)(ci - 1 + pad) & 63u;
+                int const c = cj - 1;
                 int const wslot = gw_top - w;
-                int const bslot = (t >> 4) - first_block(w, diag);
-                int const col = cj - 1 - ref_base;
+                int const bslot = (c >> 4) - first_block(w, diag);
+                int const col = c - ref_base;
                 if (wslot < (int)TBW_WORDS && bslot >= 0 && bslot < (int)TBW_BLOCKS && col >= 0) {
                     u32 const slot = (u32)wslot * TBW_BLOCKS + (u32)bslot;
-                    if ((win_valid[slot] >> ((u32)t & 15u)) & 1u) {
+                    if (win_valid[slot]) {
                         have = true;
-                        ulonglong2 const v = win[slot * 17u + ((u32)t & 15u)];
+                        ulonglong2 const v = win[slot * 17u + ((u32)c & 15u)];
                         up = (v.y >> bit) & 1ull;
                         left = (v.x >> bit) & 1ull;
                         u32 const rsym = refs[col] & 7u;

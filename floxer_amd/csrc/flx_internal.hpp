@@ -176,12 +176,11 @@ struct Vr2Buffers {
 // launch geometry for one alignment job shape
 struct AlignShape { u32 words_per_lane; u32 lanes_per_job; u32 banded; };
 
-// Banded TRACE launches do not store the trace itself. Per (step, ring lane, word) they keep the two horizontal-delta bits that
-// enter the word from above (16 steps per u32), and every TRACE_CKPT steps the word's vertical delta vectors {vp, vn}. Any word's
-// trace bits over any step range can be recomputed from that by the traceback kernel (3.25 B instead of 48 B per step and lane).
-constexpr u32 TRACE_CARRY_STEPS = 16;   // steps per u32 of carry bits
-constexpr u32 TRACE_CKPT = 16;          // steps between two checkpoints
-struct TraceLayout { u64 steps, carry_words, carry_slots, ckpt_slots; };   // slots = 16-byte units; carry region first
+// Banded TRACE launches (K4) do not store the trace itself. A lane computes its word group 16 columns (one block) per step, group g
+// takes block b at block-step T = b + g; per (block-step, ring lane, word) the launch keeps the 16 pairs of horizontal-delta bits
+// that enter the word from above (one u32) and the word's vertical delta vectors {vp, vn} before the block (one 16-byte slot). Any
+// word's trace bits over any block are recomputed from those by the traceback kernel (1.25 B instead of 16 B per column and word).
+struct TraceLayout { u64 steps, carry_words, carry_slots, ckpt_slots; };   // steps = block-steps; slots = 16-byte units; carry region first
 #if defined(__HIPCC__)
 #define FLX_HD __host__ __device__
 #else
@@ -190,11 +189,10 @@ struct TraceLayout { u64 steps, carry_words, carry_slots, ckpt_slots; };   // sl
 FLX_HD inline TraceLayout ckpt_trace_layout(u32 n, u32 m, u32 W, u32 R) {
     u64 const nw = (m + 63u) / 64u, groups = (nw + W - 1) / W;
     TraceLayout l;
-    l.steps = (u64)n + groups - 1;
-    u64 const carry_blocks = (l.steps + TRACE_CARRY_STEPS - 1) / TRACE_CARRY_STEPS;
-    l.carry_words = carry_blocks * R * W;
+    l.steps = (n ? (u64)(n - 1) / 16 : 0) + groups;
+    l.carry_words = l.steps * R * W;
     l.carry_slots = (l.carry_words + 3) / 4;
-    l.ckpt_slots = ((l.steps + TRACE_CKPT - 1) / TRACE_CKPT) * R * W;
+    l.ckpt_slots = l.steps * R * W;
     return l;
 }
 // parallel = false: the shape that occupies the fewest wave slots (launches with many jobs); true: the shape with the shortest

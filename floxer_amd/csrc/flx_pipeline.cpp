@@ -1136,7 +1136,7 @@ int run_trace_jobs_union(Lane* ctx, const u8* d_text, const u8* d_query, const u
                 row_off[id - begin] = rows;
                 jobs.push_back(DevAlignJob{r.ref_off, r.q_off, off, r.n, r.m, r.k, (u32)(id - begin), rows});
                 off += slots[id];
-                rows += r.n;
+                rows += ((u64)r.n + 15) / 16 * 16;   // K4 stores a block's 16 last-row values as two 16-byte words
                 l.word_steps += job_word_steps(r.n, r.m, r.k, shapes[id]);
                 TraceLayout const tl = ckpt_trace_layout(r.n, r.m, shapes[id].words_per_lane, shapes[id].lanes_per_job);
                 l.bytes += (u64)r.n + r.m + (tl.carry_slots + tl.ckpt_slots) * 16 + 2ull * r.n;
