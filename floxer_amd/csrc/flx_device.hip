@@ -1470,6 +1470,29 @@ __device__ __forceinline__ void ed_block_body(const u8* __restrict__ text, const
     u32 cw_out = 0x55555555u;                             // what an idle lane hands down: horizontal +1 in every column
     int botv_out = 0;
     int bot = 0, best = m, best_col = 0;
+    // The reference symbols of a block are loaded one block-step ahead, and (TRACE) what a block writes is stored at the start of the
+    // lane's next block, in front of that load: the wait for the symbols at the top of a step then only covers memory operations issued a
+    // whole block of computation earlier (loads and stores share one counter and come back in order).
+    uint4 tq_pre = make_uint4(0, 0, 0, 0);
+    int pre_b = -1;                                       // tq_pre holds the symbols of block pre_b of this job (-1: nothing)
+    bool pend = false, pend_last = false;                 // TRACE: the carries (and last-row values) of the lane's previous block are still in registers
+    u64 pend_slot = 0;
+    int pend_b = 0;
+    u32 cbits[W];
+    u32 rowv[8];                                          // last group: D[m][c] of the block's columns, two per word
+    auto flush = [&]() {
+        if (TRACE && pend) {
+#pragma unroll
+            for (int w = 0; w < W; ++w) carry_out[pend_slot + w] = cbits[w];
+            if (pend_last && lastrow) {
+                // (a job's last-row region starts at a multiple of 16 entries and covers whole blocks: 0xFFFF past column n)
+                uint4* __restrict__ dst = reinterpret_cast<uint4*>(lastrow + job.lastrow_off + 16 * (u64)pend_b);
+                dst[0] = make_uint4(rowv[0], rowv[1], rowv[2], rowv[3]);
+                dst[1] = make_uint4(rowv[4], rowv[5], rowv[6], rowv[7]);
+            }
+            pend = false;
+        }
+    };
     for (u32 T = 0; T < t_max; ++T) {
         int b = (int)T - g;
         if (has_group && b > b_hi && g + (int)R < Lg) {   // this lane's group is finished: group g + R starts strictly later
@@ -1485,13 +1508,12 @@ __device__ __forceinline__ void ed_block_body(const u8* __restrict__ text, const
             if (b == b_lo) bot = botv_in + rows_g;        // column left of the window: all vertical deltas +1 below the group above
             int const bot_start = bot;
             bool const last = g == Lg - 1;
-            uint4 tq;
-            __builtin_memcpy(&tq, ref + 16 * b, 16);
+            uint4 tq = tq_pre;
+            if (pre_b != b) __builtin_memcpy(&tq, ref + 16 * b, 16);
             u32 const quad[4] = {tq.x, tq.y, tq.z, tq.w};
             u32 cw = 0;
             u64 const slot = ((u64)T * R + p) * W;        // this lane's words at this block-step
-            u32 cbits[W];
-            u32 rowv[8];                                  // TRACE, last group: D[m][c] of the block's columns, two per word
+            flush();
             if (TRACE) {
 #pragma unroll
                 for (int w = 0; w < W; ++w) {
@@ -1504,6 +1526,7 @@ __device__ __forceinline__ void ed_block_body(const u8* __restrict__ text, const
 #pragma unroll
                 for (int q = 0; q < 8; ++q) rowv[q] = 0xFFFFFFFFu;
             }
+            if (b < b_hi) { __builtin_memcpy(&tq_pre, ref + 16 * (b + 1), 16); pre_b = b + 1; }
 #pragma unroll
             for (int qd = 0; qd < 4; ++qd) {
 #pragma unroll
@@ -1539,16 +1562,7 @@ __device__ __forceinline__ void ed_block_body(const u8* __restrict__ text, const
                     }
                 }
             }
-            if (TRACE) {
-#pragma unroll
-                for (int w = 0; w < W; ++w) carry_out[slot + w] = cbits[w];
-                if (last && lastrow) {
-                    // (a job's last-row region starts at a multiple of 16 entries and covers whole blocks: 0xFFFF past column n)
-                    uint4* __restrict__ dst = reinterpret_cast<uint4*>(lastrow + job.lastrow_off + 16 * (u64)b);
-                    dst[0] = make_uint4(rowv[0], rowv[1], rowv[2], rowv[3]);
-                    dst[1] = make_uint4(rowv[4], rowv[5], rowv[6], rowv[7]);
-                }
-            }
+            if (TRACE) { pend = true; pend_last = last; pend_slot = slot; pend_b = b; }
             cw_out = cw;
             botv_out = bot_start;
         } else {
@@ -1556,6 +1570,7 @@ __device__ __forceinline__ void ed_block_body(const u8* __restrict__ text, const
             botv_out = 0;
         }
     }
+    flush();
     if (valid && has_group && g == Lg - 1) {
         DevAlignOut o;
         o.score = best <= k ? (u32)best : 0xFFFFFFFFu;
