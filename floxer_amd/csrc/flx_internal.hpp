@@ -163,6 +163,7 @@ enum : u8 { VR_CLIMBING = 0, VR_DEAD = 1, VR_AT_ROOT = 2, VR_SOLO = 3 };      //
 // two 64-bit running sums for the accounting (word-steps and sequence bytes of the jobs so far), requests so far (anchors in rounds),
 // blocks of vr2_apply that have finished
 enum : u32 { VR2_N_JOBS = 0 /* and 1: by the round's parity */, VR2_N_CLIMBING = 2, VR2_SMALLEST = 3, VR2_WORD_STEPS = 4, VR2_BYTES = 6, VR2_N_REQ = 8, VR2_DONE = 9,
+             VR2_QUEUE = 10 /* job queue head of the lane-per-job existence kernel */, VR2_QUEUE_ERR = 11 /* windows its buffers did not hold */,
              VR2_SCALARS = 16 };
 struct Vr2Buffers {
     const DevVrAnchor* anchors; const DevVrNode* nodes;
@@ -248,6 +249,13 @@ struct DeviceApi {
     // flx_rounds.hip: a round = vr2_request (job list and count on the device), align_exists_counted on it, vr2_apply
     static int vr2_request(void* stream, Vr2Buffers const& B, u32 n_queries, u32 limit, u32 acct_words, u32 width_cap, u32 parity);
     static int vr2_apply(void* stream, Vr2Buffers const& B, u32 n_anchors, u32* host_scalars);
+    // existence tests, one lane per job with Ukkonen's cutoff (flx_lanes.hip): at most `waves` waves take the jobs from a queue (*d_queue = 0
+    // at the start, d_queue[1] counts jobs whose windows the rows did not hold); d_n_jobs (optional): the number of jobs is on the device
+    // (at most max_jobs); cap_blocks >= (64 + n - m + 2k) / 16 + 3 of every job, exists_lane_lds_bytes(cap_blocks) <= 160 KB;
+    // d_stats (optional): 8 x u64 counters
+    static size_t exists_lane_lds_bytes(u32 cap_blocks);
+    static int align_exists_lanes(void* stream, const u8* d_text, const u64* d_peq, const DevAlignJob* d_jobs, u32 max_jobs, const u32* d_n_jobs,
+                                  u32* d_queue, u32 waves, u32 cap_blocks, DevAlignOut* d_out, unsigned long long* d_stats);
     static int align_exists_counted(void* stream, const u8* d_text, const u64* d_peq, const DevAlignJob* d_jobs, u32 max_jobs, const u32* d_n_jobs,
                                     AlignShape shape, u32 max_waves, DevAlignOut* d_out);
     static AlignShape shape_holding(u32 nw, i64 width, bool parallel);

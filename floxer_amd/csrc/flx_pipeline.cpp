@@ -94,14 +94,14 @@ hipEvent_t Lane::get_event() {
 hvec<DeviceBuffer*> lane_workspaces(Lane& l) {
     return {&l.seq, &l.seq_rev, &l.peq, &l.peq_rev, &l.scheme, &l.seeds, &l.stack, &l.hits, &l.counters, &l.rows, &l.rows_out, &l.jobs,
             &l.job_out, &l.trace, &l.tjobs, &l.tjob_out, &l.cigar, &l.user_text, &l.user_text_rev, &l.lastrow, &l.row_windows, &l.row_out,
-            &l.seed_cnt, &l.hit_off, &l.grouped, &l.sel_stat, &l.sel_n, &l.sel_off, &l.sel_out, &l.sel_tmp, &l.sel_rows, &l.sel_row_off, &l.sel_sparse, &l.sel_lists, &l.vr, &l.vr_override,
+            &l.seed_cnt, &l.hit_off, &l.grouped, &l.sel_stat, &l.sel_n, &l.sel_off, &l.sel_out, &l.sel_tmp, &l.sel_rows, &l.sel_row_off, &l.sel_sparse, &l.sel_lists, &l.vr, &l.lane_rows,
             &l.qpack, &l.items};
 }
 // FLX_ALLOC_DEBUG: the address ranges of a lane's workspaces (a GPU memory fault reports an address)
 static void dump_lane_buffers(Lane& l, const char* when) {
     static const char* const names[] = {"seq", "seq_rev", "peq", "peq_rev", "scheme", "seeds", "stack", "hits", "counters", "rows", "rows_out", "jobs", "job_out",
         "trace", "tjobs", "tjob_out", "cigar", "user_text", "user_text_rev", "lastrow", "row_windows", "row_out", "seed_cnt", "hit_off", "grouped", "sel_stat",
-        "sel_n", "sel_off", "sel_out", "sel_tmp", "sel_rows", "sel_row_off", "sel_sparse", "sel_lists", "vr", "vr_override", "qpack", "items"};
+        "sel_n", "sel_off", "sel_out", "sel_tmp", "sel_rows", "sel_row_off", "sel_sparse", "sel_lists", "vr", "lane_rows", "qpack", "items"};
     auto const ws = lane_workspaces(l);
     for (size_t i = 0; i < ws.size(); ++i)
         if (ws[i]->ptr) fprintf(stderr, "[flx alloc] lane %d %s %s %p .. %p\n", l.id, when, names[i], ws[i]->ptr, (void*)((char*)ws[i]->ptr + ws[i]->cap));
@@ -837,12 +837,62 @@ int choose_shapes(hvec<AlignRequest> const& reqs, hvec<AlignShape>& shapes) {
     return FLX_OK;
 }
 
+// The lane-per-job existence kernel (flx_lanes.hip) unless FLX_EXISTS_RING is set (the ring form of flx_device.hip, for comparisons)
+static bool exists_lane_form() { return getenv("FLX_EXISTS_RING") == nullptr; }
+// its waves and the blocks its per-lane rows hold for windows of at most `width` diagonals (n - m + 2k); false: the rows would not fit the LDS
+static bool exists_lane_setup(u64 max_jobs, i64 width, u32& waves, u32& cap_blocks) {
+    cap_blocks = (u32)((64 + std::max<i64>(width, 0)) / 16 + 3) | 1u;                   // (odd: the lanes' rows start in different banks)
+    static u32 const max_waves = [] { const char* e = getenv("FLX_EXISTS_LANE_WAVES"); return (u32)(e ? std::max(1, atoi(e)) : 4096); }();
+    waves = (u32)std::max<u64>(std::min<u64>(max_waves, (max_jobs + 63) / 64), 1);
+    return DeviceApi::exists_lane_lds_bytes(cap_blocks) <= 150 * 1024;
+}
+
 // score + end column for every (distinct) request (no trace)
 int run_score_jobs_unique(Lane* ctx, const u8* d_text, const u64* d_peq, hvec<AlignRequest> const& reqs,
                           hvec<DevAlignOut>& outs, const char* kernel_name) {
     outs.assign(reqs.size(), DevAlignOut{0xFFFFFFFFu, 0});
     if (reqs.empty()) return FLX_OK;
     PhaseTimer jprof("score-jobs");
+    i64 lane_width = 0;
+    for (auto const& r : reqs) lane_width = std::max<i64>(lane_width, (i64)r.n - (i64)r.m + 2 * (i64)r.k);
+    u32 waves = 0, cap_blocks = 0;
+    if (exists_lane_form() && choose_align_shape(reqs[0].n, reqs[0].m, reqs[0].k).banded && exists_lane_setup(reqs.size(), lane_width, waves, cap_blocks)) {
+        // one launch for every shape: a lane per job
+        hvec<DevAlignJob> jobs(reqs.size());
+        u64 steps = 0, bytes = 0;
+        for (u32 i = 0; i < reqs.size(); ++i) {
+            AlignRequest const& r = reqs[i];
+            if (r.m > align_supported_max_query()) { set_error("query longer than the supported maximum"); return FLX_ERR_UNSUPPORTED; }
+            jobs[i] = DevAlignJob{r.ref_off, r.q_off, 0, r.n, r.m, r.k, i, 0};
+            steps += job_word_steps(r.n, r.m, r.k, AlignShape{1, 1, 1});
+            bytes += (u64)r.n + r.m;
+        }
+        int rc;
+        if ((rc = h2d(ctx, ctx->jobs, jobs.data(), jobs.size() * sizeof(DevAlignJob)))) return rc;
+        if ((rc = ctx->job_out.ensure(reqs.size() * sizeof(DevAlignOut)))) return rc;
+        if ((rc = ctx->counters.ensure(128))) return rc;
+        FLX_HIP(hipMemsetAsync(ctx->counters.ptr, 0, 128, ctx->stream));
+        rc = timed_launch(ctx, kernel_name, bytes, steps, [&] {
+            return DeviceApi::align_exists_lanes(ctx->stream, d_text, d_peq, ctx->jobs.as<DevAlignJob>(), (u32)jobs.size(), nullptr, ctx->counters.as<u32>(),
+                                                 waves, cap_blocks, ctx->job_out.as<DevAlignOut>(),
+                                                 getenv("FLX_ALIGN_DEBUG") ? (unsigned long long*)((char*)ctx->counters.ptr + 64) : nullptr);
+        });
+        if (rc) return rc;
+        u32 cnt[32];
+        if ((rc = d2h(ctx, outs.data(), ctx->job_out.ptr, reqs.size() * sizeof(DevAlignOut)))) return rc;
+        if ((rc = d2h(ctx, cnt, ctx->counters.ptr, 128))) return rc;
+        jprof.mark("launch");
+        rc = ctx->sync();
+        jprof.mark("wait");
+        if (rc) return rc;
+        if (cnt[1]) { set_error("existence tests: a window did not fit the row buffers"); return FLX_ERR_INTERNAL; }
+        if (getenv("FLX_ALIGN_DEBUG")) {
+            unsigned long long st[8];
+            memcpy(st, (char*)cnt + 64, sizeof(st));
+            fprintf(stderr, "[%s lanes] jobs %zu waves %u cap %u: blocks %llu, wave iterations %llu, lane iterations %llu, groups %llu\n", kernel_name, jobs.size(), waves, cap_blocks, st[0], st[1], st[2], st[3]);
+        }
+        return FLX_OK;
+    }
     std::map<ShapeKey, hvec<u32>> by_shape;
     {
         hvec<AlignShape> shapes;
@@ -1895,6 +1945,11 @@ int align_slice(Lane* lane, const flx_params* P, const flx_reads* RD, u64 first_
         vprof.mark("upload");
         u64 const few_waves = align_few_waves();
         u64 prev_jobs = n_climbing / 2, acc_steps = 0, acc_bytes = 0, acc_req = 0;
+        unsigned long long* lane_stats = nullptr;               // FLX_ALIGN_DEBUG: the lane-per-job kernel's counters, per round
+        if (getenv("FLX_ALIGN_DEBUG")) {
+            if ((rc = lane->counters.ensure(128))) return rc;
+            lane_stats = (unsigned long long*)((char*)lane->counters.ptr + 64);
+        }
         for (u32 round = 0; n_climbing > 0; ++round) {
             u64 const limit = (u64)smallest * round_span_percent() / 100;
             // One launch shape for the round: the cheapest that holds the window of every node in the round's size class, or the one
@@ -1914,11 +1969,19 @@ int align_slice(Lane* lane, const flx_params* P, const flx_reads* RD, u64 first_
             // its own, or when the ring's lanes are free again before their next group starts: 64 W (R - 1) + R + 1 > diagonals)
             u64 const cap = (nw_max + shape.words_per_lane - 1) / shape.words_per_lane <= shape.lanes_per_job
                                 ? 0xFFFFFFFFull : 64ull * shape.words_per_lane * (shape.lanes_per_job - 1) + shape.lanes_per_job;
-            int const e1 = DeviceApi::vr2_request(lane->stream, B, n_queries, (u32)std::min<u64>(limit, 0xFFFFFFFFu), shape.words_per_lane,
-                                                  (u32)std::min<u64>(cap, 0xFFFFFFFFull), round);
-            if (e1) { set_error(std::string("verification round: ") + hipGetErrorString((hipError_t)e1)); return FLX_ERR_NO_DEVICE; }
+            // (the lane-per-job kernel holds any window its row buffers hold: unions up to the ring shape's cap, or eight windows' width)
+            u32 lane_waves = 0, lane_cap = 0;
             u32 const max_jobs = (u32)std::min<u64>(2ull * n_climbing, 2ull * n);
+            u64 const lane_width_cap = std::min<u64>(cap, std::max<u64>(8 * (u64)width_max, 1024));
+            bool const lane_form = exists_lane_form() && shape.banded && exists_lane_setup(max_jobs, (i64)std::max<u64>(lane_width_cap, (u64)width_max), lane_waves, lane_cap);
+            u64 const width_cap = lane_form ? lane_width_cap : cap;
+            int const e1 = DeviceApi::vr2_request(lane->stream, B, n_queries, (u32)std::min<u64>(limit, 0xFFFFFFFFu), shape.words_per_lane,
+                                                  (u32)std::min<u64>(width_cap, 0xFFFFFFFFull), round);
+            if (e1) { set_error(std::string("verification round: ") + hipGetErrorString((hipError_t)e1)); return FLX_ERR_NO_DEVICE; }
             rc = timed_launch(lane, "ed_align_exists", 0, 0, [&] {
+                if (lane_form)
+                    return DeviceApi::align_exists_lanes(lane->stream, d_text, d_peq, B.jobs, max_jobs, B.scalars + VR2_N_JOBS + (round & 1u), B.scalars + VR2_QUEUE,
+                                                         lane_waves, lane_cap, B.outs, lane_stats);
                 return DeviceApi::align_exists_counted(lane->stream, d_text, d_peq, B.jobs, max_jobs, B.scalars + VR2_N_JOBS + (round & 1u), shape, 8192u, B.outs);
             });
             if (rc) return rc;
@@ -1927,6 +1990,7 @@ int align_slice(Lane* lane, const flx_params* P, const flx_reads* RD, u64 first_
             if ((rc = lane->sync())) return rc;
             u32 sc[VR2_SCALARS];
             memcpy(sc, lane->vr_host_scalars, sizeof(sc));            // (left there by the last block of vr2_apply)
+            if (sc[VR2_QUEUE_ERR]) { set_error("existence tests: a window did not fit the row buffers"); return FLX_ERR_INTERNAL; }
             u64 ws, by;
             memcpy(&ws, &sc[VR2_WORD_STEPS], 8);
             memcpy(&by, &sc[VR2_BYTES], 8);
@@ -1936,10 +2000,18 @@ int align_slice(Lane* lane, const flx_params* P, const flx_reads* RD, u64 first_
                 if (it != ctx->stats.end()) { it->second.algorithmic_bytes += by - acc_bytes; it->second.work_units += ws - acc_steps; }
             }
             u64 const round_req = sc[VR2_N_REQ] - acc_req;
+            u64 const round_ws = ws - acc_steps;
             acc_steps = ws; acc_bytes = by; acc_req = sc[VR2_N_REQ];
             n_inner_requested += round_req;
             if (round_req == 0 && sc[VR2_N_CLIMBING] >= n_climbing) { set_error("verification rounds do not advance"); return FLX_ERR_INTERNAL; }
             prev_jobs = sc[VR2_N_JOBS + (round & 1u)];
+            if (lane_stats) {
+                unsigned long long st[8];
+                FLX_HIP(hipMemcpy(st, lane_stats, sizeof(st), hipMemcpyDeviceToHost));
+                FLX_HIP(hipMemset(lane_stats, 0, sizeof(st)));
+                fprintf(stderr, "[exists round %u] rows %u..%llu jobs %llu waves %u cap %u: blocks %llu, wave iterations %llu (x64 = %llu), lane iterations %llu, groups %llu; word-steps %llu\n", round, smallest,
+                        (unsigned long long)limit, (unsigned long long)prev_jobs, lane_waves, lane_cap, st[0], st[1], st[1] * 64, st[2], st[3], (unsigned long long)round_ws);
+            }
             n_climbing = sc[VR2_N_CLIMBING];
             smallest = sc[VR2_SMALLEST];
             vprof.mark("round");

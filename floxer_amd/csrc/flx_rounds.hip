@@ -66,6 +66,7 @@ __global__ void __launch_bounds__(VR2_THREADS) vr2_request_kernel(Vr2Buffers B, 
     if (q == 0 && tid == 0) {
         B.scalars[VR2_N_CLIMBING] = 0u; B.scalars[VR2_SMALLEST] = 0xFFFFFFFFu; B.scalars[VR2_DONE] = 0u;      // vr2_apply counts into them
         B.scalars[VR2_N_JOBS + (parity ^ 1u)] = 0u;                                                         // the next round's job counter
+        B.scalars[VR2_QUEUE] = 0u;                                                                          // this round's existence kernel starts at job 0
     }
     u32 const a0 = B.q_first[q], a1 = B.q_first[q + 1];
     u32* const n_jobs = &B.scalars[VR2_N_JOBS + parity];

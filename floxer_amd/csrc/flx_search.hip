@@ -171,8 +171,11 @@ __device__ __forceinline__ u32 wave_slots_take(WaveSlots& S, DevHit* __restrict_
 
 __global__ void __launch_bounds__(64, 4) fm_search_filter_kernel(FmConst C, const DevSeed* __restrict__ seeds, u32 n_seeds, DevHit* __restrict__ hits,
                                                               u32 hit_cap, DevHit* __restrict__ items, u32 item_cap, u32* __restrict__ counters,
-                                                              u32* __restrict__ seed_cnt, u32 refill) {
+                                                              u32* __restrict__ seed_cnt, u32 refill, u32 prio) {
     extern __shared__ u32 lds[];                // frames: [level][FM_FRAME_WORDS][64 lanes]
+    if (prio == 3u) __builtin_amdgcn_s_setprio(3);
+    else if (prio == 2u) __builtin_amdgcn_s_setprio(2);
+    else if (prio == 1u) __builtin_amdgcn_s_setprio(1);
     u32 const lane = s_lane_id();
     u64 const lanes_below = (1ull << lane) - 1ull;
     auto fr = [&](u32 level, u32 word) -> u32& { return lds[(level * FM_FRAME_WORDS + word) * 64u + lane]; };
@@ -238,8 +241,11 @@ __global__ void __launch_bounds__(64, 4) fm_search_filter_kernel(FmConst C, cons
 
 __global__ void __launch_bounds__(64) fm_search_text_kernel(FmConst C, const DevSeed* __restrict__ seeds, const DevHit* __restrict__ items, u32 item_cap,
                                                             DevHit* __restrict__ hits, u32 hit_cap, u32* __restrict__ counters, u32* __restrict__ seed_cnt,
-                                                            u32 refill) {
+                                                            u32 refill, u32 prio) {
     extern __shared__ u32 lds[];                // frames: [level][TX_FRAME_WORDS][64 lanes]
+    if (prio == 3u) __builtin_amdgcn_s_setprio(3);
+    else if (prio == 2u) __builtin_amdgcn_s_setprio(2);
+    else if (prio == 1u) __builtin_amdgcn_s_setprio(1);
     u32 const lane = s_lane_id();
     u64 const lanes_below = (1ull << lane) - 1ull;
     auto fr = [&](u32 level, u32 word) -> u32& { return lds[(level * TX_FRAME_WORDS + word) * 64u + lane]; };
@@ -311,17 +317,18 @@ int DeviceApi::search_filtered(void* stream, const DevIndex& idx, const u8* d_se
     static u32 const looks = env_u32("FLX_FM_LOOKS", 2);
     C.use_filter = (idx.filter && d_qpack && !no_filter) ? std::max(1u, std::min(2u, looks)) : 0u;
     C.text_min_remain = (d_items && item_cap && idx.isa && !no_text) ? std::max(1u, text_min) : 0u;
+    static u32 const fm_prio = env_u32("FLX_FM_PRIO", 0);         // wave priority of the walks (0..3) on SIMDs shared with other kernels
     hipStream_t s = (hipStream_t)stream;
     dim3 const grid(std::min<u32>((n_seeds + spw - 1) / spw, max_waves));
     hipLaunchKernelGGL(fm_search_filter_kernel, grid, dim3(64), (size_t)C.levels * FM_FRAME_WORDS * 64 * sizeof(u32), s, C, d_seeds, n_seeds, d_hits, hit_cap,
-                       d_items, item_cap, d_counters, d_seed_cnt, refill_a);
+                       d_items, item_cap, d_counters, d_seed_cnt, refill_a, fm_prio);
     if (C.text_min_remain) {
         // (the number of queued subtrees is only known on the device: a fixed grid, waves without work leave at once; the walk is a
         // chain of dependent loads from the L2, so it wants every wave slot: 8 per SIMD)
         static u32 const text_waves = env_u32("FLX_FM_TEXT_WAVES", 8192);
         u32 const tw = std::max(1u, text_waves / std::max(1u, std::min(concurrent_launches, 8u)));
         hipLaunchKernelGGL(fm_search_text_kernel, dim3(std::min<u32>(std::max<u32>(grid.x * 4u, 64u), tw)), dim3(64), (size_t)C.levels * TX_FRAME_WORDS * 64 * sizeof(u32), s, C,
-                           d_seeds, d_items, item_cap, d_hits, hit_cap, d_counters, d_seed_cnt, refill_t);
+                           d_seeds, d_items, item_cap, d_hits, hit_cap, d_counters, d_seed_cnt, refill_t, fm_prio);
     }
     return (int)hipGetLastError();
 }

@@ -13,7 +13,7 @@ ev = [(s, min(e, t_end), k) for s, e, k in ev if s < t_end]
 ev = [(max(s, t0), e, k) for s, e, k in ev if e > t0]
 span = t_end - t0
 def family(k):
-    for f in ("fm_search_filter", "fm_search_text", "fm_search", "ed_band_kernel", "ed_exists_block", "ed_align_kernel", "ed_traceback", "seed_select", "seed_rows", "hit_scatter",
+    for f in ("fm_search_filter", "fm_search_text", "fm_search", "ed_trace_block", "ed_exists_lane", "ed_band_kernel", "ed_exists_block", "ed_align_kernel", "ed_traceback", "seed_select", "seed_rows", "hit_scatter",
               "vr2_request", "vr2_apply", "vr_", "lastrow", "rocprim", "hipcub", "fillBuffer", "copyBuffer", "peq_build", "pack_pool", "seed_compact"):
         if f in k: return f
     return "other"

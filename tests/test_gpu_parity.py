@@ -577,9 +577,10 @@ def test_root_unions_and_their_fallback():
 
 
 def test_existence_kernel_forms_give_the_same_records():
-    """the existence tests run 16 columns per step (ed_exists_block_kernel) by default and one column per step (ed_band_kernel) with
-    FLX_EXISTS_STEPWISE=1; the switch is read once per process, so the second form runs in a child: same records, both equal to
-    the oracle's, on reads whose trees reach every launch shape of the lower levels and the ring-scheduled upper ones"""
+    """the existence tests run one lane per job with Ukkonen's cutoff (ed_exists_lane_kernel) by default, as a ring of lanes per job over
+    the static band 16 columns per step with FLX_EXISTS_RING=1 (ed_exists_block_kernel) and one column per step with FLX_EXISTS_STEPWISE=1
+    on top (ed_band_kernel); the switches are read once per process, so the other forms run in children: same records, all equal to the
+    oracle's, on reads whose trees reach every launch shape of the lower levels and the ring-scheduled upper ones"""
     import subprocess, sys, json
     genome = S.make_genome(500000, 2, seed=161)
     reads, _, _ = S.make_reads(genome, 24, 6000, 0.08, seed=162)
@@ -591,8 +592,82 @@ def test_existence_kernel_forms_give_the_same_records():
             "g = S.make_genome(500000, 2, seed=161); r, _, _ = S.make_reads(g, 24, 6000, 0.08, seed=162);"
             "c = F.context(F.fmindex(g)); print(json.dumps(F.aligner(c, F.params(error_probability=0.08)).align_reads(r).records()))"
             % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-    out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, FLX_EXISTS_STEPWISE="1"), capture_output=True, text=True, check=True)
-    assert [tuple(r) for r in json.loads(out.stdout.strip().split("\n")[-1])] == exp.records()
+    for env in ({"FLX_EXISTS_RING": "1"}, {"FLX_EXISTS_RING": "1", "FLX_EXISTS_STEPWISE": "1"}):
+        out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env), capture_output=True, text=True, check=True)
+        assert [tuple(r) for r in json.loads(out.stdout.strip().split("\n")[-1])] == exp.records(), env
+
+
+def test_existence_with_cutoff_matches_oracle(small_genome):
+    """ed_exists_lane_kernel against the oracle's Myers on what the cutoff has to get right: several occurrences in one window (tandem
+    repeats with periods around the group height, a second occurrence far to the right of the first), budgets from 0 to more than the
+    query is long, low-complexity sequence (every diagonal alive), occurrences at either edge of the window, windows shorter than the
+    query, N runs; ragged sizes across word-group boundaries in one launch"""
+    _, _, ctx, _ = small_genome
+    rng = np.random.default_rng(77)
+    refs, queries, jobs = [], [], []
+    ro = qo = 0
+
+    def add(ref, q, k):
+        nonlocal ro, qo
+        ref = np.asarray(ref, np.uint8)
+        q = np.asarray(q, np.uint8)
+        jobs.append((ro, len(ref), qo, len(q), int(k), 0))
+        refs.append(ref)
+        queries.append(q)
+        ro += len(ref)
+        qo += len(q)
+
+    for m in (1, 5, 63, 64, 65, 128, 130, 190, 257, 400, 640, 1000, 1500, 2300):
+        for err in (0.0, 0.05, 0.12, 0.3):
+            ref, q = _rand_align_case(rng, m, err, int(rng.integers(0, m // 2 + 40)))
+            for k in sorted({0, int(m * err * 0.6), int(m * err) + 1, int(m * 0.1) + 2, int(m * 0.3) + 1, m + 3}):
+                add(ref, q, k)
+        # tandem repeats: the query is a few copies of a unit, the window many more of them (an occurrence every `period` columns)
+        for period in (7, 50, 64, 100, 150, 333):
+            unit = rng.integers(1, 5, size=period).astype(np.uint8)
+            q = np.tile(unit, m // period + 2)[:m]
+            mut = q.copy()
+            flip = rng.random(m) < 0.04
+            mut[flip] = (mut[flip] % 4 + 1).astype(np.uint8)
+            ref = np.tile(unit, (2 * m) // period + 6)
+            add(ref, mut, int(m * 0.06) + 1)
+            add(ref, mut, int(m * 0.02))
+        # two occurrences far apart, the better one second; and one at either edge
+        ref1, q = _rand_align_case(rng, m, 0.10, 0)
+        ref2, _ = _rand_align_case(rng, m, 0.0, 0)
+        ref2 = np.array([c for c in q], np.uint8)          # exact copy
+        gap = rng.integers(1, 5, size=3 * m + 50).astype(np.uint8)
+        add(np.concatenate([ref1, gap, ref2]), q, int(m * 0.12) + 1)
+        add(np.concatenate([ref2, gap, ref1]), q, int(m * 0.12) + 1)
+        add(np.concatenate([gap, ref2]), q, 2)
+        add(np.concatenate([ref2, gap]), q, 2)
+        # low complexity and N runs
+        add((rng.integers(0, 2, size=m + 60) + 1).astype(np.uint8), (rng.integers(0, 2, size=m) + 1).astype(np.uint8), int(m * 0.2) + 1)
+        rn, qn = _rand_align_case(rng, m, 0.05, 20)
+        rn = rn.copy()
+        rn[len(rn) // 3: len(rn) // 3 + max(1, m // 10)] = 5
+        add(rn, qn, int(m * 0.15) + 2)
+        # window shorter than the query
+        add(q[: max(1, m - 5)], q, 3)
+        add(q[: max(1, m - 5)], q, 6)
+    rpool, qpool = np.concatenate(refs), np.concatenate(queries)
+    got = F.align_batch(ctx, qpool, jobs, reference_pool=rpool)
+    n_yes = 0
+    for (ro_, rl, qo_, ql, k, mode), g in zip(jobs, got):
+        exp = O.align(rpool[ro_:ro_ + rl], qpool[qo_:qo_ + ql], k, mode=0, algo=1)
+        if exp is not None:
+            exp = (exp[0], 0, "")
+            n_yes += 1
+        assert g == exp, (ql, rl, k)
+    assert 0.2 * len(jobs) < n_yes < 0.95 * len(jobs)
+    # the same jobs ask for the end positions too (the cutoff keeps the rightmost minimum of the last row)
+    jobs1 = [j[:5] + (1,) for j in jobs]
+    got1 = F.align_batch(ctx, qpool, jobs1, reference_pool=rpool)
+    for (ro_, rl, qo_, ql, k, mode), g in zip(jobs1, got1):
+        exp = O.align(rpool[ro_:ro_ + rl], qpool[qo_:qo_ + ql], k, mode=1, algo=1)
+        if exp is not None:
+            exp = (exp[0], exp[1], "")
+        assert g == exp, (ql, rl, k)
 
 
 def test_caller_owned_stream():
