@@ -1600,6 +1600,7 @@ __global__ void __launch_bounds__(64) ed_trace_block_kernel(const u8* __restrict
                                                             const DevAlignJob* __restrict__ jobs, u32 n_jobs, u32 log2_r,
                                                             u64* __restrict__ trace, DevAlignOut* __restrict__ out, u16* __restrict__ lastrow) {
     extern __shared__ __attribute__((aligned(16))) u64 lds_eq[];
+    __builtin_amdgcn_s_setprio(2);                   // (few waves, long chains, 18 KB of LDS each: they go first on a shared SIMD)
     ed_block_body<W, true>(text, peq, jobs, n_jobs, log2_r, out, blockIdx.x, lds_eq, trace, lastrow);
 }
 
@@ -1886,9 +1887,11 @@ __global__ void __launch_bounds__(64) ed_traceback_wave_kernel(const u8* __restr
     __shared__ u32 win_valid[64];                    // non-zero: the window was computed
     __shared__ u64 eqm[TBW_WORDS][6];                // equality masks of the round's words
     __shared__ u8 refs[TBW_REF];                     // reference symbols of columns [ref_base, ref_base + TBW_REF)
-    u32 const id = blockIdx.x;
-    if (id >= n_jobs) return;
     u32 const lane = threadIdx.x & 63u;
+    __builtin_amdgcn_s_setprio(2);                   // (short launches that hold much LDS go first on a shared SIMD: they leave sooner)
+    // (a grid smaller than the job list: a wave takes jobs in turn, so that a launch holds no more LDS than its grid's waves)
+    for (u32 id = blockIdx.x; id < n_jobs; id += gridDim.x) {
+    __syncthreads();
     DevTraceJob const job = jobs[id];
     const u8* __restrict__ r = text + job.ref_off;
     u32* __restrict__ slab = cigar + job.cigar_off;
@@ -2073,13 +2076,15 @@ __global__ void __launch_bounds__(64) ed_traceback_wave_kernel(const u8* __restr
         o.pad = 0;
         out[job.out_index] = o;
     }
+    }
 }
 
 int DeviceApi::traceback(void* stream, const u8* d_text, const u8* d_query, const u64* d_peq, const u64* d_trace, const DevTraceJob* d_jobs,
                          u32 n_jobs, bool checkpointed, u32* d_cigar, DevTraceOut* d_out) {
     if (n_jobs == 0) return 0;
+    static u32 const tb_waves = [] { const char* e = getenv("FLX_TRACEBACK_WAVES"); return (u32)(e ? std::max(1, atoi(e)) : 1024); }();
     if (checkpointed)
-        hipLaunchKernelGGL(ed_traceback_wave_kernel, dim3(n_jobs), dim3(64), 0, (hipStream_t)stream, d_text, d_peq, d_trace, d_jobs, n_jobs,
+        hipLaunchKernelGGL(ed_traceback_wave_kernel, dim3(std::min(n_jobs, tb_waves)), dim3(64), 0, (hipStream_t)stream, d_text, d_peq, d_trace, d_jobs, n_jobs,
                            d_cigar, d_out);
     else
         hipLaunchKernelGGL(ed_traceback_kernel, dim3(n_jobs), dim3(64), 0, (hipStream_t)stream, d_text, d_query, d_trace, d_jobs,

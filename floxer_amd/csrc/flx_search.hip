@@ -320,7 +320,8 @@ int DeviceApi::search_filtered(void* stream, const DevIndex& idx, const u8* d_se
     static u32 const fm_prio = env_u32("FLX_FM_PRIO", 0);         // wave priority of the walks (0..3) on SIMDs shared with other kernels
     hipStream_t s = (hipStream_t)stream;
     dim3 const grid(std::min<u32>((n_seeds + spw - 1) / spw, max_waves));
-    hipLaunchKernelGGL(fm_search_filter_kernel, grid, dim3(64), (size_t)C.levels * FM_FRAME_WORDS * 64 * sizeof(u32), s, C, d_seeds, n_seeds, d_hits, hit_cap,
+    static u32 const extra_lds = env_u32("FLX_FM_EXTRA_LDS", 0);      // (experiments: bytes of LDS a wave holds without using them)
+    hipLaunchKernelGGL(fm_search_filter_kernel, grid, dim3(64), (size_t)C.levels * FM_FRAME_WORDS * 64 * sizeof(u32) + extra_lds, s, C, d_seeds, n_seeds, d_hits, hit_cap,
                        d_items, item_cap, d_counters, d_seed_cnt, refill_a, fm_prio);
     if (C.text_min_remain) {
         // (the number of queued subtrees is only known on the device: a fixed grid, waves without work leave at once; the walk is a

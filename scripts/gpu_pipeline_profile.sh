@@ -11,6 +11,6 @@ head -40 $R/gpurun_out/${T}_host_profile.txt
 cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/kt
 timeout -k 10 400 rocprofv3 --kernel-trace -d /tmp/kt -o kt --output-format csv -- python3 $R/bench.py --steps 8 --warmup 3 --no-cpu-baseline --no-isolated-pass "$@" > $R/gpurun_out/${T}_traced.json 2> /dev/null
 F=$(find /tmp/kt -name '*kernel_trace.csv' | head -1)
-python3 $R/scripts/trace_concurrency.py $F 28 > $R/gpurun_out/${T}_concurrency.txt
+head -1 $F > $R/gpurun_out/${T}_trace_header.txt; python3 $R/scripts/trace_concurrency.py $F 28 > $R/gpurun_out/${T}_concurrency.txt
 python3 -c "import json; d=json.load(open('$R/gpurun_out/${T}_traced.json')); print('traced run:', d['value'], 'reads/s')" >> $R/gpurun_out/${T}_concurrency.txt
 cat $R/gpurun_out/${T}_concurrency.txt

@@ -39,3 +39,33 @@ for t, d in pts:
     hist[cur] += t - last; last = t; cur += d
 hist[cur] += t_end - last
 print("concurrent fm_search launches: " + "  ".join(f"{k}: {v / span:.3f}" for k, v in sorted(hist.items())))
+
+# ---- what the launches ask of the chip while they run: wave slots, registers and LDS, as shares of the chip over the window.
+# A launch is taken to keep min(its waves, what the chip can hold of it) resident for its whole duration (an upper bound: tails are
+# emptier), 256 CUs x 4 SIMDs, 8 wave slots and 512 VGPRs per SIMD lane, 160 KB LDS per CU.
+if rows and "VGPR_Count" in rows[0] and "LDS_Block_Size" in rows[0]:
+    CUS, SIMDS = 256, 1024
+    demand = collections.defaultdict(lambda: [0.0, 0.0, 0.0])
+    for r in rows:
+        s, e = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
+        s, e = max(s, t0), min(e, t_end)
+        if e <= s: continue
+        wg = max(1, int(r.get("Workgroup_Size") or r.get("Workgroup_Size_X") or 64))
+        waves_per_wg = (wg + 63) // 64
+        n_wg = max(1, int(r.get("Grid_Size") or r.get("Grid_Size_X") or wg) // wg)
+        vg = max(8, int(r["VGPR_Count"]) + int(r.get("Accum_VGPR_Count", 0) or 0))
+        lds = int(r["LDS_Block_Size"])
+        per_simd = max(1, min(8, 512 // vg))
+        cap_waves = SIMDS * per_simd
+        if lds: cap_waves = min(cap_waves, CUS * max(1, (160 * 1024) // lds) * waves_per_wg)
+        w = min(n_wg * waves_per_wg, cap_waves)
+        d = demand[family(r["Kernel_Name"])]
+        d[0] += w * (e - s) / (SIMDS * 8 * span)
+        d[1] += w * vg * (e - s) / (SIMDS * 512 * span)
+        d[2] += (w / waves_per_wg) * lds * (e - s) / (CUS * 160 * 1024 * span)
+    print("resident demand (share of the chip over the window; > 1 in total = launches wait for room):  wave slots   VGPRs   LDS")
+    tot = [0.0, 0.0, 0.0]
+    for f, d in sorted(demand.items(), key=lambda kv: -max(kv[1])):
+        print(f"  {f:18s} {d[0]:10.3f} {d[1]:8.3f} {d[2]:8.3f}")
+        for i in range(3): tot[i] += d[i]
+    print(f"  {'total':18s} {tot[0]:10.3f} {tot[1]:8.3f} {tot[2]:8.3f}")
