@@ -164,6 +164,7 @@ enum : u8 { VR_CLIMBING = 0, VR_DEAD = 1, VR_AT_ROOT = 2, VR_SOLO = 3 };      //
 // blocks of vr2_apply that have finished
 enum : u32 { VR2_N_JOBS = 0 /* and 1: by the round's parity */, VR2_N_CLIMBING = 2, VR2_SMALLEST = 3, VR2_WORD_STEPS = 4, VR2_BYTES = 6, VR2_N_REQ = 8, VR2_DONE = 9,
              VR2_QUEUE = 10 /* job queue head of the lane-per-job existence kernel */, VR2_QUEUE_ERR = 11 /* windows its buffers did not hold */,
+             VR2_PENDING = 12 /* and 13, by parity: anchors the next round will ask for (rounds queued without the host in between) */,
              VR2_SCALARS = 16 };
 struct Vr2Buffers {
     const DevVrAnchor* anchors; const DevVrNode* nodes;
@@ -247,8 +248,10 @@ struct DeviceApi {
     static int align(void* stream, const u8* d_text, const u64* d_peq, const DevAlignJob* d_jobs, u32 n_jobs, AlignShape shape,
                      bool trace, u64* d_trace, DevAlignOut* d_out, u16* d_lastrow = nullptr);
     // flx_rounds.hip: a round = vr2_request (job list and count on the device), align_exists_counted on it, vr2_apply
-    static int vr2_request(void* stream, Vr2Buffers const& B, u32 n_queries, u32 limit, u32 acct_words, u32 width_cap, u32 parity);
-    static int vr2_apply(void* stream, Vr2Buffers const& B, u32 n_anchors, u32* host_scalars);
+    // check_pending: the round is one of a queued series; it does nothing when the round before it counted no anchor for it (next_limit of
+    // that round's vr2_apply = this round's limit; parity as for the job counters)
+    static int vr2_request(void* stream, Vr2Buffers const& B, u32 n_queries, u32 limit, u32 acct_words, u32 width_cap, u32 parity, bool check_pending = false);
+    static int vr2_apply(void* stream, Vr2Buffers const& B, u32 n_anchors, u32* host_scalars, u32 next_limit = 0xFFFFFFFFu, u32 parity = 0);
     // existence tests, one lane per job with Ukkonen's cutoff (flx_lanes.hip): at most `waves` waves take the jobs from a queue (*d_queue = 0
     // at the start, d_queue[1] counts jobs whose windows the rows did not hold); d_n_jobs (optional): the number of jobs is on the device
     // (at most max_jobs); cap_blocks >= (64 + n - m + 2k) / 16 + 3 of every job, exists_lane_lds_bytes(cap_blocks) <= 160 KB;

@@ -54,7 +54,7 @@ __device__ __forceinline__ u64 vr2_key(u32 node, u64 start, u32 solo) { return (
 
 // One wave per query: a block of 64 threads finds a free wave slot on a GPU full of other lanes' kernels far sooner than four waves
 // and their LDS at once, and the steps below are short (a query has a few hundred anchors).
-__global__ void __launch_bounds__(VR2_THREADS) vr2_request_kernel(Vr2Buffers B, u32 limit, u32 acct_words, u32 width_cap, u32 parity) {
+__global__ void __launch_bounds__(VR2_THREADS) vr2_request_kernel(Vr2Buffers B, u32 limit, u32 acct_words, u32 width_cap, u32 parity, u32 check_pending) {
     __shared__ u64 s_key[VR2_TILE];
     __shared__ u32 s_len[VR2_TILE];           // window length of the tile's anchor (by its place in the tile)
     __shared__ u16 s_val[VR2_TILE];
@@ -67,7 +67,10 @@ __global__ void __launch_bounds__(VR2_THREADS) vr2_request_kernel(Vr2Buffers B, 
         B.scalars[VR2_N_CLIMBING] = 0u; B.scalars[VR2_SMALLEST] = 0xFFFFFFFFu; B.scalars[VR2_DONE] = 0u;      // vr2_apply counts into them
         B.scalars[VR2_N_JOBS + (parity ^ 1u)] = 0u;                                                         // the next round's job counter
         B.scalars[VR2_QUEUE] = 0u;                                                                          // this round's existence kernel starts at job 0
+        B.scalars[VR2_PENDING + (parity ^ 1u)] = 0u;                                                        // vr2_apply counts the next round's anchors
     }
+    // (a round of a queued series for which the round before counted no anchor: written by that round's vr2_apply, stable during this kernel)
+    if (check_pending && B.scalars[VR2_PENDING + parity] == 0u) return;
     u32 const a0 = B.q_first[q], a1 = B.q_first[q + 1];
     u32* const n_jobs = &B.scalars[VR2_N_JOBS + parity];
     for (u32 tile = a0; tile < a1; tile += VR2_TILE) {
@@ -236,9 +239,9 @@ __global__ void __launch_bounds__(VR2_THREADS) vr2_request_kernel(Vr2Buffers B, 
 
 // host_scalars (page-locked, mapped): where the last block to finish leaves the round's scalars, so that the host reads them behind
 // an event without a copy of its own
-__global__ void __launch_bounds__(256) vr2_apply_kernel(Vr2Buffers B, u32 n, u32* __restrict__ host_scalars) {
-    __shared__ u32 s_cnt[4], s_min[4];
-    u32 count = 0, smallest = 0xFFFFFFFFu;
+__global__ void __launch_bounds__(256) vr2_apply_kernel(Vr2Buffers B, u32 n, u32* __restrict__ host_scalars, u32 next_limit, u32 parity) {
+    __shared__ u32 s_cnt[4], s_min[4], s_pend[4];
+    u32 count = 0, smallest = 0xFFFFFFFFu, pending = 0;
     for (u32 i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         u8 st = B.status[i];
         u32 const code = B.a_slot[i];
@@ -263,16 +266,24 @@ __global__ void __launch_bounds__(256) vr2_apply_kernel(Vr2Buffers B, u32 n, u32
         }
         if (st == VR_CLIMBING || st == VR_SOLO) {
             ++count;
-            smallest = min(smallest, B.nodes[B.anchors[i].tree_base + B.node[i]].rows);
+            u32 const rows = B.nodes[B.anchors[i].tree_base + B.node[i]].rows;
+            smallest = min(smallest, rows);
+            pending += rows <= next_limit ? 1u : 0u;
         }
     }
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) { count += (u32)__shfl_xor((int)count, off); smallest = min(smallest, (u32)__shfl_xor((int)smallest, off)); }
-    if ((threadIdx.x & 63u) == 0u) { s_cnt[threadIdx.x >> 6] = count; s_min[threadIdx.x >> 6] = smallest; }
+    for (int off = 32; off > 0; off >>= 1) {
+        count += (u32)__shfl_xor((int)count, off);
+        pending += (u32)__shfl_xor((int)pending, off);
+        smallest = min(smallest, (u32)__shfl_xor((int)smallest, off));
+    }
+    if ((threadIdx.x & 63u) == 0u) { s_cnt[threadIdx.x >> 6] = count; s_min[threadIdx.x >> 6] = smallest; s_pend[threadIdx.x >> 6] = pending; }
     __syncthreads();
     if (threadIdx.x == 0) {
         u32 const c = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3], m = min(min(s_min[0], s_min[1]), min(s_min[2], s_min[3]));
+        u32 const pd = s_pend[0] + s_pend[1] + s_pend[2] + s_pend[3];
         if (c) { atomicAdd(&B.scalars[VR2_N_CLIMBING], c); atomicMin(&B.scalars[VR2_SMALLEST], m); }
+        if (pd) atomicAdd(&B.scalars[VR2_PENDING + (parity ^ 1u)], pd);
         __threadfence();
         if (atomicAdd(&B.scalars[VR2_DONE], 1u) == gridDim.x - 1u && host_scalars) {
             __threadfence();
@@ -284,14 +295,16 @@ __global__ void __launch_bounds__(256) vr2_apply_kernel(Vr2Buffers B, u32 n, u32
 
 // everything up to the round's job list (B.jobs, B.scalars[VR2_N_JOBS + parity]; the other parity's counter is zeroed for the next round); acct_words: words per lane of the launch shape (accounting);
 // width_cap: most diagonals (n - m + 2k) a job of the round may have (what the launch shapes hold)
-int DeviceApi::vr2_request(void* stream, Vr2Buffers const& B, u32 n_queries, u32 limit, u32 acct_words, u32 width_cap, u32 parity) {
+int DeviceApi::vr2_request(void* stream, Vr2Buffers const& B, u32 n_queries, u32 limit, u32 acct_words, u32 width_cap, u32 parity, bool check_pending) {
     if (n_queries == 0) return 0;
-    hipLaunchKernelGGL(vr2_request_kernel, dim3(n_queries), dim3(VR2_THREADS), 0, (hipStream_t)stream, B, limit, std::max(1u, acct_words), width_cap, parity & 1u);
+    hipLaunchKernelGGL(vr2_request_kernel, dim3(n_queries), dim3(VR2_THREADS), 0, (hipStream_t)stream, B, limit, std::max(1u, acct_words), width_cap, parity & 1u,
+                       check_pending ? 1u : 0u);
     return (int)hipGetLastError();
 }
-int DeviceApi::vr2_apply(void* stream, Vr2Buffers const& B, u32 n_anchors, u32* host_scalars) {
+int DeviceApi::vr2_apply(void* stream, Vr2Buffers const& B, u32 n_anchors, u32* host_scalars, u32 next_limit, u32 parity) {
     if (n_anchors == 0) return 0;
-    hipLaunchKernelGGL(vr2_apply_kernel, dim3(std::min<u32>((n_anchors + 255) / 256, 1024u)), dim3(256), 0, (hipStream_t)stream, B, n_anchors, host_scalars);
+    hipLaunchKernelGGL(vr2_apply_kernel, dim3(std::min<u32>((n_anchors + 255) / 256, 1024u)), dim3(256), 0, (hipStream_t)stream, B, n_anchors, host_scalars, next_limit,
+                       parity & 1u);
     return (int)hipGetLastError();
 }
 
