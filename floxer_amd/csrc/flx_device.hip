@@ -1418,6 +1418,7 @@ __device__ __forceinline__ void ed_block_body(const u8* __restrict__ text, const
     int const pad = Lg * 64 * W - m;                      // 0 <= pad < 64 W: only group 0 holds padding
     int g = (int)p;
     int b_lo = 0, b_hi = -1, rows_g = 0;
+    int t_above_end = 0;                                  // last block-step of the group above (its lane may run a later group after that)
     u64 vp[W], vn[W];
     auto enter_group = [&]() {
         int const r0 = max(0, 64 * W * g - pad);
@@ -1426,6 +1427,7 @@ __device__ __forceinline__ void ed_block_body(const u8* __restrict__ text, const
         b_lo = max(0, r0 - k) >> 4;
         b_hi = min(n - 1, r1 - 1 + band_hi) >> 4;
         if (g + 1 < Lg) b_hi = max(b_hi, max(0, r1 - k) >> 4);
+        t_above_end = max(min(n - 1, r0 - 1 + band_hi) >> 4, b_lo) + g - 1;      // (group g - 1: rows up to r0, kept going for this group's first block)
 #pragma unroll
         for (int w = 0; w < W; ++w) {
             int const rs = 64 * (g * W + w) - pad;        // real row of the word's bit 0 (negative: that many padding rows first)
@@ -1505,6 +1507,7 @@ __device__ __forceinline__ void ed_block_body(const u8* __restrict__ text, const
         bool const active = has_group && b >= b_lo && b <= b_hi;
         if (active) {
             if (g == 0) { cw_in = 0u; botv_in = 0; }      // the row above the matrix: D = 0 in every column
+            else if ((int)T > t_above_end + 1) cw_in = 0x55555555u;      // the group above has ended (what its lane hands down now belongs to a later group): +1 per column
             if (b == b_lo) bot = botv_in + rows_g;        // column left of the window: all vertical deltas +1 below the group above
             int const bot_start = bot;
             bool const last = g == Lg - 1;
