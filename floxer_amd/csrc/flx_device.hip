@@ -2085,7 +2085,7 @@ __global__ void __launch_bounds__(64) ed_traceback_wave_kernel(const u8* __restr
 int DeviceApi::traceback(void* stream, const u8* d_text, const u8* d_query, const u64* d_peq, const u64* d_trace, const DevTraceJob* d_jobs,
                          u32 n_jobs, bool checkpointed, u32* d_cigar, DevTraceOut* d_out) {
     if (n_jobs == 0) return 0;
-    static u32 const tb_waves = [] { const char* e = getenv("FLX_TRACEBACK_WAVES"); return (u32)(e ? std::max(1, atoi(e)) : 1024); }();
+    static u32 const tb_waves = [] { const char* e = getenv("FLX_TRACEBACK_WAVES"); return (u32)(e ? std::max(1, atoi(e)) : 1u << 30); }();
     if (checkpointed)
         hipLaunchKernelGGL(ed_traceback_wave_kernel, dim3(std::min(n_jobs, tb_waves)), dim3(64), 0, (hipStream_t)stream, d_text, d_peq, d_trace, d_jobs, n_jobs,
                            d_cigar, d_out);

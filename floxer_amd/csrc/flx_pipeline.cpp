@@ -837,8 +837,11 @@ int choose_shapes(hvec<AlignRequest> const& reqs, hvec<AlignShape>& shapes) {
     return FLX_OK;
 }
 
-// The lane-per-job existence kernel (flx_lanes.hip) unless FLX_EXISTS_RING is set (the ring form of flx_device.hip, for comparisons)
-static bool exists_lane_form() { return getenv("FLX_EXISTS_RING") == nullptr; }
+// FLX_EXISTS_LANES=1: the existence tests through the lane-per-job kernel with Ukkonen's cutoff (flx_lanes.hip) instead of the ring form of
+// flx_device.hip. It computes a ninth of the blocks, and the pipeline runs as fast with either (it is not short of issue slots,
+// profiles/r03_experiments.txt 5-6); alone the ring form is the faster one (40 against 60 ms per 16384 reads: a job's word groups run
+// side by side on its ring, one after the other on its lane), so the ring form is the default.
+static bool exists_lane_form() { return getenv("FLX_EXISTS_LANES") != nullptr; }
 // its waves and the blocks its per-lane rows hold for windows of at most `width` diagonals (n - m + 2k); false: the rows would not fit the LDS
 static bool exists_lane_setup(u64 max_jobs, i64 width, u32& waves, u32& cap_blocks) {
     cap_blocks = (u32)((64 + std::max<i64>(width, 0)) / 16 + 3) | 1u;                   // (odd: the lanes' rows start in different banks)

@@ -577,10 +577,11 @@ def test_root_unions_and_their_fallback():
 
 
 def test_existence_kernel_forms_give_the_same_records():
-    """the existence tests run one lane per job with Ukkonen's cutoff (ed_exists_lane_kernel) by default, as a ring of lanes per job over
-    the static band 16 columns per step with FLX_EXISTS_RING=1 (ed_exists_block_kernel) and one column per step with FLX_EXISTS_STEPWISE=1
-    on top (ed_band_kernel); the switches are read once per process, so the other forms run in children: same records, all equal to the
-    oracle's, on reads whose trees reach every launch shape of the lower levels and the ring-scheduled upper ones"""
+    """the existence tests run as a ring of lanes per job over the static band, 16 columns per step (ed_exists_block_kernel), by default;
+    one column per step with FLX_EXISTS_STEPWISE=1 (ed_band_kernel); one lane per job with Ukkonen's cutoff with FLX_EXISTS_LANES=1
+    (ed_exists_lane_kernel), also with the rounds queued without the host in between (FLX_ROUNDS_QUEUED=1). The switches of the ring forms
+    are read once per process, so the other forms run in children: same records, all equal to the oracle's, on reads whose trees reach
+    every launch shape of the lower levels and the ring-scheduled upper ones"""
     import subprocess, sys, json
     genome = S.make_genome(500000, 2, seed=161)
     reads, _, _ = S.make_reads(genome, 24, 6000, 0.08, seed=162)
@@ -592,17 +593,18 @@ def test_existence_kernel_forms_give_the_same_records():
             "g = S.make_genome(500000, 2, seed=161); r, _, _ = S.make_reads(g, 24, 6000, 0.08, seed=162);"
             "c = F.context(F.fmindex(g)); print(json.dumps(F.aligner(c, F.params(error_probability=0.08)).align_reads(r).records()))"
             % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-    for env in ({"FLX_EXISTS_RING": "1"}, {"FLX_EXISTS_RING": "1", "FLX_EXISTS_STEPWISE": "1"}):
+    for env in ({"FLX_EXISTS_STEPWISE": "1"}, {"FLX_EXISTS_LANES": "1"}, {"FLX_EXISTS_LANES": "1", "FLX_ROUNDS_QUEUED": "1"}):
         out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env), capture_output=True, text=True, check=True)
         assert [tuple(r) for r in json.loads(out.stdout.strip().split("\n")[-1])] == exp.records(), env
 
 
-def test_existence_with_cutoff_matches_oracle(small_genome):
-    """ed_exists_lane_kernel against the oracle's Myers on what the cutoff has to get right: several occurrences in one window (tandem
+def test_existence_with_cutoff_matches_oracle(small_genome, monkeypatch):
+    """ed_exists_lane_kernel (FLX_EXISTS_LANES=1) against the oracle's Myers on what the cutoff has to get right: several occurrences in one window (tandem
     repeats with periods around the group height, a second occurrence far to the right of the first), budgets from 0 to more than the
     query is long, low-complexity sequence (every diagonal alive), occurrences at either edge of the window, windows shorter than the
     query, N runs; ragged sizes across word-group boundaries in one launch"""
     _, _, ctx, _ = small_genome
+    monkeypatch.setenv("FLX_EXISTS_LANES", "1")
     rng = np.random.default_rng(77)
     refs, queries, jobs = [], [], []
     ro = qo = 0
