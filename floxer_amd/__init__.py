@@ -174,7 +174,8 @@ class context:
             check(lib().flx_ctx_create(device, index.h, C.byref(self.h)))
         else:
             arr = (C.c_void_p * 5)(*[C.c_void_p(int(b.data_ptr())) for b in image])
-            check(lib().flx_ctx_create_on_image(device, index.h, arr, C.byref(self.h)))
+            sizes = np.array([int(b.numel()) * int(b.element_size()) for b in image], dtype=np.uint64)      # what the buffers hold: checked against the layout
+            check(lib().flx_ctx_create_on_image(device, index.h, arr, ptr(sizes, u64p), C.byref(self.h)))
 
     def close(self):
         if getattr(self, "h", None):

@@ -72,7 +72,7 @@ class Record(C.Structure):
 class PathCounters(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in ("seeds", "seeds_with_anchors", "seeds_excluded_by_hard_cap", "seeds_selected_on_host", "anchors",
                                           "cursor_extensions", "inner_tests_requested", "root_alignments_requested",
-                                          "root_alignments_found", "records", "reads")] + [("reserved", C.c_uint64 * 5)]
+                                          "root_alignments_found", "records", "reads", "search_reruns")] + [("reserved", C.c_uint64 * 4)]
 
 
 class KernelStat(C.Structure):
@@ -137,7 +137,7 @@ def lib():
     L.flx_index_image_upload.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]
     L.flx_index_meta_export.argtypes = [C.c_void_p, u8p, u64p]
     L.flx_index_meta_import.argtypes = [u8p, C.c_uint64, C.POINTER(C.c_void_p)]
-    L.flx_ctx_create_on_image.argtypes = [C.c_int, C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]
+    L.flx_ctx_create_on_image.argtypes = [C.c_int, C.c_void_p, C.POINTER(C.c_void_p), u64p, C.POINTER(C.c_void_p)]
     L.flx_ctx_set_stream.argtypes = [C.c_void_p, C.c_void_p]
     L.flx_search_seeds.argtypes = [C.c_void_p, u8p, C.c_uint64, C.POINTER(Seed), C.c_uint64, C.POINTER(SearchConfig),
                                    C.POINTER(Anchor), u64p, C.POINTER(SeedStats)]

@@ -188,9 +188,15 @@ int flx_ctx_create(int hip_device, const flx_index* index, flx_ctx** out) {
     return make_context(hip_device, index, nullptr, true, out);
 }
 
-int flx_ctx_create_on_image(int hip_device, const flx_index* index, void* const device_buffers[5], flx_ctx** out) {
-    if (!index || !out || !device_buffers) { set_error("flx_ctx_create_on_image: null argument"); return FLX_ERR_INVALID; }
+int flx_ctx_create_on_image(int hip_device, const flx_index* index, void* const device_buffers[5], const flx_index_image* sizes, flx_ctx** out) {
+    if (!index || !out || !device_buffers || !sizes) { set_error("flx_ctx_create_on_image: null argument"); return FLX_ERR_INVALID; }
     for (int i = 0; i < 5; ++i) if (!device_buffers[i]) { set_error("flx_ctx_create_on_image: null device buffer"); return FLX_ERR_INVALID; }
+    {
+        uint64_t want[5];
+        image_sizes(*index->host, want);
+        for (int i = 0; i < 5; ++i)
+            if (sizes->bytes[i] != want[i]) { set_error("flx_ctx_create_on_image: the buffers' sizes are not this index's image layout (flx_index_image_layout)"); return FLX_ERR_INVALID; }
+    }
     if (int const rc = check_device(hip_device, "flx_ctx_create_on_image")) return rc;
     return make_context(hip_device, index, device_buffers, false, out);
 }

@@ -52,13 +52,14 @@ struct Lane {
     hipStream_t own_stream = nullptr, stream = nullptr;
     DeviceBuffer seq, seq_rev, peq, peq_rev, scheme, seeds, stack, hits, counters, rows, rows_out, qpack, items;
     DeviceBuffer jobs, job_out, trace, tjobs, tjob_out, cigar, user_text, user_text_rev, lastrow, row_windows, row_out,
-        seed_cnt, hit_off, grouped, sel_stat, sel_n, sel_off, sel_out, sel_tmp, sel_rows, sel_row_off, sel_sparse, sel_lists, vr, lane_rows;
+        seed_cnt, hit_off, grouped, sel_stat, sel_n, sel_off, sel_out, sel_tmp, sel_rows, sel_row_off, sel_sparse, sel_lists, vr, lane_rows, seed_gen;
     size_t trace_budget_bytes = 0;
     std::vector<PendingTiming> pending;
     std::vector<hipEvent_t> event_pool;
     hipEvent_t sync_event = nullptr;
     u32* vr_host_scalars = nullptr;  // page-locked, mapped: a round's scalars, written by the device (flx_rounds.hip)
     bool has_run = false;            // a chunk has run here (its workspaces have their working sizes)
+    double hits_per_seed = 0, items_per_seed = 0, sel_rows_per_seed = 0;      // of the last search here: the next one's buffers are sized for that and a margin
     int wait_idle();                 // the stream has drained (the thread sleeps on a blocking event unless FLX_SPIN_SYNC is set)
     int sync();                      // wait_idle + fold pending timings into the context's statistics
     std::vector<DeviceBuffer*> workspaces();
@@ -142,6 +143,11 @@ struct SeedStats { u32 useful, raw, excluded_soft, fully_excluded; };
 // flx_fm_core.hpp) may be null when the host pool is given (they are read off it)
 int search_seeds_device(Lane* lane, const u8* d_seq_pool_or_null, const u8* h_seq_pool, u64 pool_len, const flx_seed* seeds,
                         u64 n_seeds, const flx_search_config& cfg, hvec<HostAnchor>& anchors, hvec<SeedStats>& stats,
-                        hvec<DevHit>* raw_hits, u64 raw_max_hits, const u32* d_qpack_or_null = nullptr, const u8* seed_flags = nullptr);
+                        hvec<DevHit>* raw_hits, u64 raw_max_hits, const u32* d_qpack_or_null = nullptr, const u8* seed_flags = nullptr,
+                        const SeedGen* gen = nullptr);
+// gen: `seeds` is null and the chunk's seeds are written on the device from this description (their ids = the order the caller would have
+// listed them in: read by read, forward then reverse complement, leaf by leaf); the anchors' leaf is left to the caller; returns
+// SEARCH_NEEDS_HOST_SEEDS (nothing done that counts) when a seed has to go through the host's selection: call again with the list.
+constexpr int SEARCH_NEEDS_HOST_SEEDS = 1;
 
 }  // namespace flx

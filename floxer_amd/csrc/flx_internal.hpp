@@ -121,6 +121,19 @@ static_assert(sizeof(DevFrame) == 64, "frame is four 16-byte slots");
 // key: position of the hit in search_n's emission order among the hits of its seed (see fm_search_kernel; 0 from the ordered kernel,
 // whose ordinals are the emission order already)
 struct DevHit { u32 seed, lb, len, errors; u64 key; };
+// ---- seeds of a chunk written on the device (flx_search.hip: seed_build_kernel): a seed is a function of (read, orientation, sampled leaf of
+// the read's PEX tree), so the host only describes the reads, their trees' leaves and where each (read, seed class) starts in launch order
+struct DevSeedLeaf { u32 from, length, cls, rank; };                  // cls: class (errors, length) index within its tree; rank among the tree's leaves of that class
+struct DevSeedClass { u32 pos_base, count, scheme_off, frames_searches; };   // per (read, class of its tree): launch position of the read's forward seeds of the class (reverse: + count)
+struct DevSeedRead { u64 pool_fwd, pool_rev; u32 leaf_first, n_leaves, seed_base, class_first, flags, pad; };
+struct SeedGen {                                                      // host side of one chunk
+    std::vector<DevSeedRead, PoolAlloc<DevSeedRead>> reads;
+    std::vector<DevSeedLeaf, PoolAlloc<DevSeedLeaf>> leaves;
+    std::vector<DevSeedClass, PoolAlloc<DevSeedClass>> classes;
+    std::vector<u64, PoolAlloc<u64>> scheme_table;
+    u64 n_seeds = 0;
+    u32 max_errors = 0, max_length = 0;
+};
 struct DevSelStat { u8 useful, raw, flag, excluded; u32 excluded_soft; };   // per seed, from the device-side selection
 struct DevOutAnchor { u32 seed_index, leaf, ref_id, errors; u64 pos; };   // = HostAnchor (leaf is filled by the host)
 
@@ -232,6 +245,8 @@ struct DeviceApi {
     static int derive_index(void* stream, DevIndex& idx, u32* d_isa, u64* d_filter);
     // reserves the hardware queue's scratch for the pipeline's kernels (see scratch_warm_kernel)
     static int warm_scratch(void* stream);
+    // DevSeeds of a chunk in launch order from the chunk's description (all pointers on the device)
+    static int build_seeds(void* stream, const DevSeedRead* reads, u32 n_reads, const DevSeedLeaf* leaves, const DevSeedClass* classes, DevSeed* out);
     // 2-bit form of a sequence pool (pack_words_for(len) words, flx_fm_core.hpp)
     static int pack_pool(void* stream, const u8* d_seq, u64 len, u32* d_qpack);
     // anchor selection on the device (see seed_select_kernel). d_seed_cnt, d_hit_offset, d_n_out, d_out_offset: n_seeds + 1 entries

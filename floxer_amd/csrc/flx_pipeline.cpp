@@ -95,13 +95,13 @@ hvec<DeviceBuffer*> lane_workspaces(Lane& l) {
     return {&l.seq, &l.seq_rev, &l.peq, &l.peq_rev, &l.scheme, &l.seeds, &l.stack, &l.hits, &l.counters, &l.rows, &l.rows_out, &l.jobs,
             &l.job_out, &l.trace, &l.tjobs, &l.tjob_out, &l.cigar, &l.user_text, &l.user_text_rev, &l.lastrow, &l.row_windows, &l.row_out,
             &l.seed_cnt, &l.hit_off, &l.grouped, &l.sel_stat, &l.sel_n, &l.sel_off, &l.sel_out, &l.sel_tmp, &l.sel_rows, &l.sel_row_off, &l.sel_sparse, &l.sel_lists, &l.vr, &l.lane_rows,
-            &l.qpack, &l.items};
+            &l.qpack, &l.items, &l.seed_gen};
 }
 // FLX_ALLOC_DEBUG: the address ranges of a lane's workspaces (a GPU memory fault reports an address)
 static void dump_lane_buffers(Lane& l, const char* when) {
     static const char* const names[] = {"seq", "seq_rev", "peq", "peq_rev", "scheme", "seeds", "stack", "hits", "counters", "rows", "rows_out", "jobs", "job_out",
         "trace", "tjobs", "tjob_out", "cigar", "user_text", "user_text_rev", "lastrow", "row_windows", "row_out", "seed_cnt", "hit_off", "grouped", "sel_stat",
-        "sel_n", "sel_off", "sel_out", "sel_tmp", "sel_rows", "sel_row_off", "sel_sparse", "sel_lists", "vr", "lane_rows", "qpack", "items"};
+        "sel_n", "sel_off", "sel_out", "sel_tmp", "sel_rows", "sel_row_off", "sel_sparse", "sel_lists", "vr", "lane_rows", "qpack", "items", "seed_gen"};
     auto const ws = lane_workspaces(l);
     for (size_t i = 0; i < ws.size(); ++i)
         if (ws[i]->ptr) fprintf(stderr, "[flx alloc] lane %d %s %s %p .. %p\n", l.id, when, names[i], ws[i]->ptr, (void*)((char*)ws[i]->ptr + ws[i]->cap));
@@ -291,20 +291,55 @@ void erase_useless(hvec<RefAnchor>& v) {
 
 int search_seeds_device(Lane* ctx, const u8* d_seq_pool_or_null, const u8* h_seq_pool, u64 pool_len, const flx_seed* seeds,
                         u64 n_seeds, const flx_search_config& cfg, hvec<HostAnchor>& anchors, hvec<SeedStats>& stats,
-                        hvec<DevHit>* raw_hits, u64 raw_max_hits, const u32* d_qpack_or_null, const u8* seed_flags) {
+                        hvec<DevHit>* raw_hits, u64 raw_max_hits, const u32* d_qpack_or_null, const u8* seed_flags, const SeedGen* gen) {
     anchors.clear();
+    if (gen) n_seeds = gen->n_seeds;
     stats.assign(n_seeds, SeedStats{0, 0, 0, 0});
     if (n_seeds == 0) return FLX_OK;
     if (n_seeds >= (1ull << 31)) { set_error("too many seeds in one call"); return FLX_ERR_INVALID; }
     HostIndex const& H = *ctx->ctx->hidx;
     PhaseTimer sprof("search");
 
-    // ---- expanded schemes (search_scheme_cache, search.cpp:328-350) and DFS stack reservations
-    std::map<std::pair<u32, u32>, std::pair<u32, u32>> scheme_of;      // (len, k) -> (offset, searches)
+    // ---- expanded schemes (search_scheme_cache, search.cpp:328-350), DFS stack reservations and the launch order
+    // Launch order = expected cost, heaviest class first (more errors, then shorter): the work of a seed grows steeply with its
+    // errors (k = 2 leaves of a 5-kb read cost 4x the k = 1 leaves), and what a wave still holds when the seed queue runs dry
+    // is the tail of the kernel. Within a class the caller's order is kept. Hits carry the seed's id, not its launch position.
+    // Two passes over the caller's seeds (a chunk of 10-kb reads has a million of them): classes and their sizes, then every DevSeed
+    // written once, at its launch position.
+    struct SeedClass { u32 scheme_off, frames_searches, count, next; };
+    std::map<u32, SeedClass> classes;                                   // key: (3 - errors) << 24 | length -> heaviest first
     hvec<u64> scheme_table;
-    hvec<DevSeed> dseeds(n_seeds);
     u64 frames = 0;
     u32 max_errors = 0, max_length = 0;
+    auto class_key = [](flx_seed const& s) { return ((3u - s.num_errors) << 24) | s.length; };
+    if (gen) { scheme_table = gen->scheme_table; max_errors = gen->max_errors; max_length = gen->max_length; }
+    else {
+        u32 last = 0xFFFFFFFFu;
+        SeedClass* slot = nullptr;                                      // consecutive seeds are mostly of one class
+        for (u64 i = 0; i < n_seeds; ++i) {
+            flx_seed const& s = seeds[i];
+            if (s.num_errors > 3) { set_error("seed errors must be in [0,3] (floxer_cli.cpp:299)"); return FLX_ERR_INVALID; }
+            if (s.length == 0 || s.length > SCH_POS_MASK || s.seq_offset + s.length > pool_len) { set_error("seed outside the sequence pool"); return FLX_ERR_INVALID; }
+            u32 const key = class_key(s);
+            if (key != last) {
+                auto it = classes.find(key);
+                if (it == classes.end()) {
+                    auto const e = expanded_scheme(s.num_errors, s.length);
+                    u32 const nsearch = e.empty() ? 0 : (u32)(e.size() / s.length);
+                    it = classes.emplace(key, SeedClass{(u32)scheme_table.size(), (s.length + s.num_errors + 3) | (nsearch << 24), 0, 0}).first;
+                    scheme_table.insert(scheme_table.end(), e.begin(), e.end());
+                    max_errors = std::max(max_errors, s.num_errors);
+                    max_length = std::max(max_length, s.length);
+                }
+                slot = &it->second;
+                last = key;
+            }
+            ++slot->count;
+        }
+        u32 pos = 0;
+        for (auto& kv : classes) { kv.second.next = pos; pos += kv.second.count; }
+    }
+    hvec<DevSeed> dseeds(gen ? 0 : n_seeds);
     // what a seed's symbols may be (SEED_* of flx_fm_core.hpp): given by the caller per seed, or read off the host pool
     auto flags_of = [&](u64 i) -> u32 {
         if (seed_flags) return seed_flags[i];
@@ -314,66 +349,23 @@ int search_seeds_device(Lane* ctx, const u8* d_seq_pool_or_null, const u8* h_seq
         for (u32 j = 0; j < seeds[i].length; ++j) { if (p[j] == 0) f |= SEED_HAS_DELIM; if (p[j] - 1u > 3u) f |= SEED_NOT_ACGT; }
         return f;
     };
-    for (u64 i = 0; i < n_seeds; ++i) {
-        flx_seed const& s = seeds[i];
-        max_errors = std::max(max_errors, s.num_errors);
-        max_length = std::max(max_length, s.length);
-        if (s.num_errors > 3) { set_error("seed errors must be in [0,3] (floxer_cli.cpp:299)"); return FLX_ERR_INVALID; }
-        if (s.length == 0 || s.length > SCH_POS_MASK || s.seq_offset + s.length > pool_len) { set_error("seed outside the sequence pool"); return FLX_ERR_INVALID; }
-        auto key = std::make_pair(s.length, s.num_errors);
-        if (i > 0 && seeds[i - 1].length == s.length && seeds[i - 1].num_errors == s.num_errors) {    // consecutive leaves are alike
-            DevSeed& d = dseeds[i];
-            d = dseeds[i - 1];
+    if (!gen) {
+        u32 last = 0xFFFFFFFFu;
+        SeedClass* slot = nullptr;
+        for (u64 i = 0; i < n_seeds; ++i) {
+            flx_seed const& s = seeds[i];
+            u32 const key = class_key(s);
+            if (key != last) { slot = &classes.find(key)->second; last = key; }
+            DevSeed& d = dseeds[slot->next++];
             d.seq_off = s.seq_offset;
-            d.stack_off = frames;
+            d.length = s.length;
+            d.scheme_off = slot->scheme_off;
+            d.frames_searches = slot->frames_searches;
+            d.stack_off = frames;                                       // (reserved in the caller's order: only the ordered walk uses it)
             d.id = (u32)i;
             d.flags = flags_of(i);
-            frames += d.frames_searches & 0xFFFFFFu;
-            continue;
-        }
-        auto it = scheme_of.find(key);
-        if (it == scheme_of.end()) {
-            auto const e = expanded_scheme(s.num_errors, s.length);
-            u32 const nsearch = e.empty() ? 0 : (u32)(e.size() / s.length);
-            it = scheme_of.emplace(key, std::make_pair((u32)scheme_table.size(), nsearch)).first;
-            scheme_table.insert(scheme_table.end(), e.begin(), e.end());
-        }
-        DevSeed& d = dseeds[i];
-        d.seq_off = s.seq_offset;
-        d.length = s.length;
-        d.scheme_off = it->second.first;
-        d.frames_searches = (s.length + s.num_errors + 3) | (it->second.second << 24);
-        d.stack_off = frames;
-        d.id = (u32)i;
-        d.flags = flags_of(i);
-        d.pad = 0;
-        frames += s.length + s.num_errors + 3;
-    }
-    // Launch order = expected cost, heaviest class first (more errors, then shorter): the work of a seed grows steeply with its
-    // errors (k = 2 leaves of a 5-kb read cost 4x the k = 1 leaves), and what a wave still holds when the seed queue runs dry
-    // is the tail of the kernel. Within a class the caller's order is kept. Hits carry the seed's id, not its launch position.
-    {
-        std::map<u32, u32> first_of_class;                      // key -> number of seeds, then first launch position
-        auto class_key = [&](u64 i) { return ((3u - seeds[i].num_errors) << 24) | std::min<u32>(seeds[i].length, 0xFFFFFFu); };
-        {
-            u32 last = 0xFFFFFFFFu, *slot = nullptr;                 // consecutive seeds are mostly of one class
-            for (u64 i = 0; i < n_seeds; ++i) {
-                u32 const key = class_key(i);
-                if (key != last) { slot = &first_of_class[key]; last = key; }
-                ++*slot;
-            }
-        }
-        if (first_of_class.size() > 1) {
-            u32 pos = 0;
-            for (auto& kv : first_of_class) { u32 const n = kv.second; kv.second = pos; pos += n; }
-            hvec<DevSeed> ordered(n_seeds);
-            u32 last_key = 0xFFFFFFFFu, *cursor = nullptr;
-            for (u64 i = 0; i < n_seeds; ++i) {
-                u32 const key = class_key(i);
-                if (key != last_key) { cursor = &first_of_class[key]; last_key = key; }
-                ordered[(*cursor)++] = dseeds[i];
-            }
-            dseeds.swap(ordered);
+            d.pad = 0;
+            frames += slot->frames_searches & 0xFFFFFFu;
         }
     }
     if (scheme_table.empty()) scheme_table.push_back(0);
@@ -386,7 +378,21 @@ int search_seeds_device(Lane* ctx, const u8* d_seq_pool_or_null, const u8* h_seq
         d_seq = ctx->seq.as<u8>();
     }
     if ((rc = h2d(ctx, ctx->scheme, scheme_table.data(), scheme_table.size() * 8))) return rc;
-    if ((rc = h2d(ctx, ctx->seeds, dseeds.data(), dseeds.size() * sizeof(DevSeed)))) return rc;
+    if (!gen) { if ((rc = h2d(ctx, ctx->seeds, dseeds.data(), dseeds.size() * sizeof(DevSeed)))) return rc; }
+    else {
+        // the chunk's description (a few hundred KB) up, the DevSeeds written where the search reads them
+        size_t const b_reads = gen->reads.size() * sizeof(DevSeedRead), b_leaves = gen->leaves.size() * sizeof(DevSeedLeaf), b_classes = gen->classes.size() * sizeof(DevSeedClass);
+        size_t const o_leaves = (b_reads + 255) / 256 * 256, o_classes = o_leaves + (b_leaves + 255) / 256 * 256;
+        if ((rc = ctx->seed_gen.ensure(o_classes + b_classes + 256))) return rc;
+        if ((rc = ctx->seeds.ensure(n_seeds * sizeof(DevSeed)))) return rc;
+        char* const g = (char*)ctx->seed_gen.ptr;
+        FLX_HIP(hipMemcpyAsync(g, gen->reads.data(), b_reads, hipMemcpyHostToDevice, ctx->stream));
+        FLX_HIP(hipMemcpyAsync(g + o_leaves, gen->leaves.data(), b_leaves, hipMemcpyHostToDevice, ctx->stream));
+        FLX_HIP(hipMemcpyAsync(g + o_classes, gen->classes.data(), b_classes, hipMemcpyHostToDevice, ctx->stream));
+        int const e = DeviceApi::build_seeds(ctx->stream, (const DevSeedRead*)g, (u32)gen->reads.size(), (const DevSeedLeaf*)(g + o_leaves), (const DevSeedClass*)(g + o_classes),
+                                             ctx->seeds.as<DevSeed>());
+        if (e) { set_error(std::string("seed_build: ") + hipGetErrorString((hipError_t)e)); return FLX_ERR_NO_DEVICE; }
+    }
     // The DFS in the reference's order (frames on a per-seed stack in HBM) where the order of discovery matters: the raw-emission
     // hook and first_reported, which want the first n rows; everywhere else the walk with its stack in LDS, whose hits carry keys
     // that restore the emission order.
@@ -403,18 +409,21 @@ int search_seeds_device(Lane* ctx, const u8* d_seq_pool_or_null, const u8* h_seq
         if (e) { set_error(std::string("pack_pool: ") + hipGetErrorString((hipError_t)e)); return FLX_ERR_NO_DEVICE; }
         d_qpack = ctx->qpack.as<u32>();
     }
-    u64 item_cap = filtered && ctx->ctx->didx.isa ? n_seeds * 8 + 4096 * 64 : 0;      // (10-kb reads at 8 %: 6.3 one-row subtrees per seed)
+    // (10-kb reads at 8 % on a random text: 6.3 one-row subtrees and 0.4 hits per seed; on a repeat-rich text several times that: what the
+    // last search on this lane needed, and a quarter more, is the starting size; a search that outgrows its buffers runs again)
+    u64 item_cap = filtered && ctx->ctx->didx.isa ? std::max<u64>(n_seeds * 8, (u64)(ctx->items_per_seed * 1.25 * (double)n_seeds)) + 4096 * 64 : 0;
 
     u32 const max_hits = raw_hits ? (u32)std::min<u64>(raw_max_hits, 0xFFFFFFF0u)
                                   : (cfg.anchor_choice_strategy == FLX_CHOICE_FIRST_REPORTED
                                          ? (u32)cfg.max_num_anchors_soft
                                          : (u32)std::max(cfg.max_num_anchors_hard, cfg.max_num_anchors_hard + 1));
     u64 const hit_slack = 4096 * 64;            // unused ends of the per-wave slot ranges (FM_MAX_WAVES x FM_HIT_GRAB)
-    u64 hit_cap = n_seeds * 6 + hit_slack;
+    u64 hit_cap = std::max<u64>(n_seeds * 6, (u64)(ctx->hits_per_seed * 1.25 * (double)n_seeds)) + hit_slack;
     // Anchor selection on the device (K1b) for the default group order and anchor choice; seeds it does not handle come back
     // flagged and go through the host code below.
     bool const device_select = !raw_hits && cfg.anchor_group_order == FLX_ORDER_COUNT_FIRST && cfg.anchor_choice_strategy == FLX_CHOICE_ROUND_ROBIN &&
                                cfg.max_num_anchors_soft >= 1 && !getenv("FLX_HOST_SELECT");
+    if (gen && (!device_select || ordered)) return SEARCH_NEEDS_HOST_SEEDS;      // (those paths read the seed list)
     size_t const scan_bytes = device_select ? DeviceApi::select_scan_bytes((u32)n_seeds) : 0;
     hvec<DevSelStat> sel_stat;                // per seed
     u32 sel_total = 0, sel_rows_total = 0;
@@ -431,7 +440,7 @@ int search_seeds_device(Lane* ctx, const u8* d_seq_pool_or_null, const u8* h_seq
         sel_stat.resize(n_seeds);
     }
     u32 counters[32];
-    u64 sel_cap = 0;                          // entries of the selected-anchor list
+    u64 sel_cap = (u64)(ctx->sel_rows_per_seed * 1.25 * (double)n_seeds);      // entries of the selected-anchor list (at least hit_cap, below)
     struct K1Token { flx_ctx* c; explicit K1Token(flx_ctx* c_) : c(c_) { c->k1_acquire(); } ~K1Token() { c->k1_release(); } };
     for (int attempt = 0;; ++attempt) {
         K1Token const token(ctx->ctx);           // (held until this attempt's kernels have finished)
@@ -488,6 +497,7 @@ int search_seeds_device(Lane* ctx, const u8* d_seq_pool_or_null, const u8* h_seq
         bool const items_fit = !item_cap || counters[16] <= item_cap;
         if (items_fit && counters[0] <= hit_cap && (!device_select || sel_rows_total <= sel_cap)) break;      // (selected anchors <= rows)
         if (attempt >= 3) { set_error("fm_search: hit buffer could not be sized"); return FLX_ERR_INTERNAL; }
+        { std::lock_guard<std::mutex> g(ctx->ctx->mu); ++ctx->ctx->path.search_reruns; }
         if (!items_fit) item_cap = (u64)counters[16] + hit_slack;             // queued subtrees were dropped: run again with room for all
         else if (counters[0] > hit_cap) hit_cap = (u64)counters[0] + hit_slack;      // the number of hits is known now; run again
         else sel_cap = (u64)sel_rows_total + 1024;
@@ -499,6 +509,9 @@ int search_seeds_device(Lane* ctx, const u8* d_seq_pool_or_null, const u8* h_seq
         auto it = ctx->ctx->stats.find("fm_search");
         if (it != ctx->ctx->stats.end()) { it->second.algorithmic_bytes += (u64)counters[2] * 128; it->second.work_units += counters[2]; }
     }
+    ctx->hits_per_seed = (double)counters[0] / (double)n_seeds;
+    ctx->items_per_seed = (double)counters[16] / (double)n_seeds;
+    ctx->sel_rows_per_seed = (double)sel_rows_total / (double)n_seeds;
     sprof.mark("kernel");
     // path counters of this call (folded into the context's at every way out of the selection below)
     u64 const n_extensions = counters[2];
@@ -520,7 +533,7 @@ int search_seeds_device(Lane* ctx, const u8* d_seq_pool_or_null, const u8* h_seq
             if ((rc = d2h(ctx, dev_anchors.data(), ctx->sel_out.ptr, (size_t)sel_total * sizeof(HostAnchor)))) return rc;
             if ((rc = ctx->sync())) return rc;
         }
-        for (auto& a : dev_anchors) a.leaf = seeds[a.seed_index].pex_leaf_index;
+        if (seeds) for (auto& a : dev_anchors) a.leaf = seeds[a.seed_index].pex_leaf_index;
         host_seed.assign(n_seeds, 0);
         bool any = false;
         for (u64 si = 0; si < n_seeds; ++si) {
@@ -536,6 +549,7 @@ int search_seeds_device(Lane* ctx, const u8* d_seq_pool_or_null, const u8* h_seq
                     (unsigned long long)with_anchors, (unsigned long long)excl, (unsigned long long)flagged, sel_total);
         }
         if (!any) { anchors.swap(dev_anchors); count_path(0); return FLX_OK; }
+        if (gen) return SEARCH_NEEDS_HOST_SEEDS;                      // (the host's selection reads the seed list)
     }
     // ---- the hits per seed in emission order: `by_seed`, seed si owns [first[si], first[si+1]). With device-side selection the
     //      device has grouped them already (only the seeds left to the host are looked at below); else the host groups them.
@@ -1746,8 +1760,6 @@ int align_slice(Lane* lane, const flx_params* P, const flx_reads* RD, u64 first_
     // ---- reads -> PEX trees, seeds on the forward and reverse-complement sequence (parallelization.cpp:77-98)
     hvec<ReadState> reads;
     hvec<flx_seed> seeds;
-    struct SeedOwner { u32 read; u8 orientation; };
-    hvec<SeedOwner> seed_owner;
     hvec<u8> seed_flags;
     std::map<std::pair<u64, u64>, std::unique_ptr<PexTree>> tree_cache;      // (length, errors) -> tree
     {
@@ -1755,9 +1767,7 @@ int align_slice(Lane* lane, const flx_params* P, const flx_reads* RD, u64 first_
         u64 bases = 0;
         for (u64 i = first_read; i < end_read; ++i) bases += RD->lens[i];
         u64 const guess = 2 * (bases / 32 + (end_read - first_read)) / std::max<u64>(1, P->seed_sampling_step_size) + 64;
-        seeds.reserve(guess);
-        seed_owner.reserve(guess);
-        seed_flags.reserve(guess);
+        (void)guess;
         reads.reserve(end_read - first_read);
     }
     for (u64 i = first_read; i < end_read; ++i) {
@@ -1778,15 +1788,80 @@ int align_slice(Lane* lane, const flx_params* P, const flx_reads* RD, u64 first_
         }
         rs.pool_off[0] = RD->pool_off[i];
         rs.pool_off[1] = RD->pool_off[i] + len;
-        for (int o = 0; o < 2; ++o)
-            for (u64 l = 0; l < rs.tree_ref().leaves.size(); l += P->seed_sampling_step_size) {      // pex.cpp:258-277
-                flx_pex_node const& leaf = rs.tree_ref().leaves[l];
-                seeds.push_back(flx_seed{rs.pool_off[o] + leaf.from, leaf.to - leaf.from + 1, leaf.num_errors, (u32)l, 0});
-                seed_owner.push_back(SeedOwner{(u32)reads.size(), (u8)o});
-                seed_flags.push_back(RD->flags[i]);
-            }
         reads.push_back(std::move(rs));
     }
+    // ---- the seeds: every step-th leaf of a read's tree, forward then reverse complement (pex.cpp:258-277). Seed s of the chunk =
+    //      (read, orientation, leaf) by the reads' seed ranges: seed_first[r] .. seed_first[r + 1], n_sampled(r) per orientation.
+    u64 const step = std::max<u64>(1, P->seed_sampling_step_size);
+    auto n_sampled = [&](ReadState const& r) { return (u32)((r.tree_ref().leaves.size() + step - 1) / step); };
+    hvec<u32> seed_first(reads.size() + 1, 0);
+    for (size_t r = 0; r < reads.size(); ++r) seed_first[r + 1] = seed_first[r] + 2u * n_sampled(reads[r]);
+    u64 const n_seeds_total = seed_first[reads.size()];
+    auto build_host_seeds = [&]() {                                    // the list form (the host's selection, statistics, FLX_HOST_SEEDS=1)
+        seeds.clear(); seed_flags.clear();
+        seeds.reserve(n_seeds_total); seed_flags.reserve(n_seeds_total);
+        for (size_t r = 0; r < reads.size(); ++r)
+            for (int o = 0; o < 2; ++o)
+                for (u64 l = 0; l < reads[r].tree_ref().leaves.size(); l += step) {
+                    flx_pex_node const& leaf = reads[r].tree_ref().leaves[l];
+                    seeds.push_back(flx_seed{reads[r].pool_off[o] + leaf.from, leaf.to - leaf.from + 1, leaf.num_errors, (u32)l, 0});
+                    seed_flags.push_back(RD->flags[reads[r].read_index]);
+                }
+    };
+    // the same as a description the device writes the seeds from: per tree its sampled leaves with their class (errors, length) and rank
+    // within the class, per read where its seeds of each class start in launch order (heaviest class first: more errors, then shorter)
+    SeedGen gen;
+    bool const use_gen = !getenv("FLX_HOST_SEEDS") && n_seeds_total > 0 && n_seeds_total < (1ull << 31);
+    if (use_gen) {
+        struct TreePlan { u32 leaf_first; hvec<u32> class_key, class_count; };
+        std::map<const PexTree*, TreePlan> plans;
+        struct GlobalClass { u64 pos = 0; u32 scheme_off = 0, nsearch = 0; };
+        std::map<u32, GlobalClass> global;                             // class key -> seeds of the class in the chunk, then its next launch position; its scheme
+        for (auto const& rs : reads) {
+            auto it = plans.find(rs.tree_ptr);
+            if (it == plans.end()) {
+                TreePlan tp;
+                tp.leaf_first = (u32)gen.leaves.size();
+                for (u64 l = 0; l < rs.tree_ref().leaves.size(); l += step) {
+                    flx_pex_node const& leaf = rs.tree_ref().leaves[l];
+                    u32 const length = leaf.to - leaf.from + 1, key = ((3u - std::min<u32>(leaf.num_errors, 3u)) << 24) | length;
+                    size_t c = 0;
+                    while (c < tp.class_key.size() && tp.class_key[c] != key) ++c;
+                    if (c == tp.class_key.size()) { tp.class_key.push_back(key); tp.class_count.push_back(0); }
+                    gen.leaves.push_back(DevSeedLeaf{leaf.from, length, (u32)c, tp.class_count[c]++});
+                    gen.max_errors = std::max(gen.max_errors, leaf.num_errors);
+                    gen.max_length = std::max(gen.max_length, length);
+                }
+                it = plans.emplace(rs.tree_ptr, std::move(tp)).first;
+            }
+            for (size_t c = 0; c < it->second.class_key.size(); ++c) global[it->second.class_key[c]].pos += 2ull * it->second.class_count[c];
+        }
+        if (gen.max_errors > 3) { set_error("seed errors must be in [0,3] (floxer_cli.cpp:299)"); return FLX_ERR_INVALID; }
+        u64 pos = 0;
+        for (auto& kv : global) {                                      // ascending key = heaviest class first
+            u32 const errors = 3u - (kv.first >> 24), length = kv.first & 0xFFFFFFu;
+            auto const e = expanded_scheme(errors, length);
+            kv.second.scheme_off = (u32)gen.scheme_table.size();
+            kv.second.nsearch = e.empty() ? 0 : (u32)(e.size() / length);
+            gen.scheme_table.insert(gen.scheme_table.end(), e.begin(), e.end());
+            u64 const n = kv.second.pos;
+            kv.second.pos = pos;
+            pos += n;
+        }
+        gen.reads.reserve(reads.size());
+        for (size_t r = 0; r < reads.size(); ++r) {
+            ReadState const& rs = reads[r];
+            TreePlan const& tp = plans.find(rs.tree_ptr)->second;
+            gen.reads.push_back(DevSeedRead{rs.pool_off[0], rs.pool_off[1], tp.leaf_first, n_sampled(rs), seed_first[r], (u32)gen.classes.size(), RD->flags[rs.read_index], 0});
+            for (size_t c = 0; c < tp.class_key.size(); ++c) {
+                auto& g = global[tp.class_key[c]];
+                u32 const errors = 3u - (tp.class_key[c] >> 24), length = tp.class_key[c] & 0xFFFFFFu;
+                gen.classes.push_back(DevSeedClass{(u32)g.pos, tp.class_count[c], g.scheme_off, (length + errors + 3) | (g.nsearch << 24)});
+                g.pos += 2ull * tp.class_count[c];
+            }
+        }
+        gen.n_seeds = n_seeds_total;
+    } else build_host_seeds();
 
     int rc;
     const u8* d_pool = RD->d_pool.as<u8>();
@@ -1802,8 +1877,15 @@ int align_slice(Lane* lane, const flx_params* P, const flx_reads* RD, u64 first_
     hvec<SeedStats> sstats;
     // (K1 starts behind K0 and the pool's 2-bit form: the event is recorded when the first call on these reads has queued both)
     FLX_HIP(hipStreamWaitEvent(lane->stream, RD->peq_event, 0));
-    if ((rc = search_seeds_device(lane, d_pool, pool.data(), pool.size(), seeds.data(), seeds.size(), P->search, anchors, sstats, nullptr, 0,
-                                  RD->d_pack.ptr ? RD->d_pack.as<u32>() : nullptr, seed_flags.data()))) return rc;
+    rc = use_gen ? search_seeds_device(lane, d_pool, pool.data(), pool.size(), nullptr, 0, P->search, anchors, sstats, nullptr, 0,
+                                       RD->d_pack.ptr ? RD->d_pack.as<u32>() : nullptr, nullptr, &gen)
+                 : SEARCH_NEEDS_HOST_SEEDS;
+    if (rc == SEARCH_NEEDS_HOST_SEEDS) {
+        if (use_gen) build_host_seeds();
+        rc = search_seeds_device(lane, d_pool, pool.data(), pool.size(), seeds.data(), seeds.size(), P->search, anchors, sstats, nullptr, 0,
+                                 RD->d_pack.ptr ? RD->d_pack.as<u32>() : nullptr, seed_flags.data());
+    }
+    if (rc) return rc;
 
     prof.mark("search");
     double const search_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_slice).count();
@@ -1811,13 +1893,14 @@ int align_slice(Lane* lane, const flx_params* P, const flx_reads* RD, u64 first_
         // per query: its length, its seeds (forward then reverse complement: one contiguous run of the seed list) and their
         // selection counters (statistics.cpp:283-295, 367-419)
         hvec<SeedStatRow> rows;
-        size_t si = 0;
         for (size_t r = 0; r < reads.size(); ++r) {
             st_local->at(Stats::QUERY_LENGTHS).add(reads[r].len);
             rows.clear();
-            for (; si < seeds.size() && seed_owner[si].read == r; ++si) {
-                st_local->at(Stats::ERRORS_PER_SEED).add(seeds[si].num_errors);
-                st_local->at(Stats::SEED_LENGTHS).add(seeds[si].length);
+            u32 const nl = n_sampled(reads[r]);
+            for (u32 si = seed_first[r]; si < seed_first[r + 1]; ++si) {
+                flx_pex_node const& leaf = reads[r].tree_ref().leaves[(u64)((si - seed_first[r]) % nl) * step];
+                st_local->at(Stats::ERRORS_PER_SEED).add(leaf.num_errors);
+                st_local->at(Stats::SEED_LENGTHS).add(leaf.to - leaf.from + 1);
                 rows.push_back(SeedStatRow{sstats[si].useful, sstats[si].raw, sstats[si].excluded_soft});
             }
             st_local->at(Stats::SEEDS_PER_QUERY).add(rows.size());
@@ -1826,11 +1909,19 @@ int align_slice(Lane* lane, const flx_params* P, const flx_reads* RD, u64 first_
         }
     }
     hvec<AnchorState> A(anchors.size());
+    u32 rd_i = 0;
     for (size_t a = 0; a < anchors.size(); ++a) {
-        SeedOwner const so = seed_owner[anchors[a].seed_index];
+        // the anchor's seed -> (read, orientation, leaf); the anchors come seed by seed, so the read mostly stays or moves on by one
+        u32 const si = anchors[a].seed_index;
+        if (si < seed_first[rd_i] || si >= seed_first[rd_i + 1]) {
+            if (si >= seed_first[rd_i + 1] && rd_i + 2 < seed_first.size() && si < seed_first[rd_i + 2]) ++rd_i;
+            else rd_i = (u32)(std::upper_bound(seed_first.begin(), seed_first.end(), si) - seed_first.begin() - 1);
+        }
+        u32 const nl = n_sampled(reads[rd_i]), local = si - seed_first[rd_i];
+        struct { u32 read; u8 orientation; } const so{rd_i, (u8)(local >= nl ? 1 : 0)};
         A[a].read = so.read;
         A[a].orientation = so.orientation;
-        A[a].leaf = anchors[a].leaf;
+        A[a].leaf = (u32)((u64)(local - (so.orientation ? nl : 0u)) * step);
         A[a].ref_id = anchors[a].ref_id;
         A[a].pos = anchors[a].pos;
         reads[so.read].anchor_ids[so.orientation].push_back((u32)a);

@@ -86,6 +86,34 @@ int DeviceApi::derive_index(void* stream, DevIndex& idx, u32* d_isa, u64* d_filt
 // A kernel that needs scratch (private segment) makes the runtime reserve it for the kernel's hardware queue when it is first launched
 // there; when HBM is full by then the runtime aborts the process. Launched once per lane when the context is made, this reserves what
 // the largest scratch user of the pipeline needs (seed_select_kernel<8>: 400 B per lane) while memory is still free.
+// one block per read: its 2 x n_leaves seeds (forward then reverse complement, leaf by leaf: the caller's order, which the ids follow)
+__global__ void __launch_bounds__(256) seed_build_kernel(const DevSeedRead* __restrict__ reads, u32 n_reads, const DevSeedLeaf* __restrict__ leaves,
+                                                         const DevSeedClass* __restrict__ classes, DevSeed* __restrict__ out) {
+    u32 const r = blockIdx.x;
+    if (r >= n_reads) return;
+    DevSeedRead const rd = reads[r];
+    for (u32 t = threadIdx.x; t < 2u * rd.n_leaves; t += blockDim.x) {
+        u32 const o = t >= rd.n_leaves ? 1u : 0u, l = t - o * rd.n_leaves;
+        DevSeedLeaf const lf = leaves[rd.leaf_first + l];
+        DevSeedClass const c = classes[rd.class_first + lf.cls];
+        DevSeed d;
+        d.seq_off = (o ? rd.pool_rev : rd.pool_fwd) + lf.from;
+        d.length = lf.length;
+        d.scheme_off = c.scheme_off;
+        d.frames_searches = c.frames_searches;
+        d.stack_off = 0;
+        d.id = rd.seed_base + t;
+        d.flags = rd.flags;
+        d.pad = 0;
+        out[c.pos_base + o * c.count + lf.rank] = d;
+    }
+}
+int DeviceApi::build_seeds(void* stream, const DevSeedRead* reads, u32 n_reads, const DevSeedLeaf* leaves, const DevSeedClass* classes, DevSeed* out) {
+    if (n_reads == 0) return 0;
+    hipLaunchKernelGGL(seed_build_kernel, dim3(n_reads), dim3(256), 0, (hipStream_t)stream, reads, n_reads, leaves, classes, out);
+    return (int)hipGetLastError();
+}
+
 __global__ void __launch_bounds__(64) scratch_warm_kernel(u32* __restrict__ sink) {
     volatile u32 a[128];
     a[threadIdx.x & 127u] = threadIdx.x;

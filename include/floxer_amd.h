@@ -96,7 +96,9 @@ int flx_index_image_layout(const flx_index* index, flx_index_image* out);
 int flx_index_image_upload(const flx_index* index, int hip_device, void* const device_buffers[5]);
 int flx_index_meta_export(const flx_index* index, uint8_t* buf, uint64_t* len /* in: capacity, out: needed */);
 int flx_index_meta_import(const uint8_t* buf, uint64_t len, flx_index** out);   /* an index without arrays: for flx_ctx_create_on_image */
-int flx_ctx_create_on_image(int hip_device, const flx_index* index, void* const device_buffers[5], flx_ctx** out);
+/* sizes: the bytes the caller's five buffers hold; they must be the index's layout (a stale image, e.g. of another build's block size,
+ * is refused instead of read out of bounds) */
+int flx_ctx_create_on_image(int hip_device, const flx_index* index, void* const device_buffers[5], const flx_index_image* sizes, flx_ctx** out);
 /* use a caller-owned HIP stream (hipStream_t passed as void*) for all launches; NULL restores the context's own stream */
 int flx_ctx_set_stream(flx_ctx* ctx, void* hip_stream);
 
@@ -234,7 +236,8 @@ int flx_ctx_get_kernel_stats(flx_ctx* ctx, flx_kernel_stat* out, uint32_t* n /* 
 typedef struct flx_path_counters {
     uint64_t seeds, seeds_with_anchors, seeds_excluded_by_hard_cap, seeds_selected_on_host, anchors, cursor_extensions;
     uint64_t inner_tests_requested, root_alignments_requested, root_alignments_found, records, reads;
-    uint64_t reserved[5];
+    uint64_t search_reruns;      /* search launches repeated because a chunk's hits or queued subtrees outgrew their buffers */
+    uint64_t reserved[4];
 } flx_path_counters;
 int flx_ctx_get_path_counters(flx_ctx* ctx, flx_path_counters* out);
 int flx_ctx_reset_path_counters(flx_ctx* ctx);

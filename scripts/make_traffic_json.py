@@ -7,7 +7,7 @@ import csv, json, os, sys
 fetch_csv, write_csv, iso_json, out_dir, prefix = sys.argv[1:6]
 iso = json.load(open(iso_json))
 # accounting name -> substrings of the kernel symbols it covers (fm_search = the filter walk + the text walk)
-KERNELS = {"fm_search": ("fm_search_filter_kernel", "fm_search_text_kernel"), "ed_align_trace": ("true>(",), "ed_align_exists": ("ed_exists_block_kernel",),
+KERNELS = {"fm_search": ("fm_search_filter_kernel", "fm_search_text_kernel"), "ed_align_trace": ("ed_trace_block_kernel",), "ed_align_exists": ("ed_exists_block_kernel", "ed_exists_lane_kernel"),
            "ed_traceback": ("traceback",)}
 # bytes per FETCH_SIZE unit / 1024: 2 for wide coalesced reads (128-B requests tallied at 64 B, MI355X guide); 1 for fm_search, whose reads are
 # random 32-byte blocks fetched as 64-byte requests and tallied exactly (calibration: scripts/micro/gather_cost.hip ... calib,

@@ -1167,6 +1167,8 @@ def test_context_on_an_index_image_and_two_contexts():
             assert fa.result().records() == base and fb.result().records() == base
     with pytest.raises(F.FloxerError):
         F.context(light)                                   # an index without arrays cannot upload itself
+    with pytest.raises(F.FloxerError):                     # buffers that are not this index's layout (a stale image) are refused
+        F.context(idx, image=image[:4] + [torch.empty(int(image[4].numel()) + 64, dtype=torch.uint8, device="cuda:0")])
     for c in (a, b, base_ctx):
         c.close()
 
@@ -1203,3 +1205,28 @@ def test_device_rounds_equal_host_rounds():
             n_total += n_reads
     assert stats.num_queries == n_total
     dev_ctx.close(); host_ctx.close()
+
+
+@pytest.mark.gpu
+def test_seeds_written_on_the_device_equal_the_host_list(monkeypatch):
+    """A chunk's seeds are written by a kernel from the reads' description (seed = function of read, orientation and sampled leaf;
+    FLX_HOST_SEEDS=1: the host lists them and copies them over): same records, ragged read lengths (many trees and seed classes in one
+    chunk), seed sampling steps 1 and 3, 1 and 2 seed errors, statistics attached (they read per-seed counters back)"""
+    genome = S.make_genome(300_000, 3, seed=71)
+    rng = np.random.default_rng(5)
+    reads = []
+    for i, length in enumerate(rng.integers(400, 4000, size=96)):
+        r, _, _ = S.make_reads(genome, 1, int(length), 0.06, seed=900 + i)
+        reads += r
+    ctx = F.context(F.fmindex(genome))
+    for kw in (dict(), dict(seed_sampling_step_size=3), dict(seed_errors=1), dict(interval_optimization=True), dict(max_anchors_soft=501, max_anchors_hard=100000)):
+        p = F.params(error_probability=0.06, **kw)
+        monkeypatch.delenv("FLX_HOST_SEEDS", raising=False)
+        dev = F.aligner(ctx, p).align_reads(reads).records()
+        monkeypatch.setenv("FLX_HOST_SEEDS", "1")
+        host = F.aligner(ctx, p).align_reads(reads).records()
+        assert dev == host and len(dev) >= len(reads) // 2, kw
+    monkeypatch.delenv("FLX_HOST_SEEDS", raising=False)
+    exp = O.Index(genome).run(reads, O.params(error_probability=0.06), threads=8)
+    assert F.aligner(ctx, F.params(error_probability=0.06)).align_reads(reads).records() == exp.records()
+    ctx.close()
