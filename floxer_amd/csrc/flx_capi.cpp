@@ -94,8 +94,10 @@ int make_context(int hip_device, const flx_index* index, void* const image[5], b
         auto lane = std::make_unique<Lane>();
         lane->ctx = ctx.get();
         lane->id = (int)l;
-        FLX_HIP(hipStreamCreateWithFlags(&lane->own_stream, hipStreamNonBlocking));
-        lane->stream = lane->own_stream;
+        // (FLX_STREAMS=N, experiment: lanes beyond the N-th share the streams of the first N; a lane's waits then cover its partner's launches)
+        static size_t const n_streams = [] { const char* e = getenv("FLX_STREAMS"); return e ? (size_t)std::max(1, atoi(e)) : (size_t)64; }();
+        if (l < n_streams) { FLX_HIP(hipStreamCreateWithFlags(&lane->own_stream, hipStreamNonBlocking)); lane->stream = lane->own_stream; }
+        else lane->stream = ctx->lanes[l % n_streams]->own_stream;
         ctx->lanes.push_back(std::move(lane));
         ctx->free_lanes.push_back((int)l);
     }
