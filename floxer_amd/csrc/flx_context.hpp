@@ -147,7 +147,7 @@ int search_seeds_device(Lane* lane, const u8* d_seq_pool_or_null, const u8* h_se
                         const SeedGen* gen = nullptr);
 // gen: `seeds` is null and the chunk's seeds are written on the device from this description (their ids = the order the caller would have
 // listed them in: read by read, forward then reverse complement, leaf by leaf); the anchors' leaf is left to the caller; returns
-// SEARCH_NEEDS_HOST_SEEDS (nothing done that counts) when a seed has to go through the host's selection: call again with the list.
+// SEARCH_NEEDS_HOST_SEEDS (nothing done that counts) for the forms that read the list (ordered walk, host-side grouping): call again with it.
 constexpr int SEARCH_NEEDS_HOST_SEEDS = 1;
 
 }  // namespace flx

@@ -549,7 +549,6 @@ int search_seeds_device(Lane* ctx, const u8* d_seq_pool_or_null, const u8* h_seq
                     (unsigned long long)with_anchors, (unsigned long long)excl, (unsigned long long)flagged, sel_total);
         }
         if (!any) { anchors.swap(dev_anchors); count_path(0); return FLX_OK; }
-        if (gen) return SEARCH_NEEDS_HOST_SEEDS;                      // (the host's selection reads the seed list)
     }
     // ---- the hits per seed in emission order: `by_seed`, seed si owns [first[si], first[si+1]). With device-side selection the
     //      device has grouped them already (only the seeds left to the host are looked at below); else the host groups them.
@@ -689,7 +688,7 @@ int search_seeds_device(Lane* ctx, const u8* d_seq_pool_or_null, const u8* h_seq
             if (p >= H.n) { set_error("fm_locate returned a position outside the text"); return FLX_ERR_INTERNAL; }
             size_t const s = nref == 1 ? 0 : std::upper_bound(H.seq_start.begin(), H.seq_start.end(), p) - H.seq_start.begin() - 1;
             stats[si] = SeedStats{1, 1, (u32)(total_raw[si] - 1), 0};
-            anchors.push_back(HostAnchor{(u32)si, seeds[si].pex_leaf_index, (u32)s, reqs[ri].errors, p - H.seq_start[s]});
+            anchors.push_back(HostAnchor{(u32)si, (seeds ? seeds[si].pex_leaf_index : 0u), (u32)s, reqs[ri].errors, p - H.seq_start[s]});
             ++ri;
             continue;
         }
@@ -712,7 +711,7 @@ int search_seeds_device(Lane* ctx, const u8* d_seq_pool_or_null, const u8* h_seq
         }
         stats[si] = SeedStats{useful, raw, (u32)(total_raw[si] - raw), 0};
         for (u32 r : touched) {
-            for (auto const& a : by_ref[r]) anchors.push_back(HostAnchor{(u32)si, seeds[si].pex_leaf_index, r, (u32)a.errors, a.pos});
+            for (auto const& a : by_ref[r]) anchors.push_back(HostAnchor{(u32)si, (seeds ? seeds[si].pex_leaf_index : 0u), r, (u32)a.errors, a.pos});
             by_ref[r].clear();
         }
     }
