@@ -57,19 +57,139 @@ struct BlockDeflater {
     }
 };
 
+// ---- A deflate stream of literals only: one dynamic-Huffman block per BGZF block, no string matching (FLX_BGZF_FAST=1). BAM records of
+// long reads are CIGAR arrays (32-bit words whose upper bytes are zero), 4-bit packed bases and qualities; an order-0 code runs at 570 MB/s
+// per thread against zlib level 1's 100, and the writer's deflate threads are what bounds the CLI with -I (46.7 k -> 61.6 k reads/s,
+// profiles/r03_cli_throughput_fast_bgzf.txt). It gives up the repeats zlib finds between CIGAR words, though: files are half as large
+// again (5.6 against 3.7 GB for 2.85 M records with 1600-operation CIGARs), so with default flags, where the output volume is what
+// costs, it gains little on a disk that writes 0.6 GB/s. Off by default.
+bool bgzf_use_zlib() {
+    static bool const v = getenv("FLX_BGZF_FAST") == nullptr;
+    return v;
+}
+struct BitSink {
+    uint8_t* p;
+    uint64_t acc = 0;
+    unsigned n = 0;                                        // bits held (< 32 between calls)
+    explicit BitSink(uint8_t* out) : p(out) {}
+    inline void put(uint32_t bits, unsigned count) {       // count <= 32
+        acc |= (uint64_t)bits << n;
+        n += count;
+        if (n >= 32) { memcpy(p, &acc, 4); p += 4; acc >>= 32; n -= 32; }
+    }
+    uint8_t* finish() { while (n > 0) { *p++ = (uint8_t)acc; acc >>= 8; n = n > 8 ? n - 8 : 0; } return p; }
+};
+inline uint32_t bit_reverse(uint32_t v, unsigned bits) { uint32_t r = 0; for (unsigned i = 0; i < bits; ++i) { r = (r << 1) | (v & 1u); v >>= 1; } return r; }
+
+// code lengths (<= 15) of an optimal prefix code for freq[0..n): Huffman by the two-queue method over the used symbols, then lengths
+// beyond the limit moved down (the longest codes lengthen one another until the Kraft sum fits). At least two symbols are used.
+void huffman_lengths(const uint32_t* freq, unsigned n, uint8_t* len) {
+    constexpr unsigned MAXL = 15;
+    struct Node { uint64_t w; int left, right; };
+    unsigned order[320];
+    unsigned m = 0;
+    for (unsigned i = 0; i < n; ++i) { len[i] = 0; if (freq[i]) order[m++] = i; }
+    std::sort(order, order + m, [&](unsigned a, unsigned b) { return freq[a] != freq[b] ? freq[a] < freq[b] : a < b; });
+    Node nodes[640];
+    for (unsigned i = 0; i < m; ++i) nodes[i] = Node{freq[order[i]], -1, -1};
+    unsigned leaf = 0, inner = m, made = m;
+    auto take = [&]() -> int {                             // the lighter of the next leaf and the next inner node
+        if (leaf < m && (inner >= made || nodes[leaf].w <= nodes[inner].w)) return (int)leaf++;
+        return (int)inner++;
+    };
+    while (m - leaf + (made - inner) > 1) {
+        int const a = take(), b = take();
+        nodes[made] = Node{nodes[a].w + nodes[b].w, a, b};
+        ++made;
+    }
+    // depths: parents come after their children, so one pass from the root down
+    unsigned depth[640];
+    depth[made - 1] = 0;
+    for (unsigned i = made; i-- > m;) { depth[nodes[i].left] = depth[i] + 1; depth[nodes[i].right] = depth[i] + 1; }
+    unsigned count[64] = {0};
+    for (unsigned i = 0; i < m; ++i) ++count[std::min(depth[i], 63u)];
+    // enforce the limit: everything deeper than MAXL comes up to MAXL, then codes are lengthened until the Kraft sum is 2^MAXL
+    for (unsigned d = MAXL + 1; d < 64; ++d) { count[MAXL] += count[d]; count[d] = 0; }
+    uint64_t total = 0;
+    for (unsigned d = 1; d <= MAXL; ++d) total += (uint64_t)count[d] << (MAXL - d);
+    while (total > (1ull << MAXL)) {
+        --count[MAXL];
+        for (unsigned d = MAXL - 1; d > 0; --d) if (count[d]) { --count[d]; count[d + 1] += 2; break; }
+        --total;
+    }
+    // the rarest symbols get the longest codes (order is by ascending frequency)
+    unsigned at = 0;
+    for (unsigned d = MAXL; d > 0; --d) for (unsigned c = 0; c < count[d]; ++c) len[order[at++]] = (uint8_t)d;
+}
+
+// raw deflate stream for data[0, n), n <= BGZF_BLOCK, into out (capacity >= n + 600); returns its length
+size_t literal_deflate(const uint8_t* data, size_t n, uint8_t* out) {
+    if (n == 0) { out[0] = 0x03; out[1] = 0x00; return 2; }          // an empty fixed-Huffman block
+    uint32_t f4[4][256];
+    memset(f4, 0, sizeof(f4));
+    size_t i = 0;
+    for (; i + 4 <= n; i += 4) { ++f4[0][data[i]]; ++f4[1][data[i + 1]]; ++f4[2][data[i + 2]]; ++f4[3][data[i + 3]]; }
+    for (; i < n; ++i) ++f4[0][data[i]];
+    uint32_t freq[257];
+    for (unsigned b = 0; b < 256; ++b) freq[b] = f4[0][b] + f4[1][b] + f4[2][b] + f4[3][b];
+    freq[256] = 1;                                                    // end of block
+    uint8_t len[257];
+    huffman_lengths(freq, 257, len);
+    uint64_t bits = 3 + 5 + 5 + 4 + 19 * 3 + 258 * 4;
+    for (unsigned b = 0; b < 257; ++b) bits += (uint64_t)freq[b] * len[b];
+    if ((bits + 7) / 8 >= n + 5) {                                    // does not pay: a stored block
+        out[0] = 0x01;
+        uint16_t const l = (uint16_t)n, nl = (uint16_t)~l;
+        memcpy(out + 1, &l, 2);
+        memcpy(out + 3, &nl, 2);
+        memcpy(out + 5, data, n);
+        return n + 5;
+    }
+    // canonical codes, stored bit-reversed (deflate packs Huffman codes most significant bit first into a least-significant-bit-first stream)
+    uint32_t code[257];
+    {
+        unsigned bl_count[16] = {0}, next[16];
+        for (unsigned b = 0; b < 257; ++b) ++bl_count[len[b]];
+        bl_count[0] = 0;
+        unsigned c = 0;
+        for (unsigned d = 1; d <= 15; ++d) { c = (c + bl_count[d - 1]) << 1; next[d] = c; }
+        for (unsigned b = 0; b < 257; ++b) code[b] = len[b] ? bit_reverse(next[len[b]]++, len[b]) : 0;
+    }
+    BitSink bs(out);
+    bs.put(1, 1);                                                     // BFINAL
+    bs.put(2, 2);                                                     // BTYPE = dynamic Huffman
+    bs.put(0, 5);                                                     // HLIT: 257 literal / length codes
+    bs.put(0, 5);                                                     // HDIST: 1 distance code (of zero bits: no distances)
+    bs.put(15, 4);                                                    // HCLEN: all 19 code length codes
+    // the code length code: lengths 0..15 get 4 bits each (a complete code), the run symbols 16..18 are not used
+    static const uint8_t cl_order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
+    for (unsigned k = 0; k < 19; ++k) bs.put(cl_order[k] >= 16 ? 0u : 4u, 3);
+    for (unsigned b = 0; b < 257; ++b) bs.put(bit_reverse(len[b], 4), 4);
+    bs.put(bit_reverse(0, 4), 4);                                     // the one distance code: length 0
+    uint64_t packed[256];                                             // code | length << 32
+    for (unsigned b = 0; b < 256; ++b) packed[b] = code[b] | ((uint64_t)len[b] << 32);
+    for (size_t k = 0; k < n; ++k) { uint64_t const e = packed[data[k]]; bs.put((uint32_t)e, (unsigned)(e >> 32)); }
+    bs.put(code[256], len[256]);
+    return (size_t)(bs.finish() - out);
+}
+
 // one BGZF block (a gzip member with the BC extra field) for `len` <= BGZF_BLOCK bytes; returns its size, 0 on failure
 size_t bgzf_compress_block(const uint8_t* data, size_t len, uint8_t* out) {
-    thread_local BlockDeflater deflater;
-    z_stream* const zp = deflater.get();
-    if (!zp) return 0;
-    z_stream& zs = *zp;
-    zs.next_in = const_cast<Bytef*>(data);
-    zs.avail_in = (uInt)len;
-    zs.next_out = out + 18;
-    zs.avail_out = (uInt)(BGZF_MAX_OUT - 18 - 8);
-    int const rc = deflate(&zs, Z_FINISH);
-    size_t const clen = zs.total_out;
-    if (rc != Z_STREAM_END) return 0;
+    size_t clen;
+    if (!bgzf_use_zlib()) clen = literal_deflate(data, len, out + 18);
+    else {
+        thread_local BlockDeflater deflater;
+        z_stream* const zp = deflater.get();
+        if (!zp) return 0;
+        z_stream& zs = *zp;
+        zs.next_in = const_cast<Bytef*>(data);
+        zs.avail_in = (uInt)len;
+        zs.next_out = out + 18;
+        zs.avail_out = (uInt)(BGZF_MAX_OUT - 18 - 8);
+        int const rc = deflate(&zs, Z_FINISH);
+        clen = zs.total_out;
+        if (rc != Z_STREAM_END) return 0;
+    }
     size_t const bsize = clen + 18 + 8;
     static const uint8_t hdr[16] = {31, 139, 8, 4, 0, 0, 0, 0, 0, 255, 6, 0, 'B', 'C', 2, 0};
     memcpy(out, hdr, 16);

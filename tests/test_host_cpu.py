@@ -195,6 +195,16 @@ def test_fm_core_matches_oracle(tmp_path):
     assert out.returncode == 0 and "fm_core_check ok" in out.stdout, out.stdout[-3000:] + out.stderr[-3000:]
 
 
+def test_literal_deflate_round_trips(tmp_path):
+    """the BAM writer's own deflate encoder (one dynamic-Huffman block of literals per BGZF block) decoded by zlib: tests/bgzf_check.cpp"""
+    import subprocess
+    exe = str(tmp_path / "bgzf_check")
+    src = [os.path.join(ROOT, "tests", "bgzf_check.cpp"), os.path.join(ROOT, "floxer_amd", "csrc", "flx_host.cpp")]
+    subprocess.run(["g++", "-O2", "-std=c++17", "-Wno-unknown-pragmas", "-pthread", "-o", exe] + src + ["-lz"], check=True)
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "bgzf_check ok" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
+
+
 def test_writer_threads_long_cigar_and_name_limit(tmp_path):
     """flx_sam_set_threads: output bytes do not depend on the thread count; a CIGAR of more than 65535 operations goes into the
     CG:B,I tag behind a kSmN placeholder (SAM spec 4.2.2); a read name of 255 characters or more is refused for BAM"""
