@@ -271,6 +271,7 @@ struct FastqReader {
     std::vector<char, DefaultInit<char>> carry; // text behind the last complete record of the previous batch
     bool eof = false;
     unsigned threads;
+    size_t file_pos = 0, last_batch_bytes = 0;  // plain input: where the next read starts; the text the last batch took
     FastqReader(const char* path, unsigned threads_) : threads(threads_) {
         int const probe = open(path, O_RDONLY);
         if (probe < 0) return;
@@ -296,22 +297,60 @@ struct FastqReader {
         // ---- read until the text holds max_reads records (4 lines each) or the file ends
         size_t lines = 0, scanned = 0;
         std::vector<size_t> nl;                 // positions of the line ends
-        auto scan = [&]() {
-            while (scanned < raw.size()) {
-                const char* p = (const char*)memchr(raw.data() + scanned, '\n', raw.size() - scanned);
-                if (!p) { scanned = raw.size(); break; }
-                nl.push_back((size_t)(p - raw.data()));
-                scanned = (size_t)(p - raw.data()) + 1;
-                ++lines;
-            }
+        auto scan = [&]() {                     // line ends of raw[scanned, size): pieces of at least 8 MB, one thread each
+            size_t const lo = scanned, hi = raw.size();
+            unsigned const t = (unsigned)std::min<size_t>(std::max(1u, threads), std::max<size_t>(1, (hi - lo) >> 23));
+            std::vector<std::vector<size_t>> found(t);
+            auto piece = [&](unsigned i) {
+                size_t at = lo + (hi - lo) * i / t;
+                size_t const end = lo + (hi - lo) * (i + 1) / t;
+                while (at < end) {
+                    const char* p = (const char*)memchr(raw.data() + at, '\n', end - at);
+                    if (!p) break;
+                    found[i].push_back((size_t)(p - raw.data()));
+                    at = (size_t)(p - raw.data()) + 1;
+                }
+            };
+            std::vector<std::thread> pool;
+            for (unsigned i = 1; i < t; ++i) pool.emplace_back(piece, i);
+            piece(0);
+            for (auto& th : pool) th.join();
+            for (auto const& v : found) { nl.insert(nl.end(), v.begin(), v.end()); lines += v.size(); }
+            scanned = hi;
         };
         scan();
         while (!eof && lines < 4 * max_reads) {
-            size_t const at = raw.size(), want = 16u << 20;
+            // plain input: as much as the last batch took (and a little more) in one go, the pieces read by several threads (pread);
+            // gzip input: 16 MB at a time through zlib
+            size_t const at = raw.size(), want = f ? (size_t)16 << 20 : std::max<size_t>((size_t)16 << 20, last_batch_bytes > at ? last_batch_bytes - at + (1u << 20) : (size_t)16 << 20);
             raw.resize(at + want);
             long got;
             if (f) got = gzread(f, raw.data() + at, (unsigned)want);
-            else do got = (long)read(fd, raw.data() + at, want); while (got < 0 && errno == EINTR);
+            else {
+                unsigned const t = (unsigned)std::min<size_t>(std::max(1u, threads), std::max<size_t>(1, want >> 24));      // >= 16 MB per thread
+                std::vector<long> part(t, 0);
+                std::vector<std::thread> pool;
+                auto piece = [&](unsigned i) {
+                    size_t const lo = want * i / t, hi = want * (i + 1) / t;
+                    size_t done = 0;
+                    while (lo + done < hi) {
+                        ssize_t const r = pread(fd, raw.data() + at + lo + done, hi - lo - done, (off_t)(file_pos + lo + done));
+                        if (r < 0) { if (errno == EINTR) continue; part[i] = -1; return; }
+                        if (r == 0) break;
+                        done += (size_t)r;
+                    }
+                    part[i] = (long)done;
+                };
+                for (unsigned i = 1; i < t; ++i) pool.emplace_back(piece, i);
+                piece(0);
+                for (auto& th : pool) th.join();
+                got = 0;
+                for (unsigned i = 0; i < t && got >= 0; ++i) {
+                    if (part[i] < 0) got = -1;
+                    else { got += part[i]; if ((size_t)part[i] < want * (i + 1) / t - want * i / t) break; }      // a short piece: the file ends inside it
+                }
+                if (got > 0) file_pos += (size_t)got;
+            }
             if (got < 0) { err = "read error on the query file"; return false; }
             raw.resize(at + (size_t)got);
             if (f && (size_t)got < want) {
@@ -332,6 +371,7 @@ struct FastqReader {
         size_t const used = n_rec ? nl[4 * n_rec - 1] + 1 : 0;
         carry.assign(raw.begin() + (long)used, raw.end());
         raw.resize(used);
+        last_batch_bytes = used;
         if (n_rec == 0) return false;
         // ---- records: id (up to the first blank, input.cpp:161-163), sequence, quality; terminated in place
         struct Rec { size_t id, seq, seq_len, qual; bool keep; };
