@@ -837,7 +837,7 @@ __global__ void __launch_bounds__(256) seed_rows_kernel(const DevHit* __restrict
 
 // the seeds of one list: their anchors to their slots of the sparse list (row_offset), n_out says how many
 template <u32 CAP>
-__global__ void __launch_bounds__(64) seed_select_kernel(const u32* __restrict__ list, const u32* __restrict__ list_count,
+__global__ void __launch_bounds__(64, 4) seed_select_kernel(const u32* __restrict__ list, const u32* __restrict__ list_count,
                                                          const DevHit* __restrict__ grouped, const u32* __restrict__ hit_offset,
                                                          const u32* __restrict__ sa, u32 n_text, const u64* __restrict__ seq_start, u32 n_ref,
                                                          u32 erase, SelStat* __restrict__ stat, u32* __restrict__ n_out,
@@ -866,7 +866,7 @@ __global__ void __launch_bounds__(64) seed_select_kernel(const u32* __restrict__
 // (MAXG: groups a seed of the list may have; 64 groups keep the block at 2.7 KB of LDS, which finds room on a CU next to the DP
 // kernels of other lanes; the few seeds with up to 512 groups take the 17-KB form)
 template <u32 MAXG>
-__global__ void __launch_bounds__(64) seed_select_wave_kernel(const u32* __restrict__ list, const u32* __restrict__ list_count,
+__global__ void __launch_bounds__(64, MAXG <= 64 ? 4 : 2) seed_select_wave_kernel(const u32* __restrict__ list, const u32* __restrict__ list_count,
                                                               const DevHit* __restrict__ grouped, const u32* __restrict__ hit_offset,
                                                               const u32* __restrict__ sa, u32 n_text, const u64* __restrict__ seq_start, u32 n_ref,
                                                               u32 erase, SelStat* __restrict__ stat, u32* __restrict__ n_out,
