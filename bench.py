@@ -67,6 +67,9 @@ def parse():
     ap.add_argument("--gather-cigars", action="store_true", help="N > 1: the per-step gather to rank 0 also moves the CIGAR words (default: the fixed-size records)")
     ap.add_argument("--cpu-sample", type=int, default=int(os.environ.get("FLX_BENCH_CPU_SAMPLE", 768)))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-host-inputs-leg", action="store_true", help="skip the second timed region (reads in pageable host memory: H2D and Peq build inside the clock)")
+    ap.add_argument("--no-repeat-rich-leg", action="store_true", help="metric configuration only: skip the secondary line on the repeat-rich (hg38-like) reference")
+    ap.add_argument("--repeat-rich-steps", type=int, default=4)
     args = ap.parse_args()
     cfg = CONFIGS[args.config]
     args.genome = args.genome or cfg["genome"]
@@ -87,6 +90,32 @@ def usable_cores():
     except (OSError, ValueError):
         pass
     return n
+
+
+def compare_with_oracle(got, exp, n_sample):
+    """records of the reads [0, n_sample) of a product result against an oracle run over exactly those reads: same number of records,
+    and record by record (in output order) the same read, flag, reference, position, edit distance and CIGAR words"""
+    import numpy as np
+    g = got.rows[got.rows[:, 0] < n_sample]
+    e = exp.rows
+    out = {"reads": int(n_sample), "records": int(len(e)), "product_records": int(len(g)), "equal": False}
+    if len(g) != len(e):
+        return out
+    if len(e) and not np.array_equal(g[:, :5], e[:, :5]):
+        out["first_difference"] = int(np.nonzero((g[:, :5] != e[:, :5]).any(axis=1))[0][0])
+        return out
+    if not np.array_equal(g[:, 6], e[:, 6]):
+        return out
+    # CIGAR words: gather both sides' slabs in record order and compare once
+    def words(rows, cig):
+        if not len(rows):
+            return np.zeros(0, np.uint32)
+        lens = rows[:, 6]
+        idx = np.repeat(rows[:, 5] - np.concatenate(([0], np.cumsum(lens)[:-1])), lens) + np.arange(int(lens.sum()))
+        return np.asarray(cig, dtype=np.uint32)[idx]
+    out["cigar_words"] = int(e[:, 6].sum())
+    out["equal"] = bool(np.array_equal(words(g, got.cigars), words(e, exp.cigars)))
+    return out
 
 
 def log(msg):
@@ -190,6 +219,8 @@ def main():
 
     n_records = 0
     elapsed = 1.0
+    host_elapsed = None
+    first_result = None
     gather_s = None
     stats = {}
     path = {}
@@ -209,50 +240,64 @@ def main():
         ctx.reset_kernel_stats()
         ctx.path_counters(reset=True)
 
-        tpool = ThreadPoolExecutor(max_workers=max(1, args.inflight))
-        gather_s = 0.0 if world > 1 else None
-        gathered_rows = 0
-
-        barrier()
-        t_start = time.perf_counter()
-        # a step = the whole hot path over one batch. Batches are independent (floxer itself streams reads through a thread
-        # pool without a barrier between them), so up to --inflight steps are in the context at once: while one batch's lanes
-        # are in a host phase another batch's kernels keep the GPU busy. All K steps start and finish inside the timed region.
-        futures = [tpool.submit(al.align_reads, resident[first_timed + s % n_timed_batches]) for s in range(args.steps)]
-        for si, f in enumerate(futures):
-            res = f.result()
-            # the only exchanges between ranks: the sizes of the ranks' parts of this step (= where each part goes in the job's
-            # output, which is the parts in rank order), then the step's records to rank 0 - while the next steps compute
-            counts = D.exchange_counts(res.n_records, len(res.cigars), rank, world, device=dev)
-            n_records += int(counts[:, 0].sum())
+        def timed_region(inputs):
+            """K steps over `inputs` (one per timed batch): (seconds (max over ranks), records, seconds rank 0 spent gathering, result of step 0)"""
+            tpool = ThreadPoolExecutor(max_workers=max(1, args.inflight))
+            g_s = 0.0 if world > 1 else None
+            gathered_rows = 0
+            n_rec = 0
+            first = None
+            barrier()
+            t_start = time.perf_counter()
+            # a step = the whole hot path over one batch. Batches are independent (floxer itself streams reads through a thread
+            # pool without a barrier between them), so up to --inflight steps are in the context at once: while one batch's lanes
+            # are in a host phase another batch's kernels keep the GPU busy. All K steps start and finish inside the timed region.
+            futures = [tpool.submit(al.align_reads, inputs[s % n_timed_batches]) for s in range(args.steps)]
+            for si, f in enumerate(futures):
+                res = f.result()
+                if si == 0:
+                    first = res
+                # the only exchanges between ranks: the sizes of the ranks' parts of this step (= where each part goes in the job's
+                # output, which is the parts in rank order), then the step's records to rank 0 - while the next steps compute
+                counts = D.exchange_counts(res.n_records, len(res.cigars), rank, world, device=dev)
+                n_rec += int(counts[:, 0].sum())
+                if world > 1:
+                    t_g = time.perf_counter()
+                    if args.gather_cigars:
+                        got = D.gather_records(res.rows, res.cigars, (si * world + rank) * B, rank, world, device=dev)
+                        if rank == 0:
+                            gathered_rows += len(got[0])
+                    else:
+                        rows = res.rows.copy()
+                        rows[:, 0] += (si * world + rank) * B          # global read index of this step's shard
+                        table = D.gather_rows(rows, counts, rank, world, device=dev)
+                        if rank == 0:
+                            gathered_rows += int(table.shape[0])
+                        del table
+                    g_s += time.perf_counter() - t_g
+            barrier()
+            secs = time.perf_counter() - t_start
+            tpool.shutdown()
             if world > 1:
-                t_g = time.perf_counter()
-                if args.gather_cigars:
-                    got = D.gather_records(res.rows, res.cigars, (si * world + rank) * B, rank, world, device=dev)
-                    if rank == 0:
-                        gathered_rows += len(got[0])
-                else:
-                    rows = res.rows.copy()
-                    rows[:, 0] += (si * world + rank) * B          # global read index of this step's shard
-                    table = D.gather_rows(rows, counts, rank, world, device=dev)
-                    if rank == 0:
-                        gathered_rows += int(table.shape[0])
-                    del table
-                gather_s += time.perf_counter() - t_g
-        barrier()
-        elapsed = time.perf_counter() - t_start
-        tpool.shutdown()
-        if world > 1:
-            t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            elapsed = float(t.item())
-            if rank == 0:
-                assert gathered_rows == n_records, (gathered_rows, n_records)
+                t = torch.tensor([secs], device=dev, dtype=torch.float64)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                secs = float(t.item())
+                if rank == 0:
+                    assert gathered_rows == n_rec, (gathered_rows, n_rec)
+            return secs, n_rec, g_s, first
+
+        elapsed, n_records, gather_s, first_result = timed_region(resident[first_timed:first_timed + n_timed_batches])
         log(f"timed region {elapsed:.2f} s")
 
         stats = ctx.kernel_stats()
         path = ctx.path_counters()
         ctx.enable_kernel_timing(False)
+        # ---- what floxer's own stopwatch spans (floxer.cpp:154-179: query reading to last record): the same K steps with the reads in
+        #      pageable host memory, flx_align_reads: the H2D copy, the reverse complements, the 2-bit form and the Peq planes inside the clock
+        if not args.no_host_inputs_leg:
+            host_elapsed, host_records, _, _ = timed_region(batches[first_timed:first_timed + n_timed_batches])
+            assert host_records == n_records, (host_records, n_records)
+            log(f"timed region, host inputs {host_elapsed:.2f} s")
     # the timed region's context and its resident batches leave the GPU before the one-lane pass makes its own (a repeat-rich reference
     # grows the lanes' workspaces: both contexts together ran out of HBM)
     for rr in resident:
@@ -263,6 +308,7 @@ def main():
     # ---- isolated pass (rank 0): the first timed batch once more on ONE lane, so that no two kernels overlap and a launch's
     #      HIP-event time (on the launch stream) is its own duration. Outside the timed region; feeds "roofline".
     iso_stats = {}
+    parity_failed = False
     if rank == 0 and not args.no_isolated_pass:
         os.environ["FLX_LANES"] = "1"
         ctx1 = F.context(index, device=local_rank, image=image)
@@ -271,7 +317,9 @@ def main():
         al1.align_reads(rr1)                                   # warm the workspaces
         ctx1.enable_kernel_timing(True)
         ctx1.reset_kernel_stats()
-        al1.align_reads(rr1)
+        iso_result = al1.align_reads(rr1)
+        if first_result is None:
+            first_result = iso_result
         iso_stats = ctx1.kernel_stats()
         rr1.close()
         ctx1.close()
@@ -285,6 +333,7 @@ def main():
 
         # ---- CPU baseline: the oracle on a sample of the same reads; it also counts the cursor extensions the reference's walk makes
         cpu = None
+        parity = None
         ext_per_read = None
         ext_source = None
         if not args.no_cpu_baseline and world == 1:            # (rank 0 at N = 1 only)
@@ -302,6 +351,11 @@ def main():
             ores = oidx.run(sample, O.params(error_probability=args.error_rate, interval_opt=args.interval_optimization), threads=ncores)
             log(f"oracle run {ores.seconds:.1f} s")
             ext_per_read = float(int(ores.counters[0]) + int(ores.counters[1])) / max(1, len(sample))
+            # the oracle's records of the sample against the product's records of the same reads (step 0 of the timed region, or the
+            # one-lane pass): the comparison the reference's own end-to-end test makes (floxer_whole_program_via_cli_test.cpp:40-94),
+            # at the metric's size
+            parity = compare_with_oracle(first_result, ores, len(sample)) if first_result is not None else None
+            log(f"parity sample {parity}")
             ext_source = f"counted by the oracle on the cpu_baseline sample ({len(sample)} reads)"
             cpu = {"value": round(len(sample) / ores.seconds, 3), "unit": "reads/s", "cores": ncores, "kind": "port",
                    "sample": f"first {len(sample)} reads of the first timed batch against the same {args.genome / 1e9:.1f} Gb reference, oracle "
@@ -332,17 +386,24 @@ def main():
             return None
 
         def roof(name, st, note, reads_per_launch=None):
+            # algorithmic bytes = what THIS build's kernels must touch (flx_pipeline.cpp, k1_bytes: rank blocks, filter words, text / SA /
+            # ISA, seed records, hits and queued subtrees, each from a device counter, random accesses at the 64-B request size): a
+            # fraction of what the memory system can deliver, <= 1 by construction, the same model for every --config
             alg = st["algorithmic_bytes"]
-            if name == "fm_search" and ext_per_read is not None and reads_per_launch:
-                # bytes of the seeding = 2 x 64 B per cursor extension OF THE REFERENCE'S WALK on this input (counted by
-                # the restatement), whatever this build does instead of an extension (filter lookups, text comparisons)
-                alg = 128.0 * ext_per_read * reads_per_launch * st["launches"]
             achieved = alg / 1e9 / (st["device_ms"] / 1e3)
-            return {"kernel": name, "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": load_traffic(name, st),
-                    "avg_launch_ms": round(st["device_ms"] / st["launches"], 4),
-                    "algorithmic_bytes_per_launch": int(alg / st["launches"]), "launches": st["launches"],
-                    "work_units_per_launch": int(st["work_units"] / st["launches"]), "note": note}
+            r = {"kernel": name, "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                 "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": load_traffic(name, st),
+                 "avg_launch_ms": round(st["device_ms"] / st["launches"], 4),
+                 "algorithmic_bytes_per_launch": int(alg / st["launches"]), "launches": st["launches"],
+                 "work_units_per_launch": int(st["work_units"] / st["launches"]), "note": note}
+            if name == "fm_search" and ext_per_read is not None and reads_per_launch:
+                # SURVEY.md 8(d) prices the seeding at 2 x 64 B per cursor extension OF THE REFERENCE'S WALK on this input (counted by the
+                # restatement). This build answers the same questions with fewer rank queries (presence filter, text walk), so that
+                # figure is a speed-up over a rank-query walk at the same memory rate - NOT a fraction of the HBM peak (it can exceed it)
+                ref_bytes = 128.0 * ext_per_read * reads_per_launch * st["launches"]
+                r["reference_walk_equivalent_GBps"] = round(ref_bytes / 1e9 / (st["device_ms"] / 1e3), 2)
+                r["reference_walk_extensions_per_read"] = round(ext_per_read, 1)
+            return r
 
         def table(sts):
             return {k: {"launches": v["launches"], "device_ms": round(v["device_ms"], 3),
@@ -350,9 +411,10 @@ def main():
                         "GBps": round(v["algorithmic_bytes"] / 1e6 / v["device_ms"], 2) if v["device_ms"] > 0 else None}
                     for k, v in sts.items()}
 
-        fm_note = ("fm_search = the filter walk + the text walk (two kernels, one HIP-event bracket); bytes = 2 x 64 B per cursor extension of the "
-                   f"reference's walk (SURVEY.md 8d), extensions {ext_source}" if ext_per_read is not None else
-                   "fm_search bytes = 2 x 64 B per rank pair this build makes (no oracle count for this workload at hand)")
+        fm_note = ("fm_search = the filter walk + the text walk (two kernels, one HIP-event bracket); bytes = what this walk touches, from its "
+                   "device counters: 2 x 64 B per rank pair, 64 B per filter word, per queued subtree its record written and read + SA + "
+                   "text + seed record, per hit its record + ISA, per seed its record + symbols"
+                   + (f"; reference_walk_equivalent_GBps prices the reference's walk instead (128 B x extensions {ext_source})" if ext_per_read is not None else ""))
         # the dominant kernel = largest device time when nothing overlaps (the one-lane pass); its roofline is that pass's:
         # summed event times of the timed region count the time a launch shares the chip with the other lanes' kernels
         roofline = roofline_timed = roofline_fm = None
@@ -372,6 +434,35 @@ def main():
                                   reads_per_launch=B * args.steps / max(1, stats[name]["launches"]))
         if roofline is None:
             roofline = roofline_timed
+
+        # ---- the metric says "vs hg38": half of a human genome is repeats, and there the seeding is a different workload (intervals of
+        #      many rows inside diverged families, nothing for the presence filter to reject). The default run of the metric's
+        #      configuration therefore carries a second, shorter measurement on the repeat-rich synthetic reference (same size, same
+        #      reads, same flags), made by a child process once this one has given the GPU's memory back.
+        repeat_rich_line = None
+        index_device_bytes = int(index.device_bytes)
+        if (world == 1 and not args.no_repeat_rich_leg and not args.repeat_rich and not args.isolated_only and args.config == "grch38"
+                and (args.genome, args.read_length, args.error_rate) == (CONFIGS["grch38"]["genome"], 10000, 0.08)):
+            del image, index, genome, pool, batches
+            if not args.no_cpu_baseline:
+                del oidx, ores
+            import gc
+            gc.collect()
+            torch.cuda.empty_cache()
+            cmd = [sys.executable, os.path.abspath(__file__), "--repeat-rich", "--steps", str(args.repeat_rich_steps), "--warmup", "2", "--no-cpu-baseline",
+                   "--no-isolated-pass", "--no-host-inputs-leg", "--lanes", str(args.lanes), "--inflight", str(args.inflight)]
+            if args.interval_optimization:
+                cmd.append("--interval-optimization")
+            t0 = time.time()
+            try:
+                child = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
+                d = json.loads(child.stdout.strip().splitlines()[-1])
+                repeat_rich_line = {"value": d["value"], "unit": d["unit"], "ms_per_step": d["ms_per_step"], "steps": d["steps"], "gbases_per_s": d["gbases_per_s"],
+                                    "records": d["records"], "workload": d["config"]["workload"], "path": d["path"],
+                                    "kernels": {k: v["device_ms"] for k, v in d["kernels"].items()}, "wall_s": round(time.time() - t0, 1)}
+            except Exception as ex:          # the secondary line must not cost the primary one
+                repeat_rich_line = {"error": f"{type(ex).__name__}: {ex}"[:300]}
+            log(f"repeat-rich leg {time.time() - t0:.1f} s")
 
         cfg = CONFIGS[args.config]
         is_cfg = (args.genome, args.chromosomes, args.read_length, args.error_rate) == (cfg["genome"], cfg["chromosomes"], cfg["read_length"], cfg["error_rate"])
@@ -396,16 +487,28 @@ def main():
                        "parallelism": f"read-sharded x{world}, index replicated",
                        "gather": None if world == 1 else ("records + CIGAR words" if args.gather_cigars else "fixed-size records") + " to rank 0 per step, inside the timed region"},
             "gbases_per_s": round(value * mean_len / 1e9, 5), "records": n_records, "index_build_s": round(index_s, 2),
-            "index_device_bytes": int(index.device_bytes),
+            "index_device_bytes": index_device_bytes,
             "gather_s": None if gather_s is None else round(gather_s, 3),      # time rank 0 spent in the per-step gathers (inside the timed region)
             "roofline": roofline, "roofline_fm_search": roofline_fm, "roofline_timed_region": roofline_timed, "cpu_baseline": cpu,
+            "parity_sample": parity,
+            # `value` = inputs resident in HBM when the clock starts (the contract's definition); value_host_inputs = the same K steps with
+            # the reads in pageable host memory (flx_align_reads: H2D, reverse complements, 2-bit form and Peq planes inside the clock) -
+            # what floxer's own stopwatch spans (floxer.cpp:154-179) minus file parsing
+            "value_host_inputs": None if host_elapsed is None else round(total_reads / host_elapsed, 2),
+            "ms_per_step_host_inputs": None if host_elapsed is None else round(host_elapsed / args.steps * 1e3, 3),
+            "repeat_rich": repeat_rich_line,
             "path": {k: int(v) for k, v in path.items()} if path else None,
             "kernels": table(stats), "kernels_isolated": table(iso_stats),
         }
         print(json.dumps(line), flush=True)
+        if parity is not None and not parity["equal"]:
+            print(f"bench.py: the product's records differ from the oracle's on the parity sample: {parity}", file=sys.stderr, flush=True)
+            parity_failed = True
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    if parity_failed:
+        sys.exit(3)
 
 
 if __name__ == "__main__":

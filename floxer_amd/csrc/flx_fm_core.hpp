@@ -202,6 +202,7 @@ struct FmConst {                            // the same for every lane of a laun
     const u8* seq;                          // sequence pool, one byte per symbol
     const u32* qpack;                       // its 2-bit form (null: no filter)
     const u64* scheme;
+    const DevSeed* seeds;                   // the launch's seed records (a lane keeps a seed's launch position and reads what it needs rarely from here)
     u32 max_hits;
     u32 levels;                             // frames a lane may hold
     u32 text_min_remain;                    // a one-row node is queued when at least this many scheme entries remain (0: never)
@@ -211,39 +212,56 @@ struct FmConst {                            // the same for every lane of a laun
 constexpr u32 FM_FRAME_WORDS = 18;          // oth[1..5], end, abs[1..5], lb, lb_rev, state, mask, key lo, key hi, abs[0]
 constexpr u32 TX_FRAME_WORDS = 6;           // state, mask, pL, pR, key lo, key hi
 
+// A lane's registers are what bounds the number of resident search waves (and what the compiler spilled to scratch memory in round 3:
+// 72 B per lane, written and re-read through HBM in every DFS step), so the state is packed:
+//   ws (the seed and the search): len:14 | flags:2 @14 | searches:3 @16 | search:3 @19 | l_last:3 @22 | u_last:3 @25 | stolen:1 @28
+//   wn (the node): x:14 | e:3 @14 | linfo:2 @17 | rinfo:2 @19 | depth:3 @21 | need_child:1 @24 | dlen+4:3 @25 | out:2 @28 | busy:1 @30 |
+//      in_search:1 @31  - bits 0..20 and 25..27 are where a frame's state word and a queued subtree's word have the same fields
+// What a step produces (out = FM_OUT_HIT / FM_OUT_ITEM) is read from the node's own registers by the caller before the next step:
+// hit = {nlb, nlen (rows, capped), e, nkey}; item = {nlb, item word, nkey}.
 struct FmLane {
-    // the seed
-    u32 pos = 0, sid = 0, len = 0, num_searches = 0, flags = 0;
+    u32 pos = 0;                            // launch position of the seed (C.seeds[pos])
     u64 qoff = 0;
-    const u64* ex_base = nullptr;
-    // the search
-    u32 srch = 0, ct = 0;
-    bool busy = false, in_search = false, need_child = false;
-    const u64* ex = nullptr;
-    u32 l_last = 0, u_last = 0;
-    // the node under inspection
-    u32 nlb = 0, nlbr = 0, nlen = 0, nx = 0, ne = 0, nli = 0, nri = 0, ndl = 4;
+    u32 exo = 0;                            // first scheme entry of the current search (C.scheme + exo)
+    u32 ws = 0, wn = 0;
+    u32 ct = 0;
+    u32 nlb = 0, nlbr = 0, nlen = 0;
     u64 nkey = 0;
-    u32 depth = 0;
-    // what the last step produced (the caller takes it and resets out to FM_OUT_NONE)
-    u32 out = FM_OUT_NONE, out_lb = 0, out_len = 0, out_e = 0;
-    u64 out_key = 0;
-    // counters
-    u32 n_ext = 0, n_lookup = 0, n_pruned = 0, n_prefix_kills = 0;
-    bool overflow = false;
+    u32 n_ext = 0, n_lookup = 0, n_pruned = 0, n_prefix_kills = 0;     // (the last two only count in the STATS form of fm_step)
+
+    FLX_HD u32 len() const { return ws & 0x3FFFu; }
+    FLX_HD u32 flags() const { return (ws >> 14) & 3u; }
+    FLX_HD u32 num_searches() const { return (ws >> 16) & 7u; }
+    FLX_HD u32 srch() const { return (ws >> 19) & 7u; }
+    FLX_HD u32 l_last() const { return (ws >> 22) & 7u; }
+    FLX_HD u32 u_last() const { return (ws >> 25) & 7u; }
+    FLX_HD bool stolen() const { return (ws >> 28) & 1u; }
+    FLX_HD u32 nx() const { return wn & 0x3FFFu; }
+    FLX_HD u32 ne() const { return (wn >> 14) & 7u; }
+    FLX_HD u32 nli() const { return (wn >> 17) & 3u; }
+    FLX_HD u32 nri() const { return (wn >> 19) & 3u; }
+    FLX_HD u32 depth() const { return (wn >> 21) & 7u; }
+    FLX_HD bool need_child() const { return (wn >> 24) & 1u; }
+    FLX_HD u32 ndl() const { return (wn >> 25) & 7u; }
+    FLX_HD u32 out() const { return (wn >> 28) & 3u; }
+    FLX_HD bool busy() const { return (wn >> 30) & 1u; }
+    FLX_HD bool in_search() const { return wn >> 31; }
+    FLX_HD bool overflow() const { return out() == 3u; }                // (frames ran out: the lane stops, the launch is repeated with the ordered kernel)
+    FLX_HD void clear_out() { wn &= ~(3u << 28); }
+    FLX_HD u32 item_word() const { return (wn & 0x0E1FFFFFu) | (srch() << 21); }    // = item_pack(x, e, li, ri, search, dlen)
+    FLX_HD const u64* ex(FmConst const& C) const { return C.scheme + exo; }
 };
+constexpr u32 WN_NODE_MASK = 0x0E1FFFFFu;                              // x, e, linfo, rinfo, dlen
+constexpr u32 WN_DEPTH1 = 1u << 21, WN_NEED_CHILD = 1u << 24, WN_BUSY = 1u << 30, WN_IN_SEARCH = 1u << 31, WN_OUT_SHIFT = 28;
+FLX_HD inline u32 wn_node(u32 x, u32 e, u32 li, u32 ri, u32 dl) { return x | (e << 14) | (li << 17) | (ri << 19) | (dl << 25); }
 
 FLX_HD inline void fm_take_seed(FmConst const& C, FmLane& L, DevSeed const& seed, u32 pos) {
     L.pos = pos;
-    L.sid = seed.id;
     L.qoff = seed.seq_off;
-    L.len = seed.length;
-    L.num_searches = seed.frames_searches >> 24;
-    L.flags = seed.flags;
-    L.ex_base = C.scheme + seed.scheme_off;
-    L.srch = 0; L.ct = 0;
-    L.busy = true;
-    L.in_search = false;
+    L.exo = seed.scheme_off;
+    L.ws = seed.length | ((seed.flags & 3u) << 14) | ((seed.frames_searches >> 24) << 16);
+    L.ct = 0;
+    L.wn = WN_BUSY;
 }
 
 // what the filter needs from memory besides the table itself, asked for before the rank queries of the node so that both are in
@@ -251,7 +269,7 @@ FLX_HD inline void fm_take_seed(FmConst const& C, FmLane& L, DevSeed const& seed
 struct FmFilterPre { u64 e1, xs, xf; };
 FLX_HD inline FmFilterPre fm_filter_prefetch(FmConst const& C, FmLane const& L, u32 x, u64 e64, u32 right) {
     FmFilterPre P;
-    P.e1 = x + 1u < L.len ? L.ex[x + 1u] : 0ull;
+    P.e1 = x + 1u < L.len() ? L.ex(C)[x + 1u] : 0ull;
     u32 const a = sch_lo(e64);
     i64 const g0 = (i64)L.qoff;
     //   right: xs = seed[b-31 .. b] with b = a + x - 1 the string's last position, xf = seed[b+1 ...]
@@ -294,12 +312,13 @@ FLX_HD inline FmFilterKind fm_filter_kind(u32 kind, u32 K, u32 tmin, u32 x, u32 
 // left at the positions that follow are dropped from the mask when the string they are bound to reach does not occur in the text.
 // Two looks: one window of K symbols around the junction per child, then a second, shifted window for the children that passed
 // (a K-mer drawn at random is present with probability n / 4^K, 4.5 % at hg38 size: two windows leave 0.2 % of the wrong children).
+template <bool STATS>
 FLX_HD inline u32 fm_filter_children(FmConst const& C, FmLane& L, u32 x, u64 e64, u32 right, u32 mask, FmFilterPre const& P) {
     u32 const K = C.idx.filter_k, tmin = C.idx.filter_tmin;
     // forced positions behind the children: F1 for the children that move on to entry x + 1 (substitution, insertion), F0 for
     // the deletion children, which stay at entry x
     u32 F1 = 0, F0 = 0;
-    if (x + 1u < L.len && sch_upper((u32)P.e1) == 1u && sch_right((u32)P.e1) == right) F1 = sch_run_end(P.e1) - (x + 1u);
+    if (x + 1u < L.len() && sch_upper((u32)P.e1) == 1u && sch_right((u32)P.e1) == right) F1 = sch_run_end(P.e1) - (x + 1u);
     if (sch_upper((u32)e64) == 1u) F0 = sch_run_end(e64) - x;
     if ((F1 | F0) == 0u) return mask;
     const u64* __restrict__ bits = C.idx.filter;
@@ -333,7 +352,7 @@ FLX_HD inline u32 fm_filter_children(FmConst const& C, FmLane& L, u32 x, u64 e64
         }
         if (((wi >> ((u32)(qi.base << qi.ush) & 63u)) & span_i) == 0ull) drop_i = 1u;
         L.n_lookup += fm_popc(qs.want) + fm_popc(qd.want) + qi.want;
-        L.n_pruned += fm_popc(drop_s) + fm_popc(drop_d) + drop_i;
+        if (STATS) L.n_pruned += fm_popc(drop_s) + fm_popc(drop_d) + drop_i;
         mask &= ~((drop_s << 2) | (drop_d << 1) | (drop_i << 11));
         // the second look: only the children the first one was asked about and let pass
         want_s = qs.want & ~drop_s; want_d = qd.want & ~drop_d; want_i = qi.want & ~drop_i;
@@ -342,16 +361,19 @@ FLX_HD inline u32 fm_filter_children(FmConst const& C, FmLane& L, u32 x, u64 e64
     return mask;
 }
 
-// start of search `srch` of the seed: the root cursor, or the cursor of the seed's first KMER_Q symbols when the search begins
-// with an exact, rightward part that long and free of N. false: the search finds nothing.
-FLX_HD inline bool fm_begin_search(FmConst const& C, FmLane& L) {
+// start of the current search of the seed: the root cursor, or the cursor of the seed's first KMER_Q symbols when the search begins
+// with an exact, rightward part that long and free of N. false: the search finds nothing. Sets nlb, nlbr, nlen; returns x in *x0.
+template <bool STATS>
+FLX_HD inline bool fm_begin_search(FmConst const& C, FmLane& L, u32* x0) {
     DevIndex const& idx = C.idx;
-    L.nlb = 0; L.nlbr = 0; L.nlen = idx.n; L.nx = 0;
-    u64 const e0 = L.ex[0];
-    if (L.len >= KMER_Q && (((u32)L.ex[KMER_Q - 1] >> 27) & 1u)) {
+    L.nlb = 0; L.nlbr = 0; L.nlen = idx.n; *x0 = 0;
+    const u64* __restrict__ ex = L.ex(C);
+    u32 const len = L.len();
+    u64 const e0 = ex[0];
+    if (len >= KMER_Q && (((u32)ex[KMER_Q - 1] >> 27) & 1u)) {
         u32 const p0 = (u32)e0 & SCH_POS_MASK;
         // presence of the exact prefix (its first K symbols): most searches of a read with errors end here
-        if (C.use_filter && !(L.flags & SEED_NOT_ACGT)) {
+        if (C.use_filter && !(L.flags() & SEED_NOT_ACGT)) {
             u32 const run = sch_run_end(e0);                            // entries 0 .. run-1: exact, rightward, consecutive positions
             u32 const K = idx.filter_k;
             u32 const T = run < K ? run : K;
@@ -359,7 +381,7 @@ FLX_HD inline bool fm_begin_search(FmConst const& C, FmLane& L) {
                 u64 const code = low_syms(pack_extract(C.qpack, (i64)L.qoff + (i64)p0), T);
                 FilterQuery const fq = filter_query(K, code, T);
                 ++L.n_lookup;
-                if ((idx.filter[fq.word] & fq.mask) == 0ull) { ++L.n_prefix_kills; return false; }
+                if ((idx.filter[fq.word] & fq.mask) == 0ull) { if (STATS) ++L.n_prefix_kills; return false; }
             }
         }
         u32 w[2];
@@ -370,99 +392,108 @@ FLX_HD inline bool fm_begin_search(FmConst const& C, FmLane& L) {
             u32 const code = (((t0 * 0x40100401u) >> 24) << 8) | ((t1 * 0x40100401u) >> 24);
             const u32* __restrict__ e = idx.kmer + 3u * code;
             L.nlb = e[0]; L.nlbr = e[1]; L.nlen = e[2];
-            L.nx = KMER_Q;
+            *x0 = KMER_Q;
             if (L.nlen == 0) return false;
         }
     }
     return true;
 }
 
+// the search after the current one (or the end of the seed)
+FLX_HD inline void fm_next_search(FmLane& L) {
+    u32 const s = L.srch() + 1u;
+    if (s >= L.num_searches() || L.stolen()) { L.wn = 0; return; }      // (a lane that works on children taken from another lane ends with them)
+    L.ws += 1u << 19;
+    L.exo += L.len();
+    L.wn = WN_BUSY;
+}
+
 // One DFS step of a busy lane. FR: u32& fr(level, word), the lane's frames.
-template <class FR>
+template <bool STATS, class FR>
 FLX_HD inline void fm_step(FmConst const& C, FmLane& L, FR&& fr) {
     DevIndex const& idx = C.idx;
-    if (!L.in_search) {
-        if (L.srch >= L.num_searches) { L.busy = false; return; }
-        L.ex = L.ex_base + (u64)L.srch * L.len;
-        u32 const last_entry = (u32)L.ex[L.len - 1];
-        L.l_last = sch_lower(last_entry);
-        L.u_last = sch_upper(last_entry);
-        L.ne = 0; L.nli = FM_INFO_M; L.nri = FM_INFO_M; L.ndl = 4;
-        L.nkey = (u64)L.srch << (3u * FMK_BITS);
-        L.depth = 0;
-        L.need_child = false;
-        L.in_search = true;
-        if (!fm_begin_search(C, L)) { L.in_search = false; ++L.srch; if (L.srch >= L.num_searches) L.busy = false; return; }
+    u32 const len = L.len();
+    const u64* __restrict__ ex = L.ex(C);
+    if (!L.in_search()) {
+        if (L.srch() >= L.num_searches()) { L.wn = 0; return; }
+        u32 const last_entry = (u32)ex[len - 1];
+        L.ws = (L.ws & ~(63u << 22)) | (sch_lower(last_entry) << 22) | (sch_upper(last_entry) << 25);
+        L.nkey = (u64)L.srch() << (3u * FMK_BITS);
+        u32 x0;
+        if (!fm_begin_search<STATS>(C, L, &x0)) { fm_next_search(L); return; }
+        L.wn = WN_BUSY | WN_IN_SEARCH | wn_node(x0, 0u, FM_INFO_M, FM_INFO_M, 4u);
     }
 
     // ---- the next child of the top frame becomes the node: children that cost an error first, the match child last
-    if (L.need_child) {
-        if (L.depth == 0u) { L.in_search = false; ++L.srch; if (L.srch >= L.num_searches) L.busy = false; return; }        // search exhausted
-        u32 const lv = L.depth - 1u;
+    if (L.need_child()) {
+        u32 const depth = L.depth();
+        if (depth == 0u) { fm_next_search(L); return; }                      // search exhausted
+        u32 const lv = depth - 1u;
         u32 const mask = fr(lv, 14);
         u32 const st = fr(lv, 13);
         u32 const costly = mask & ~1u;
         u32 const ci = costly ? (u32)__builtin_ctz(costly) : 0u;
         u32 const rest = mask & ~(1u << ci);
+        u32 wn = (L.wn & ~(WN_NODE_MASK | WN_NEED_CHILD));                   // depth, busy, in_search stay
         if (rest) fr(lv, 14) = rest;
-        else --L.depth;                                                      // the last child of a frame is a tail call: the frame is gone
+        else wn -= WN_DEPTH1;                                                // the last child of a frame is a tail call: the frame is gone
         u32 const right = fst_right(st);
         u32 const px = fst_x(st), pe = fst_e(st);
-        u32 info, sym, dl = fst_dl(st);
-        if (ci == 0) { sym = fst_sym(st); L.nx = px + 1; L.ne = pe; info = FM_INFO_M; }
-        else if (ci == 11) { sym = 1; L.nx = px + 1; L.ne = pe + 1; info = FM_INFO_I; dl -= 1u; }
+        u32 info, sym, dl = fst_dl(st), cx, ce;
+        if (ci == 0) { sym = fst_sym(st); cx = px + 1; ce = pe; info = FM_INFO_M; }
+        else if (ci == 11) { sym = 1; cx = px + 1; ce = pe + 1; info = FM_INFO_I; dl -= 1u; }
         else {
             sym = (ci + 1) >> 1;
             bool const del = ci & 1u;
-            L.nx = del ? px : px + 1;
-            L.ne = pe + 1;
+            cx = del ? px : px + 1;
+            ce = pe + 1;
             info = del ? FM_INFO_D : FM_INFO_S;
             dl += del ? 1u : 0u;
         }
-        L.ndl = dl;
         // sym is 1..5 for every child but the match of a '$' (symbol 0: its cursor starts where the node's does)
         u32 const p_lb = fr(lv, 11), p_lbr = fr(lv, 12);
         u32 const c_oth = sym ? fr(lv, sym - 1u) : (right ? p_lb : p_lbr), c_end = fr(lv, sym), c_abs = fr(lv, sym ? 5u + sym : 17u);
         u64 const pkey = (u64)fr(lv, 15) | ((u64)fr(lv, 16) << 32);
         if (ci == 11) { L.nlb = p_lb; L.nlbr = p_lbr; L.nlen = fr(lv, 5) - (right ? p_lb : p_lbr); }
         else { L.nlen = c_end - c_oth; L.nlb = right ? c_oth : c_abs; L.nlbr = right ? c_abs : c_oth; }
-        L.nli = right ? fst_li(st) : info;
-        L.nri = right ? info : fst_ri(st);
+        L.wn = wn | wn_node(cx, ce, right ? fst_li(st) : info, right ? info : fst_ri(st), dl);
         L.nkey = ci ? fm_key_edge(pkey, px, pe, ci) : pkey;
-        L.need_child = false;
     }
 
     // ---- inspect node (nlb, nlbr, nlen, nx, ne, nli, nri); nlen > 0 by construction
-    if (L.nx == L.len) {
-        bool const ok_l = L.nli == FM_INFO_M || L.nli == FM_INFO_I, ok_r = L.nri == FM_INFO_M || L.nri == FM_INFO_I;
-        if (ok_l && ok_r && L.l_last <= L.ne && L.ne <= L.u_last) {
+    u32 const nx = L.nx(), ne = L.ne();
+    if (nx == len) {
+        u32 const nli = L.nli(), nri = L.nri();
+        bool const ok_l = nli == FM_INFO_M || nli == FM_INFO_I, ok_r = nri == FM_INFO_M || nri == FM_INFO_I;
+        L.wn |= WN_NEED_CHILD;
+        if (ok_l && ok_r && L.l_last() <= ne && ne <= L.u_last()) {
             u32 rep = L.nlen;
             if (L.ct + rep > C.max_hits) rep = C.max_hits - L.ct;     // more rows than the caller wants to know of
             L.ct += rep;
-            L.out = FM_OUT_HIT; L.out_lb = L.nlb; L.out_len = rep; L.out_e = L.ne; L.out_key = L.nkey;
-            if (L.ct == C.max_hits) { L.busy = false; return; }       // the seed has too many rows: its other hits do not matter
+            L.nlen = rep;
+            L.wn |= FM_OUT_HIT << WN_OUT_SHIFT;
+            if (L.ct == C.max_hits) L.wn &= ~(WN_BUSY | WN_IN_SEARCH);  // the seed has too many rows: its other hits do not matter
         }
-        L.need_child = true;
         return;
     }
-    u64 const e64 = L.ex[L.nx];
+    u64 const e64 = ex[nx];
     u32 const sch = (u32)e64;
     u32 const lower = sch_lower(sch), upper = sch_upper(sch), right = sch_right(sch);
-    if (L.ne > upper) { L.need_child = true; return; }
-    bool const mismatch_allowed = lower <= L.ne + 1 && L.ne + 1 <= upper;
-    bool const match_allowed = lower <= L.ne && L.ne <= upper;
-    if (!mismatch_allowed && !match_allowed) { L.need_child = true; return; }
+    if (ne > upper) { L.wn |= WN_NEED_CHILD; return; }
+    bool const mismatch_allowed = lower <= ne + 1 && ne + 1 <= upper;
+    bool const match_allowed = lower <= ne && ne <= upper;
+    if (!mismatch_allowed && !match_allowed) { L.wn |= WN_NEED_CHILD; return; }
 
     // ---- one row: what is below this node is a comparison with the text at SA[row] (tx_step)
-    if (L.nlen == 1u && C.text_min_remain && L.len - L.nx >= C.text_min_remain && !(L.flags & SEED_HAS_DELIM)) {
-        L.out = FM_OUT_ITEM; L.out_lb = L.nlb; L.out_len = item_pack(L.nx, L.ne, L.nli, L.nri, L.srch, L.ndl); L.out_e = 0; L.out_key = L.nkey;
-        L.need_child = true;
+    u32 const flags = L.flags();
+    if (L.nlen == 1u && C.text_min_remain && len - nx >= C.text_min_remain && !(flags & SEED_HAS_DELIM)) {
+        L.wn |= WN_NEED_CHILD | (FM_OUT_ITEM << WN_OUT_SHIFT);
         return;
     }
 
-    bool const filtered = mismatch_allowed && C.use_filter && L.ne == 0u && L.nx >= 1u && !(L.flags & SEED_NOT_ACGT);
+    bool const filtered = mismatch_allowed && C.use_filter && ne == 0u && nx >= 1u && !(flags & SEED_NOT_ACGT);
     FmFilterPre pre{0ull, 0ull, 0ull};
-    if (filtered) pre = fm_filter_prefetch(C, L, L.nx, e64, right);
+    if (filtered) pre = fm_filter_prefetch(C, L, nx, e64, right);
     u32 const next_sym = C.seq[L.qoff + (sch & SCH_POS_MASK)];
     u32 const lo = right ? L.nlbr : L.nlb, other = right ? L.nlb : L.nlbr;
     u32 ab[6], cl[6];
@@ -471,28 +502,30 @@ FLX_HD inline void fm_step(FmConst const& C, FmLane& L, FR&& fr) {
 
     if (mismatch_allowed) {
         // this node branches: its frame goes on top of the frames of the error edges taken so far (at most `ne` of them)
-        u32 const tinfo = right ? L.nri : L.nli;
+        u32 const tinfo = right ? L.nri() : L.nli();
         u32 mask = fm_child_mask6(cl, next_sym, match_allowed, tinfo == FM_INFO_M || tinfo == FM_INFO_D, tinfo == FM_INFO_M || tinfo == FM_INFO_I);
-        if (mask == 0u) { L.need_child = true; return; }
-        if (filtered && (mask & ~1u)) {
-            mask = fm_filter_children(C, L, L.nx, e64, right, mask, pre);
-            if (mask == 0u) { L.need_child = true; return; }
-        }
-        if (L.depth >= C.levels) { L.overflow = true; L.busy = false; return; }
-        u32 const lv = L.depth;
+        if (mask == 0u) { L.wn |= WN_NEED_CHILD; return; }
+        u32 const lv = L.depth();
+        if (lv >= C.levels) { L.wn = 3u << WN_OUT_SHIFT; return; }           // overflow: not busy any more
+        // (the frame is written before the filter is asked: the child bounds need not stay in registers across its lookups; a frame
+        // whose children the filter drops is simply not kept)
         u32 const o1 = other + cl[0], o2 = o1 + cl[1], o3 = o2 + cl[2], o4 = o3 + cl[3], o5 = o4 + cl[4];
         fr(lv, 0) = o1; fr(lv, 1) = o2; fr(lv, 2) = o3; fr(lv, 3) = o4; fr(lv, 4) = o5; fr(lv, 5) = o5 + cl[5];
         fr(lv, 6) = ab[1]; fr(lv, 7) = ab[2]; fr(lv, 8) = ab[3]; fr(lv, 9) = ab[4]; fr(lv, 10) = ab[5];
         fr(lv, 11) = L.nlb; fr(lv, 12) = L.nlbr;
-        fr(lv, 13) = fst_pack(L.nx, L.ne, L.nli, L.nri, next_sym, right, L.ndl);
-        fr(lv, 14) = mask;
+        fr(lv, 13) = (L.wn & WN_NODE_MASK) | (next_sym << 21) | (right << 24);      // = fst_pack(x, e, li, ri, next_sym, right, dlen)
         fr(lv, 15) = (u32)L.nkey; fr(lv, 16) = (u32)(L.nkey >> 32);
         fr(lv, 17) = ab[0];
-        ++L.depth;
-        L.need_child = true;
+        if (filtered && (mask & ~1u)) {
+            mask = fm_filter_children<STATS>(C, L, nx, e64, right, mask, pre);
+            if (mask == 0u) { L.wn |= WN_NEED_CHILD; return; }
+        }
+        fr(lv, 14) = mask;
+        L.wn += WN_DEPTH1;
+        L.wn |= WN_NEED_CHILD;
     } else {
         // only an exact extension is possible: continue in place (no frame)
-        if (next_sym > 5u) { L.need_child = true; return; }
+        if (next_sym > 5u) { L.wn |= WN_NEED_CHILD; return; }
         u32 clen = cl[0], cabs = ab[0], coth = other;
 #pragma unroll
         for (u32 c = 1; c < 6; ++c) {
@@ -501,12 +534,12 @@ FLX_HD inline void fm_step(FmConst const& C, FmLane& L, FR&& fr) {
             clen = take ? cl[c] : clen;
             cabs = take ? ab[c] : cabs;
         }
-        if (clen == 0) { L.need_child = true; return; }
+        if (clen == 0) { L.wn |= WN_NEED_CHILD; return; }
         L.nlb = right ? coth : cabs;
         L.nlbr = right ? cabs : coth;
-        if (right) L.nri = FM_INFO_M; else L.nli = FM_INFO_M;
+        // x + 1; the extended side's info becomes "match"
+        L.wn = (L.wn & ~(right ? 3u << 19 : 3u << 17)) + 1u;
         L.nlen = clen;
-        L.nx = L.nx + 1;
     }
 }
 

@@ -498,16 +498,30 @@ int search_seeds_device(Lane* ctx, const u8* d_seq_pool_or_null, const u8* h_seq
         if (items_fit && counters[0] <= hit_cap && (!device_select || sel_rows_total <= sel_cap)) break;      // (selected anchors <= rows)
         if (attempt >= 3) { set_error("fm_search: hit buffer could not be sized"); return FLX_ERR_INTERNAL; }
         { std::lock_guard<std::mutex> g(ctx->ctx->mu); ++ctx->ctx->path.search_reruns; }
-        if (!items_fit) item_cap = (u64)counters[16] + hit_slack;             // queued subtrees were dropped: run again with room for all
-        else if (counters[0] > hit_cap) hit_cap = (u64)counters[0] + hit_slack;      // the number of hits is known now; run again
+        // (a wave reserves 64 slots at a time and leaves the rest of a range unused when a ballot's records do not fit into it: the slots
+        // reserved are at most twice the records written plus one range per wave of both kernels, however the waves were scheduled)
+        u64 const wave_ranges = (u64)(4096 + 8192 + 64) * 64;
+        if (!items_fit) item_cap = std::max<u64>((u64)counters[16], 2 * (u64)counters[3]) + wave_ranges;      // queued subtrees were dropped: run again with room for all
+        else if (counters[0] > hit_cap) hit_cap = std::max<u64>((u64)counters[0], 2 * (u64)counters[13]) + wave_ranges;      // the number of hits is known now; run again
         else sel_cap = (u64)sel_rows_total + 1024;
     }
-    // fold the extension count into the kernel's accounting: SURVEY.md 8(d) prices a cursor extension at 2 x 64 B (rank data at both
-    // ends of the interval), whatever the block size of this build
+    // The kernel's accounting: the bytes THIS walk has to touch, from its own device counters (work units = rank pairs). Random accesses
+    // count at the 64-B size the memory system fetches them in; records that stream count at their size:
+    //   rank pair                2 x 64 B   (a 32-B block at either end of the interval; both ends in one block still count twice)
+    //   filter lookup            64 B       (one 64-bit word of the presence table)
+    //   queued one-row subtree   24 B written + 24 B read (the record) + 64 B (SA[row]) + 64 B (the text next to it) + 64 B (its seed's record)
+    //   hit                      24 B written; a hit of the text walk reads ISA[position] (64 B): charged for every hit
+    //   seed                     40 B (its record) + 64 B (its symbols) + 64 B (their 2-bit form, filter walk only)
+    // The ordered walk (no filter, no text walk) prices its rank pairs and its 64-B frames written and read back.
+    // SURVEY.md 8(d)'s figure - 128 B per cursor extension of the REFERENCE's walk - is computed by bench.py from the oracle's count and
+    // reported beside this one; it is not a fraction of the HBM peak for a walk that answers with fewer rank queries.
     if (ctx->ctx->timing) {
+        u64 bytes = (u64)counters[2] * 128;
+        if (filtered) bytes += (u64)counters[10] * 64 + (u64)counters[3] * (24 + 24 + 64 + 64 + 64) + (u64)counters[13] * (24 + 64) + n_seeds * (u64)(40 + 64 + (d_qpack ? 64 : 0));
+        else bytes += (u64)counters[2] * 128 + n_seeds * (u64)(40 + 64);
         std::lock_guard<std::mutex> g(ctx->ctx->mu);
         auto it = ctx->ctx->stats.find("fm_search");
-        if (it != ctx->ctx->stats.end()) { it->second.algorithmic_bytes += (u64)counters[2] * 128; it->second.work_units += counters[2]; }
+        if (it != ctx->ctx->stats.end()) { it->second.algorithmic_bytes += bytes; it->second.work_units += counters[2]; }
     }
     ctx->hits_per_seed = (double)counters[0] / (double)n_seeds;
     ctx->items_per_seed = (double)counters[16] / (double)n_seeds;

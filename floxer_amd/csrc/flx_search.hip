@@ -132,7 +132,8 @@ int DeviceApi::pack_pool(void* stream, const u8* d_seq, u64 len, u32* d_qpack) {
 }
 
 // ================================================================================================ the search kernels
-// counters (32 words): [0] hit slots reserved, [1] frame overflow flag, [2] cursor extensions (rank pairs), [3] subtrees queued,
+// counters (32 words): [0] hit slots reserved, [1] frame overflow flag, [2] cursor extensions (rank pairs), [3] subtrees queued (records
+//   written, without the unused ends of the slot ranges), [13] hits written (both kernels),
 //   [4] wave-iterations, [5] their maximum over the waves, [6] busy lane-iterations, [7] seed queue head, [8] wave-iterations after the
 //   seed queue ran dry, [9] their maximum, [10] filter lookups, [11] children dropped by the filter, [12] searches ended by the prefix
 //   lookup, [16] item slots reserved, [17] item queue head, [18] text-mode lane-steps, [19] text-mode wave-iterations
@@ -197,7 +198,10 @@ __device__ __forceinline__ u32 wave_slots_take(WaveSlots& S, DevHit* __restrict_
 }
 }  // namespace
 
-__global__ void __launch_bounds__(64, 4) fm_search_filter_kernel(FmConst C, const DevSeed* __restrict__ seeds, u32 n_seeds, DevHit* __restrict__ hits,
+// STATS: the diagnostic counters [11], [12] are kept (two more registers per lane). 111 VGPRs, no scratch (round 3: 128 + 72 B per lane
+// of spills inside the DFS loop, which went through HBM).
+template <bool STATS>
+__global__ void __launch_bounds__(64, 4) fm_search_filter_kernel(FmConst C, u32 n_seeds, DevHit* __restrict__ hits,
                                                               u32 hit_cap, DevHit* __restrict__ items, u32 item_cap, u32* __restrict__ counters,
                                                               u32* __restrict__ seed_cnt, u32 refill, u32 prio) {
     extern __shared__ u32 lds[];                // frames: [level][FM_FRAME_WORDS][64 lanes]
@@ -207,39 +211,43 @@ __global__ void __launch_bounds__(64, 4) fm_search_filter_kernel(FmConst C, cons
     u32 const lane = s_lane_id();
     u64 const lanes_below = (1ull << lane) - 1ull;
     auto fr = [&](u32 level, u32 word) -> u32& { return lds[(level * FM_FRAME_WORDS + word) * 64u + lane]; };
+    const DevSeed* __restrict__ seeds = C.seeds;
     WaveQueue Q;
     WaveSlots HS, IS;
     FmLane L;
     bool exhausted = false;
-    u32 n_iter = 0, n_busy_iter = 0, n_tail_iter = 0;
+    u32 n_iter = 0, n_busy_iter = 0, n_tail_iter = 0, n_hits = 0, n_items = 0;      // (wave-uniform but n_busy_iter)
 
     while (true) {
-        // ---- what the lanes produced in the last iteration
-        u64 const emit_h = __ballot(L.out == FM_OUT_HIT);
+        // ---- what the lanes produced in the last iteration (read from the node's registers, see FmLane)
+        u32 const out = L.out();
+        u64 const emit_h = __ballot(out == FM_OUT_HIT);
         if (emit_h) {
+            n_hits += (u32)__popcll(emit_h);
             u32 const slot = wave_slots_take(HS, hits, hit_cap, &counters[0], emit_h, lane, lanes_below);
-            if (L.out == FM_OUT_HIT) {
-                u32 const ord = seed_cnt ? atomicAdd(&seed_cnt[L.sid], 1u) : 0u;
-                if (slot < hit_cap) hits[slot] = DevHit{L.sid, L.out_lb, L.out_len, seed_cnt ? L.out_e | (min(ord, 0xFFFFFFu) << 8) : L.out_e, L.out_key};
-                L.out = FM_OUT_NONE;
+            if (out == FM_OUT_HIT) {
+                u32 const sid = seeds[L.pos].id;
+                u32 const ord = seed_cnt ? atomicAdd(&seed_cnt[sid], 1u) : 0u;
+                if (slot < hit_cap) hits[slot] = DevHit{sid, L.nlb, L.nlen, seed_cnt ? L.ne() | (min(ord, 0xFFFFFFu) << 8) : L.ne(), L.nkey};
             }
         }
-        u64 const emit_i = __ballot(L.out == FM_OUT_ITEM);
+        u64 const emit_i = __ballot(out == FM_OUT_ITEM);
         if (emit_i) {
+            n_items += (u32)__popcll(emit_i);
             u32 const slot = wave_slots_take(IS, items, item_cap, &counters[16], emit_i, lane, lanes_below);
-            if (L.out == FM_OUT_ITEM) {
-                if (slot < item_cap) items[slot] = DevHit{L.pos, L.out_lb, L.out_len, 0u, L.out_key};
-                L.out = FM_OUT_NONE;
-            }
+            if (out == FM_OUT_ITEM && slot < item_cap) items[slot] = DevHit{L.pos, L.nlb, L.item_word(), 0u, L.nkey};
         }
+        if (out == 3u) { atomicOr(&counters[1], 1u); L.wn = 0; }        // frames ran out (the caller repeats the launch another way)
+        else L.clear_out();
         // ---- seeds for the idle lanes, and the start of the next search for the lanes between two searches - in batches. Taking a seed
         //      and starting a search are chains of dependent loads (seed record, scheme entries, packed symbols, filter word, k-mer
         //      table: ~7 us) that every lane of the wave waits for; a lane gets there every dozen iterations, so with 64 lanes some lane
         //      is there in every iteration. Lanes at that point therefore wait until `refill` of them are, or no lane is inside a search.
-        bool const want = !L.busy && !exhausted;
-        bool const boundary = want || (L.busy && !L.in_search);
+        bool const busy = L.busy(), in_search = L.in_search();
+        bool const want = !busy && !exhausted;
+        bool const boundary = want || (busy && !in_search);
         u64 const at_boundary = __ballot(boundary);
-        bool const go = (u32)__popcll(at_boundary) >= refill || !__any(L.busy && L.in_search);
+        bool const go = (u32)__popcll(at_boundary) >= refill || !__any(busy && in_search);
         u64 const idle = go ? __ballot(want) : 0ull;
         if (idle) {                                                     // wave-uniform
             u32 const k = wave_queue_take(Q, &counters[7], n_seeds, want, idle, lane, lanes_below);
@@ -248,22 +256,24 @@ __global__ void __launch_bounds__(64, 4) fm_search_filter_kernel(FmConst C, cons
                 else exhausted = true;
             }
         }
-        if (__all(exhausted && !L.busy)) break;
+        if (__all(exhausted && !L.busy())) break;
         ++n_iter;
         if (Q.done && Q.next == Q.end) ++n_tail_iter;
-        if (!L.busy || (!go && !L.in_search)) continue;
+        if (!L.busy() || (!go && !L.in_search())) continue;
         ++n_busy_iter;
-        fm_step(C, L, fr);
+        fm_step<STATS>(C, L, fr);
     }
     wave_slots_close(HS, hits, hit_cap, lane);
     wave_slots_close(IS, items, item_cap, lane);
-    if (__any(L.overflow) && lane == 0) atomicOr(&counters[1], 1u);
-    u32 const s_ext = s_wave_sum(L.n_ext), s_busy = s_wave_sum(n_busy_iter), s_look = s_wave_sum(L.n_lookup),
-              s_pruned = s_wave_sum(L.n_pruned), s_kills = s_wave_sum(L.n_prefix_kills);
+    u32 const s_ext = s_wave_sum(L.n_ext), s_busy = s_wave_sum(n_busy_iter), s_look = s_wave_sum(L.n_lookup);
     if (lane == 0) {
-        atomicAdd(&counters[2], s_ext); atomicAdd(&counters[6], s_busy); 
+        atomicAdd(&counters[2], s_ext); atomicAdd(&counters[6], s_busy);
         atomicAdd(&counters[4], n_iter); atomicMax(&counters[5], n_iter); atomicAdd(&counters[8], n_tail_iter); atomicMax(&counters[9], n_tail_iter);
-        atomicAdd(&counters[10], s_look); atomicAdd(&counters[11], s_pruned); atomicAdd(&counters[12], s_kills);
+        atomicAdd(&counters[10], s_look); atomicAdd(&counters[13], n_hits); atomicAdd(&counters[3], n_items);
+    }
+    if (STATS) {
+        u32 const s_pruned = s_wave_sum(L.n_pruned), s_kills = s_wave_sum(L.n_prefix_kills);
+        if (lane == 0) { atomicAdd(&counters[11], s_pruned); atomicAdd(&counters[12], s_kills); }
     }
 }
 
@@ -282,11 +292,12 @@ __global__ void __launch_bounds__(64) fm_search_text_kernel(FmConst C, const Dev
     WaveSlots HS;
     TxLane L;
     bool exhausted = false;
-    u32 n_iter = 0;
+    u32 n_iter = 0, n_hits = 0;
 
     while (true) {
         u64 const emit_h = __ballot(L.out == FM_OUT_HIT);
         if (emit_h) {
+            n_hits += (u32)__popcll(emit_h);
             u32 const slot = wave_slots_take(HS, hits, hit_cap, &counters[0], emit_h, lane, lanes_below);
             if (L.out == FM_OUT_HIT) {
                 u32 const ord = seed_cnt ? atomicAdd(&seed_cnt[L.sid], 1u) : 0u;
@@ -315,7 +326,7 @@ __global__ void __launch_bounds__(64) fm_search_text_kernel(FmConst C, const Dev
     wave_slots_close(HS, hits, hit_cap, lane);
     if (__any(L.overflow) && lane == 0) atomicOr(&counters[1], 1u);
     u32 const s_nodes = s_wave_sum(L.n_nodes);
-    if (lane == 0) { atomicAdd(&counters[18], s_nodes); atomicAdd(&counters[19], n_iter); }
+    if (lane == 0) { atomicAdd(&counters[18], s_nodes); atomicAdd(&counters[19], n_iter); atomicAdd(&counters[13], n_hits); }
 }
 
 static u32 env_u32(const char* name, u32 dflt) {
@@ -340,6 +351,7 @@ int DeviceApi::search_filtered(void* stream, const DevIndex& idx, const u8* d_se
     C.seq = d_seq;
     C.qpack = d_qpack;
     C.scheme = d_scheme;
+    C.seeds = d_seeds;
     C.max_hits = max_hits_per_seed;
     C.levels = std::max(1u, frame_levels);
     static u32 const looks = env_u32("FLX_FM_LOOKS", 2);
@@ -349,8 +361,10 @@ int DeviceApi::search_filtered(void* stream, const DevIndex& idx, const u8* d_se
     hipStream_t s = (hipStream_t)stream;
     dim3 const grid(std::min<u32>((n_seeds + spw - 1) / spw, max_waves));
     static u32 const extra_lds = env_u32("FLX_FM_EXTRA_LDS", 0);      // (experiments: bytes of LDS a wave holds without using them)
-    hipLaunchKernelGGL(fm_search_filter_kernel, grid, dim3(64), (size_t)C.levels * FM_FRAME_WORDS * 64 * sizeof(u32) + extra_lds, s, C, d_seeds, n_seeds, d_hits, hit_cap,
-                       d_items, item_cap, d_counters, d_seed_cnt, refill_a, fm_prio);
+    size_t const lds_bytes = (size_t)C.levels * FM_FRAME_WORDS * 64 * sizeof(u32) + extra_lds;
+    static u32 const stats = env_u32("FLX_SEARCH_DEBUG", 0);           // the diagnostic counters [11], [12] cost two registers per lane
+    auto const kernel = stats ? fm_search_filter_kernel<true> : fm_search_filter_kernel<false>;
+    hipLaunchKernelGGL(kernel, grid, dim3(64), lds_bytes, s, C, n_seeds, d_hits, hit_cap, d_items, item_cap, d_counters, d_seed_cnt, refill_a, fm_prio);
     if (C.text_min_remain) {
         // (the number of queued subtrees is only known on the device: a fixed grid, waves without work leave at once; the walk is a
         // chain of dependent loads from the L2, so it wants every wave slot: 8 per SIMD)

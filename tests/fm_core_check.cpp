@@ -89,14 +89,16 @@ struct Harness {
         FmLane L;
         fm_take_seed(C, L, seed, 0);
         u64 guard = 0;
-        while (L.busy) {
-            fm_step(C, L, fr);
-            if (L.out == FM_OUT_HIT) hits.push_back(Hit{L.out_lb, L.out_len, L.out_e, L.out_key});
-            else if (L.out == FM_OUT_ITEM) queued.push_back(DevHit{0u, L.out_lb, L.out_len, 0u, L.out_key});
-            L.out = FM_OUT_NONE;
+        C.seeds = &seed;
+        while (L.busy()) {
+            fm_step<true>(C, L, fr);
+            // (what a step produced is read from the node's registers before the next step, as the kernel does)
+            if (L.out() == FM_OUT_HIT) hits.push_back(Hit{L.nlb, L.nlen, L.ne(), L.nkey});
+            else if (L.out() == FM_OUT_ITEM) queued.push_back(DevHit{0u, L.nlb, L.item_word(), 0u, L.nkey});
+            if (L.overflow()) { fprintf(stderr, "frame overflow\n"); exit(2); }
+            L.clear_out();
             if (++guard > (1ull << 32)) { fprintf(stderr, "fm_step does not terminate\n"); exit(2); }
         }
-        if (L.overflow) { fprintf(stderr, "frame overflow\n"); exit(2); }
         lookups += L.n_lookup; pruned += L.n_pruned; ext += L.n_ext; items += queued.size(); kills += L.n_prefix_kills;
         std::vector<u32> tframes((size_t)C.levels * TX_FRAME_WORDS);
         auto tfr = [&](u32 level, u32 word) -> u32& { return tframes[level * TX_FRAME_WORDS + word]; };
