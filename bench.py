@@ -67,6 +67,7 @@ def parse():
     ap.add_argument("--gather-cigars", action="store_true", help="N > 1: the per-step gather to rank 0 also moves the CIGAR words (default: the fixed-size records)")
     ap.add_argument("--cpu-sample", type=int, default=int(os.environ.get("FLX_BENCH_CPU_SAMPLE", 768)))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dump-gathered", default="", help="rank 0 saves the record table of timed step 0 as it arrives from all ranks (numpy .npy; tests)")
     ap.add_argument("--no-host-inputs-leg", action="store_true", help="skip the second timed region (reads in pageable host memory: H2D and Peq build inside the clock)")
     ap.add_argument("--no-repeat-rich-leg", action="store_true", help="metric configuration only: skip the secondary line on the repeat-rich (hg38-like) reference")
     ap.add_argument("--repeat-rich-steps", type=int, default=4)
@@ -273,8 +274,14 @@ def main():
                         table = D.gather_rows(rows, counts, rank, world, device=dev)
                         if rank == 0:
                             gathered_rows += int(table.shape[0])
+                            if args.dump_gathered and si == 0:
+                                np.save(args.dump_gathered, np.asarray(table.cpu() if hasattr(table, "cpu") else table))
                         del table
                     g_s += time.perf_counter() - t_g
+                elif args.dump_gathered and si == 0:
+                    rows = res.rows.copy()
+                    rows[:, 0] += (si * world + rank) * B
+                    np.save(args.dump_gathered, rows)
             barrier()
             secs = time.perf_counter() - t_start
             tpool.shutdown()

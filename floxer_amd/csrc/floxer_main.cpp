@@ -275,6 +275,14 @@ struct FastqReader {
     FastqReader(const char* path, unsigned threads_) : threads(threads_) {
         int const probe = open(path, O_RDONLY);
         if (probe < 0) return;
+        // the pread path needs a file that can be read at an offset; a FIFO, /dev/stdin or a socket (plain or gzip: the reference reads a
+        // pipe named *.fastq through an ifstream just as well) goes through zlib, whose transparent mode passes plain text through
+        struct stat st;
+        if (fstat(probe, &st) != 0 || !S_ISREG(st.st_mode)) {
+            f = gzdopen(probe, "rb");
+            if (f) gzbuffer(f, 1 << 20); else close(probe);
+            return;
+        }
         unsigned char magic[2] = {0, 0};
         ssize_t const got = pread(probe, magic, 2, 0);
         if (got == 2 && magic[0] == 0x1f && magic[1] == 0x8b) {

@@ -455,7 +455,8 @@ int search_seeds_device(Lane* ctx, const u8* d_seq_pool_or_null, const u8* h_seq
             if ((rc = ctx->grouped.ensure(hit_cap * sizeof(DevHit)))) return rc;
             if ((rc = ctx->sel_out.ensure(sel_cap * sizeof(DevOutAnchor)))) return rc;
             if ((rc = ctx->sel_sparse.ensure(sel_cap * sizeof(DevOutAnchor)))) return rc;
-            FLX_HIP(hipMemsetAsync((char*)ctx->sel_rows.ptr + n_seeds * 4, 0, 4, ctx->stream));
+            // (the search counts a seed's rows here while it runs; seed_rows_kernel then writes every entry but the last)
+            FLX_HIP(hipMemsetAsync(ctx->sel_rows.ptr, 0, (n_seeds + 1) * 4, ctx->stream));
             FLX_HIP(hipMemsetAsync(ctx->seed_cnt.ptr, 0, (n_seeds + 1) * 4, ctx->stream));
             FLX_HIP(hipMemsetAsync((char*)ctx->sel_n.ptr + n_seeds * 4, 0, 4, ctx->stream));
         }
@@ -466,7 +467,8 @@ int search_seeds_device(Lane* ctx, const u8* d_seq_pool_or_null, const u8* h_seq
                 return DeviceApi::search_filtered(ctx->stream, ctx->ctx->didx, d_seq, d_qpack, ctx->scheme.as<u64>(), ctx->seeds.as<DevSeed>(), (u32)n_seeds,
                                                   max_hits, max_errors, ctx->hits.as<DevHit>(), (u32)std::min<u64>(hit_cap, 0xFFFFFFFFu),
                                                   item_cap ? ctx->items.as<DevHit>() : nullptr, (u32)std::min<u64>(item_cap, 0xFFFFFFFFu),
-                                                  ctx->counters.as<u32>(), device_select ? ctx->seed_cnt.as<u32>() : nullptr, concurrent);
+                                                  ctx->counters.as<u32>(), device_select ? ctx->seed_cnt.as<u32>() : nullptr,
+                                                  device_select ? ctx->sel_rows.as<u32>() : nullptr, concurrent);
             return DeviceApi::search(ctx->stream, ctx->ctx->didx, d_seq, ctx->scheme.as<u64>(), ctx->seeds.as<DevSeed>(), (u32)n_seeds,
                                      max_hits, ctx->stack.as<DevFrame>(), ctx->hits.as<DevHit>(), (u32)std::min<u64>(hit_cap, 0xFFFFFFFFu),
                                      ctx->counters.as<u32>(), device_select ? ctx->seed_cnt.as<u32>() : nullptr);
@@ -491,7 +493,7 @@ int search_seeds_device(Lane* ctx, const u8* d_seq_pool_or_null, const u8* h_seq
             if ((rc = d2h(ctx, sel_stat.data(), ctx->sel_stat.ptr, n_seeds * sizeof(DevSelStat)))) return rc;
         }
         if ((rc = ctx->sync())) return rc;
-        if (getenv("FLX_SEARCH_DEBUG")) fprintf(stderr, "[fm_search] seeds %llu ext %u (of single-row intervals %u) wave-iterations %u (max per wave %u) busy pair-iterations %u, after the queue ran dry %u (max %u)\n", (unsigned long long)n_seeds, counters[2], counters[3], counters[4], counters[5], counters[6], counters[8], counters[9]);
+        if (getenv("FLX_SEARCH_DEBUG")) fprintf(stderr, "[fm_search] seeds %llu ext %u (of single-row intervals %u) wave-iterations %u (max per wave %u) busy pair-iterations %u, after the queue ran dry %u (max %u), subtrees handed over %u\n", (unsigned long long)n_seeds, counters[2], counters[3], counters[4], counters[5], counters[6], counters[8], counters[9], counters[14]);
         if (getenv("FLX_SEARCH_DEBUG") && filtered) fprintf(stderr, "[fm_search filtered] subtrees queued %u (slots %u of %llu), filter lookups %u, children dropped %u, searches ended by the prefix lookup %u; text walk: lane-steps %u, wave-iterations %u\n", counters[3], counters[16], (unsigned long long)item_cap, counters[10], counters[11], counters[12], counters[18], counters[19]);
         if (counters[1]) { set_error("fm_search: DFS stack reservation exceeded"); return FLX_ERR_INTERNAL; }
         bool const items_fit = !item_cap || counters[16] <= item_cap;

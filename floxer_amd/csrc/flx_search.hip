@@ -133,7 +133,7 @@ int DeviceApi::pack_pool(void* stream, const u8* d_seq, u64 len, u32* d_qpack) {
 
 // ================================================================================================ the search kernels
 // counters (32 words): [0] hit slots reserved, [1] frame overflow flag, [2] cursor extensions (rank pairs), [3] subtrees queued (records
-//   written, without the unused ends of the slot ranges), [13] hits written (both kernels),
+//   written, without the unused ends of the slot ranges), [13] hits written (both kernels), [14] subtrees handed from lane to lane,
 //   [4] wave-iterations, [5] their maximum over the waves, [6] busy lane-iterations, [7] seed queue head, [8] wave-iterations after the
 //   seed queue ran dry, [9] their maximum, [10] filter lookups, [11] children dropped by the filter, [12] searches ended by the prefix
 //   lookup, [16] item slots reserved, [17] item queue head, [18] text-mode lane-steps, [19] text-mode wave-iterations
@@ -200,11 +200,20 @@ __device__ __forceinline__ u32 wave_slots_take(WaveSlots& S, DevHit* __restrict_
 
 // STATS: the diagnostic counters [11], [12] are kept (two more registers per lane). 111 VGPRs, no scratch (round 3: 128 + 72 B per lane
 // of spills inside the DFS loop, which went through HBM).
+//
+// Work sharing inside a wave (seed_rows != null). On a text with repeat families a launch used to be the tail of its heaviest seeds: a
+// seed inside a diverged family walks tens of thousands of steps while the other lanes of its wave have run out of seeds (round 3: 97 %
+// of the wave-iterations after the queue ran dry, a tenth of the lanes busy). Once the wave's part of the seed queue is dry, an idle
+// lane takes the upper half of the not yet visited error children of a busy lane's BOTTOM frame (the shallowest one: the largest
+// subtrees): it copies the frame (18 words, LDS to LDS) with that half as its mask and carries on as if it had got there itself, under
+// the donor's seed, search and keys; the donor keeps the lower half and the match child. Hits carry keys that restore the reference's
+// emission order whoever emits them, so nothing downstream changes. What the walk of one seed may stop on - more rows than the hard
+// cap - is counted per seed in global memory (seed_rows), so that the lanes sharing a seed stop together.
 template <bool STATS>
 __global__ void __launch_bounds__(64, 4) fm_search_filter_kernel(FmConst C, u32 n_seeds, DevHit* __restrict__ hits,
                                                               u32 hit_cap, DevHit* __restrict__ items, u32 item_cap, u32* __restrict__ counters,
-                                                              u32* __restrict__ seed_cnt, u32 refill, u32 prio) {
-    extern __shared__ u32 lds[];                // frames: [level][FM_FRAME_WORDS][64 lanes]
+                                                              u32* __restrict__ seed_cnt, u32* __restrict__ seed_rows, u32 refill, u32 prio, u32 steal_min) {
+    extern __shared__ u32 lds[];                // frames: [level][FM_FRAME_WORDS][64 lanes], then 64 words for the pairing of lanes
     if (prio == 3u) __builtin_amdgcn_s_setprio(3);
     else if (prio == 2u) __builtin_amdgcn_s_setprio(2);
     else if (prio == 1u) __builtin_amdgcn_s_setprio(1);
@@ -216,7 +225,8 @@ __global__ void __launch_bounds__(64, 4) fm_search_filter_kernel(FmConst C, u32 
     WaveSlots HS, IS;
     FmLane L;
     bool exhausted = false;
-    u32 n_iter = 0, n_busy_iter = 0, n_tail_iter = 0, n_hits = 0, n_items = 0;      // (wave-uniform but n_busy_iter)
+    u32 n_iter = 0, n_busy_iter = 0, n_tail_iter = 0, n_hits = 0, n_items = 0, n_steals = 0;      // (wave-uniform but n_busy_iter)
+    u32* const pair = lds + C.levels * FM_FRAME_WORDS * 64u;
 
     while (true) {
         // ---- what the lanes produced in the last iteration (read from the node's registers, see FmLane)
@@ -227,8 +237,17 @@ __global__ void __launch_bounds__(64, 4) fm_search_filter_kernel(FmConst C, u32 
             u32 const slot = wave_slots_take(HS, hits, hit_cap, &counters[0], emit_h, lane, lanes_below);
             if (out == FM_OUT_HIT) {
                 u32 const sid = seeds[L.pos].id;
-                u32 const ord = seed_cnt ? atomicAdd(&seed_cnt[sid], 1u) : 0u;
-                if (slot < hit_cap) hits[slot] = DevHit{sid, L.nlb, L.nlen, seed_cnt ? L.ne() | (min(ord, 0xFFFFFFu) << 8) : L.ne(), L.nkey};
+                bool keep = true;
+                if (seed_rows) {
+                    // rows of this seed over all the lanes that walk it (one lane unless children were handed over: then the lane's own count
+                    // in fm_step is only a part). A seed with max_hits rows is excluded downstream whatever else it has (search.cpp:190-202).
+                    u32 const before = atomicAdd(&seed_rows[sid], L.nlen);
+                    keep = before < C.max_hits;
+                    if (before + L.nlen >= C.max_hits) L.wn &= ~(WN_BUSY | WN_IN_SEARCH);
+                }
+                u32 const ord = seed_cnt && keep ? atomicAdd(&seed_cnt[sid], 1u) : 0u;
+                if (slot < hit_cap) hits[slot] = keep ? DevHit{sid, L.nlb, L.nlen, seed_cnt ? L.ne() | (min(ord, 0xFFFFFFu) << 8) : L.ne(), L.nkey}
+                                                      : DevHit{0xFFFFFFFFu, 0u, 0u, 0u, 0ull};
             }
         }
         u64 const emit_i = __ballot(out == FM_OUT_ITEM);
@@ -256,9 +275,53 @@ __global__ void __launch_bounds__(64, 4) fm_search_filter_kernel(FmConst C, u32 
                 else exhausted = true;
             }
         }
+        bool const tail = Q.done && Q.next == Q.end;                   // wave-uniform: this wave gets no more seeds
+        if (tail && seed_rows) {
+            if (!L.busy()) exhausted = true;                            // (a lane that waited for a batch of seeds: there is none)
+            bool const idle_lane = !L.busy();
+            u64 const thieves = __ballot(idle_lane);
+            if ((u32)__popcll(thieves) >= steal_min) {
+                // donors: lanes inside a search whose bottom frame has error children to spare
+                u32 fmask = 0;
+                if (L.busy() && L.in_search() && L.depth() >= 1u) fmask = fr(0, 14);
+                u32 const costly = fmask & ~1u;
+                u32 const n_costly = fm_popc(costly);
+                bool const donor = n_costly >= 2u || (n_costly == 1u && (fmask & 1u));
+                u64 const donors = __ballot(donor);
+                if (donors) {
+                    u32 const n_pairs = min((u32)__popcll(thieves), (u32)__popcll(donors));
+                    u32 const my_rank = (u32)__popcll((donor ? donors : thieves) & lanes_below);
+                    if (donor) pair[my_rank] = lane;
+                    __syncthreads();
+                    bool const takes = idle_lane && my_rank < n_pairs, gives = donor && my_rank < n_pairs;
+                    u32 const from = takes ? pair[my_rank] : lane;
+                    // the donor's seed and search
+                    u32 const d_pos = (u32)__shfl((int)L.pos, (int)from), d_exo = (u32)__shfl((int)L.exo, (int)from), d_ws = (u32)__shfl((int)L.ws, (int)from);
+                    u32 const d_qlo = (u32)__shfl((int)(u32)L.qoff, (int)from), d_qhi = (u32)__shfl((int)(u32)(L.qoff >> 32), (int)from);
+                    u32 w[FM_FRAME_WORDS];
+#pragma unroll
+                    for (u32 i = 0; i < FM_FRAME_WORDS; ++i) w[i] = lds[i * 64u + from];          // frame 0 of lane `from`
+                    __syncthreads();
+                    // the upper half of the error children goes (all of them but one when there is no match child to stay behind)
+                    u32 const m = w[14], mc = m & ~1u, nc = fm_popc(mc), g = (m & 1u) ? (nc + 1u) / 2u : nc / 2u;
+                    u32 give = mc;
+                    for (u32 i = g; i < nc; ++i) give &= give - 1u;                                 // drop the lowest nc - g
+                    if (gives) fr(0, 14) = m & ~give;
+                    if (takes) {
+#pragma unroll
+                        for (u32 i = 0; i < FM_FRAME_WORDS; ++i) if (i != 14u) fr(0, i) = w[i];
+                        fr(0, 14) = give;
+                        L.pos = d_pos; L.exo = d_exo; L.ws = d_ws | (1u << 28); L.qoff = (u64)d_qlo | ((u64)d_qhi << 32);
+                        L.ct = 0;
+                        L.wn = WN_BUSY | WN_IN_SEARCH | WN_NEED_CHILD | WN_DEPTH1;
+                    }
+                    n_steals += n_pairs;
+                }
+            }
+        }
         if (__all(exhausted && !L.busy())) break;
         ++n_iter;
-        if (Q.done && Q.next == Q.end) ++n_tail_iter;
+        if (tail) ++n_tail_iter;
         if (!L.busy() || (!go && !L.in_search())) continue;
         ++n_busy_iter;
         fm_step<STATS>(C, L, fr);
@@ -269,7 +332,7 @@ __global__ void __launch_bounds__(64, 4) fm_search_filter_kernel(FmConst C, u32 
     if (lane == 0) {
         atomicAdd(&counters[2], s_ext); atomicAdd(&counters[6], s_busy);
         atomicAdd(&counters[4], n_iter); atomicMax(&counters[5], n_iter); atomicAdd(&counters[8], n_tail_iter); atomicMax(&counters[9], n_tail_iter);
-        atomicAdd(&counters[10], s_look); atomicAdd(&counters[13], n_hits); atomicAdd(&counters[3], n_items);
+        atomicAdd(&counters[10], s_look); atomicAdd(&counters[13], n_hits); atomicAdd(&counters[3], n_items); atomicAdd(&counters[14], n_steals);
     }
     if (STATS) {
         u32 const s_pruned = s_wave_sum(L.n_pruned), s_kills = s_wave_sum(L.n_prefix_kills);
@@ -338,7 +401,7 @@ static u32 env_u32(const char* name, u32 dflt) {
 // queued). frame_levels = largest error count of a seed. d_counters: 32 words, zeroed by the caller.
 int DeviceApi::search_filtered(void* stream, const DevIndex& idx, const u8* d_seq, const u32* d_qpack, const u64* d_scheme, const DevSeed* d_seeds,
                                u32 n_seeds, u32 max_hits_per_seed, u32 frame_levels, DevHit* d_hits, u32 hit_cap, DevHit* d_items, u32 item_cap,
-                               u32* d_counters, u32* d_seed_cnt, u32 concurrent_launches) {
+                               u32* d_counters, u32* d_seed_cnt, u32* d_seed_rows, u32 concurrent_launches) {
     if (n_seeds == 0) return 0;
     static u32 const spw = env_u32("FLX_FM_SEEDS_PER_WAVE", 256);
     static u32 const forced_waves = env_u32("FLX_FM_MAX_WAVES", 0);
@@ -361,10 +424,12 @@ int DeviceApi::search_filtered(void* stream, const DevIndex& idx, const u8* d_se
     hipStream_t s = (hipStream_t)stream;
     dim3 const grid(std::min<u32>((n_seeds + spw - 1) / spw, max_waves));
     static u32 const extra_lds = env_u32("FLX_FM_EXTRA_LDS", 0);      // (experiments: bytes of LDS a wave holds without using them)
-    size_t const lds_bytes = (size_t)C.levels * FM_FRAME_WORDS * 64 * sizeof(u32) + extra_lds;
+    size_t const lds_bytes = (size_t)C.levels * FM_FRAME_WORDS * 64 * sizeof(u32) + 64 * sizeof(u32) + extra_lds;
+    u32 const steal_min = env_u32("FLX_FM_STEAL_MIN", 1);              // idle lanes a wave waits for before it shares work (0: never)
+    u32* const seed_rows = steal_min ? d_seed_rows : nullptr;
     static u32 const stats = env_u32("FLX_SEARCH_DEBUG", 0);           // the diagnostic counters [11], [12] cost two registers per lane
     auto const kernel = stats ? fm_search_filter_kernel<true> : fm_search_filter_kernel<false>;
-    hipLaunchKernelGGL(kernel, grid, dim3(64), lds_bytes, s, C, n_seeds, d_hits, hit_cap, d_items, item_cap, d_counters, d_seed_cnt, refill_a, fm_prio);
+    hipLaunchKernelGGL(kernel, grid, dim3(64), lds_bytes, s, C, n_seeds, d_hits, hit_cap, d_items, item_cap, d_counters, d_seed_cnt, seed_rows, refill_a, fm_prio, std::max(1u, steal_min));
     if (C.text_min_remain) {
         // (the number of queued subtrees is only known on the device: a fixed grid, waves without work leave at once; the walk is a
         // chain of dependent loads from the L2, so it wants every wave slot: 8 per SIMD)

@@ -13,6 +13,11 @@ import oracle_lib as O
 pytestmark = pytest.mark.gpu
 
 
+def _recs_of(result, read):
+    """the records of one read of a run as comparable tuples (CIGAR words as bytes)"""
+    return [(int(r[1]), int(r[2]), int(r[3]), int(r[4]), result.cigars[r[5]: r[5] + r[6]].tobytes()) for r in result.rows[result.rows[:, 0] == read]]
+
+
 @pytest.fixture(scope="module")
 def small_genome():
     rng = np.random.default_rng(11)
@@ -849,33 +854,6 @@ def test_index_at_scale_checked_without_the_products_arrays():
             assert lo < hi, "an LF walk over the reverse BWT spelled a string the text does not hold"
 
 
-def test_hifi_shape_at_grch38_size_properties():
-    """BASELINE.json configs[4]'s shape at full size: 20 kb reads @ 2 % against the 3.1 Gb reference (25 sequences), floxer defaults.
-    Every read has one primary at its simulated sequence, place and strand; the CIGARs of a sample are consistent with both texts and
-    their NM; batch invariance; -I keeps every primary."""
-    chrom = 124_000_000
-    pool, genome = S.make_genome_fast(chrom, 25, seed=S.DEFAULT_SEED)
-    idx = F.fmindex(genome, device=0)
-    ctx = F.context(idx)
-    (rpool, offs), (tc, tp, tr) = S.make_reads_fast(pool, [chrom] * 25, 192, 20000, 0.02, seed=77)
-    reads = [rpool[int(offs[i]):int(offs[i + 1])] for i in range(192)]
-    p = F.params(error_probability=0.02)
-    got = F.aligner(ctx, p).align_reads(reads)
-    recs = got.records()
-    prim = {r[0]: r for r in recs if not r[1] & 256 and not r[1] & 4}
-    assert len(prim) == 192
-    for i in range(192):
-        r = prim[i]
-        assert r[2] == int(tc[i]) and bool(r[1] & 16) == bool(tr[i]) and abs(r[3] - int(tp[i])) <= 2000, (i, r[:5], int(tc[i]), int(tp[i]))
-    _check_cigars(genome, reads, [r for r in recs if r[0] < 24], 0.02)
-    half = F.aligner(ctx, p).align_reads(reads[:96]).records()
-    assert half == [r for r in recs if r[0] < 96]
-    with_i = F.aligner(ctx, F.params(error_probability=0.02, interval_optimization=True)).align_reads(reads).records()
-    prim_i = {r[0]: r for r in with_i if not r[1] & 256 and not r[1] & 4}
-    assert {k: v[:5] for k, v in prim_i.items()} == {k: v[:5] for k, v in prim.items()}
-    ctx.close()
-
-
 # ---------------------------------------------------------------- '$' in a read, repeat-rich text, scale
 def test_dollar_in_reads_and_seeds_matches_oracle(small_genome):
     """input.cpp:165-176 maps '$' to rank 0, the rank of the sequence delimiters: search_ng21 extends a cursor with it like with any
@@ -1017,34 +995,37 @@ def test_scale_250mb_multi_sequence():
     ctx.close()
 
 
-def test_scale_grch38_size_truth_cigars_and_batch_invariance():
-    """The metric's configuration (BASELINE.json configs[3] shape): 3.1 Gb in 25 sequences, index built on the GPU, 10-kb reads @ 8 %,
-    floxer defaults. The oracle cannot take this size in test time, so the properties the domain offers: every read has exactly one
-    primary, at the simulated sequence / position / strand; the CIGARs of a sample are consistent with the two texts and their edit
-    counts equal NM; a read's records do not depend on the batch it arrives in; `-I` keeps the primary of every read."""
-    G, NSEQ, NR, L, rate = 3_100_000_000, 25, 512, 10000, 0.08
-    pool, genome = S.make_genome_fast(G // NSEQ, NSEQ, seed=91)
-    (rpool, offs), (chrom, pos, rev) = S.make_reads_fast(pool, [G // NSEQ] * NSEQ, NR, L, rate, seed=92)
-    ctx = F.context(F.fmindex(genome, device=0))
+def test_scale_250mb_repeat_rich_matches_oracle(capsys):
+    """A repeat-rich reference at BASELINE.json configs[2] size (250 Mb in 5 sequences, flx_sim_genome_repeats: interspersed families,
+    tandem repeats, low complexity, N runs, segmental duplications - the bench's --repeat-rich generator): 512 reads of 10 kb @ 8 %,
+    floxer defaults. Here the search is the tail of its heaviest seeds and the lanes of a wave share their subtrees
+    (fm_search_filter_kernel); the records must not notice: a read's records do not depend on its batch (another batch = other seeds
+    next to it on a wave = other hand-overs), and a sample of reads equals the oracle record for record, defaults and -I."""
+    G, NSEQ, NR, L, rate = 250_000_000, 5, 512, 10000, 0.08
+    pool, genome = S.make_genome_fast(G // NSEQ, NSEQ, seed=177, repeat_rich=True)
+    (rpool, offs), (chrom, pos, rev) = S.make_reads_fast(pool, [G // NSEQ] * NSEQ, NR, L, rate, seed=178)
+    fidx = F.fmindex(genome, device=0)
+    ctx = F.context(fidx)
+    ctx.path_counters(reset=True)
     res = F.aligner(ctx, F.params(error_probability=rate)).align_reads((rpool, offs))
-    rows = res.rows
-    prim = rows[(rows[:, 1] & 256) == 0]
-    assert len(prim) == NR and (prim[:, 0] == np.arange(NR)).all()
-    assert ((prim[:, 1] & 4) == 0).all()
-    assert (prim[:, 2] == chrom).all() and (np.abs(prim[:, 3] - pos.astype(np.int64)) <= 0.1 * L).all()
-    assert (((prim[:, 1] & 16) != 0) == (rev != 0)).all()
-    sample = list(range(0, NR, 64))
+    pc = ctx.path_counters()
+    sample = list(range(0, NR, 16))
     reads = [rpool[int(offs[i]):int(offs[i + 1])] for i in sample]
     sub = F.aligner(ctx, F.params(error_probability=rate)).align_reads(reads)
-
-    def recs_of(result, read):
-        return [(int(r[1]), int(r[2]), int(r[3]), int(r[4]), result.cigars[r[5]: r[5] + r[6]].tobytes()) for r in result.rows[result.rows[:, 0] == read]]
     for j, i in enumerate(sample):
-        assert recs_of(sub, j) == recs_of(res, i)
-    _check_cigars(genome, reads, sub.records(), rate)
-    opt = F.aligner(ctx, F.params(error_probability=rate, interval_optimization=True)).align_reads((rpool, offs))
-    oprim = opt.rows[(opt.rows[:, 1] & 256) == 0]
-    assert len(oprim) == NR and (oprim[:, 2] == chrom).all() and (np.abs(oprim[:, 3] - pos.astype(np.int64)) <= 0.1 * L).all()
+        assert _recs_of(sub, j) == _recs_of(res, i)
+    oidx = O.Index(genome, imported=(fidx.suffix_array_u32(), fidx.bwt(False), fidx.bwt(True)), pool=pool)
+    exp = oidx.run(reads, O.params(error_probability=rate), threads=16)
+    assert sub.skipped.tolist() == exp.skipped.tolist()
+    assert np.array_equal(sub.rows[:, :5], exp.rows[:, :5]) and sub.records() == exp.records()
+    sub_i = F.aligner(ctx, F.params(error_probability=rate, interval_optimization=True)).align_reads(reads)
+    exp_i = oidx.run(reads, O.params(error_probability=rate, interval_opt=True), threads=16)
+    assert sub_i.records() == exp_i.records()
+    with capsys.disabled():
+        print(f"\nrepeat-rich 250 Mb: seeds {pc['seeds']}, excluded by the hard cap {pc['seeds_excluded_by_hard_cap']} "
+              f"({pc['seeds_excluded_by_hard_cap'] / pc['seeds']:.1%}), selected on the host {pc['seeds_selected_on_host']}, rank pairs per read "
+              f"{pc['cursor_extensions'] / NR:.0f}, search reruns {pc['search_reruns']}, records {pc['records']}")
+    assert pc["seeds_excluded_by_hard_cap"] > 0.01 * pc["seeds"]
     ctx.close()
 
 
@@ -1229,4 +1210,142 @@ def test_seeds_written_on_the_device_equal_the_host_list(monkeypatch):
     monkeypatch.delenv("FLX_HOST_SEEDS", raising=False)
     exp = O.Index(genome).run(reads, O.params(error_probability=0.06), threads=8)
     assert F.aligner(ctx, F.params(error_probability=0.06)).align_reads(reads).records() == exp.records()
+    ctx.close()
+
+
+# ---------------------------------------------------------------- BASELINE.json configs[0]: the reference's own CPU-runnable case
+def test_config0_1mb_reference_1k_reads_of_1kb_match_oracle():
+    """BASELINE.json configs[0] at its own shape: 1 Mb random reference + 1 000 simulated reads of 1 kb @ 5 %, floxer defaults and -I:
+    every record equal to the oracle's (flag, reference, position, NM, CIGAR), every read mapped at its simulated place."""
+    genome = S.make_genome(1_000_000, 1, seed=S.DEFAULT_SEED)
+    reads, names, truth = S.make_reads(genome, 1000, 1000, 0.05, seed=S.DEFAULT_SEED + 1)
+    fidx = F.fmindex(genome)
+    ctx = F.context(fidx)
+    oidx = O.Index(genome, imported=(fidx.suffix_array_u32(), fidx.bwt(False), fidx.bwt(True)))      # (oracle SA == product SA: test_host_cpu)
+    for kw, okw in ((dict(), dict()), (dict(interval_optimization=True), dict(interval_opt=True))):
+        got = F.aligner(ctx, F.params(error_probability=0.05, **kw)).align_reads(reads)
+        exp = oidx.run(reads, O.params(error_probability=0.05, **okw), threads=16)
+        assert got.skipped.tolist() == exp.skipped.tolist()
+        assert np.array_equal(got.rows[:, :5], exp.rows[:, :5]) and got.records() == exp.records(), kw
+        prim = got.rows[(got.rows[:, 1] & 256) == 0]
+        assert len(prim) == 1000 and ((prim[:, 1] & 4) == 0).all()
+        assert (np.abs(prim[:, 3] - np.array([t[1] for t in truth])) <= 100).all()
+    ctx.close()
+
+
+# ---------------------------------------------------------------- the metric's size: 3.1 Gb in 25 sequences, against the oracle
+@pytest.fixture(scope="module")
+def grch38_size():
+    """the bench's reference (BASELINE.json configs[3] / [4]: 3.1 Gb in 25 sequences, flx_sim_genome with the default seed), its index built
+    on the GPU, a context on it, and the oracle's index laid out around the product's suffix array and BWTs (a text has one suffix array;
+    oracle SA == product SA is tested on small inputs, the device-built index against the text alone at 250 Mb)"""
+    chrom = 124_000_000
+    pool, genome = S.make_genome_fast(chrom, 25, seed=S.DEFAULT_SEED)
+    fidx = F.fmindex(genome, device=0)
+    ctx = F.context(fidx)
+    oidx = O.Index(genome, imported=(fidx.suffix_array_u32(), fidx.bwt(False), fidx.bwt(True)), pool=pool)
+    yield pool, genome, [chrom] * 25, ctx, oidx
+    ctx.close()
+
+
+def test_scale_grch38_size_matches_oracle_truth_and_batch_invariance(grch38_size):
+    """The metric's configuration (BASELINE.json configs[3] shape): 3.1 Gb in 25 sequences, 10-kb reads @ 8 %, floxer defaults and -I.
+    All 512 reads: exactly one primary, at the simulated sequence / position / strand; CIGARs of a sample consistent with the two texts
+    and their NM; a read's records do not depend on its batch. And record for record the ORACLE's output on a sample of 32 reads, without
+    and with -I (what floxer_whole_program_via_cli_test.cpp:40-94 compares, at the size the metric is quoted on)."""
+    pool, genome, chrom_lens, ctx, oidx = grch38_size
+    NR, L, rate = 512, 10000, 0.08
+    (rpool, offs), (chrom, pos, rev) = S.make_reads_fast(pool, chrom_lens, NR, L, rate, seed=92)
+    res = F.aligner(ctx, F.params(error_probability=rate)).align_reads((rpool, offs))
+    rows = res.rows
+    prim = rows[(rows[:, 1] & 256) == 0]
+    assert len(prim) == NR and (prim[:, 0] == np.arange(NR)).all()
+    assert ((prim[:, 1] & 4) == 0).all()
+    assert (prim[:, 2] == chrom).all() and (np.abs(prim[:, 3] - pos.astype(np.int64)) <= 0.1 * L).all()
+    assert (((prim[:, 1] & 16) != 0) == (rev != 0)).all()
+    sample = list(range(0, NR, 16))
+    reads = [rpool[int(offs[i]):int(offs[i + 1])] for i in sample]
+    sub = F.aligner(ctx, F.params(error_probability=rate)).align_reads(reads)
+    for j, i in enumerate(sample):
+        assert _recs_of(sub, j) == _recs_of(res, i)
+    _check_cigars(genome, reads[:8], [r for r in sub.records() if r[0] < 8], rate)
+    exp = oidx.run(reads, O.params(error_probability=rate), threads=16)
+    assert sub.skipped.tolist() == exp.skipped.tolist()
+    assert np.array_equal(sub.rows[:, :5], exp.rows[:, :5]) and sub.records() == exp.records()
+    opt = F.aligner(ctx, F.params(error_probability=rate, interval_optimization=True)).align_reads((rpool, offs))
+    oprim = opt.rows[(opt.rows[:, 1] & 256) == 0]
+    assert len(oprim) == NR and (oprim[:, 2] == chrom).all() and (np.abs(oprim[:, 3] - pos.astype(np.int64)) <= 0.1 * L).all()
+    sub_i = F.aligner(ctx, F.params(error_probability=rate, interval_optimization=True)).align_reads(reads)
+    exp_i = oidx.run(reads, O.params(error_probability=rate, interval_opt=True), threads=16)
+    assert sub_i.records() == exp_i.records()
+
+
+def test_hifi_shape_at_grch38_size_matches_oracle(grch38_size):
+    """BASELINE.json configs[4]'s shape at full size: 20 kb reads @ 2 % against the 3.1 Gb reference (25 sequences), floxer defaults.
+    Every read has one primary at its simulated sequence, place and strand; the CIGARs of a sample are consistent with both texts and
+    their NM; batch invariance; -I keeps every primary; and the oracle's records, one for one, on a sample of 32 reads (defaults and -I)."""
+    pool, genome, chrom_lens, ctx, oidx = grch38_size
+    (rpool, offs), (tc, tp, tr) = S.make_reads_fast(pool, chrom_lens, 192, 20000, 0.02, seed=77)
+    reads = [rpool[int(offs[i]):int(offs[i + 1])] for i in range(192)]
+    p = F.params(error_probability=0.02)
+    got = F.aligner(ctx, p).align_reads(reads)
+    recs = got.records()
+    prim = {r[0]: r for r in recs if not r[1] & 256 and not r[1] & 4}
+    assert len(prim) == 192
+    for i in range(192):
+        r = prim[i]
+        assert r[2] == int(tc[i]) and bool(r[1] & 16) == bool(tr[i]) and abs(r[3] - int(tp[i])) <= 2000, (i, r[:5], int(tc[i]), int(tp[i]))
+    _check_cigars(genome, reads, [r for r in recs if r[0] < 24], 0.02)
+    half = F.aligner(ctx, p).align_reads(reads[:96]).records()
+    assert half == [r for r in recs if r[0] < 96]
+    with_i = F.aligner(ctx, F.params(error_probability=0.02, interval_optimization=True)).align_reads(reads).records()
+    prim_i = {r[0]: r for r in with_i if not r[1] & 256 and not r[1] & 4}
+    assert {k: v[:5] for k, v in prim_i.items()} == {k: v[:5] for k, v in prim.items()}
+    exp = oidx.run(reads[:32], O.params(error_probability=0.02), threads=16)
+    assert [r for r in recs if r[0] < 32] == exp.records()
+    exp_i = oidx.run(reads[:32], O.params(error_probability=0.02, interval_opt=True), threads=16)
+    assert [r for r in with_i if r[0] < 32] == exp_i.records()
+
+
+# ---------------------------------------------------------------- N > 1: the bench's own control flow, two ranks on the one GPU
+def test_bench_two_ranks_share_one_gpu_and_gather_what_one_rank_computes(tmp_path):
+    """`bench.py --gpus 2` as the driver starts it (child ranks before any GPU call, rendezvous on 127.0.0.1), rehearsed on one GPU:
+    FLX_BENCH_BACKEND=gloo lets both ranks use device 0. Rank 0 builds the index and hands its HBM image to rank 1
+    (distributed.replicate_index), the reads shard by rank (parallelization.cpp:77-87: reads are the independent units), every step's
+    counts are exchanged and its records gathered to rank 0 inside the timed region. Checked: the line says two GPUs and carries
+    gather_s; its record count is the sum of both shards; and the table rank 0 gathered for step 0 is, row for row, what one context
+    in this process computes for rank 0's and rank 1's reads of that step (global read indices, rank order)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    dump = str(tmp_path / "gathered.npy")
+    B, steps, warm = 1024, 2, 1
+    env = dict(os.environ, FLX_BENCH_BACKEND="gloo", FLX_LANES="4")
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--config", "ecoli", "--steps", str(steps), "--warmup", str(warm), "--reads-per-step", str(B),
+           "--no-cpu-baseline", "--no-isolated-pass", "--no-host-inputs-leg", "--dump-gathered", dump]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
+    line = json.loads(out.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 2 and line["gather_s"] is not None and line["scaling"] == "weak"
+    assert line["config"]["reads_per_step_per_gpu"] == B and line["value"] > 0
+    table = np.load(dump)
+    # the same reads here: bench.py gives rank r, batch b the simulator seed DEFAULT_SEED + 1 + 1000 r + b; step 0 is batch `warm`
+    cfg = dict(genome=4_600_000, read_length=5000, error_rate=0.08)
+    pool, genome = S.make_genome_fast(cfg["genome"], 1, seed=S.DEFAULT_SEED)
+    ctx = F.context(F.fmindex(genome, device=0))
+    al = F.aligner(ctx, F.params(error_probability=cfg["error_rate"]))
+    parts, total = [], 0
+    for rank in range(2):
+        reads = S.make_reads_fast(pool, [cfg["genome"]], B, cfg["read_length"], cfg["error_rate"], seed=S.DEFAULT_SEED + 1 + rank * 1000 + warm)[0]
+        res = al.align_reads(reads)
+        rows = res.rows.copy()
+        rows[:, 0] += rank * B                    # (step 0: global read index = rank * B + local)
+        parts.append(rows)
+    expected = np.concatenate(parts)
+    # (column 5 is the CIGAR's offset within its owner's part: where a chunk's CIGARs land depends on the lanes' timing)
+    keep = [0, 1, 2, 3, 4, 6]
+    assert table.shape == expected.shape and np.array_equal(table[:, keep], expected[:, keep])
+    # records of the whole run = both shards of both steps; step 0's share is known exactly
+    assert line["records"] >= len(expected) and line["records"] > 2 * B * steps * 0.9
     ctx.close()
