@@ -714,29 +714,35 @@ __global__ void __launch_bounds__(256) hit_scatter_kernel(const DevHit* __restri
 }
 
 struct SelGroup { u32 lb, len, errors; };
-struct SelAnchor { u64 pos; u32 ref; u32 errors; };
+struct SelAnchor { u32 pos; u32 ref; u32 errors; };           // pos within its reference sequence (the text has fewer than 2^32 symbols)
+struct SelKey { u32 lo, hi; };
+__device__ __forceinline__ bool sel_key_less(u64 k, SelKey const& o) { return k < ((u64)o.lo | ((u64)o.hi << 32)); }
 
-// the selection of one seed whose groups (cnt <= CAP) hold `total` <= CAP rows; returns false when the seed has to go to the host
+// the selection of one seed whose groups (cnt <= CAP) hold `total` <= CAP rows; returns false when the seed has to go to the host.
+// Working storage from the caller (a thread's indexed private arrays would live in scratch memory: round 3 had 720 B per lane there):
+// g: CAP groups; w: CAP SelKeys while the groups are put into emission order, CAP SelAnchors afterwards (the two do not overlap in
+// time); stacks: 48 ints when CAP > 16 (std::sort's partitions)
 template <u32 CAP, bool WRITE>
 __device__ __forceinline__ bool select_seed(const DevHit* __restrict__ groups, u32 cnt, u32 total, const u32* __restrict__ sa, u32 n_text,
                                             const u64* __restrict__ seq_start, u32 n_ref, u32 erase, u32 sid, SelStat& st, u32& produced,
-                                            DevOutAnchor* __restrict__ out, u32 at, u32 out_cap) {
+                                            DevOutAnchor* __restrict__ out, u32 at, u32 out_cap, SelGroup* g, void* w, int* stacks) {
     // the groups in search_n's emission order (the keys of fm_search_kernel; all 0 from the ordered kernel, whose hits are in it already:
     // the insertion sort is stable), then ordered by (count, errors) (search.cpp:200-212)
-    SelGroup g[CAP];
     {
-        u64 key[CAP];
+        SelKey* const key = static_cast<SelKey*>(w);
         for (u32 i = 0; i < cnt; ++i) {
             DevHit const h = groups[i];
             u32 j = i;
-            while (j > 0 && h.key < key[j - 1]) { key[j] = key[j - 1]; g[j] = g[j - 1]; --j; }
-            key[j] = h.key;
+            while (j > 0 && sel_key_less(h.key, key[j - 1])) { key[j] = key[j - 1]; g[j] = g[j - 1]; --j; }
+            key[j] = SelKey{(u32)h.key, (u32)(h.key >> 32)};
             g[j] = SelGroup{h.lb, h.len, h.errors};
         }
     }
-    if (!std_sort_emulated(g, (int)cnt, [](SelGroup const& x, SelGroup const& y) { return x.len != y.len ? x.len < y.len : x.errors < y.errors; })) return false;
+    auto less_g = [](SelGroup const& x, SelGroup const& y) { return x.len != y.len ? x.len < y.len : x.errors < y.errors; };
+    if (CAP <= 16u) insertion_sort_emulated(g, (int)cnt, less_g);
+    else if (!std_sort_emulated(g, (int)cnt, less_g, stacks)) return false;
     // rows round robin over the groups (search.cpp:239-272), located
-    SelAnchor an[CAP];
+    SelAnchor* const an = static_cast<SelAnchor*>(w);
     u32 kept = 0;
     bool bad = false;
     // (`total` = the rows to keep: all of them, or the soft cap when the seed has more: the cycle then stops in the middle of a round)
@@ -752,7 +758,7 @@ __device__ __forceinline__ bool select_seed(const DevHit* __restrict__ groups, u
                 while (hi - lo > 1) { u32 const mid = (lo + hi) >> 1; if (seq_start[mid] <= p) lo = mid; else hi = mid; }
                 r = lo;
             }
-            an[kept++] = SelAnchor{p - seq_start[r], r, g[gi].errors};
+            an[kept++] = SelAnchor{(u32)(p - seq_start[r]), r, g[gi].errors};
         }
     if (bad) return false;                                  // the host reports the error
     // buckets per reference in id order, each keeping the order of selection (search.cpp:78-100, 304-318)
@@ -768,7 +774,9 @@ __device__ __forceinline__ bool select_seed(const DevHit* __restrict__ groups, u
         while (b0 < kept) {                                 // one bucket = one reference (search.cpp:352-389)
             u32 b1 = b0;
             while (b1 < kept && an[b1].ref == an[b0].ref) ++b1;
-            if (!std_sort_emulated(an + b0, (int)(b1 - b0), [](SelAnchor const& x, SelAnchor const& y) { return x.pos < y.pos; })) return false;
+            auto less_p = [](SelAnchor const& x, SelAnchor const& y) { return x.pos < y.pos; };
+            if (CAP <= 16u) insertion_sort_emulated(an + b0, (int)(b1 - b0), less_p);
+            else if (!std_sort_emulated(an + b0, (int)(b1 - b0), less_p, stacks)) return false;
             // an erased anchor compares with "infinitely many" errors
             auto better = [&](u32 a, u32 b) {
                 u64 const ea = (gone >> a) & 1 ? ~0ull : (u64)an[a].errors, eb = (gone >> b) & 1 ? ~0ull : (u64)an[b].errors;
@@ -787,7 +795,7 @@ __device__ __forceinline__ bool select_seed(const DevHit* __restrict__ groups, u
     st.raw = (u8)kept;
     for (u32 i = 0; i < kept; ++i)
         if (!((gone >> i) & 1)) {
-            if (WRITE && at + produced < out_cap) out[at + produced] = DevOutAnchor{sid, 0u, an[i].ref, an[i].errors, an[i].pos};
+            if (WRITE && at + produced < out_cap) out[at + produced] = DevOutAnchor{sid, 0u, an[i].ref, an[i].errors, (u64)an[i].pos};
             ++produced;
         }
     st.useful = (u8)produced;
@@ -835,7 +843,9 @@ __global__ void __launch_bounds__(256) seed_rows_kernel(const DevHit* __restrict
     }
 }
 
-// the seeds of one list: their anchors to their slots of the sparse list (row_offset), n_out says how many
+// the seeds of one list: their anchors to their slots of the sparse list (row_offset), n_out says how many. A thread's arrays are in LDS
+// for the light seeds (CAP groups + CAP keys / anchors, 12 B each, a word of padding per thread against bank conflicts); a seed with one
+// group of one row - most seeds of a read with one locus - takes neither.
 template <u32 CAP>
 __global__ void __launch_bounds__(64, 4) seed_select_kernel(const u32* __restrict__ list, const u32* __restrict__ list_count,
                                                          const DevHit* __restrict__ grouped, const u32* __restrict__ hit_offset,
@@ -843,13 +853,35 @@ __global__ void __launch_bounds__(64, 4) seed_select_kernel(const u32* __restric
                                                          u32 erase, SelStat* __restrict__ stat, u32* __restrict__ n_out,
                                                          const u32* __restrict__ row_offset, const u32* __restrict__ rows,
                                                          DevOutAnchor* __restrict__ sparse, u32 sparse_cap) {
+    constexpr u32 IN_LDS = CAP <= 16u ? 1u : 0u;
+    constexpr u32 STRIDE = 6u * CAP + 1u;                       // words per thread
+    __shared__ u32 s_pool[IN_LDS ? 64u * STRIDE : 1u];
+    SelGroup g_priv[IN_LDS ? 1u : CAP];
+    SelAnchor w_priv[IN_LDS ? 1u : CAP];
+    int stacks_priv[IN_LDS ? 1 : 48];
+    SelGroup* const g = IN_LDS ? reinterpret_cast<SelGroup*>(s_pool + threadIdx.x * STRIDE) : g_priv;
+    void* const w = IN_LDS ? static_cast<void*>(s_pool + threadIdx.x * STRIDE + 3u * CAP) : static_cast<void*>(w_priv);
     u32 const n = *list_count;
     for (u32 i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         u32 const sid = list[i];
         u32 const g0 = hit_offset[sid], cnt = hit_offset[sid + 1] - g0;
         SelStat st{0, 0, 0, 0, stat[sid].excluded_soft};
         u32 produced = 0;
-        if (!select_seed<CAP, true>(grouped + g0, cnt, rows[sid], sa, n_text, seq_start, n_ref, erase, sid, st, produced, sparse, row_offset[sid], sparse_cap)) {
+        bool ok;
+        if (cnt == 1u && rows[sid] == 1u) {
+            // one group, one row: every order and strategy keeps exactly it
+            DevHit const h = grouped[g0];
+            u64 const p = h.lb < n_text ? sa[h.lb] : 0xFFFFFFFFull;
+            ok = p < n_text;
+            if (ok) {
+                u32 r = 0;
+                if (n_ref > 1) { u32 lo = 0, hi = n_ref; while (hi - lo > 1) { u32 const mid = (lo + hi) >> 1; if (seq_start[mid] <= p) lo = mid; else hi = mid; } r = lo; }
+                u32 const at = row_offset[sid];
+                if (at < sparse_cap) sparse[at] = DevOutAnchor{sid, 0u, r, h.errors, p - seq_start[r]};
+                produced = 1; st.raw = 1; st.useful = 1;
+            }
+        } else ok = select_seed<CAP, true>(grouped + g0, cnt, rows[sid], sa, n_text, seq_start, n_ref, erase, sid, st, produced, sparse, row_offset[sid], sparse_cap, g, w, stacks_priv);
+        if (!ok) {
             st = SelStat{0, 0, 1, 0, 0};
             produced = 0;
         }
@@ -877,6 +909,7 @@ __global__ void __launch_bounds__(64, MAXG <= 64 ? 4 : 2) seed_select_wave_kerne
     __shared__ u32 s_row[SEL_MAX], s_err[SEL_MAX];
     __shared__ SelAnchor s_an[SEL_MAX];
     __shared__ u32 s_flag[4];                 // [0] a sort gave up (host), [1..2] erased anchors (bits)
+    __shared__ int s_stacks[48];              // std::sort's partitions still to do (one lane sorts)
     u32 const lane = lane_id();
     u64 const below = (1ull << lane) - 1ull;
     u32 const n = *list_count;
@@ -905,7 +938,7 @@ __global__ void __launch_bounds__(64, MAXG <= 64 ? 4 : 2) seed_select_wave_kerne
                 s_a[r] = me;
             }
         } else {
-            if (lane == 0u && !std_sort_emulated(s_b, (int)cnt, less_g)) s_flag[0] = 1u;
+            if (lane == 0u && !std_sort_emulated(s_b, (int)cnt, less_g, s_stacks)) s_flag[0] = 1u;
             __syncthreads();
             for (u32 i = lane; i < cnt; i += 64u) s_a[i] = s_b[i];
         }
@@ -947,7 +980,7 @@ __global__ void __launch_bounds__(64, MAXG <= 64 ? 4 : 2) seed_select_wave_kerne
         if (__any(bad)) s_flag[0] = 1u;
         u32 r3 = 0;
         for (u32 j = 0; j < kept; ++j) { u32 const rj = (u32)__shfl((int)ref, (int)j); r3 += (rj < ref || (rj == ref && j < lane)) ? 1u : 0u; }
-        if (mine && !bad) s_an[r3] = SelAnchor{p - seq_start[ref], ref, err};
+        if (mine && !bad) s_an[r3] = SelAnchor{(u32)(p - seq_start[ref]), ref, err};
         __syncthreads();
         // ---- erase_useless_anchors (search.cpp:352-389) bucket by bucket: std::sort by position, then the sweep
         if (erase && lane == 0u && s_flag[0] == 0u) {
@@ -956,7 +989,7 @@ __global__ void __launch_bounds__(64, MAXG <= 64 ? 4 : 2) seed_select_wave_kerne
             while (b0 < kept) {
                 u32 b1 = b0;
                 while (b1 < kept && s_an[b1].ref == s_an[b0].ref) ++b1;
-                if (!std_sort_emulated(s_an + b0, (int)(b1 - b0), [](SelAnchor const& x, SelAnchor const& y) { return x.pos < y.pos; })) { s_flag[0] = 1u; break; }
+                if (!std_sort_emulated(s_an + b0, (int)(b1 - b0), [](SelAnchor const& x, SelAnchor const& y) { return x.pos < y.pos; }, s_stacks)) { s_flag[0] = 1u; break; }
                 auto better = [&](u32 a, u32 b) {          // an erased anchor compares with "infinitely many" errors
                     u64 const ea = (gone >> a) & 1 ? ~0ull : (u64)s_an[a].errors, eb = (gone >> b) & 1 ? ~0ull : (u64)s_an[b].errors;
                     u64 const d = s_an[a].pos < s_an[b].pos ? s_an[b].pos - s_an[a].pos : s_an[a].pos - s_an[b].pos;
@@ -982,7 +1015,7 @@ __global__ void __launch_bounds__(64, MAXG <= 64 ? 4 : 2) seed_select_wave_kerne
         if (keep) {
             u32 const at = row_offset[sid] + (u32)__popcll(km & below);
             SelAnchor const a = s_an[lane];
-            if (at < sparse_cap) sparse[at] = DevOutAnchor{sid, 0u, a.ref, a.errors, a.pos};
+            if (at < sparse_cap) sparse[at] = DevOutAnchor{sid, 0u, a.ref, a.errors, (u64)a.pos};
         }
         if (lane == 0u) {
             SelStat st{(u8)produced, (u8)kept, 0, 0, stat[sid].excluded_soft};

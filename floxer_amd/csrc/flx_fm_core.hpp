@@ -574,9 +574,17 @@ FLX_HD inline void tx_take_item(FmConst const& C, TxLane& L, DevHit const& item,
     L.busy = true;
 }
 
-template <class FR>
-FLX_HD inline void tx_step(FmConst const& C, TxLane& L, FR&& fr) {
-    const u8* __restrict__ text = C.idx.text;
+// How a text-mode lane reads symbols. The plain form goes to memory for every symbol (text and sequence pool, one byte each); the kernel's
+// form reads 4-bit copies of the seed and of the text around the subtree's string from LDS (fm_search_text_kernel).
+struct TxPlainAccess {
+    const u8* text; const u8* q;
+    FLX_HD u32 text_at(i64 pos) const { return text[pos]; }
+    FLX_HD u32 q_at(u32 qp) const { return q[qp]; }
+};
+
+// AC: text_at(absolute text position), q_at(seed position)
+template <class FR, class AC>
+FLX_HD inline void tx_step(FmConst const& C, TxLane& L, FR&& fr, AC const& ac) {
     ++L.n_nodes;
     if (L.need_child) {
         if (L.depth == 0u) { L.busy = false; return; }                       // subtree exhausted
@@ -627,21 +635,20 @@ FLX_HD inline void tx_step(FmConst const& C, TxLane& L, FR&& fr) {
     bool const match_allowed = lower <= L.ne && L.ne <= upper;
     if (!mismatch_allowed && !match_allowed) { L.need_child = true; return; }
     u32 const qp = sch & SCH_POS_MASK;
-    const u8* __restrict__ q = C.seq + L.qoff;
     if (!mismatch_allowed) {
         // a run of forced positions: seed and text symbol by symbol up to the end of the run (entries of one direction and one
         // upper bound = ne; their lower bounds cannot exceed it)
         u32 const run = sch_run_end(e64) - L.nx;
         u32 i = 0;
-        if (right) { while (i < run && q[qp + i] == text[(i64)L.pR + 1 + (i64)i] && q[qp + i] - 1u < 5u) ++i; }
-        else { while (i < run && q[qp - i] == text[(i64)L.pL - 1 - (i64)i] && q[qp - i] - 1u < 5u) ++i; }
+        if (right) { for (; i < run; ++i) { u32 const c = ac.q_at(qp + i); if (c != ac.text_at((i64)L.pR + 1 + (i64)i) || c - 1u >= 5u) break; } }
+        else { for (; i < run; ++i) { u32 const c = ac.q_at(qp - i); if (c != ac.text_at((i64)L.pL - 1 - (i64)i) || c - 1u >= 5u) break; } }
         if (i < run) { L.need_child = true; return; }
         if (right) { L.pR += run; L.nri = FM_INFO_M; } else { L.pL -= run; L.nli = FM_INFO_M; }
         L.nx += run;
         return;
     }
-    u32 const next_sym = q[qp];
-    u32 const tc = right ? text[(i64)L.pR + 1] : text[(i64)L.pL - 1];
+    u32 const next_sym = ac.q_at(qp);
+    u32 const tc = right ? ac.text_at((i64)L.pR + 1) : ac.text_at((i64)L.pL - 1);
     u32 const tinfo = right ? L.nri : L.nli;
     bool const deletion = tinfo == FM_INFO_M || tinfo == FM_INFO_D, insertion = tinfo == FM_INFO_M || tinfo == FM_INFO_I;
     u32 mask = 0;
@@ -660,6 +667,11 @@ FLX_HD inline void tx_step(FmConst const& C, TxLane& L, FR&& fr) {
     fr(lv, 4) = (u32)L.nkey; fr(lv, 5) = (u32)(L.nkey >> 32);
     ++L.depth;
     L.need_child = true;
+}
+
+template <class FR>
+FLX_HD inline void tx_step(FmConst const& C, TxLane& L, FR&& fr) {
+    tx_step(C, L, fr, TxPlainAccess{C.idx.text, C.seq + L.qoff});
 }
 
 }  // namespace flx

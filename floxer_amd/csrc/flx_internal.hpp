@@ -237,10 +237,13 @@ struct DeviceApi {
     // flx_search.hip: the walk with its stack in LDS plus the presence filter (d_qpack: 2-bit form of d_seq, null: no filter) and the
     // text walk of one-row subtrees (d_items: room for item_cap queued subtrees, null: none are queued). d_counters: 32 zeroed words.
     // d_seed_rows (n_seeds zeroed words, or null): rows reported per seed over all lanes; with it the lanes of a wave share the subtrees
-    // of heavy seeds once the seed queue is dry (see fm_search_filter_kernel)
+    // of heavy seeds once the seed queue is dry, and busy waves hand subtrees to a follow-up launch through d_frame_queues
+    // (see fm_search_filter_kernel)
     static int search_filtered(void* stream, const DevIndex& idx, const u8* d_seq, const u32* d_qpack, const u64* d_scheme, const DevSeed* d_seeds,
                                u32 n_seeds, u32 max_hits_per_seed, u32 frame_levels, DevHit* d_hits, u32 hit_cap, DevHit* d_items, u32 item_cap,
-                               u32* d_counters, u32* d_seed_cnt, u32* d_seed_rows, u32 concurrent_launches);
+                               u32* d_counters, u32* d_seed_cnt, u32* d_seed_rows, void* d_frame_queues, u32 frame_queue_cap, u32 concurrent_launches);
+    // the two queues through which the launches of the filter walk hand subtrees on (frame_queue_cap entries each; may be null)
+    static size_t frame_queue_bytes(u32 frame_queue_cap);
     // the tables a context derives from text and suffix array: bytes of isa + filter for a text of n symbols; derive_index fills
     // d_isa (n words) and d_filter (null: no filter) and sets idx.isa / filter / filter_k / filter_tmin
     static size_t derived_bytes(u64 n, u32* filter_k_out);

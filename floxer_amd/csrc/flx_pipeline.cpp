@@ -95,13 +95,13 @@ hvec<DeviceBuffer*> lane_workspaces(Lane& l) {
     return {&l.seq, &l.seq_rev, &l.peq, &l.peq_rev, &l.scheme, &l.seeds, &l.stack, &l.hits, &l.counters, &l.rows, &l.rows_out, &l.jobs,
             &l.job_out, &l.trace, &l.tjobs, &l.tjob_out, &l.cigar, &l.user_text, &l.user_text_rev, &l.lastrow, &l.row_windows, &l.row_out,
             &l.seed_cnt, &l.hit_off, &l.grouped, &l.sel_stat, &l.sel_n, &l.sel_off, &l.sel_out, &l.sel_tmp, &l.sel_rows, &l.sel_row_off, &l.sel_sparse, &l.sel_lists, &l.vr, &l.lane_rows,
-            &l.qpack, &l.items, &l.seed_gen};
+            &l.qpack, &l.items, &l.seed_gen, &l.frame_q};
 }
 // FLX_ALLOC_DEBUG: the address ranges of a lane's workspaces (a GPU memory fault reports an address)
 static void dump_lane_buffers(Lane& l, const char* when) {
     static const char* const names[] = {"seq", "seq_rev", "peq", "peq_rev", "scheme", "seeds", "stack", "hits", "counters", "rows", "rows_out", "jobs", "job_out",
         "trace", "tjobs", "tjob_out", "cigar", "user_text", "user_text_rev", "lastrow", "row_windows", "row_out", "seed_cnt", "hit_off", "grouped", "sel_stat",
-        "sel_n", "sel_off", "sel_out", "sel_tmp", "sel_rows", "sel_row_off", "sel_sparse", "sel_lists", "vr", "lane_rows", "qpack", "items", "seed_gen"};
+        "sel_n", "sel_off", "sel_out", "sel_tmp", "sel_rows", "sel_row_off", "sel_sparse", "sel_lists", "vr", "lane_rows", "qpack", "items", "seed_gen", "frame_q"};
     auto const ws = lane_workspaces(l);
     for (size_t i = 0; i < ws.size(); ++i)
         if (ws[i]->ptr) fprintf(stderr, "[flx alloc] lane %d %s %s %p .. %p\n", l.id, when, names[i], ws[i]->ptr, (void*)((char*)ws[i]->ptr + ws[i]->cap));
@@ -439,6 +439,9 @@ int search_seeds_device(Lane* ctx, const u8* d_seq_pool_or_null, const u8* h_seq
         if ((rc = ctx->sel_lists.ensure((3 * n_seeds + 3) * 4))) return rc;
         sel_stat.resize(n_seeds);
     }
+    // subtrees handed from one launch of the filter walk to the next (96 B each): room for one per two seeds, at least 256 k
+    u32 const frame_q_cap = device_select ? (u32)std::min<u64>(std::max<u64>(n_seeds / 2, 262144), 4u << 20) : 0u;
+    if (frame_q_cap && (rc = ctx->frame_q.ensure(DeviceApi::frame_queue_bytes(frame_q_cap)))) return rc;
     u32 counters[32];
     u64 sel_cap = (u64)(ctx->sel_rows_per_seed * 1.25 * (double)n_seeds);      // entries of the selected-anchor list (at least hit_cap, below)
     struct K1Token { flx_ctx* c; explicit K1Token(flx_ctx* c_) : c(c_) { c->k1_acquire(); } ~K1Token() { c->k1_release(); } };
@@ -468,7 +471,7 @@ int search_seeds_device(Lane* ctx, const u8* d_seq_pool_or_null, const u8* h_seq
                                                   max_hits, max_errors, ctx->hits.as<DevHit>(), (u32)std::min<u64>(hit_cap, 0xFFFFFFFFu),
                                                   item_cap ? ctx->items.as<DevHit>() : nullptr, (u32)std::min<u64>(item_cap, 0xFFFFFFFFu),
                                                   ctx->counters.as<u32>(), device_select ? ctx->seed_cnt.as<u32>() : nullptr,
-                                                  device_select ? ctx->sel_rows.as<u32>() : nullptr, concurrent);
+                                                  device_select ? ctx->sel_rows.as<u32>() : nullptr, device_select ? ctx->frame_q.ptr : nullptr, frame_q_cap, concurrent);
             return DeviceApi::search(ctx->stream, ctx->ctx->didx, d_seq, ctx->scheme.as<u64>(), ctx->seeds.as<DevSeed>(), (u32)n_seeds,
                                      max_hits, ctx->stack.as<DevFrame>(), ctx->hits.as<DevHit>(), (u32)std::min<u64>(hit_cap, 0xFFFFFFFFu),
                                      ctx->counters.as<u32>(), device_select ? ctx->seed_cnt.as<u32>() : nullptr);
@@ -493,7 +496,7 @@ int search_seeds_device(Lane* ctx, const u8* d_seq_pool_or_null, const u8* h_seq
             if ((rc = d2h(ctx, sel_stat.data(), ctx->sel_stat.ptr, n_seeds * sizeof(DevSelStat)))) return rc;
         }
         if ((rc = ctx->sync())) return rc;
-        if (getenv("FLX_SEARCH_DEBUG")) fprintf(stderr, "[fm_search] seeds %llu ext %u (of single-row intervals %u) wave-iterations %u (max per wave %u) busy pair-iterations %u, after the queue ran dry %u (max %u), subtrees handed over %u\n", (unsigned long long)n_seeds, counters[2], counters[3], counters[4], counters[5], counters[6], counters[8], counters[9], counters[14]);
+        if (getenv("FLX_SEARCH_DEBUG")) fprintf(stderr, "[fm_search] seeds %llu ext %u (of single-row intervals %u) wave-iterations %u (max per wave %u) busy pair-iterations %u, after the queue ran dry %u (max %u), subtrees handed over %u, to the next launch %u (queues %u, %u)\n", (unsigned long long)n_seeds, counters[2], counters[3], counters[4], counters[5], counters[6], counters[8], counters[9], counters[14], counters[15], counters[20], counters[22]);
         if (getenv("FLX_SEARCH_DEBUG") && filtered) fprintf(stderr, "[fm_search filtered] subtrees queued %u (slots %u of %llu), filter lookups %u, children dropped %u, searches ended by the prefix lookup %u; text walk: lane-steps %u, wave-iterations %u\n", counters[3], counters[16], (unsigned long long)item_cap, counters[10], counters[11], counters[12], counters[18], counters[19]);
         if (counters[1]) { set_error("fm_search: DFS stack reservation exceeded"); return FLX_ERR_INTERNAL; }
         bool const items_fit = !item_cap || counters[16] <= item_cap;
@@ -2232,7 +2235,8 @@ int align_slice(Lane* lane, const flx_params* P, const flx_reads* RD, u64 first_
             }
             g_build_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tb0).count();
             n_inner_requested += reqs.size();
-            if (st_local) for (auto const& rq : reqs) st_local->at(Stats::SPAN_INNER).add(rq.n);      // verification.cpp:241 (one per anchor and node)
+            // (statistics: the inner tests are counted per anchor in the interval pass below - under -I the reference never starts on an
+            // anchor whose root window is already verified, verification.cpp:45)
             if ((rc = run_exists_jobs(lane, d_text, d_peq, reqs, outs))) return rc;
             for (size_t i = 0; i < outs.size(); ++i) {
                 AnchorState& a = A[sel[i].anchor];
@@ -2257,6 +2261,17 @@ int align_slice(Lane* lane, const flx_params* P, const flx_reads* RD, u64 first_
     hvec<AlignRequest> root_reqs;
     hvec<u32> root_anchor;
     hvec<Span> root_spans;
+    // statistics: the inner nodes an anchor tested (verification.cpp:241) - its leaf's parent, upwards, to the node it failed at or to
+    // the node below the root
+    auto add_inner_spans = [&](AnchorState const& a) {
+        auto const& tree = reads[a.read].tree_ref();
+        flx_pex_node const& leaf = tree.leaves[a.leaf];
+        if (P->direct_full_verification || leaf.parent_id == FLX_NULL_ID) return;
+        for (u32 nd = leaf.parent_id; tree.inner[nd].parent_id != FLX_NULL_ID; nd = tree.inner[nd].parent_id) {
+            st_local->at(Stats::SPAN_INNER).add(window_request(a, tree.inner[nd], 0.0, nullptr).n);
+            if (!a.alive && nd == a.node) break;
+        }
+    };
     for (size_t r = 0; r < reads.size(); ++r) {
         hvec<VerifiedIntervals> cache[2];
         if (P->use_interval_optimization) { cache[0].resize(H.seq_len.size()); cache[1].resize(H.seq_len.size()); }
@@ -2271,9 +2286,13 @@ int align_slice(Lane* lane, const flx_params* P, const flx_reads* RD, u64 first_
                     if (st_local) st_local->at(Stats::SPAN_ROOT_AVOIDED).add(sp.length);                // verification.cpp:130
                     continue;
                 }
+                if (st_local) add_inner_spans(a);
                 if (!(a.alive && a.at_root)) continue;
                 ivs.insert({sp.offset, sp.offset + sp.length});
-            } else if (!(a.alive && a.at_root)) continue;
+            } else {
+                if (st_local) add_inner_spans(a);
+                if (!(a.alive && a.at_root)) continue;
+            }
             a.wants_root = true;
             if (st_local) st_local->at(Stats::SPAN_ROOT).add(sp.length);                               // verification.cpp:239
             root_reqs.push_back(req);

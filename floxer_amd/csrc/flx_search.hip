@@ -15,6 +15,14 @@
 
 namespace flx {
 
+struct FrameItem { u32 w[24]; };               // [0..17] the frame (word 14: the children that go), [18] seed position, [19] exo, [20] ws, [21..22] qoff
+struct FrameQueues {
+    const FrameItem* in; FrameItem* out;       // in: FROM_FRAMES launches; out: null in the last round
+    u32 cap;                                   // entries of either queue
+    u32 in_count, in_head, out_count, done;    // indices into counters
+    u32 room_div;                              // waves hand work to the next launch once 1 / room_div of this launch's waves have finished
+};
+
 namespace {
 
 __device__ __forceinline__ u32 s_lane_id() { return threadIdx.x & 63u; }
@@ -55,6 +63,8 @@ static u32 filter_k_for(u64 n) {        // FLX_FILTER_K overrides the default (0
     }
     return filter_k_default(n);
 }
+
+size_t DeviceApi::frame_queue_bytes(u32 cap) { return (size_t)cap * 2 * sizeof(FrameItem); }
 
 size_t DeviceApi::derived_bytes(u64 n, u32* k_out) {
     u32 const k = filter_k_for(n);
@@ -133,7 +143,8 @@ int DeviceApi::pack_pool(void* stream, const u8* d_seq, u64 len, u32* d_qpack) {
 
 // ================================================================================================ the search kernels
 // counters (32 words): [0] hit slots reserved, [1] frame overflow flag, [2] cursor extensions (rank pairs), [3] subtrees queued (records
-//   written, without the unused ends of the slot ranges), [13] hits written (both kernels), [14] subtrees handed from lane to lane,
+//   written, without the unused ends of the slot ranges), [13] hits written (both kernels), [14] subtrees handed from lane to lane, [15] subtrees handed to the next launch,
+//   [20], [22] entries of the two queues between the launches of the filter walk, [21], [23] their heads, [24..26] waves of those launches that have finished,
 //   [4] wave-iterations, [5] their maximum over the waves, [6] busy lane-iterations, [7] seed queue head, [8] wave-iterations after the
 //   seed queue ran dry, [9] their maximum, [10] filter lookups, [11] children dropped by the filter, [12] searches ended by the prefix
 //   lookup, [16] item slots reserved, [17] item queue head, [18] text-mode lane-steps, [19] text-mode wave-iterations
@@ -198,21 +209,26 @@ __device__ __forceinline__ u32 wave_slots_take(WaveSlots& S, DevHit* __restrict_
 }
 }  // namespace
 
-// STATS: the diagnostic counters [11], [12] are kept (two more registers per lane). 111 VGPRs, no scratch (round 3: 128 + 72 B per lane
+// STATS: the diagnostic counters [11], [12] are kept (two more registers per lane). 112 VGPRs, no scratch (round 3: 128 + 72 B per lane
 // of spills inside the DFS loop, which went through HBM).
 //
-// Work sharing inside a wave (seed_rows != null). On a text with repeat families a launch used to be the tail of its heaviest seeds: a
-// seed inside a diverged family walks tens of thousands of steps while the other lanes of its wave have run out of seeds (round 3: 97 %
-// of the wave-iterations after the queue ran dry, a tenth of the lanes busy). Once the wave's part of the seed queue is dry, an idle
-// lane takes the upper half of the not yet visited error children of a busy lane's BOTTOM frame (the shallowest one: the largest
-// subtrees): it copies the frame (18 words, LDS to LDS) with that half as its mask and carries on as if it had got there itself, under
-// the donor's seed, search and keys; the donor keeps the lower half and the match child. Hits carry keys that restore the reference's
-// emission order whoever emits them, so nothing downstream changes. What the walk of one seed may stop on - more rows than the hard
-// cap - is counted per seed in global memory (seed_rows), so that the lanes sharing a seed stop together.
-template <bool STATS>
+// Work sharing (seed_rows != null). On a text with repeat families a launch used to be the tail of its heaviest seeds: a seed inside a
+// diverged family walks tens of thousands of steps while the other lanes of its wave have run out of seeds (round 3: 97 % of the
+// wave-iterations after the queue ran dry, a tenth of the lanes busy).
+//  (1) inside a wave: once the wave's part of the work queue is dry, an idle lane takes the upper half of the not yet visited error
+//      children of a busy lane's BOTTOM frame (the shallowest one: the largest subtrees): it copies the frame (18 words, LDS to LDS) with
+//      that half as its mask and carries on as if it had got there itself, under the donor's seed, search and keys; the donor keeps the
+//      lower half and the match child.
+//  (2) between waves: when a quarter of the launch's waves have finished (the chip has room) the busy lanes of the others put such
+//      halves into a queue in HBM (FrameItem: the frame + the seed's identity, 96 B); the next launch of this kernel (FROM_FRAMES) takes
+//      its work from that queue instead of the seed list, and may fill a queue for a third launch. No wave ever waits for another one.
+// Hits carry keys that restore the reference's emission order whoever emits them, so nothing downstream changes. What the walk of one
+// seed may stop on - more rows than the hard cap - is counted per seed in global memory (seed_rows), so that the lanes and waves that
+// share a seed stop together.
+template <bool STATS, bool FROM_FRAMES>
 __global__ void __launch_bounds__(64, 4) fm_search_filter_kernel(FmConst C, u32 n_seeds, DevHit* __restrict__ hits,
                                                               u32 hit_cap, DevHit* __restrict__ items, u32 item_cap, u32* __restrict__ counters,
-                                                              u32* __restrict__ seed_cnt, u32* __restrict__ seed_rows, u32 refill, u32 prio, u32 steal_min) {
+                                                              u32* __restrict__ seed_cnt, u32* __restrict__ seed_rows, FrameQueues FQ, u32 refill, u32 prio, u32 steal_min, u32 steal_after) {
     extern __shared__ u32 lds[];                // frames: [level][FM_FRAME_WORDS][64 lanes], then 64 words for the pairing of lanes
     if (prio == 3u) __builtin_amdgcn_s_setprio(3);
     else if (prio == 2u) __builtin_amdgcn_s_setprio(2);
@@ -221,11 +237,14 @@ __global__ void __launch_bounds__(64, 4) fm_search_filter_kernel(FmConst C, u32 
     u64 const lanes_below = (1ull << lane) - 1ull;
     auto fr = [&](u32 level, u32 word) -> u32& { return lds[(level * FM_FRAME_WORDS + word) * 64u + lane]; };
     const DevSeed* __restrict__ seeds = C.seeds;
+    u32 const n_work = FROM_FRAMES ? min(counters[FQ.in_count], FQ.cap) : n_seeds;      // (the launch that filled the queue has finished: same stream)
+    u32* const work_head = &counters[FROM_FRAMES ? FQ.in_head : 7u];
     WaveQueue Q;
     WaveSlots HS, IS;
     FmLane L;
     bool exhausted = false;
-    u32 n_iter = 0, n_busy_iter = 0, n_tail_iter = 0, n_hits = 0, n_items = 0, n_steals = 0;      // (wave-uniform but n_busy_iter)
+    u32 n_iter = 0, n_busy_iter = 0, n_tail_iter = 0, n_hits = 0, n_items = 0, n_steals = 0, n_given = 0;      // (wave-uniform but n_busy_iter)
+    bool room = false;                          // enough waves of this launch have finished for handing work to the next one to pay
     u32* const pair = lds + C.levels * FM_FRAME_WORDS * 64u;
 
     while (true) {
@@ -258,7 +277,7 @@ __global__ void __launch_bounds__(64, 4) fm_search_filter_kernel(FmConst C, u32 
         }
         if (out == 3u) { atomicOr(&counters[1], 1u); L.wn = 0; }        // frames ran out (the caller repeats the launch another way)
         else L.clear_out();
-        // ---- seeds for the idle lanes, and the start of the next search for the lanes between two searches - in batches. Taking a seed
+        // ---- work for the idle lanes, and the start of the next search for the lanes between two searches - in batches. Taking a seed
         //      and starting a search are chains of dependent loads (seed record, scheme entries, packed symbols, filter word, k-mer
         //      table: ~7 us) that every lane of the wave waits for; a lane gets there every dozen iterations, so with 64 lanes some lane
         //      is there in every iteration. Lanes at that point therefore wait until `refill` of them are, or no lane is inside a search.
@@ -269,53 +288,99 @@ __global__ void __launch_bounds__(64, 4) fm_search_filter_kernel(FmConst C, u32 
         bool const go = (u32)__popcll(at_boundary) >= refill || !__any(busy && in_search);
         u64 const idle = go ? __ballot(want) : 0ull;
         if (idle) {                                                     // wave-uniform
-            u32 const k = wave_queue_take(Q, &counters[7], n_seeds, want, idle, lane, lanes_below);
+            u32 const k = wave_queue_take(Q, work_head, n_work, want, idle, lane, lanes_below);
             if (want) {
-                if (k != 0xFFFFFFFFu) fm_take_seed(C, L, seeds[k], k);
-                else exhausted = true;
+                if (k == 0xFFFFFFFFu) exhausted = true;
+                else if (!FROM_FRAMES) fm_take_seed(C, L, seeds[k], k);
+                else {
+                    // a subtree another wave handed over: its frame becomes this lane's bottom frame
+                    const uint4* __restrict__ src = reinterpret_cast<const uint4*>(FQ.in[k].w);
+                    uint4 const q0 = src[0], q1 = src[1], q2 = src[2], q3 = src[3], q4 = src[4], q5 = src[5];
+                    fr(0, 0) = q0.x; fr(0, 1) = q0.y; fr(0, 2) = q0.z; fr(0, 3) = q0.w; fr(0, 4) = q1.x; fr(0, 5) = q1.y; fr(0, 6) = q1.z; fr(0, 7) = q1.w;
+                    fr(0, 8) = q2.x; fr(0, 9) = q2.y; fr(0, 10) = q2.z; fr(0, 11) = q2.w; fr(0, 12) = q3.x; fr(0, 13) = q3.y; fr(0, 14) = q3.z; fr(0, 15) = q3.w;
+                    fr(0, 16) = q4.x; fr(0, 17) = q4.y;
+                    L.pos = q4.z; L.exo = q4.w; L.ws = q5.x | (1u << 28); L.qoff = (u64)q5.y | ((u64)q5.z << 32);
+                    L.ct = 0;
+                    L.wn = WN_BUSY | WN_IN_SEARCH | WN_NEED_CHILD | WN_DEPTH1;
+                }
             }
         }
-        bool const tail = Q.done && Q.next == Q.end;                   // wave-uniform: this wave gets no more seeds
+        bool const tail = Q.done && Q.next == Q.end;                   // wave-uniform: this wave gets no more work from the queue
         if (tail && seed_rows) {
             if (!L.busy()) exhausted = true;                            // (a lane that waited for a batch of seeds: there is none)
+            if (FQ.out && !room && n_tail_iter >= steal_after && (n_iter & 15u) == 0u) {
+                u32 d = 0;
+                if (lane == 0) d = __hip_atomic_load(&counters[FQ.done], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                room = (u32)__builtin_amdgcn_readfirstlane((int)d) * FQ.room_div >= gridDim.x;
+            }
             bool const idle_lane = !L.busy();
-            u64 const thieves = __ballot(idle_lane);
-            if ((u32)__popcll(thieves) >= steal_min) {
+            // (a short tail - a uniform text: 100 iterations - is over before sharing it pays for its ballots and copies)
+            u64 const thieves = n_tail_iter >= steal_after ? __ballot(idle_lane) : 0ull;
+            bool const to_next = room && (n_iter & 3u) == 0u;           // (wave-uniform)
+            if ((thieves && (u32)__popcll(thieves) >= steal_min) || to_next) {
                 // donors: lanes inside a search whose bottom frame has error children to spare
                 u32 fmask = 0;
                 if (L.busy() && L.in_search() && L.depth() >= 1u) fmask = fr(0, 14);
                 u32 const costly = fmask & ~1u;
                 u32 const n_costly = fm_popc(costly);
-                bool const donor = n_costly >= 2u || (n_costly == 1u && (fmask & 1u));
+                bool const donor = n_costly >= 2u || (n_costly == 1u && (fmask & 1u));      // (something goes and something stays)
                 u64 const donors = __ballot(donor);
-                if (donors) {
+                // What goes: the MATCH child when there is one - the continuation of the path without a further error, i.e. everything the
+                // seed still has to do at its later positions, by far the largest subtree (the error children of one node are at most eleven
+                // chains); the lane that takes it becomes a donor itself one step later, so a heavy seed's spine spreads over the wave in a
+                // few iterations. Without a match child: the upper half of the error children.
+                u32 give = 1u;
+                if (!(fmask & 1u)) {
+                    give = costly;
+                    for (u32 i = n_costly / 2u; i < n_costly; ++i) give &= give - 1u;                // drop the lowest n_costly - n_costly / 2
+                }
+                bool gives = false;
+                if (donors && thieves) {
                     u32 const n_pairs = min((u32)__popcll(thieves), (u32)__popcll(donors));
                     u32 const my_rank = (u32)__popcll((donor ? donors : thieves) & lanes_below);
                     if (donor) pair[my_rank] = lane;
                     __syncthreads();
-                    bool const takes = idle_lane && my_rank < n_pairs, gives = donor && my_rank < n_pairs;
+                    bool const takes = idle_lane && my_rank < n_pairs;
+                    gives = donor && my_rank < n_pairs;
                     u32 const from = takes ? pair[my_rank] : lane;
                     // the donor's seed and search
                     u32 const d_pos = (u32)__shfl((int)L.pos, (int)from), d_exo = (u32)__shfl((int)L.exo, (int)from), d_ws = (u32)__shfl((int)L.ws, (int)from);
                     u32 const d_qlo = (u32)__shfl((int)(u32)L.qoff, (int)from), d_qhi = (u32)__shfl((int)(u32)(L.qoff >> 32), (int)from);
+                    u32 const d_give = (u32)__shfl((int)give, (int)from);
                     u32 w[FM_FRAME_WORDS];
 #pragma unroll
                     for (u32 i = 0; i < FM_FRAME_WORDS; ++i) w[i] = lds[i * 64u + from];          // frame 0 of lane `from`
                     __syncthreads();
-                    // the upper half of the error children goes (all of them but one when there is no match child to stay behind)
-                    u32 const m = w[14], mc = m & ~1u, nc = fm_popc(mc), g = (m & 1u) ? (nc + 1u) / 2u : nc / 2u;
-                    u32 give = mc;
-                    for (u32 i = g; i < nc; ++i) give &= give - 1u;                                 // drop the lowest nc - g
-                    if (gives) fr(0, 14) = m & ~give;
+                    if (gives) fr(0, 14) = fmask & ~give;
                     if (takes) {
 #pragma unroll
                         for (u32 i = 0; i < FM_FRAME_WORDS; ++i) if (i != 14u) fr(0, i) = w[i];
-                        fr(0, 14) = give;
+                        fr(0, 14) = d_give;
                         L.pos = d_pos; L.exo = d_exo; L.ws = d_ws | (1u << 28); L.qoff = (u64)d_qlo | ((u64)d_qhi << 32);
                         L.ct = 0;
                         L.wn = WN_BUSY | WN_IN_SEARCH | WN_NEED_CHILD | WN_DEPTH1;
                     }
                     n_steals += n_pairs;
+                }
+                // what no lane of this wave took goes to the next launch while the chip has room
+                bool const sends = to_next && donor && !gives;
+                u64 const sending = __ballot(sends);
+                if (sending) {
+                    u32 base = 0;
+                    if (lane == 0) base = atomicAdd(&counters[FQ.out_count], (u32)__popcll(sending));
+                    base = (u32)__builtin_amdgcn_readfirstlane((int)base);
+                    u32 const slot = base + (u32)__popcll(sending & lanes_below);
+                    if (sends && slot < FQ.cap) {
+                        uint4* __restrict__ dst = reinterpret_cast<uint4*>(FQ.out[slot].w);
+                        dst[0] = uint4{fr(0, 0), fr(0, 1), fr(0, 2), fr(0, 3)};
+                        dst[1] = uint4{fr(0, 4), fr(0, 5), fr(0, 6), fr(0, 7)};
+                        dst[2] = uint4{fr(0, 8), fr(0, 9), fr(0, 10), fr(0, 11)};
+                        dst[3] = uint4{fr(0, 12), fr(0, 13), give, fr(0, 15)};
+                        dst[4] = uint4{fr(0, 16), fr(0, 17), L.pos, L.exo};
+                        dst[5] = uint4{L.ws, (u32)L.qoff, (u32)(L.qoff >> 32), 0u};
+                        fr(0, 14) = fmask & ~give;
+                    }
+                    n_given += (u32)__popcll(sending);
                 }
             }
         }
@@ -330,9 +395,11 @@ __global__ void __launch_bounds__(64, 4) fm_search_filter_kernel(FmConst C, u32 
     wave_slots_close(IS, items, item_cap, lane);
     u32 const s_ext = s_wave_sum(L.n_ext), s_busy = s_wave_sum(n_busy_iter), s_look = s_wave_sum(L.n_lookup);
     if (lane == 0) {
+        atomicAdd(&counters[FQ.done], 1u);
         atomicAdd(&counters[2], s_ext); atomicAdd(&counters[6], s_busy);
         atomicAdd(&counters[4], n_iter); atomicMax(&counters[5], n_iter); atomicAdd(&counters[8], n_tail_iter); atomicMax(&counters[9], n_tail_iter);
         atomicAdd(&counters[10], s_look); atomicAdd(&counters[13], n_hits); atomicAdd(&counters[3], n_items); atomicAdd(&counters[14], n_steals);
+        atomicAdd(&counters[15], n_given);
     }
     if (STATS) {
         u32 const s_pruned = s_wave_sum(L.n_pruned), s_kills = s_wave_sum(L.n_prefix_kills);
@@ -340,20 +407,50 @@ __global__ void __launch_bounds__(64, 4) fm_search_filter_kernel(FmConst C, u32 
     }
 }
 
+// The text walk reads the seed and the text next to its string symbol by symbol, each read a dependent load that used to miss the L2
+// (round 3: 17.7 HBM requests per queued subtree, 48 GB per 16384 reads). A lane now copies both once, when it takes a subtree: the
+// seed (up to TX_WIN_MAXLEN symbols) and the text from 4 symbols left of the leftmost position the subtree can reach to 4 right of the
+// rightmost (string + remaining seed symbols + one per error either side), four bits per symbol, into LDS; the walk then reads LDS.
+// Longer seeds (the one leaf of a PEX tree that takes the remainder, 20-kb reads at 2 %) keep reading memory.
+constexpr u32 TX_WIN_MAXLEN = 64, TX_WIN_T = 10, TX_WIN_Q = 9;      // seed symbols; 8-symbol words of the text window (64 + 3 + 8 + 3 <= 80) and of the seed (64 + 3 <= 72)
+__device__ __forceinline__ u32 nibbles_of(u32 lo, u32 hi) {          // eight bytes (values 0..15) -> eight nibbles, first byte lowest
+    u32 a = (lo | (lo >> 4)) & 0x00FF00FFu, b = (hi | (hi >> 4)) & 0x00FF00FFu;
+    a = (a | (a >> 8)) & 0xFFFFu; b = (b | (b >> 8)) & 0xFFFFu;
+    return a | (b << 16);
+}
+struct TxWinAccess {
+    const u32* t; const u32* q;                 // this lane's windows in LDS, [word][lane]
+    i64 w0; u32 qshift; bool win;               // text position of the window's first symbol; seed symbol i is window symbol i + qshift
+    const u8* text; const u8* seq;
+    __device__ __forceinline__ u32 text_at(i64 pos) const {
+        if (!win) return text[pos];
+        u32 const i = (u32)(pos - w0);
+        return (t[(i >> 3) * 64u] >> ((i & 7u) * 4u)) & 15u;
+    }
+    __device__ __forceinline__ u32 q_at(u32 qp) const {
+        if (!win) return seq[qp];
+        u32 const i = qp + qshift;
+        return (q[(i >> 3) * 64u] >> ((i & 7u) * 4u)) & 15u;
+    }
+};
+
 __global__ void __launch_bounds__(64) fm_search_text_kernel(FmConst C, const DevSeed* __restrict__ seeds, const DevHit* __restrict__ items, u32 item_cap,
                                                             DevHit* __restrict__ hits, u32 hit_cap, u32* __restrict__ counters, u32* __restrict__ seed_cnt,
-                                                            u32 refill, u32 prio) {
-    extern __shared__ u32 lds[];                // frames: [level][TX_FRAME_WORDS][64 lanes]
+                                                            u32 refill, u32 prio, u32 windows) {
+    extern __shared__ u32 lds[];                // frames: [level][TX_FRAME_WORDS][64 lanes]; then the text windows and the seed windows, [word][lane]
     if (prio == 3u) __builtin_amdgcn_s_setprio(3);
     else if (prio == 2u) __builtin_amdgcn_s_setprio(2);
     else if (prio == 1u) __builtin_amdgcn_s_setprio(1);
     u32 const lane = s_lane_id();
     u64 const lanes_below = (1ull << lane) - 1ull;
     auto fr = [&](u32 level, u32 word) -> u32& { return lds[(level * TX_FRAME_WORDS + word) * 64u + lane]; };
+    u32* const win_t = lds + C.levels * TX_FRAME_WORDS * 64u + lane;
+    u32* const win_q = win_t + TX_WIN_T * 64u;
     u32 const n_slots = min(counters[16], item_cap);      // (the filter kernel has finished: same stream)
     WaveQueue Q;
     WaveSlots HS;
     TxLane L;
+    TxWinAccess ac{win_t, win_q, 0, 0u, false, C.idx.text, C.seq};
     bool exhausted = false;
     u32 n_iter = 0, n_hits = 0;
 
@@ -377,14 +474,32 @@ __global__ void __launch_bounds__(64) fm_search_text_kernel(FmConst C, const Dev
             if (want) {
                 if (k != 0xFFFFFFFFu) {
                     DevHit const item = items[k];
-                    if (item.seed != 0xFFFFFFFFu) tx_take_item(C, L, item, seeds[item.seed]);      // (an unused slot: ask again)
+                    if (item.seed != 0xFFFFFFFFu) {                                                  // (an unused slot: ask again)
+                        tx_take_item(C, L, item, seeds[item.seed]);
+                        ac.seq = C.seq + L.qoff;
+                        ac.win = windows && L.len <= TX_WIN_MAXLEN && L.nx >= 1u;
+                        if (ac.win) {
+                            // the leftmost seed position the string covers (the scheme entry knows it): that many symbols are still to come on
+                            // the left, the rest of the seed on the right, plus a text symbol per error (at most 3) and the one read that fails
+                            u32 const a = sch_lo(L.ex[L.nx]);
+                            ac.w0 = ((i64)L.pL - (i64)a - 4) & ~(i64)3;
+                            const u32* __restrict__ tsrc = reinterpret_cast<const u32*>(C.idx.text + ac.w0);
+#pragma unroll
+                            for (u32 j = 0; j < TX_WIN_T; ++j) win_t[j * 64u] = nibbles_of(tsrc[2u * j], tsrc[2u * j + 1u]);
+                            ac.qshift = (u32)(L.qoff & 3ull);
+                            const u32* __restrict__ qsrc = reinterpret_cast<const u32*>(C.seq + (L.qoff & ~3ull));
+                            u32 const q_words = (L.len + ac.qshift + 7u) >> 3;
+#pragma unroll
+                            for (u32 j = 0; j < TX_WIN_Q; ++j) if (j < q_words) win_q[j * 64u] = nibbles_of(qsrc[2u * j], qsrc[2u * j + 1u]);
+                        }
+                    }
                 } else exhausted = true;
             }
         }
         if (__all(exhausted && !L.busy)) break;
         ++n_iter;
         if (!L.busy) continue;
-        tx_step(C, L, fr);
+        tx_step(C, L, fr, ac);
     }
     wave_slots_close(HS, hits, hit_cap, lane);
     if (__any(L.overflow) && lane == 0) atomicOr(&counters[1], 1u);
@@ -401,7 +516,7 @@ static u32 env_u32(const char* name, u32 dflt) {
 // queued). frame_levels = largest error count of a seed. d_counters: 32 words, zeroed by the caller.
 int DeviceApi::search_filtered(void* stream, const DevIndex& idx, const u8* d_seq, const u32* d_qpack, const u64* d_scheme, const DevSeed* d_seeds,
                                u32 n_seeds, u32 max_hits_per_seed, u32 frame_levels, DevHit* d_hits, u32 hit_cap, DevHit* d_items, u32 item_cap,
-                               u32* d_counters, u32* d_seed_cnt, u32* d_seed_rows, u32 concurrent_launches) {
+                               u32* d_counters, u32* d_seed_cnt, u32* d_seed_rows, void* d_frame_queues, u32 frame_queue_cap, u32 concurrent_launches) {
     if (n_seeds == 0) return 0;
     static u32 const spw = env_u32("FLX_FM_SEEDS_PER_WAVE", 256);
     static u32 const forced_waves = env_u32("FLX_FM_MAX_WAVES", 0);
@@ -427,16 +542,39 @@ int DeviceApi::search_filtered(void* stream, const DevIndex& idx, const u8* d_se
     size_t const lds_bytes = (size_t)C.levels * FM_FRAME_WORDS * 64 * sizeof(u32) + 64 * sizeof(u32) + extra_lds;
     u32 const steal_min = env_u32("FLX_FM_STEAL_MIN", 1);              // idle lanes a wave waits for before it shares work (0: never)
     u32* const seed_rows = steal_min ? d_seed_rows : nullptr;
+    u32 const steal_after = env_u32("FLX_FM_STEAL_AFTER", 64);         // iterations a wave's queue has been dry before its lanes share work
     static u32 const stats = env_u32("FLX_SEARCH_DEBUG", 0);           // the diagnostic counters [11], [12] cost two registers per lane
-    auto const kernel = stats ? fm_search_filter_kernel<true> : fm_search_filter_kernel<false>;
-    hipLaunchKernelGGL(kernel, grid, dim3(64), lds_bytes, s, C, n_seeds, d_hits, hit_cap, d_items, item_cap, d_counters, d_seed_cnt, seed_rows, refill_a, fm_prio, std::max(1u, steal_min));
+    // rounds: the walk over the seeds, then (with work sharing) up to two more launches over the subtrees the launch before handed on
+    u32 const rounds = (seed_rows && d_frame_queues && frame_queue_cap) ? std::max(1u, std::min(3u, env_u32("FLX_FM_ROUNDS", 1))) : 1u;
+    FrameItem* const q0 = (FrameItem*)d_frame_queues;
+    FrameItem* const q1 = q0 ? q0 + frame_queue_cap : nullptr;
+    for (u32 r = 0; r < rounds; ++r) {
+        FrameQueues FQ{};
+        FQ.cap = frame_queue_cap;
+        FQ.in = r == 0 ? nullptr : (r == 1 ? q0 : q1);
+        FQ.out = r + 1 < rounds ? (r == 0 ? q0 : q1) : nullptr;
+        FQ.in_count = r == 1 ? 20u : 22u; FQ.in_head = r == 1 ? 21u : 23u;
+        FQ.out_count = r == 0 ? 20u : (r == 1 ? 22u : 27u);
+        FQ.done = 24u + r;
+        FQ.room_div = std::max(1u, env_u32("FLX_FM_ROOM_DIV", 4));
+        if (r == 0) {
+            auto const kernel = stats ? fm_search_filter_kernel<true, false> : fm_search_filter_kernel<false, false>;
+            hipLaunchKernelGGL(kernel, grid, dim3(64), lds_bytes, s, C, n_seeds, d_hits, hit_cap, d_items, item_cap, d_counters, d_seed_cnt, seed_rows, FQ, refill_a, fm_prio, std::max(1u, steal_min), steal_after);
+        } else {
+            auto const kernel = stats ? fm_search_filter_kernel<true, true> : fm_search_filter_kernel<false, true>;
+            hipLaunchKernelGGL(kernel, grid, dim3(64), lds_bytes, s, C, n_seeds, d_hits, hit_cap, d_items, item_cap, d_counters, d_seed_cnt, seed_rows, FQ, refill_a, fm_prio, std::max(1u, steal_min), steal_after);
+        }
+    }
     if (C.text_min_remain) {
         // (the number of queued subtrees is only known on the device: a fixed grid, waves without work leave at once; the walk is a
         // chain of dependent loads from the L2, so it wants every wave slot: 8 per SIMD)
         static u32 const text_waves = env_u32("FLX_FM_TEXT_WAVES", 8192);
         u32 const tw = std::max(1u, text_waves / std::max(1u, std::min(concurrent_launches, 8u)));
-        hipLaunchKernelGGL(fm_search_text_kernel, dim3(std::min<u32>(std::max<u32>(grid.x * 4u, 64u), tw)), dim3(64), (size_t)C.levels * TX_FRAME_WORDS * 64 * sizeof(u32), s, C,
-                           d_seeds, d_items, item_cap, d_hits, hit_cap, d_counters, d_seed_cnt, refill_t, fm_prio);
+        // (the windows need 4-byte aligned bases: the text is, a sequence pool handed in at an odd address is read byte by byte as before)
+        u32 const windows = env_u32("FLX_FM_NO_WINDOWS", 0) == 0 && ((uintptr_t)d_seq & 3u) == 0 && ((uintptr_t)idx.text & 3u) == 0;
+        hipLaunchKernelGGL(fm_search_text_kernel, dim3(std::min<u32>(std::max<u32>(grid.x * 4u, 64u), tw)), dim3(64),
+                           ((size_t)C.levels * TX_FRAME_WORDS + TX_WIN_T + TX_WIN_Q) * 64 * sizeof(u32), s, C,
+                           d_seeds, d_items, item_cap, d_hits, hit_cap, d_counters, d_seed_cnt, refill_t, fm_prio, windows);
     }
     return (int)hipGetLastError();
 }

@@ -14,8 +14,23 @@ namespace flx {
 // libstdc++'s std::sort (bits/stl_algo.h: introsort with median-of-three pivots down to 16 elements, then insertion sort), step
 // for step: the reference orders hit groups and anchor buckets with it, its comparators tie often, and what it does with equal
 // elements shows in the output. Returns false if the depth limit is reached (the heap-sort fallback is left to the host).
+// (up to 16 elements std::sort is its final insertion sort alone: no pivots, no stack - and stable)
 template <class T, class Less>
-FLX_SORT_HD bool std_sort_emulated(T* a, int n, Less less) {
+FLX_SORT_HD void insertion_sort_emulated(T* a, int n, Less less) {
+    for (int i = 1; i < n; ++i) {
+        T const val = a[i];
+        if (less(val, a[0])) { for (int j = i; j > 0; --j) a[j] = a[j - 1]; a[0] = val; }
+        else {
+            int last = i, next = i - 1;
+            while (less(val, a[next])) { a[last] = a[next]; last = next; --next; }
+            a[last] = val;
+        }
+    }
+}
+
+// stacks: 48 ints of working storage for the partitions still to do (a kernel passes LDS: indexed private arrays live in scratch memory)
+template <class T, class Less>
+FLX_SORT_HD bool std_sort_emulated(T* a, int n, Less less, int* stacks) {
     auto swap_at = [&](int i, int j) { T const t = a[i]; a[i] = a[j]; a[j] = t; };
     auto unguarded_linear_insert = [&](int last) {
         T const val = a[last];
@@ -35,7 +50,8 @@ FLX_SORT_HD bool std_sort_emulated(T* a, int n, Less less) {
         int depth0 = 0;
         for (int m = n; m > 1; m >>= 1) ++depth0;
         depth0 *= 2;
-        int stack_first[16], stack_last[16], stack_depth[16], sp = 0;
+        int* const stack_first = stacks; int* const stack_last = stacks + 16; int* const stack_depth = stacks + 32;
+        int sp = 0;
         int first = 0, last = n, depth = depth0;
         while (true) {
             while (last - first > 16) {
@@ -77,6 +93,11 @@ FLX_SORT_HD bool std_sort_emulated(T* a, int n, Less less) {
     }
     insertion_sort(0, n);
     return true;
+}
+template <class T, class Less>
+FLX_SORT_HD bool std_sort_emulated(T* a, int n, Less less) {
+    int stacks[48];
+    return std_sort_emulated(a, n, less, stacks);
 }
 
 }  // namespace flx

@@ -772,6 +772,7 @@ struct verifier {
     verified_intervals& ivs;
     std::vector<query_alignment>& out;
     verify_counters* ctr;
+    run_statistics* st;
 
     span_config root_span() const {
         return compute_reference_span_start_and_length(anchor.reference_position, tree.root(), leaf.from, reference_len,
@@ -780,7 +781,11 @@ struct verifier {
     bool root_was_already_verified() const {                                                   // verification.cpp:119-136
         auto const sc = root_span();
         auto const target = trim_from_both_sides({sc.offset, sc.offset + sc.length}, sc.extra);
-        return ivs.contains(target);
+        if (ivs.contains(target)) {
+            if (st) st->values[13].push_back(sc.length);                                        // verification.cpp:130
+            return true;
+        }
+        return false;
     }
     bool try_align(const pex_node& node, span_config sc) {                                     // verification.cpp:186-245
         int mode = MODE_EXISTS;
@@ -794,6 +799,7 @@ struct verifier {
             else { ctr->inner_jobs++; ctr->inner_word_steps += ws; }
             ctr->ref_query_bytes += sc.length + node.length();
         }
+        if (st) st->values[node.is_root() ? 12 : 11].push_back(sc.length);                      // verification.cpp:238-242
         if (r.exists && mode != MODE_EXISTS)
             out.push_back(query_alignment{sc.offset + r.begin, r.num_errors, reverse, std::move(r.cigar)});
         return r.exists;
@@ -829,8 +835,8 @@ struct verifier {
 
 void verify_anchor(const pex_tree& tree, const anchor_t& anchor, const uint8_t* query, bool reverse, const uint8_t* reference,
                    uint64_t reference_len, const params& p, verified_intervals& ivs, std::vector<query_alignment>& out,
-                   verify_counters* ctr) {
-    verifier v{tree, anchor, tree.leaves.at(anchor.pex_leaf_index), query, reverse, reference, reference_len, p, ivs, out, ctr};
+                   verify_counters* ctr, run_statistics* st) {
+    verifier v{tree, anchor, tree.leaves.at(anchor.pex_leaf_index), query, reverse, reference, reference_len, p, ivs, out, ctr, st};
     if (p.direct_full) v.direct_full();
     else v.hierarchical();
 }
@@ -876,6 +882,7 @@ struct read_result {
     std::vector<uint32_t> cigars;
     search_counters sc;
     verify_counters vc;
+    run_statistics st;
 };
 
 read_result align_one_read(const fm_index& idx, const std::vector<std::vector<uint8_t>>& refs, const std::vector<uint8_t>& read,
@@ -896,6 +903,32 @@ read_result align_one_read(const fm_index& idx, const std::vector<std::vector<ui
     std::vector<anchor_package> packages;                                                      // parallelization.cpp:14-43
     append_anchor_packages(fwd_res, packages, p.anchors_per_task, false);
     append_anchor_packages(rev_res, packages, p.anchors_per_task, true);
+    {   // parallelization.cpp:107-110 -> statistics.cpp:269-285 (seeds), :367-419 (search results)
+        run_statistics& st = rr.st;
+        st.values[0].push_back(len);
+        st.values[3].push_back(fwd_seeds.size() + rev_seeds.size());
+        for (auto const* seeds : {&fwd_seeds, &rev_seeds})
+            for (auto const& sd : *seeds) { st.values[2].push_back(sd.num_errors); st.values[1].push_back(sd.len); }
+        uint64_t fully_excluded = 0, kept = 0, by_soft = 0, by_erase = 0;
+        bool all_excluded = true;
+        for (auto const* res : {&fwd_res, &rev_res})
+            for (auto const& a : *res) {
+                if (a.num_kept_useful_anchors == 0) { ++fully_excluded; continue; }
+                all_excluded = false;
+                kept += a.num_kept_useful_anchors;
+                st.values[8].push_back(a.num_kept_useful_anchors);
+                by_soft += a.num_excluded_raw_anchors_by_soft_cap;
+                st.values[9].push_back(a.num_excluded_raw_anchors_by_soft_cap);
+                uint64_t const erased = a.num_kept_raw_anchors - a.num_kept_useful_anchors;
+                by_erase += erased;
+                st.values[10].push_back(erased);
+            }
+        st.values[4].push_back(fully_excluded);
+        st.values[5].push_back(kept);
+        st.values[6].push_back(by_soft);
+        st.values[7].push_back(by_erase);
+        if (all_excluded) ++st.completely_excluded_queries;
+    }
 
     size_t const nref = refs.size();
     std::vector<verified_intervals> iv_fwd(nref), iv_rev(nref);
@@ -908,7 +941,7 @@ read_result align_one_read(const fm_index& idx, const std::vector<std::vector<ui
         for (auto const& a : pkg.anchors) {
             auto& ivs = (pkg.reverse ? iv_rev : iv_fwd)[a.reference_id];
             verify_anchor(tree, a, pkg.reverse ? rc.data() : read.data(), pkg.reverse, refs[a.reference_id].data(),
-                          refs[a.reference_id].size(), p, ivs, mine[a.reference_id], &rr.vc);
+                          refs[a.reference_id].size(), p, ivs, mine[a.reference_id], &rr.vc, &rr.st);
         }
         for (size_t r = 0; r < nref; ++r)
             for (auto& al : mine[r]) all[r].push_back(std::move(al));
@@ -930,6 +963,11 @@ read_result align_one_read(const fm_index& idx, const std::vector<std::vector<ui
             rr.records.push_back(rec);
         }
     if (!primary_written) rr.records.push_back(record{read_index, 4u, -1, 0, 0, 0, 0});
+    {   // parallelization.cpp:262-269
+        uint64_t n_al = 0;
+        for (auto const& v : all) { n_al += v.size(); for (auto const& al : v) rr.st.values[15].push_back(al.num_errors); }
+        rr.st.values[14].push_back(n_al);
+    }
     return rr;
 }
 
@@ -961,6 +999,7 @@ run_output align_reads(const fm_index& idx, const std::vector<std::vector<uint8_
         out.vc.inner_jobs += rr.vc.inner_jobs; out.vc.root_jobs += rr.vc.root_jobs;
         out.vc.inner_word_steps += rr.vc.inner_word_steps; out.vc.root_word_steps += rr.vc.root_word_steps;
         out.vc.ref_query_bytes += rr.vc.ref_query_bytes;
+        out.st.merge(rr.st);
     }
     return out;
 }

@@ -190,10 +190,26 @@ struct params {
 
 struct verify_counters { uint64_t inner_jobs = 0, root_jobs = 0, inner_word_steps = 0, root_word_steps = 0, ref_query_bytes = 0; };
 
+// The values the reference feeds its statistics (statistics.hpp:24-172; statistics.cpp:223-240 gives the order of the histograms), as
+// raw lists: [0] query lengths, [1] seed lengths, [2] errors per seed, [3] seeds per query, [4] fully excluded seeds per query, [5] kept
+// anchors per query, [6] / [7] raw anchors excluded by the soft cap / by erase-useless per query, [8] kept anchors per kept seed,
+// [9] / [10] excluded by the soft cap / by erase-useless per kept seed, [11] / [12] reference span sizes aligned of inner nodes / of roots,
+// [13] root spans avoided (verification.cpp:130), [14] alignments per query, [15] alignments' edit distance. The two wall-clock
+// histograms (milliseconds per query) are not restated. Binning (statistics.cpp:80-94) is left to the checker.
+constexpr int N_STAT_LISTS = 16;
+struct run_statistics {
+    uint64_t completely_excluded_queries = 0;
+    std::vector<uint64_t> values[N_STAT_LISTS];
+    void merge(run_statistics const& o) {
+        completely_excluded_queries += o.completely_excluded_queries;
+        for (int i = 0; i < N_STAT_LISTS; ++i) values[i].insert(values[i].end(), o.values[i].begin(), o.values[i].end());
+    }
+};
+
 // one anchor, query_verifier::verify
 void verify_anchor(const pex_tree& tree, const anchor_t& anchor, const uint8_t* query, bool reverse,
                    const uint8_t* reference, uint64_t reference_len, const params& p, verified_intervals& ivs,
-                   std::vector<query_alignment>& out, verify_counters* ctr = nullptr);
+                   std::vector<query_alignment>& out, verify_counters* ctr = nullptr, run_statistics* st = nullptr);
 
 // ---------------------------------------------------------------- whole path for a set of reads (parallelization.cpp, output.cpp)
 struct record {
@@ -210,6 +226,7 @@ struct run_output {
     std::vector<uint8_t> skipped;         // per read: 1 if filtered (input.cpp:95-129) -> no record
     search_counters sc;
     verify_counters vc;
+    run_statistics st;
 };
 run_output align_reads(const fm_index& idx, const std::vector<std::vector<uint8_t>>& refs,
                        const std::vector<std::vector<uint8_t>>& reads, const params& p, unsigned threads);

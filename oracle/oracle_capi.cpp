@@ -239,4 +239,15 @@ void orc_run_counters(void* r, uint64_t* c) {
     c[4] = o.vc.inner_jobs; c[5] = o.vc.root_jobs; c[6] = o.vc.inner_word_steps; c[7] = o.vc.root_word_steps; c[8] = o.vc.ref_query_bytes;
 }
 
+// the raw values behind histogram `id` (run_statistics, floxer_oracle.hpp): returns their number, copies them when out != null;
+// id == N_STAT_LISTS: one value, the number of completely excluded queries
+uint64_t orc_run_stat_values(void* r, uint32_t id, uint64_t* out) {
+    auto& st = ((run_handle*)r)->out.st;
+    if (id == (uint32_t)N_STAT_LISTS) { if (out) out[0] = st.completely_excluded_queries; return 1; }
+    if (id > (uint32_t)N_STAT_LISTS) return 0;
+    auto const& v = st.values[id];
+    if (out && !v.empty()) memcpy(out, v.data(), v.size() * 8);
+    return v.size();
+}
+
 }  // extern "C"

@@ -17,4 +17,19 @@ print('$tag', d['value'], 'reads/s', d['ms_per_step'], 'ms/step; isolated', {n: 
 PY
     grep -h "^\[fm_search\]" $O/$tag.err | tail -1 | cut -c1-330
 }
-run steal FLX_FM_STEAL_MIN=1 && run nosteal FLX_FM_STEAL_MIN=0
+run rounds3 FLX_FM_ROUNDS=3 && run rounds1 FLX_FM_ROUNDS=1 || exit 1
+# the text walk with and without its LDS windows, one-lane pass on the uniform reference
+for w in 0 1; do
+  FLX_FM_NO_WINDOWS=$w FLX_SEARCH_DEBUG=1 timeout -k 10 400 python3 $R/bench.py --isolated-only --no-cpu-baseline > $O/iso_nowin$w.json 2> $O/iso_nowin$w.err || { tail -5 $O/iso_nowin$w.err; exit 1; }
+  python3 -c "
+import json
+d=json.load(open('$O/iso_nowin$w.json'))
+print('uniform one-lane, FLX_FM_NO_WINDOWS=$w:', {n: round(v['device_ms'],1) for n,v in d['kernels_isolated'].items()})"
+done
+# the uniform reference (the metric's configuration) with the same build
+FLX_BENCH_VERBOSE=1 timeout -k 10 500 python3 $R/bench.py --steps 12 --warmup 3 --no-cpu-baseline --no-repeat-rich-leg > $O/uniform.json 2> $O/uniform.err || { tail -5 $O/uniform.err; exit 1; }
+python3 - <<PY
+import json
+d=json.load(open('$O/uniform.json'))
+print('uniform', d['value'], 'reads/s', d['ms_per_step'], 'ms/step; host inputs', d['value_host_inputs'], '; isolated', {n: round(v['device_ms'],1) for n,v in d['kernels_isolated'].items()}, 'roofline', d['roofline']['frac'], d['roofline']['achieved'])
+PY

@@ -88,6 +88,8 @@ def lib():
         L.orc_run_num_cigar_words.argtypes = [C.c_void_p]
         L.orc_run_get.argtypes = [C.c_void_p, i64p, u32p, u8p]
         L.orc_run_counters.argtypes = [C.c_void_p, u64p]
+        L.orc_run_stat_values.restype = C.c_uint64
+        L.orc_run_stat_values.argtypes = [C.c_void_p, C.c_uint32, u64p]
     return _lib
 
 
@@ -100,6 +102,7 @@ def as_u8(x):
 
 
 CIGAR_OPS = "MIDNSHP=X"
+N_STAT_LISTS = 16          # run_statistics, oracle/floxer_oracle.hpp
 
 
 def cigar_str(words):
@@ -225,9 +228,17 @@ class Index:
             ctr = np.zeros(9, dtype=np.uint64)
             lib().orc_run_counters(h, _p(ctr, u64p))
             secs = lib().orc_run_seconds(h)
+            stats = []
+            for i in range(N_STAT_LISTS + 1):
+                n = lib().orc_run_stat_values(h, i, None)
+                v = np.zeros(max(n, 1), dtype=np.uint64)
+                lib().orc_run_stat_values(h, i, _p(v, u64p))
+                stats.append(v[:n])
         finally:
             lib().orc_run_free(h)
-        return RunResult(rows, cig[:nc], skipped[: len(reads)], ctr, secs)
+        res = RunResult(rows, cig[:nc], skipped[: len(reads)], ctr, secs)
+        res.stat_values = stats          # the raw values behind the reference's 16 count histograms + [16] = (completely excluded queries,)
+        return res
 
 
 class RunResult:

@@ -1349,3 +1349,77 @@ def test_bench_two_ranks_share_one_gpu_and_gather_what_one_rank_computes(tmp_pat
     # records of the whole run = both shards of both steps; step 0's share is known exactly
     assert line["records"] >= len(expected) and line["records"] > 2 * B * steps * 0.9
     ctx.close()
+
+
+# ---------------------------------------------------------------- --stats: every bin of the reference's histograms
+def _parse_stats_toml(text):
+    """{section: {key: value}} of `floxer --stats` output (statistics.cpp:70-74, 126-145); '' = the counts in front of the first section"""
+    import ast
+    out, cur = {"": {}}, ""
+    for line in text.splitlines():
+        line = line.strip()
+        if not line:
+            continue
+        if line.startswith("["):
+            cur = line.strip("[]")
+            out[cur] = {}
+        else:
+            k, v = line.split(" = ", 1)
+            out[cur][k] = ast.literal_eval(v)
+    return out
+
+
+@pytest.mark.parametrize("kw,okw", [(dict(), dict()), (dict(interval_optimization=True), dict(interval_opt=True)),
+                                     (dict(direct_full_verification=True), dict(direct_full=True))])
+def test_statistics_bins_match_oracle(kw, okw):
+    """statistics::search_and_alignment_statistics (statistics.hpp:24-172): the count and the sixteen histograms that do not measure
+    wall-clock time, bin by bin. The oracle keeps the raw values the reference's call sites insert (parallelization.cpp:107-110, 262-269;
+    verification.cpp:130, 238-242); this test bins them itself (statistics.cpp:80-94: the first threshold >= value, else the last bin) over
+    the reference's "simulated" scales (statistics.cpp:35-62) and compares with the TOML the product writes: thresholds, occurrences,
+    num_values, min, max, mean. A text with repeats (caps bite, windows avoided under -I), two read shapes."""
+    genome = S.make_genome(300_000, 3, seed=31)
+    rng = np.random.default_rng(8)
+    for g in genome:
+        for _ in range(10):
+            a, b, ln = rng.integers(0, len(g) - 4000), rng.integers(0, len(g) - 4000), int(rng.integers(200, 3000))
+            g[b:b + ln] = g[a:a + ln]
+    genome[0][5000:5600] = 2
+    reads = S.make_reads(genome, 90, 2500, 0.07, seed=41)[0] + S.make_reads(genome, 60, 700, 0.05, seed=42)[0]
+    fidx = F.fmindex(genome)
+    ctx = F.context(fidx)
+    stats = F.statistics("simulated").attach(ctx)
+    # (one error probability for both shapes: the statistics object sees one run, as `floxer --stats` does)
+    got = F.aligner(ctx, F.params(error_probability=0.07, **kw)).align_reads(reads)
+    exp = O.Index(genome).run(reads, O.params(error_probability=0.07, **okw), threads=8)
+    assert got.records() == exp.records()
+    toml = _parse_stats_toml(stats.format(toml=True))
+
+    def linear_range(steps, mx):
+        return [i * mx // steps for i in range(steps)]
+    small, medium, tiny = linear_range(30, 100), linear_range(30, 1000), [0, 1, 2, 3, 4]
+    qlen, anchor, per_seed, edit = linear_range(30, 10_000), linear_range(30, 1000), linear_range(30, 200), linear_range(30, 1000)
+    sections = [("query_lengths", qlen), ("seed_lengths", small), ("errors_per_seed", tiny), ("seeds_per_query", medium),
+                ("fully_excluded_seeds_per_query", medium), ("kept_anchors_per_query", anchor), ("excluded_raw_anchors_by_soft_cap_per_query", anchor),
+                ("excluded_raw_anchors_by_erase_useless_per_query", anchor), ("kept_anchors_per_kept_seed", per_seed),
+                ("excluded_raw_anchors_by_soft_cap_per_kept_seed", per_seed), ("excluded_raw_anchors_by_erase_useless_per_kept_seed", per_seed),
+                ("reference_span_sizes_aligned_of_inner_nodes", qlen), ("reference_span_sizes_aligned_of_roots", qlen),
+                ("reference_span_sizes_alignment_avoided_of_roots", qlen), ("alignments_per_query", small), ("alignments_edit_distance", edit)]
+    assert toml[""]["completely_excluded_queries"] == int(exp.stat_values[16][0])
+    for i, (name, thresholds) in enumerate(sections):
+        values = [int(v) for v in exp.stat_values[i]]
+        occ = [0] * (len(thresholds) + 1)
+        for v in values:
+            occ[next((j for j, t in enumerate(thresholds) if v <= t), len(thresholds))] += 1
+        sec = toml[name]
+        assert sec["thresholds"] == thresholds, name
+        assert sec["num_values"] == len(values), (name, sec["num_values"], len(values))
+        assert sec["occurrences"] == occ, (name, sec["occurrences"], occ)
+        if values:
+            assert sec["min_value"] == min(values) and sec["max_value"] == max(values), name
+            assert sec["mean"] == float(f"{sum(values) / len(values):.2f}"), name
+    if kw.get("interval_optimization"):
+        assert len(exp.stat_values[13]) > 0          # windows were avoided: the histogram is exercised
+    # the two wall-clock histograms exist with one value per query
+    for name in ("milliseconds_spent_in_search_per_query", "milliseconds_spent_in_verification_per_query"):
+        assert toml[name]["num_values"] == len(exp.stat_values[0])
+    ctx.close()
