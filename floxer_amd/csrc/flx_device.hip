@@ -1059,14 +1059,9 @@ int DeviceApi::select(void* stream, const DevHit* d_hits, const u32* d_counters,
     // grids sized for the usual shares (a quarter of the seeds light, a per cent heavy); the kernels loop over their lists
     hipLaunchKernelGGL((seed_select_kernel<SEL_LIGHT>), dim3(std::max(1u, (n_seeds / 4 + 63) / 64)), dim3(64), 0, s, d_lists, list_counts, d_grouped, d_hit_offset,
                        idx.sa, idx.n, d_seq_start, n_ref, erase ? 1u : 0u, stat, d_n_out, d_row_offset, d_rows, d_sparse, sparse_cap);
-    // (one wave per heavy seed; FLX_SELECT_THREADS=1: the thread-per-seed form, for seeds of at most SEL_MAX groups)
-    static int const thread_form = getenv("FLX_SELECT_THREADS") ? 1 : 0;
-    if (thread_form)
-        hipLaunchKernelGGL((seed_select_kernel<SEL_MAX>), dim3(std::max(1u, (n_seeds / 64 + 63) / 64)), dim3(64), 0, s, d_lists + n_seeds, list_counts + 1, d_grouped,
-                           d_hit_offset, idx.sa, idx.n, d_seq_start, n_ref, erase ? 1u : 0u, stat, d_n_out, d_row_offset, d_rows, d_sparse, sparse_cap);
-    else
-        hipLaunchKernelGGL((seed_select_wave_kernel<SELW_FEW_GROUPS>), dim3(std::max(1u, std::min(n_seeds / 8u + 1u, 16384u))), dim3(64), 0, s, d_lists + n_seeds, list_counts + 1, d_grouped,
-                           d_hit_offset, idx.sa, idx.n, d_seq_start, n_ref, erase ? 1u : 0u, stat, d_n_out, d_row_offset, d_rows, d_sparse, sparse_cap);
+    // (one wave per heavy seed)
+    hipLaunchKernelGGL((seed_select_wave_kernel<SELW_FEW_GROUPS>), dim3(std::max(1u, std::min(n_seeds / 8u + 1u, 16384u))), dim3(64), 0, s, d_lists + n_seeds, list_counts + 1, d_grouped,
+                       d_hit_offset, idx.sa, idx.n, d_seq_start, n_ref, erase ? 1u : 0u, stat, d_n_out, d_row_offset, d_rows, d_sparse, sparse_cap);
     hipLaunchKernelGGL((seed_select_wave_kernel<SELW_MAX_GROUPS>), dim3(std::max(1u, std::min(n_seeds / 256u + 1u, 2048u))), dim3(64), 0, s, d_lists + 2 * (size_t)n_seeds, list_counts + 2, d_grouped,
                        d_hit_offset, idx.sa, idx.n, d_seq_start, n_ref, erase ? 1u : 0u, stat, d_n_out, d_row_offset, d_rows, d_sparse, sparse_cap);
     if ((e = hipGetLastError()) != hipSuccess) return (int)e;

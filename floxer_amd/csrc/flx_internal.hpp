@@ -237,13 +237,13 @@ struct DeviceApi {
     // flx_search.hip: the walk with its stack in LDS plus the presence filter (d_qpack: 2-bit form of d_seq, null: no filter) and the
     // text walk of one-row subtrees (d_items: room for item_cap queued subtrees, null: none are queued). d_counters: 32 zeroed words.
     // d_seed_rows (n_seeds zeroed words, or null): rows reported per seed over all lanes; with it the lanes of a wave share the subtrees
-    // of heavy seeds once the seed queue is dry, and busy waves hand subtrees to a follow-up launch through d_frame_queues
+    // of heavy seeds once the seed queue is dry, and busy waves hand subtrees to waves that have run out of work through d_mailboxes
     // (see fm_search_filter_kernel)
     static int search_filtered(void* stream, const DevIndex& idx, const u8* d_seq, const u32* d_qpack, const u64* d_scheme, const DevSeed* d_seeds,
                                u32 n_seeds, u32 max_hits_per_seed, u32 frame_levels, DevHit* d_hits, u32 hit_cap, DevHit* d_items, u32 item_cap,
-                               u32* d_counters, u32* d_seed_cnt, u32* d_seed_rows, void* d_frame_queues, u32 frame_queue_cap, u32 concurrent_launches);
-    // the two queues through which the launches of the filter walk hand subtrees on (frame_queue_cap entries each; may be null)
-    static size_t frame_queue_bytes(u32 frame_queue_cap);
+                               u32* d_counters, u32* d_seed_cnt, u32* d_seed_rows, void* d_mailboxes, u32 mailbox_waves, u32 concurrent_launches);
+    // the mailboxes through which the waves of one launch of the filter walk hand subtrees to each other (room for `waves` waves; may be null)
+    static size_t mailbox_bytes(u32 waves);
     // the tables a context derives from text and suffix array: bytes of isa + filter for a text of n symbols; derive_index fills
     // d_isa (n words) and d_filter (null: no filter) and sets idx.isa / filter / filter_k / filter_tmin
     static size_t derived_bytes(u64 n, u32* filter_k_out);
@@ -275,10 +275,11 @@ struct DeviceApi {
     // existence tests, one lane per job with Ukkonen's cutoff (flx_lanes.hip): at most `waves` waves take the jobs from a queue (*d_queue = 0
     // at the start, d_queue[1] counts jobs whose windows the rows did not hold); d_n_jobs (optional): the number of jobs is on the device
     // (at most max_jobs); cap_blocks >= (64 + n - m + 2k) / 16 + 3 of every job, exists_lane_lds_bytes(cap_blocks) <= 160 KB;
-    // d_stats (optional): 8 x u64 counters
+    // d_stats (optional): 8 x u64 counters; lanes_per_job (1, 2, 4, 8, 16): a team of lanes per job, each on every P-th word group, one block
+    // behind the lane of the group above (jobs with long chains and too few of them to fill the chip one lane each)
     static size_t exists_lane_lds_bytes(u32 cap_blocks);
     static int align_exists_lanes(void* stream, const u8* d_text, const u64* d_peq, const DevAlignJob* d_jobs, u32 max_jobs, const u32* d_n_jobs,
-                                  u32* d_queue, u32 waves, u32 cap_blocks, DevAlignOut* d_out, unsigned long long* d_stats);
+                                  u32* d_queue, u32 waves, u32 cap_blocks, DevAlignOut* d_out, unsigned long long* d_stats, u32 lanes_per_job = 1);
     static int align_exists_counted(void* stream, const u8* d_text, const u64* d_peq, const DevAlignJob* d_jobs, u32 max_jobs, const u32* d_n_jobs,
                                     AlignShape shape, u32 max_waves, DevAlignOut* d_out);
     static AlignShape shape_holding(u32 nw, i64 width, bool parallel);

@@ -62,11 +62,7 @@ struct BlockDeflater {
 // per thread against zlib level 1's 100, and the writer's deflate threads are what bounds the CLI with -I (46.7 k -> 61.6 k reads/s,
 // profiles/r03_cli_throughput_fast_bgzf.txt). It gives up the repeats zlib finds between CIGAR words, though: files are half as large
 // again (5.6 against 3.7 GB for 2.85 M records with 1600-operation CIGARs), so with default flags, where the output volume is what
-// costs, it gains little on a disk that writes 0.6 GB/s. Off by default.
-bool bgzf_use_zlib() {
-    static bool const v = getenv("FLX_BGZF_FAST") == nullptr;
-    return v;
-}
+// costs, it gains little on a disk that writes 0.6 GB/s. Off by default (FLX_BGZF_FAST=1; see lz_deflate below for the default).
 struct BitSink {
     uint8_t* p;
     uint64_t acc = 0;
@@ -173,10 +169,171 @@ size_t literal_deflate(const uint8_t* data, size_t n, uint8_t* out) {
     return (size_t)(bs.finish() - out);
 }
 
+// ---- A deflate stream with string matching of the cheap kind (the default): long repeats only - every eighth position enters a hash
+// table of eight-byte strings, every position is looked up, a hit is extended both ways eight bytes at a time and taken from 24 bytes
+// on - then one dynamic-Huffman block. What it is for: without
+// --interval-optimization the windows of one locus all take their union's alignment, so a read's forty records carry the same 6-8 KB
+// CIGAR array one after the other - a back-reference of a few bytes instead of 8 KB of literals (zlib level 1 finds the same repeats
+// at 100 MB/s per thread, and the writer's deflate threads were what bounded the CLI at default flags: 4.9 k reads/s, 12.1 of 13.4 s).
+// Inside a CIGAR array (words (length << 4 | op), three zero bytes in four) it finds nothing and costs a hash per byte: the order-0 code
+// of the literals does the rest. FLX_BGZF_ZLIB=1 selects zlib, FLX_BGZF_FAST=1 the literal-only encoder.
+enum BgzfEncoder { ENC_LZ = 0, ENC_ZLIB = 1, ENC_LITERAL = 2 };
+BgzfEncoder bgzf_encoder() {
+    static BgzfEncoder const v = getenv("FLX_BGZF_ZLIB") ? ENC_ZLIB : getenv("FLX_BGZF_FAST") ? ENC_LITERAL : ENC_LZ;
+    return v;
+}
+struct LzToken { uint16_t lit_run; uint16_t len; uint16_t dist; };    // lit_run literals, then a match of len (3..258; 0: none) at dist
+// deflate's length and distance codes (RFC 1951, 3.2.5)
+struct LenCode { uint16_t code; uint8_t extra_bits; uint16_t base; };
+inline void length_code(unsigned len, unsigned& code, unsigned& ebits, unsigned& eval) {
+    static const uint16_t base[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258};
+    static const uint8_t bits[29] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0};
+    unsigned c = 28;
+    if (len < 258) { c = 0; while (c + 1 < 28 && base[c + 1] <= len) ++c; }
+    code = 257 + c; ebits = bits[c]; eval = len - base[c];
+}
+inline void distance_code(unsigned dist, unsigned& code, unsigned& ebits, unsigned& eval) {
+    static const uint16_t base[30] = {1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 97, 129, 193, 257, 385, 513, 769, 1025, 1537, 2049, 3073, 4097, 6145, 8193, 12289, 16385, 24577};
+    static const uint8_t bits[30] = {0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13};
+    unsigned c = 0;
+    while (c + 1 < 30 && base[c + 1] <= dist) ++c;
+    code = c; ebits = bits[c]; eval = dist - base[c];
+}
+void canonical_codes(const uint8_t* len, unsigned n, uint32_t* code) {
+    unsigned bl_count[16] = {0}, next[16];
+    for (unsigned b = 0; b < n; ++b) ++bl_count[len[b]];
+    bl_count[0] = 0;
+    unsigned c = 0;
+    for (unsigned d = 1; d <= 15; ++d) { c = (c + bl_count[d - 1]) << 1; next[d] = c; }
+    for (unsigned b = 0; b < n; ++b) code[b] = len[b] ? bit_reverse(next[len[b]]++, len[b]) : 0;
+}
+
+// raw deflate stream for data[0, n), n <= BGZF_BLOCK, into out (capacity >= n + 1200); returns its length
+size_t lz_deflate(const uint8_t* data, size_t n, uint8_t* out) {
+    if (n < 64) return literal_deflate(data, n, out);
+    // ---- parse
+    constexpr unsigned HASH_BITS = 13;
+    uint16_t table[1u << HASH_BITS];                      // position + 1 of the last occurrence of a hash (0: none); positions < 65536
+    memset(table, 0, sizeof(table));
+    thread_local std::vector<LzToken> tokens;
+    tokens.clear();
+    uint32_t lfreq[286], dfreq[30];
+    memset(lfreq, 0, sizeof(lfreq));
+    memset(dfreq, 0, sizeof(dfreq));
+    auto read64 = [&](size_t i) { uint64_t v; memcpy(&v, data + i, 8); return v; };
+    size_t i = 0, lit_start = 0;
+    size_t const last = n - 8;                             // positions from which eight bytes can be read
+    unsigned miss = 0;
+    auto flush_literals = [&](size_t upto) {
+        size_t run = upto - lit_start;
+        while (run > 65535) { tokens.push_back(LzToken{65535, 0, 0}); run -= 65535; }
+        return (uint16_t)run;
+    };
+    auto hash8 = [&](size_t k) { return (uint32_t)((read64(k) * 0x9E3779B97F4A7C15ull) >> (64 - HASH_BITS)); };
+    constexpr size_t MIN_MATCH = 24;                       // shorter repeats (the zero bytes of CIGAR words) are left to the entropy code
+    size_t next_insert = 0;                                // every eighth position enters the table: a repeat of MIN_MATCH bytes holds two of them
+    while (i <= last) {
+        while (next_insert <= i) { if (next_insert <= last) table[hash8(next_insert)] = (uint16_t)(next_insert + 1); next_insert += 8; }
+        size_t const cand1 = (i & 7u) == 0 ? 0 : table[hash8(i)];      // (position i itself has just entered: nothing to find there)
+        size_t c = cand1 ? cand1 - 1 : 0;
+        if (cand1 && c < i && i - c <= 32768 && read64(c) == read64(i)) {
+            size_t len = 8;
+            while (i + len <= last && read64(c + len) == read64(i + len)) len += 8;
+            while (i + len < n && data[c + len] == data[i + len]) ++len;
+            size_t at = i;
+            while (at > lit_start && c > 0 && data[c - 1] == data[at - 1]) { --c; --at; ++len; }      // the match began before the table's position
+            if (len >= MIN_MATCH) {
+                unsigned const dist = (unsigned)(at - c);
+                uint16_t const run = flush_literals(at);
+                // a long match goes out as pieces of at most 258 bytes (never leaving a piece shorter than 3)
+                size_t left = len;
+                bool first = true;
+                while (left) {
+                    size_t const piece = left > 258 ? (left - 258 < 3 ? 255 : 258) : left;
+                    tokens.push_back(LzToken{first ? run : (uint16_t)0, (uint16_t)piece, (uint16_t)dist});
+                    unsigned code, eb, ev;
+                    length_code((unsigned)piece, code, eb, ev);
+                    ++lfreq[code];
+                    distance_code(dist, code, eb, ev);
+                    ++dfreq[code];
+                    left -= piece;
+                    first = false;
+                }
+                i = at + len;
+                lit_start = i;
+                miss = 0;
+                continue;
+            }
+        }
+        ++miss;
+        i += 1 + (miss >> 7);                              // data without repeats: look less and less often
+        if (i >= 16384 && tokens.empty()) return literal_deflate(data, n, out);      // a quarter of the block without one: records that share nothing (-I)
+    }
+    uint16_t const tail_run = flush_literals(n);
+    // literal frequencies: everything outside the matches
+    {
+        size_t pos = 0;
+        for (auto const& t : tokens) {
+            for (size_t k = 0; k < t.lit_run; ++k) ++lfreq[data[pos + k]];
+            pos += (size_t)t.lit_run + t.len;
+        }
+        for (size_t k = 0; k < tail_run; ++k) ++lfreq[data[pos + k]];
+    }
+    lfreq[256] = 1;
+    bool any_dist = false;
+    for (unsigned d = 0; d < 30; ++d) any_dist |= dfreq[d] != 0;
+    if (!any_dist) return literal_deflate(data, n, out);
+    // (a Huffman code needs two symbols)
+    { unsigned used = 0; for (unsigned d = 0; d < 30; ++d) used += dfreq[d] != 0; if (used == 1) { for (unsigned d = 0; d < 30; ++d) if (!dfreq[d]) { dfreq[d] = 1; break; } } }
+    uint8_t llen[286], dlen[30];
+    huffman_lengths(lfreq, 286, llen);
+    huffman_lengths(dfreq, 30, dlen);
+    uint64_t bits = 3 + 5 + 5 + 4 + 19 * 3 + (286 + 30) * 4;
+    for (unsigned b = 0; b < 286; ++b) bits += (uint64_t)lfreq[b] * llen[b];
+    for (unsigned d = 0; d < 30; ++d) bits += (uint64_t)dfreq[d] * (dlen[d] + 13);      // (extra bits: an upper bound)
+    for (unsigned c = 265; c < 285; ++c) bits += (uint64_t)lfreq[c] * 5;
+    if ((bits + 7) / 8 >= n + 5) return literal_deflate(data, n, out);                  // (it falls back to a stored block itself)
+    uint32_t lcode[286], dcode[30];
+    canonical_codes(llen, 286, lcode);
+    canonical_codes(dlen, 30, dcode);
+    BitSink bs(out);
+    bs.put(1, 1);                                                     // BFINAL
+    bs.put(2, 2);                                                     // BTYPE = dynamic Huffman
+    bs.put(286 - 257, 5);                                             // HLIT
+    bs.put(30 - 1, 5);                                                // HDIST
+    bs.put(15, 4);                                                    // HCLEN: all 19 code length codes
+    static const uint8_t cl_order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
+    for (unsigned k = 0; k < 19; ++k) bs.put(cl_order[k] >= 16 ? 0u : 4u, 3);
+    for (unsigned b = 0; b < 286; ++b) bs.put(bit_reverse(llen[b], 4), 4);
+    for (unsigned d = 0; d < 30; ++d) bs.put(bit_reverse(dlen[d], 4), 4);
+    uint64_t packed[256];
+    for (unsigned b = 0; b < 256; ++b) packed[b] = lcode[b] | ((uint64_t)llen[b] << 32);
+    size_t pos = 0;
+    for (auto const& t : tokens) {
+        for (size_t k = 0; k < t.lit_run; ++k) { uint64_t const e = packed[data[pos + k]]; bs.put((uint32_t)e, (unsigned)(e >> 32)); }
+        pos += t.lit_run;
+        if (t.len) {
+            unsigned code, eb, ev;
+            length_code(t.len, code, eb, ev);
+            bs.put(lcode[code], llen[code]);
+            if (eb) bs.put(ev, eb);
+            distance_code(t.dist, code, eb, ev);
+            bs.put(dcode[code], dlen[code]);
+            if (eb) bs.put(ev, eb);
+            pos += t.len;
+        }
+    }
+    for (size_t k = 0; k < tail_run; ++k) { uint64_t const e = packed[data[pos + k]]; bs.put((uint32_t)e, (unsigned)(e >> 32)); }
+    bs.put(lcode[256], llen[256]);
+    return (size_t)(bs.finish() - out);
+}
+
 // one BGZF block (a gzip member with the BC extra field) for `len` <= BGZF_BLOCK bytes; returns its size, 0 on failure
 size_t bgzf_compress_block(const uint8_t* data, size_t len, uint8_t* out) {
     size_t clen;
-    if (!bgzf_use_zlib()) clen = literal_deflate(data, len, out + 18);
+    BgzfEncoder const enc = bgzf_encoder();
+    if (enc == ENC_LZ) clen = lz_deflate(data, len, out + 18);
+    else if (enc == ENC_LITERAL) clen = literal_deflate(data, len, out + 18);
     else {
         thread_local BlockDeflater deflater;
         z_stream* const zp = deflater.get();

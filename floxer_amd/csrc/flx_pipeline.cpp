@@ -439,9 +439,9 @@ int search_seeds_device(Lane* ctx, const u8* d_seq_pool_or_null, const u8* h_seq
         if ((rc = ctx->sel_lists.ensure((3 * n_seeds + 3) * 4))) return rc;
         sel_stat.resize(n_seeds);
     }
-    // subtrees handed from one launch of the filter walk to the next (96 B each): room for one per two seeds, at least 256 k
-    u32 const frame_q_cap = device_select ? (u32)std::min<u64>(std::max<u64>(n_seeds / 2, 262144), 4u << 20) : 0u;
-    if (frame_q_cap && (rc = ctx->frame_q.ensure(DeviceApi::frame_queue_bytes(frame_q_cap)))) return rc;
+    // the mailboxes through which the waves of a search launch hand subtrees to each other (at most 4096 waves per launch, 6 KB each)
+    u32 const mailbox_waves = device_select ? 4096u : 0u;
+    if (mailbox_waves && (rc = ctx->frame_q.ensure(DeviceApi::mailbox_bytes(mailbox_waves)))) return rc;
     u32 counters[32];
     u64 sel_cap = (u64)(ctx->sel_rows_per_seed * 1.25 * (double)n_seeds);      // entries of the selected-anchor list (at least hit_cap, below)
     struct K1Token { flx_ctx* c; explicit K1Token(flx_ctx* c_) : c(c_) { c->k1_acquire(); } ~K1Token() { c->k1_release(); } };
@@ -471,7 +471,7 @@ int search_seeds_device(Lane* ctx, const u8* d_seq_pool_or_null, const u8* h_seq
                                                   max_hits, max_errors, ctx->hits.as<DevHit>(), (u32)std::min<u64>(hit_cap, 0xFFFFFFFFu),
                                                   item_cap ? ctx->items.as<DevHit>() : nullptr, (u32)std::min<u64>(item_cap, 0xFFFFFFFFu),
                                                   ctx->counters.as<u32>(), device_select ? ctx->seed_cnt.as<u32>() : nullptr,
-                                                  device_select ? ctx->sel_rows.as<u32>() : nullptr, device_select ? ctx->frame_q.ptr : nullptr, frame_q_cap, concurrent);
+                                                  device_select ? ctx->sel_rows.as<u32>() : nullptr, device_select ? ctx->frame_q.ptr : nullptr, mailbox_waves, concurrent);
             return DeviceApi::search(ctx->stream, ctx->ctx->didx, d_seq, ctx->scheme.as<u64>(), ctx->seeds.as<DevSeed>(), (u32)n_seeds,
                                      max_hits, ctx->stack.as<DevFrame>(), ctx->hits.as<DevHit>(), (u32)std::min<u64>(hit_cap, 0xFFFFFFFFu),
                                      ctx->counters.as<u32>(), device_select ? ctx->seed_cnt.as<u32>() : nullptr);
@@ -496,9 +496,9 @@ int search_seeds_device(Lane* ctx, const u8* d_seq_pool_or_null, const u8* h_seq
             if ((rc = d2h(ctx, sel_stat.data(), ctx->sel_stat.ptr, n_seeds * sizeof(DevSelStat)))) return rc;
         }
         if ((rc = ctx->sync())) return rc;
-        if (getenv("FLX_SEARCH_DEBUG")) fprintf(stderr, "[fm_search] seeds %llu ext %u (of single-row intervals %u) wave-iterations %u (max per wave %u) busy pair-iterations %u, after the queue ran dry %u (max %u), subtrees handed over %u, to the next launch %u (queues %u, %u)\n", (unsigned long long)n_seeds, counters[2], counters[3], counters[4], counters[5], counters[6], counters[8], counters[9], counters[14], counters[15], counters[20], counters[22]);
+        if (getenv("FLX_SEARCH_DEBUG")) fprintf(stderr, "[fm_search] seeds %llu ext %u (of single-row intervals %u) wave-iterations %u (max per wave %u) busy pair-iterations %u, after the queue ran dry %u (max %u), subtrees handed over %u, from wave to wave %u\n", (unsigned long long)n_seeds, counters[2], counters[3], counters[4], counters[5], counters[6], counters[8], counters[9], counters[14], counters[15]);
         if (getenv("FLX_SEARCH_DEBUG") && filtered) fprintf(stderr, "[fm_search filtered] subtrees queued %u (slots %u of %llu), filter lookups %u, children dropped %u, searches ended by the prefix lookup %u; text walk: lane-steps %u, wave-iterations %u\n", counters[3], counters[16], (unsigned long long)item_cap, counters[10], counters[11], counters[12], counters[18], counters[19]);
-        if (counters[1]) { set_error("fm_search: DFS stack reservation exceeded"); return FLX_ERR_INTERNAL; }
+        if (counters[1]) { set_error(counters[1] & 2u ? "fm_search: a subtree handed between waves was not taken" : "fm_search: DFS stack reservation exceeded"); return FLX_ERR_INTERNAL; }
         bool const items_fit = !item_cap || counters[16] <= item_cap;
         if (items_fit && counters[0] <= hit_cap && (!device_select || sel_rows_total <= sel_cap)) break;      // (selected anchors <= rows)
         if (attempt >= 3) { set_error("fm_search: hit buffer could not be sized"); return FLX_ERR_INTERNAL; }
@@ -875,10 +875,17 @@ int choose_shapes(hvec<AlignRequest> const& reqs, hvec<AlignShape>& shapes) {
 // side by side on its ring, one after the other on its lane), so the ring form is the default.
 static bool exists_lane_form() { return getenv("FLX_EXISTS_LANES") != nullptr; }
 // its waves and the blocks its per-lane rows hold for windows of at most `width` diagonals (n - m + 2k); false: the rows would not fit the LDS
-static bool exists_lane_setup(u64 max_jobs, i64 width, u32& waves, u32& cap_blocks) {
+// lanes a job gets in the lane form (ed_exists_team_kernel): one for small nodes (many jobs, short chains), more for the large ones of
+// which there are few with thousands of blocks each; rows = the smallest node of the launch. FLX_EXISTS_TEAM fixes it.
+static u32 exists_team_size(u64 rows) {
+    if (const char* e = getenv("FLX_EXISTS_TEAM")) { int const fixed = atoi(e); if (fixed > 0) return (u32)fixed; }      // (read per call: tests switch it)
+    u64 const groups = (rows + 63) / 64;
+    return groups >= 48 ? 16u : groups >= 20 ? 8u : groups >= 8 ? 4u : groups >= 4 ? 2u : 1u;
+}
+static bool exists_lane_setup(u64 max_jobs, i64 width, u32& waves, u32& cap_blocks, u32 team = 1) {
     cap_blocks = (u32)((64 + std::max<i64>(width, 0)) / 16 + 3) | 1u;                   // (odd: the lanes' rows start in different banks)
     static u32 const max_waves = [] { const char* e = getenv("FLX_EXISTS_LANE_WAVES"); return (u32)(e ? std::max(1, atoi(e)) : 4096); }();
-    waves = (u32)std::max<u64>(std::min<u64>(max_waves, (max_jobs + 63) / 64), 1);
+    waves = (u32)std::max<u64>(std::min<u64>(max_waves, (max_jobs * team + 63) / 64), 1);
     return DeviceApi::exists_lane_lds_bytes(cap_blocks) <= 150 * 1024;
 }
 
@@ -891,7 +898,10 @@ int run_score_jobs_unique(Lane* ctx, const u8* d_text, const u64* d_peq, hvec<Al
     i64 lane_width = 0;
     for (auto const& r : reqs) lane_width = std::max<i64>(lane_width, (i64)r.n - (i64)r.m + 2 * (i64)r.k);
     u32 waves = 0, cap_blocks = 0;
-    if (exists_lane_form() && choose_align_shape(reqs[0].n, reqs[0].m, reqs[0].k).banded && exists_lane_setup(reqs.size(), lane_width, waves, cap_blocks)) {
+    u64 rows_min = ~0ull;
+    for (auto const& r : reqs) rows_min = std::min<u64>(rows_min, r.m);
+    u32 const team = exists_team_size(rows_min);
+    if (exists_lane_form() && choose_align_shape(reqs[0].n, reqs[0].m, reqs[0].k).banded && exists_lane_setup(reqs.size(), lane_width, waves, cap_blocks, team)) {
         // one launch for every shape: a lane per job
         hvec<DevAlignJob> jobs(reqs.size());
         u64 steps = 0, bytes = 0;
@@ -910,7 +920,7 @@ int run_score_jobs_unique(Lane* ctx, const u8* d_text, const u64* d_peq, hvec<Al
         rc = timed_launch(ctx, kernel_name, bytes, steps, [&] {
             return DeviceApi::align_exists_lanes(ctx->stream, d_text, d_peq, ctx->jobs.as<DevAlignJob>(), (u32)jobs.size(), nullptr, ctx->counters.as<u32>(),
                                                  waves, cap_blocks, ctx->job_out.as<DevAlignOut>(),
-                                                 getenv("FLX_ALIGN_DEBUG") ? (unsigned long long*)((char*)ctx->counters.ptr + 64) : nullptr);
+                                                 getenv("FLX_ALIGN_DEBUG") ? (unsigned long long*)((char*)ctx->counters.ptr + 64) : nullptr, team);
         });
         if (rc) return rc;
         u32 cnt[32];
@@ -2157,7 +2167,8 @@ int align_slice(Lane* lane, const flx_params* P, const flx_reads* RD, u64 first_
             u32 lane_waves = 0, lane_cap = 0;
             u32 const max_jobs = (u32)std::min<u64>(2ull * n_climbing, 2ull * n);
             u64 const lane_width_cap = std::min<u64>(cap, std::max<u64>(8 * (u64)width_max, 1024));
-            bool const lane_form = exists_lane_form() && shape.banded && exists_lane_setup(max_jobs, (i64)std::max<u64>(lane_width_cap, (u64)width_max), lane_waves, lane_cap);
+            u32 const team = exists_team_size(smallest);
+            bool const lane_form = exists_lane_form() && shape.banded && exists_lane_setup(max_jobs, (i64)std::max<u64>(lane_width_cap, (u64)width_max), lane_waves, lane_cap, team);
             u64 const width_cap = lane_form ? lane_width_cap : cap;
             int const e1 = DeviceApi::vr2_request(lane->stream, B, n_queries, (u32)std::min<u64>(limit, 0xFFFFFFFFu), shape.words_per_lane,
                                                   (u32)std::min<u64>(width_cap, 0xFFFFFFFFull), round);
@@ -2165,7 +2176,7 @@ int align_slice(Lane* lane, const flx_params* P, const flx_reads* RD, u64 first_
             rc = timed_launch(lane, "ed_align_exists", 0, 0, [&] {
                 if (lane_form)
                     return DeviceApi::align_exists_lanes(lane->stream, d_text, d_peq, B.jobs, max_jobs, B.scalars + VR2_N_JOBS + (round & 1u), B.scalars + VR2_QUEUE,
-                                                         lane_waves, lane_cap, B.outs, lane_stats);
+                                                         lane_waves, lane_cap, B.outs, lane_stats, team);
                 return DeviceApi::align_exists_counted(lane->stream, d_text, d_peq, B.jobs, max_jobs, B.scalars + VR2_N_JOBS + (round & 1u), shape, 8192u, B.outs);
             });
             if (rc) return rc;

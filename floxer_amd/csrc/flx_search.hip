@@ -16,12 +16,18 @@
 namespace flx {
 
 struct FrameItem { u32 w[24]; };               // [0..17] the frame (word 14: the children that go), [18] seed position, [19] exo, [20] ws, [21..22] qoff
-struct FrameQueues {
-    const FrameItem* in; FrameItem* out;       // in: FROM_FRAMES launches; out: null in the last round
-    u32 cap;                                   // entries of either queue
-    u32 in_count, in_head, out_count, done;    // indices into counters
-    u32 room_div;                              // waves hand work to the next launch once 1 / room_div of this launch's waves have finished
+// Hand-over of subtrees between the waves of one launch (see fm_search_filter_kernel). All in HBM, zeroed before the launch but `items`:
+//   ctrl: waves started (MBC_STARTED), waves waiting or gone (MBC_WAITING), tail / head of the hungry list (MBC_TAIL, MBC_HEAD), a flag set once a
+//   wave's queue has been dry for long (MBC_LONG: the launch has heavy seeds: finished waves then wait for work instead of leaving) - each in
+//   a 128-byte line of its own: thousands of waiting waves poll MBC_WAITING, and the busy waves' looks at the list must not queue behind them
+//   state[w]: a wave's mailbox (MB_*); count[w]: the subtrees in it; hungry[]: waves waiting, in the order they asked (wave + 1)
+enum : u32 { MB_INACTIVE = 0, MB_WAITING = 1, MB_FILLING = 2, MB_FILLED = 3, MB_CLOSED = 4 };
+struct Mailboxes {
+    u32* ctrl; u32* state; u32* count; u32* hungry; FrameItem* items;      // null ctrl: no hand-over between waves
+    u32 n_hungry;                                                           // entries of the hungry list
 };
+constexpr u32 MBC_STARTED = 0, MBC_WAITING = 32, MBC_TAIL = 64, MBC_HEAD = 96, MBC_LONG = 128;
+constexpr u32 MB_CTRL_WORDS = 160, MB_HUNGRY_PER_WAVE = 4;
 
 namespace {
 
@@ -64,7 +70,8 @@ static u32 filter_k_for(u64 n) {        // FLX_FILTER_K overrides the default (0
     return filter_k_default(n);
 }
 
-size_t DeviceApi::frame_queue_bytes(u32 cap) { return (size_t)cap * 2 * sizeof(FrameItem); }
+// one launch's mailboxes for up to `waves` waves: the words that are zeroed per launch first, then the subtree slots
+size_t DeviceApi::mailbox_bytes(u32 waves) { return ((size_t)MB_CTRL_WORDS + (size_t)waves * (2 + MB_HUNGRY_PER_WAVE)) * 4 + 256 + (size_t)waves * 64 * sizeof(FrameItem); }
 
 size_t DeviceApi::derived_bytes(u64 n, u32* k_out) {
     u32 const k = filter_k_for(n);
@@ -143,8 +150,7 @@ int DeviceApi::pack_pool(void* stream, const u8* d_seq, u64 len, u32* d_qpack) {
 
 // ================================================================================================ the search kernels
 // counters (32 words): [0] hit slots reserved, [1] frame overflow flag, [2] cursor extensions (rank pairs), [3] subtrees queued (records
-//   written, without the unused ends of the slot ranges), [13] hits written (both kernels), [14] subtrees handed from lane to lane, [15] subtrees handed to the next launch,
-//   [20], [22] entries of the two queues between the launches of the filter walk, [21], [23] their heads, [24..26] waves of those launches that have finished,
+//   written, without the unused ends of the slot ranges), [13] hits written (both kernels), [14] subtrees handed from lane to lane, [15] subtrees handed from wave to wave,
 //   [4] wave-iterations, [5] their maximum over the waves, [6] busy lane-iterations, [7] seed queue head, [8] wave-iterations after the
 //   seed queue ran dry, [9] their maximum, [10] filter lookups, [11] children dropped by the filter, [12] searches ended by the prefix
 //   lookup, [16] item slots reserved, [17] item queue head, [18] text-mode lane-steps, [19] text-mode wave-iterations
@@ -209,26 +215,38 @@ __device__ __forceinline__ u32 wave_slots_take(WaveSlots& S, DevHit* __restrict_
 }
 }  // namespace
 
-// STATS: the diagnostic counters [11], [12] are kept (two more registers per lane). 112 VGPRs, no scratch (round 3: 128 + 72 B per lane
-// of spills inside the DFS loop, which went through HBM).
+// STATS: the diagnostic counters [11], [12] are kept (two more registers per lane). No scratch (round 3: 128 VGPRs + 72 B per lane of
+// spills inside the DFS loop, which went through HBM).
 //
 // Work sharing (seed_rows != null). On a text with repeat families a launch used to be the tail of its heaviest seeds: a seed inside a
 // diverged family walks tens of thousands of steps while the other lanes of its wave have run out of seeds (round 3: 97 % of the
 // wave-iterations after the queue ran dry, a tenth of the lanes busy).
-//  (1) inside a wave: once the wave's part of the work queue is dry, an idle lane takes the upper half of the not yet visited error
-//      children of a busy lane's BOTTOM frame (the shallowest one: the largest subtrees): it copies the frame (18 words, LDS to LDS) with
-//      that half as its mask and carries on as if it had got there itself, under the donor's seed, search and keys; the donor keeps the
-//      lower half and the match child.
-//  (2) between waves: when a quarter of the launch's waves have finished (the chip has room) the busy lanes of the others put such
-//      halves into a queue in HBM (FrameItem: the frame + the seed's identity, 96 B); the next launch of this kernel (FROM_FRAMES) takes
-//      its work from that queue instead of the seed list, and may fill a queue for a third launch. No wave ever waits for another one.
+//  (1) inside a wave: once the wave's part of the seed queue is dry, an idle lane takes work from a busy lane's BOTTOM frame (the
+//      shallowest one: the largest subtrees): the match child when there is one, else the upper half of the error children. It copies the
+//      frame (18 words, LDS to LDS) with those children as its mask and carries on as if it had got there itself, under the donor's
+//      seed, search and keys.
+//  (2) between waves (MB.ctrl != null): a wave with nothing left asks for work - it puts itself on a list in HBM and polls its mailbox;
+//      a busy wave that sees the list non-empty hands one subtree per lane that can spare one (FrameItem: the frame + the seed's
+//      identity, 96 B) into the asking wave's mailbox. No wave waits without a bound: a waiting wave leaves when every wave of the
+//      launch is waiting or gone, when not all waves of the launch are resident yet (it would hold their room), or after MB_POLLS polls;
+//      a mailbox changes hands by compare-and-swap (WAITING -> FILLING by the giver, WAITING -> CLOSED by its owner), so a subtree is
+//      never written into a mailbox nobody reads. Waves only wait in launches that have shown a long tail (ctrl[6]): on a uniform text
+//      a launch's waves finish within a hundred iterations of each other and leave at once.
 // Hits carry keys that restore the reference's emission order whoever emits them, so nothing downstream changes. What the walk of one
 // seed may stop on - more rows than the hard cap - is counted per seed in global memory (seed_rows), so that the lanes and waves that
 // share a seed stop together.
-template <bool STATS, bool FROM_FRAMES>
+constexpr u32 MB_POLLS = 100000;               // x (s_sleep of 3.4 us + one load) ~ 0.5 s: the bound, not the expected wait
+// (relaxed: a look at a control word must not cost the compute unit its vector cache, which an acquire would invalidate - the busy waves
+// look every few iterations, the waiting ones every few microseconds; the two places where data follows a flag fence explicitly)
+__device__ __forceinline__ u32 mb_load(const u32* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void mb_store(u32* p, u32 v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void mb_acquire() { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); }
+__device__ __forceinline__ void mb_release() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); }
+
+template <bool STATS>
 __global__ void __launch_bounds__(64, 4) fm_search_filter_kernel(FmConst C, u32 n_seeds, DevHit* __restrict__ hits,
                                                               u32 hit_cap, DevHit* __restrict__ items, u32 item_cap, u32* __restrict__ counters,
-                                                              u32* __restrict__ seed_cnt, u32* __restrict__ seed_rows, FrameQueues FQ, u32 refill, u32 prio, u32 steal_min, u32 steal_after) {
+                                                              u32* __restrict__ seed_cnt, u32* __restrict__ seed_rows, Mailboxes MB, u32 refill, u32 prio, u32 steal_min, u32 steal_after) {
     extern __shared__ u32 lds[];                // frames: [level][FM_FRAME_WORDS][64 lanes], then 64 words for the pairing of lanes
     if (prio == 3u) __builtin_amdgcn_s_setprio(3);
     else if (prio == 2u) __builtin_amdgcn_s_setprio(2);
@@ -237,15 +255,15 @@ __global__ void __launch_bounds__(64, 4) fm_search_filter_kernel(FmConst C, u32 
     u64 const lanes_below = (1ull << lane) - 1ull;
     auto fr = [&](u32 level, u32 word) -> u32& { return lds[(level * FM_FRAME_WORDS + word) * 64u + lane]; };
     const DevSeed* __restrict__ seeds = C.seeds;
-    u32 const n_work = FROM_FRAMES ? min(counters[FQ.in_count], FQ.cap) : n_seeds;      // (the launch that filled the queue has finished: same stream)
-    u32* const work_head = &counters[FROM_FRAMES ? FQ.in_head : 7u];
     WaveQueue Q;
     WaveSlots HS, IS;
     FmLane L;
     bool exhausted = false;
     u32 n_iter = 0, n_busy_iter = 0, n_tail_iter = 0, n_hits = 0, n_items = 0, n_steals = 0, n_given = 0;      // (wave-uniform but n_busy_iter)
-    bool room = false;                          // enough waves of this launch have finished for handing work to the next one to pay
+    bool counted_waiting = false, flagged_long = false;                                                         // (wave-uniform)
     u32* const pair = lds + C.levels * FM_FRAME_WORDS * 64u;
+    u32 const me = blockIdx.x;
+    if (MB.ctrl && lane == 0) atomicAdd(&MB.ctrl[MBC_STARTED], 1u);
 
     while (true) {
         // ---- what the lanes produced in the last iteration (read from the node's registers, see FmLane)
@@ -277,7 +295,7 @@ __global__ void __launch_bounds__(64, 4) fm_search_filter_kernel(FmConst C, u32 
         }
         if (out == 3u) { atomicOr(&counters[1], 1u); L.wn = 0; }        // frames ran out (the caller repeats the launch another way)
         else L.clear_out();
-        // ---- work for the idle lanes, and the start of the next search for the lanes between two searches - in batches. Taking a seed
+        // ---- seeds for the idle lanes, and the start of the next search for the lanes between two searches - in batches. Taking a seed
         //      and starting a search are chains of dependent loads (seed record, scheme entries, packed symbols, filter word, k-mer
         //      table: ~7 us) that every lane of the wave waits for; a lane gets there every dozen iterations, so with 64 lanes some lane
         //      is there in every iteration. Lanes at that point therefore wait until `refill` of them are, or no lane is inside a search.
@@ -288,37 +306,28 @@ __global__ void __launch_bounds__(64, 4) fm_search_filter_kernel(FmConst C, u32 
         bool const go = (u32)__popcll(at_boundary) >= refill || !__any(busy && in_search);
         u64 const idle = go ? __ballot(want) : 0ull;
         if (idle) {                                                     // wave-uniform
-            u32 const k = wave_queue_take(Q, work_head, n_work, want, idle, lane, lanes_below);
+            u32 const k = wave_queue_take(Q, &counters[7], n_seeds, want, idle, lane, lanes_below);
             if (want) {
-                if (k == 0xFFFFFFFFu) exhausted = true;
-                else if (!FROM_FRAMES) fm_take_seed(C, L, seeds[k], k);
-                else {
-                    // a subtree another wave handed over: its frame becomes this lane's bottom frame
-                    const uint4* __restrict__ src = reinterpret_cast<const uint4*>(FQ.in[k].w);
-                    uint4 const q0 = src[0], q1 = src[1], q2 = src[2], q3 = src[3], q4 = src[4], q5 = src[5];
-                    fr(0, 0) = q0.x; fr(0, 1) = q0.y; fr(0, 2) = q0.z; fr(0, 3) = q0.w; fr(0, 4) = q1.x; fr(0, 5) = q1.y; fr(0, 6) = q1.z; fr(0, 7) = q1.w;
-                    fr(0, 8) = q2.x; fr(0, 9) = q2.y; fr(0, 10) = q2.z; fr(0, 11) = q2.w; fr(0, 12) = q3.x; fr(0, 13) = q3.y; fr(0, 14) = q3.z; fr(0, 15) = q3.w;
-                    fr(0, 16) = q4.x; fr(0, 17) = q4.y;
-                    L.pos = q4.z; L.exo = q4.w; L.ws = q5.x | (1u << 28); L.qoff = (u64)q5.y | ((u64)q5.z << 32);
-                    L.ct = 0;
-                    L.wn = WN_BUSY | WN_IN_SEARCH | WN_NEED_CHILD | WN_DEPTH1;
-                }
+                if (k != 0xFFFFFFFFu) fm_take_seed(C, L, seeds[k], k);
+                else exhausted = true;
             }
         }
-        bool const tail = Q.done && Q.next == Q.end;                   // wave-uniform: this wave gets no more work from the queue
+        bool const tail = Q.done && Q.next == Q.end;                   // wave-uniform: this wave gets no more seeds
         if (tail && seed_rows) {
             if (!L.busy()) exhausted = true;                            // (a lane that waited for a batch of seeds: there is none)
-            if (FQ.out && !room && n_tail_iter >= steal_after && (n_iter & 15u) == 0u) {
-                u32 d = 0;
-                if (lane == 0) d = __hip_atomic_load(&counters[FQ.done], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                room = (u32)__builtin_amdgcn_readfirstlane((int)d) * FQ.room_div >= gridDim.x;
-            }
+            bool const long_tail = n_tail_iter >= steal_after;          // (a short tail - a uniform text: 100 iterations - is over before sharing it pays)
+            if (MB.ctrl && !flagged_long && n_tail_iter >= 4u * steal_after) { flagged_long = true; if (lane == 0) mb_store(&MB.ctrl[MBC_LONG], 1u); }
             bool const idle_lane = !L.busy();
-            // (a short tail - a uniform text: 100 iterations - is over before sharing it pays for its ballots and copies)
-            u64 const thieves = n_tail_iter >= steal_after ? __ballot(idle_lane) : 0ull;
-            bool const to_next = room && (n_iter & 3u) == 0u;           // (wave-uniform)
-            if ((thieves && (u32)__popcll(thieves) >= steal_min) || to_next) {
-                // donors: lanes inside a search whose bottom frame has error children to spare
+            u64 const thieves = long_tail ? __ballot(idle_lane) : 0ull;
+            // is a wave asking for work? (one look every fourth iteration of a long tail)
+            bool asked = false;
+            if (MB.ctrl && long_tail && (n_iter & 3u) == 0u) {
+                u32 a = 0;
+                if (lane == 0) { u32 const t = min(mb_load(&MB.ctrl[MBC_TAIL]), MB.n_hungry); a = mb_load(&MB.ctrl[MBC_HEAD]) < t ? 1u : 0u; }
+                asked = __builtin_amdgcn_readfirstlane((int)a) != 0;
+            }
+            if ((thieves && (u32)__popcll(thieves) >= steal_min) || asked) {
+                // donors: lanes inside a search whose bottom frame has something to spare
                 u32 fmask = 0;
                 if (L.busy() && L.in_search() && L.depth() >= 1u) fmask = fr(0, 14);
                 u32 const costly = fmask & ~1u;
@@ -362,29 +371,89 @@ __global__ void __launch_bounds__(64, 4) fm_search_filter_kernel(FmConst C, u32 
                     }
                     n_steals += n_pairs;
                 }
-                // what no lane of this wave took goes to the next launch while the chip has room
-                bool const sends = to_next && donor && !gives;
+                // what no lane of this wave took goes to a wave that asked
+                bool const sends = asked && donor && !gives;
                 u64 const sending = __ballot(sends);
                 if (sending) {
-                    u32 base = 0;
-                    if (lane == 0) base = atomicAdd(&counters[FQ.out_count], (u32)__popcll(sending));
-                    base = (u32)__builtin_amdgcn_readfirstlane((int)base);
-                    u32 const slot = base + (u32)__popcll(sending & lanes_below);
-                    if (sends && slot < FQ.cap) {
-                        uint4* __restrict__ dst = reinterpret_cast<uint4*>(FQ.out[slot].w);
-                        dst[0] = uint4{fr(0, 0), fr(0, 1), fr(0, 2), fr(0, 3)};
-                        dst[1] = uint4{fr(0, 4), fr(0, 5), fr(0, 6), fr(0, 7)};
-                        dst[2] = uint4{fr(0, 8), fr(0, 9), fr(0, 10), fr(0, 11)};
-                        dst[3] = uint4{fr(0, 12), fr(0, 13), give, fr(0, 15)};
-                        dst[4] = uint4{fr(0, 16), fr(0, 17), L.pos, L.exo};
-                        dst[5] = uint4{L.ws, (u32)L.qoff, (u32)(L.qoff >> 32), 0u};
-                        fr(0, 14) = fmask & ~give;
+                    // the first asking wave whose mailbox is still open (lane 0 negotiates)
+                    u32 to = 0xFFFFFFFFu;
+                    if (lane == 0) {
+                        u32 const h = mb_load(&MB.ctrl[MBC_HEAD]);
+                        if (h < min(mb_load(&MB.ctrl[MBC_TAIL]), MB.n_hungry) && atomicCAS(&MB.ctrl[MBC_HEAD], h, h + 1u) == h) {
+                            u32 id = 0;
+                            for (u32 spin = 0; spin < 100000u && (id = mb_load(&MB.hungry[h])) == 0u; ++spin) __builtin_amdgcn_s_sleep(1);      // (written right after the slot was taken)
+                            if (id && atomicCAS(&MB.state[id - 1u], (u32)MB_WAITING, (u32)MB_FILLING) == MB_WAITING) to = id - 1u;      // (a read-modify-write sees the latest value)
+                        }
                     }
-                    n_given += (u32)__popcll(sending);
+                    to = (u32)__builtin_amdgcn_readfirstlane((int)to);
+                    if (to != 0xFFFFFFFFu) {
+                        if (sends) {
+                            uint4* __restrict__ dst = reinterpret_cast<uint4*>(MB.items[(size_t)to * 64u + (u32)__popcll(sending & lanes_below)].w);
+                            dst[0] = uint4{fr(0, 0), fr(0, 1), fr(0, 2), fr(0, 3)};
+                            dst[1] = uint4{fr(0, 4), fr(0, 5), fr(0, 6), fr(0, 7)};
+                            dst[2] = uint4{fr(0, 8), fr(0, 9), fr(0, 10), fr(0, 11)};
+                            dst[3] = uint4{fr(0, 12), fr(0, 13), give, fr(0, 15)};
+                            dst[4] = uint4{fr(0, 16), fr(0, 17), L.pos, L.exo};
+                            dst[5] = uint4{L.ws, (u32)L.qoff, (u32)(L.qoff >> 32), 0u};
+                            fr(0, 14) = fmask & ~give;
+                        }
+                        if (lane == 0) MB.count[to] = (u32)__popcll(sending);
+                        mb_release();                                   // the subtrees and their number before the flag
+                        if (lane == 0) mb_store(&MB.state[to], (u32)MB_FILLED);
+                        n_given += (u32)__popcll(sending);
+                    }
                 }
             }
         }
-        if (__all(exhausted && !L.busy())) break;
+        if (__all(exhausted && !L.busy())) {
+            // ---- nothing left in this wave: leave, or ask the waves that are still busy for work
+            if (!MB.ctrl) break;
+            u32 verdict = 0;                                            // 0 leave, 1 a mailbox with work
+            if (lane == 0) {
+                bool const all_started = mb_load(&MB.ctrl[MBC_STARTED]) >= gridDim.x, long_launch = mb_load(&MB.ctrl[MBC_LONG]) != 0u;
+                if (all_started && long_launch) {
+                    mb_store(&MB.state[me], (u32)MB_WAITING);
+                    mb_release();                                       // (the mailbox is open before anyone can find it on the list)
+                    u32 const slot = atomicAdd(&MB.ctrl[MBC_TAIL], 1u);
+                    if (slot < MB.n_hungry) mb_store(&MB.hungry[slot], me + 1u);
+                    if (!counted_waiting) atomicAdd(&MB.ctrl[MBC_WAITING], 1u);
+                    u32 st = MB_WAITING;
+                    if (slot < MB.n_hungry)
+                        for (u32 p = 0; p < MB_POLLS; ++p) {
+                            st = mb_load(&MB.state[me]);
+                            if (st == MB_FILLED) break;
+                            if ((p & 7u) == 7u && mb_load(&MB.ctrl[MBC_WAITING]) >= gridDim.x) break;      // nobody is left to give any
+                            __builtin_amdgcn_s_sleep(127);
+                        }
+                    if (st != MB_FILLED) {
+                        u32 const old = atomicCAS(&MB.state[me], (u32)MB_WAITING, (u32)MB_CLOSED);
+                        if (old == MB_FILLING || old == MB_FILLED) {                              // a giver got in first: it is writing (it never waits)
+                            for (u32 p = 0; p < MB_POLLS && (st = mb_load(&MB.state[me])) != MB_FILLED; ++p) __builtin_amdgcn_s_sleep(8);
+                            if (st != MB_FILLED) atomicOr(&counters[1], 2u);                      // (cannot happen; if it does the call fails instead of losing a subtree)
+                        }
+                    }
+                    if (st == MB_FILLED) { verdict = 1; atomicSub(&MB.ctrl[MBC_WAITING], 1u); }
+                    else verdict = 2;                                   // (counted as waiting for good)
+                }
+            }
+            verdict = (u32)__builtin_amdgcn_readfirstlane((int)verdict);
+            if (verdict == 2u) counted_waiting = true;
+            if (verdict != 1u) break;
+            mb_acquire();                                               // the flag before the subtrees
+            u32 const n_in = min(MB.count[me], 64u);
+            if (lane < n_in) {
+                // a subtree another wave handed over: its frame becomes this lane's bottom frame
+                const uint4* __restrict__ src = reinterpret_cast<const uint4*>(MB.items[(size_t)me * 64u + lane].w);
+                uint4 const q0 = src[0], q1 = src[1], q2 = src[2], q3 = src[3], q4 = src[4], q5 = src[5];
+                fr(0, 0) = q0.x; fr(0, 1) = q0.y; fr(0, 2) = q0.z; fr(0, 3) = q0.w; fr(0, 4) = q1.x; fr(0, 5) = q1.y; fr(0, 6) = q1.z; fr(0, 7) = q1.w;
+                fr(0, 8) = q2.x; fr(0, 9) = q2.y; fr(0, 10) = q2.z; fr(0, 11) = q2.w; fr(0, 12) = q3.x; fr(0, 13) = q3.y; fr(0, 14) = q3.z; fr(0, 15) = q3.w;
+                fr(0, 16) = q4.x; fr(0, 17) = q4.y;
+                L.pos = q4.z; L.exo = q4.w; L.ws = q5.x | (1u << 28); L.qoff = (u64)q5.y | ((u64)q5.z << 32);
+                L.ct = 0;
+                L.wn = WN_BUSY | WN_IN_SEARCH | WN_NEED_CHILD | WN_DEPTH1;
+            }
+            if (lane == 0) mb_store(&MB.state[me], (u32)MB_INACTIVE);
+        }
         ++n_iter;
         if (tail) ++n_tail_iter;
         if (!L.busy() || (!go && !L.in_search())) continue;
@@ -395,7 +464,7 @@ __global__ void __launch_bounds__(64, 4) fm_search_filter_kernel(FmConst C, u32 
     wave_slots_close(IS, items, item_cap, lane);
     u32 const s_ext = s_wave_sum(L.n_ext), s_busy = s_wave_sum(n_busy_iter), s_look = s_wave_sum(L.n_lookup);
     if (lane == 0) {
-        atomicAdd(&counters[FQ.done], 1u);
+        if (MB.ctrl && !counted_waiting) atomicAdd(&MB.ctrl[MBC_WAITING], 1u);       // gone: nothing more to give
         atomicAdd(&counters[2], s_ext); atomicAdd(&counters[6], s_busy);
         atomicAdd(&counters[4], n_iter); atomicMax(&counters[5], n_iter); atomicAdd(&counters[8], n_tail_iter); atomicMax(&counters[9], n_tail_iter);
         atomicAdd(&counters[10], s_look); atomicAdd(&counters[13], n_hits); atomicAdd(&counters[3], n_items); atomicAdd(&counters[14], n_steals);
@@ -516,7 +585,7 @@ static u32 env_u32(const char* name, u32 dflt) {
 // queued). frame_levels = largest error count of a seed. d_counters: 32 words, zeroed by the caller.
 int DeviceApi::search_filtered(void* stream, const DevIndex& idx, const u8* d_seq, const u32* d_qpack, const u64* d_scheme, const DevSeed* d_seeds,
                                u32 n_seeds, u32 max_hits_per_seed, u32 frame_levels, DevHit* d_hits, u32 hit_cap, DevHit* d_items, u32 item_cap,
-                               u32* d_counters, u32* d_seed_cnt, u32* d_seed_rows, void* d_frame_queues, u32 frame_queue_cap, u32 concurrent_launches) {
+                               u32* d_counters, u32* d_seed_cnt, u32* d_seed_rows, void* d_mailboxes, u32 mailbox_waves, u32 concurrent_launches) {
     if (n_seeds == 0) return 0;
     static u32 const spw = env_u32("FLX_FM_SEEDS_PER_WAVE", 256);
     static u32 const forced_waves = env_u32("FLX_FM_MAX_WAVES", 0);
@@ -544,27 +613,19 @@ int DeviceApi::search_filtered(void* stream, const DevIndex& idx, const u8* d_se
     u32* const seed_rows = steal_min ? d_seed_rows : nullptr;
     u32 const steal_after = env_u32("FLX_FM_STEAL_AFTER", 64);         // iterations a wave's queue has been dry before its lanes share work
     static u32 const stats = env_u32("FLX_SEARCH_DEBUG", 0);           // the diagnostic counters [11], [12] cost two registers per lane
-    // rounds: the walk over the seeds, then (with work sharing) up to two more launches over the subtrees the launch before handed on
-    u32 const rounds = (seed_rows && d_frame_queues && frame_queue_cap) ? std::max(1u, std::min(3u, env_u32("FLX_FM_ROUNDS", 1))) : 1u;
-    FrameItem* const q0 = (FrameItem*)d_frame_queues;
-    FrameItem* const q1 = q0 ? q0 + frame_queue_cap : nullptr;
-    for (u32 r = 0; r < rounds; ++r) {
-        FrameQueues FQ{};
-        FQ.cap = frame_queue_cap;
-        FQ.in = r == 0 ? nullptr : (r == 1 ? q0 : q1);
-        FQ.out = r + 1 < rounds ? (r == 0 ? q0 : q1) : nullptr;
-        FQ.in_count = r == 1 ? 20u : 22u; FQ.in_head = r == 1 ? 21u : 23u;
-        FQ.out_count = r == 0 ? 20u : (r == 1 ? 22u : 27u);
-        FQ.done = 24u + r;
-        FQ.room_div = std::max(1u, env_u32("FLX_FM_ROOM_DIV", 4));
-        if (r == 0) {
-            auto const kernel = stats ? fm_search_filter_kernel<true, false> : fm_search_filter_kernel<false, false>;
-            hipLaunchKernelGGL(kernel, grid, dim3(64), lds_bytes, s, C, n_seeds, d_hits, hit_cap, d_items, item_cap, d_counters, d_seed_cnt, seed_rows, FQ, refill_a, fm_prio, std::max(1u, steal_min), steal_after);
-        } else {
-            auto const kernel = stats ? fm_search_filter_kernel<true, true> : fm_search_filter_kernel<false, true>;
-            hipLaunchKernelGGL(kernel, grid, dim3(64), lds_bytes, s, C, n_seeds, d_hits, hit_cap, d_items, item_cap, d_counters, d_seed_cnt, seed_rows, FQ, refill_a, fm_prio, std::max(1u, steal_min), steal_after);
-        }
+    // the mailboxes of this launch's waves: control words, states, counts and the hungry list zeroed, then the subtree slots
+    Mailboxes MB{};
+    if (seed_rows && d_mailboxes && mailbox_waves >= grid.x && env_u32("FLX_FM_NO_MAILBOXES", 0) == 0) {
+        u32* const words = (u32*)d_mailboxes;
+        size_t const zeroed = ((size_t)MB_CTRL_WORDS + (size_t)grid.x * (2 + MB_HUNGRY_PER_WAVE)) * 4;
+        hipError_t const e = hipMemsetAsync(words, 0, zeroed, s);
+        if (e != hipSuccess) return (int)e;
+        MB.ctrl = words; MB.state = words + MB_CTRL_WORDS; MB.count = MB.state + grid.x; MB.hungry = MB.count + grid.x;
+        MB.n_hungry = grid.x * MB_HUNGRY_PER_WAVE;
+        MB.items = reinterpret_cast<FrameItem*>((char*)d_mailboxes + (zeroed + 255) / 256 * 256);
     }
+    auto const kernel = stats ? fm_search_filter_kernel<true> : fm_search_filter_kernel<false>;
+    hipLaunchKernelGGL(kernel, grid, dim3(64), lds_bytes, s, C, n_seeds, d_hits, hit_cap, d_items, item_cap, d_counters, d_seed_cnt, seed_rows, MB, refill_a, fm_prio, std::max(1u, steal_min), steal_after);
     if (C.text_min_remain) {
         // (the number of queued subtrees is only known on the device: a fixed grid, waves without work leave at once; the walk is a
         // chain of dependent loads from the L2, so it wants every wave slot: 8 per SIMD)

@@ -14,16 +14,30 @@ namespace flx {
 // libstdc++'s std::sort (bits/stl_algo.h: introsort with median-of-three pivots down to 16 elements, then insertion sort), step
 // for step: the reference orders hit groups and anchor buckets with it, its comparators tie often, and what it does with equal
 // elements shows in the output. Returns false if the depth limit is reached (the heap-sort fallback is left to the host).
+// An element held aside while others move. Word by word: a struct copied whole between LDS and a local is a memcpy the GPU compiler
+// leaves in scratch memory.
+template <class T>
+struct SortVal {
+    static_assert(sizeof(T) % 4 == 0, "elements are whole words");
+    unsigned w[sizeof(T) / 4];
+    // (four-byte memcpys: one load / store each, and no aliasing assumptions for the host compiler to act on)
+    FLX_SORT_HD explicit SortVal(T const& src) { for (unsigned k = 0; k < sizeof(T) / 4; ++k) __builtin_memcpy(&w[k], reinterpret_cast<const char*>(&src) + 4 * k, 4); }
+    FLX_SORT_HD T get() const { T t; for (unsigned k = 0; k < sizeof(T) / 4; ++k) __builtin_memcpy(reinterpret_cast<char*>(&t) + 4 * k, &w[k], 4); return t; }
+    FLX_SORT_HD void put(T& dst) const { for (unsigned k = 0; k < sizeof(T) / 4; ++k) __builtin_memcpy(reinterpret_cast<char*>(&dst) + 4 * k, &w[k], 4); }
+};
+template <class T>
+FLX_SORT_HD inline void sort_move(T& dst, T const& src) { SortVal<T>(src).put(dst); }
+
 // (up to 16 elements std::sort is its final insertion sort alone: no pivots, no stack - and stable)
 template <class T, class Less>
 FLX_SORT_HD void insertion_sort_emulated(T* a, int n, Less less) {
     for (int i = 1; i < n; ++i) {
-        T const val = a[i];
-        if (less(val, a[0])) { for (int j = i; j > 0; --j) a[j] = a[j - 1]; a[0] = val; }
+        SortVal<T> const val(a[i]);
+        if (less(val.get(), a[0])) { for (int j = i; j > 0; --j) sort_move(a[j], a[j - 1]); val.put(a[0]); }
         else {
             int last = i, next = i - 1;
-            while (less(val, a[next])) { a[last] = a[next]; last = next; --next; }
-            a[last] = val;
+            while (less(val.get(), a[next])) { sort_move(a[last], a[next]); last = next; --next; }
+            val.put(a[last]);
         }
     }
 }
@@ -31,16 +45,16 @@ FLX_SORT_HD void insertion_sort_emulated(T* a, int n, Less less) {
 // stacks: 48 ints of working storage for the partitions still to do (a kernel passes LDS: indexed private arrays live in scratch memory)
 template <class T, class Less>
 FLX_SORT_HD bool std_sort_emulated(T* a, int n, Less less, int* stacks) {
-    auto swap_at = [&](int i, int j) { T const t = a[i]; a[i] = a[j]; a[j] = t; };
+    auto swap_at = [&](int i, int j) { SortVal<T> const t(a[i]); sort_move(a[i], a[j]); t.put(a[j]); };
     auto unguarded_linear_insert = [&](int last) {
-        T const val = a[last];
+        SortVal<T> const val(a[last]);
         int next = last - 1;
-        while (less(val, a[next])) { a[last] = a[next]; last = next; --next; }
-        a[last] = val;
+        while (less(val.get(), a[next])) { sort_move(a[last], a[next]); last = next; --next; }
+        val.put(a[last]);
     };
     auto insertion_sort = [&](int first, int last) {
         for (int i = first + 1; i < last; ++i) {
-            if (less(a[i], a[first])) { T const val = a[i]; for (int j = i; j > first; --j) a[j] = a[j - 1]; a[first] = val; }
+            if (less(a[i], a[first])) { SortVal<T> const val(a[i]); for (int j = i; j > first; --j) sort_move(a[j], a[j - 1]); val.put(a[first]); }
             else unguarded_linear_insert(i);
         }
     };

@@ -17,9 +17,10 @@ print('$tag', d['value'], 'reads/s', d['ms_per_step'], 'ms/step; isolated', {n: 
 PY
     grep -h "^\[fm_search\]" $O/$tag.err | tail -1 | cut -c1-330
 }
-run rounds3 FLX_FM_ROUNDS=3 && run rounds1 FLX_FM_ROUNDS=1 || exit 1
+run mailboxes FLX_FM_NO_MAILBOXES=0 || exit 1
+exit 0
 # the text walk with and without its LDS windows, one-lane pass on the uniform reference
-for w in 0 1; do
+for w in 0; do
   FLX_FM_NO_WINDOWS=$w FLX_SEARCH_DEBUG=1 timeout -k 10 400 python3 $R/bench.py --isolated-only --no-cpu-baseline > $O/iso_nowin$w.json 2> $O/iso_nowin$w.err || { tail -5 $O/iso_nowin$w.err; exit 1; }
   python3 -c "
 import json

@@ -5,14 +5,16 @@
 #include <vector>
 #include <random>
 #include <chrono>
-// The literal-only deflate encoder of the BAM writer (flx_io.cpp: literal_deflate) against zlib's inflate: every block must come back
+// The deflate encoders of the BAM writer (flx_io.cpp: lz_deflate, the default: hash-chainless string matching + one dynamic-Huffman block;
+// literal_deflate: literals only) against zlib's inflate: every block must come back
 // byte for byte - empty and tiny blocks, one symbol, all 256 symbols, skewed distributions whose Huffman trees are deeper than the 15
 // bits deflate allows, incompressible data (stored block), full-size blocks. Test infrastructure; the encoder is pulled in by including
 // the source (it lives in an anonymous namespace).
 #include "../floxer_amd/csrc/flx_io.cpp"
-static bool roundtrip(const std::vector<uint8_t>& in) {
-    std::vector<uint8_t> out(in.size() + 1024);
-    size_t const c = literal_deflate(in.data(), in.size(), out.data());
+static bool roundtrip_with(const std::vector<uint8_t>& in, bool lz) {
+    std::vector<uint8_t> out(in.size() + 2048);
+    size_t const c = lz ? lz_deflate(in.data(), in.size(), out.data()) : literal_deflate(in.data(), in.size(), out.data());
+    if (c > in.size() + 600) { printf("FAIL n=%zu: %zu bytes out\n", in.size(), c); return false; }
     std::vector<uint8_t> back(in.size() + 16);
     z_stream zs; memset(&zs, 0, sizeof(zs));
     inflateInit2(&zs, -15);
@@ -20,8 +22,23 @@ static bool roundtrip(const std::vector<uint8_t>& in) {
     int rc = inflate(&zs, Z_FINISH);
     bool ok = rc == Z_STREAM_END && zs.total_out == in.size() && memcmp(back.data(), in.data(), in.size()) == 0 && zs.avail_in == 0;
     inflateEnd(&zs);
-    if (!ok) printf("FAIL n=%zu rc=%d out=%lu c=%zu\n", in.size(), rc, zs.total_out, c);
+    if (!ok) printf("FAIL (%s) n=%zu rc=%d out=%lu c=%zu\n", lz ? "lz" : "literal", in.size(), rc, zs.total_out, c);
     return ok;
+}
+static bool roundtrip(const std::vector<uint8_t>& in) { return roundtrip_with(in, false) & roundtrip_with(in, true); }
+// BAM-like payload: records of a fixed head + a CIGAR array of `words` words; `repeat` consecutive records share the array
+static std::vector<uint8_t> bam_like(std::mt19937& rng, size_t n, unsigned words, unsigned repeat) {
+    std::vector<uint8_t> v;
+    std::vector<uint32_t> cig;
+    unsigned k = 0;
+    while (v.size() < n) {
+        if (k++ % repeat == 0) { cig.clear(); for (unsigned w = 0; w < words; ++w) cig.push_back(w % 2 ? ((1u << 4) | (rng() % 3 == 0 ? 8 : rng() % 2 + 1)) : (((rng() % 23) + 1) << 4 | 7)); }
+        uint8_t head[36]; for (auto& b : head) b = (uint8_t)rng();
+        v.insert(v.end(), head, head + 36);
+        const uint8_t* p = (const uint8_t*)cig.data(); v.insert(v.end(), p, p + cig.size() * 4);
+    }
+    v.resize(n);
+    return v;
 }
 int main() {
     std::mt19937 rng(1);
@@ -44,6 +61,36 @@ int main() {
     }
     // fibonacci-like frequencies force lengths > 15
     { std::vector<uint8_t> v; unsigned a = 1, b = 1; for (unsigned s = 0; s < 24 && v.size() < 65000; ++s) { for (unsigned k = 0; k < a && v.size() < 65280; ++k) v.push_back((uint8_t)s); unsigned t = a + b; a = b; b = t; } ok &= roundtrip(v); }
+    // repeats: records that share their CIGAR array (default flags), at distances below and above the 32-KB window, runs longer than 258,
+    // overlapping matches (runs of one byte / one word), a repeat that ends at the block's last byte
+    for (unsigned words : {3u, 70u, 1600u, 9000u}) for (unsigned rep : {1u, 2u, 40u}) for (size_t n : {500ul, 65280ul}) ok &= roundtrip(bam_like(rng, n, words, rep));
+    { std::vector<uint8_t> v(65280, 7); ok &= roundtrip(v); for (size_t i = 0; i < v.size(); ++i) v[i] = (uint8_t)("ACGT"[i % 4]); ok &= roundtrip(v); }
+    { std::vector<uint8_t> v(40000); for (auto& b : v) b = (uint8_t)rng(); std::vector<uint8_t> w = v; w.insert(w.end(), v.begin(), v.begin() + 25280); ok &= roundtrip(w); }
+    for (int r = 0; r < 200; ++r) {                                       // random mixtures of literal stretches and copies
+        std::vector<uint8_t> v;
+        size_t const n = 64 + rng() % 65217;
+        while (v.size() < n) {
+            if (v.size() > 8 && rng() % 3) { size_t const d = 1 + rng() % std::min<size_t>(v.size(), 40000), l = 3 + rng() % 700; for (size_t k = 0; k < l && v.size() < n; ++k) v.push_back(v[v.size() - d]); }
+            else { size_t const l = 1 + rng() % 300; for (size_t k = 0; k < l && v.size() < n; ++k) v.push_back((uint8_t)(rng() % (1 + rng() % 255))); }
+        }
+        ok &= roundtrip(v);
+    }
+    // speed and size on BAM-like data: one record per read (-I) and forty records sharing a CIGAR (default flags), against zlib level 1
+    for (unsigned rep : {1u, 40u}) {
+        std::vector<uint8_t> b = bam_like(rng, 65280, 1600, rep);
+        std::vector<uint8_t> o(70000);
+        for (int enc = 0; enc < 3; ++enc) {
+            auto t0 = std::chrono::steady_clock::now(); size_t c = 0;
+            int const reps = enc == 2 ? 300 : 2000;
+            for (int r = 0; r < reps; ++r) {
+                if (enc == 0) c = lz_deflate(b.data(), b.size(), o.data());
+                else if (enc == 1) c = literal_deflate(b.data(), b.size(), o.data());
+                else { uLongf dl = (uLongf)o.size(); compress2(o.data(), &dl, b.data(), (uLong)b.size(), 1); c = dl; }
+            }
+            double const s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+            printf("records sharing a CIGAR: %2u  %-8s %6.0f MB/s  ratio %6.2f\n", rep, enc == 0 ? "lz" : enc == 1 ? "literal" : "zlib -1", reps * 65280 / 1e6 / s, 65280.0 / c);
+        }
+    }
     // speed on CIGAR-like data
     std::vector<uint8_t> buf(65280);
     for (size_t i = 0; i + 4 <= buf.size(); i += 4) { uint32_t w = (i / 4) % 2 ? ((1u << 4) | (rng() % 3 == 0 ? 8 : rng() % 2 + 1)) : (((rng() % 23) + 1) << 4 | 7); memcpy(&buf[i], &w, 4); }

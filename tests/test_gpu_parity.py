@@ -598,18 +598,23 @@ def test_existence_kernel_forms_give_the_same_records():
             "g = S.make_genome(500000, 2, seed=161); r, _, _ = S.make_reads(g, 24, 6000, 0.08, seed=162);"
             "c = F.context(F.fmindex(g)); print(json.dumps(F.aligner(c, F.params(error_probability=0.08)).align_reads(r).records()))"
             % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-    for env in ({"FLX_EXISTS_STEPWISE": "1"}, {"FLX_EXISTS_LANES": "1"}, {"FLX_EXISTS_LANES": "1", "FLX_ROUNDS_QUEUED": "1"}):
+    for env in ({"FLX_EXISTS_STEPWISE": "1"}, {"FLX_EXISTS_LANES": "1"}, {"FLX_EXISTS_LANES": "1", "FLX_ROUNDS_QUEUED": "1"},
+                {"FLX_EXISTS_LANES": "1", "FLX_EXISTS_TEAM": "1"}, {"FLX_EXISTS_LANES": "1", "FLX_EXISTS_TEAM": "8"}):
         out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env), capture_output=True, text=True, check=True)
         assert [tuple(r) for r in json.loads(out.stdout.strip().split("\n")[-1])] == exp.records(), env
 
 
-def test_existence_with_cutoff_matches_oracle(small_genome, monkeypatch):
-    """ed_exists_lane_kernel (FLX_EXISTS_LANES=1) against the oracle's Myers on what the cutoff has to get right: several occurrences in one window (tandem
+@pytest.mark.parametrize("team", [None, "2", "4", "8", "16"])
+def test_existence_with_cutoff_matches_oracle(small_genome, monkeypatch, team):
+    """ed_exists_lane_kernel / ed_exists_team_kernel<P> (FLX_EXISTS_LANES=1; team: P lanes per job, each on every P-th word group one block
+    behind the lane of the group above - also with more lanes than a job has groups) against the oracle's Myers on what the cutoff has to get right: several occurrences in one window (tandem
     repeats with periods around the group height, a second occurrence far to the right of the first), budgets from 0 to more than the
     query is long, low-complexity sequence (every diagonal alive), occurrences at either edge of the window, windows shorter than the
     query, N runs; ragged sizes across word-group boundaries in one launch"""
     _, _, ctx, _ = small_genome
     monkeypatch.setenv("FLX_EXISTS_LANES", "1")
+    if team:
+        monkeypatch.setenv("FLX_EXISTS_TEAM", team)
     rng = np.random.default_rng(77)
     refs, queries, jobs = [], [], []
     ro = qo = 0
