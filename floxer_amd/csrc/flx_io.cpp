@@ -170,7 +170,7 @@ size_t literal_deflate(const uint8_t* data, size_t n, uint8_t* out) {
 }
 
 // ---- A deflate stream with string matching of the cheap kind (the default): long repeats only - every eighth position enters a hash
-// table of eight-byte strings, every position is looked up, a hit is extended both ways eight bytes at a time and taken from 24 bytes
+// table of sixteen-byte strings, every position is looked up, a hit is extended both ways eight bytes at a time and taken from 24 bytes
 // on - then one dynamic-Huffman block. What it is for: without
 // --interval-optimization the windows of one locus all take their union's alignment, so a read's forty records carry the same 6-8 KB
 // CIGAR array one after the other - a back-reference of a few bytes instead of 8 KB of literals (zlib level 1 finds the same repeats
@@ -222,23 +222,30 @@ size_t lz_deflate(const uint8_t* data, size_t n, uint8_t* out) {
     memset(dfreq, 0, sizeof(dfreq));
     auto read64 = [&](size_t i) { uint64_t v; memcpy(&v, data + i, 8); return v; };
     size_t i = 0, lit_start = 0;
-    size_t const last = n - 8;                             // positions from which eight bytes can be read
-    unsigned miss = 0;
+    size_t const last = n - 16;                            // positions from which sixteen bytes can be read
     auto flush_literals = [&](size_t upto) {
         size_t run = upto - lit_start;
         while (run > 65535) { tokens.push_back(LzToken{65535, 0, 0}); run -= 65535; }
         return (uint16_t)run;
     };
-    auto hash8 = [&](size_t k) { return (uint32_t)((read64(k) * 0x9E3779B97F4A7C15ull) >> (64 - HASH_BITS)); };
-    constexpr size_t MIN_MATCH = 24;                       // shorter repeats (the zero bytes of CIGAR words) are left to the entropy code
+    // (sixteen bytes per table entry: two CIGAR words repeat all over an array, four rarely do - the table keeps one position per hash, and
+    // it has to be the one in the record before)
+    auto hash8 = [&](size_t k) { return (uint32_t)(((read64(k) * 0x9E3779B97F4A7C15ull) ^ (read64(k + 8) * 0xC2B2AE3D27D4EB4Full)) >> (64 - HASH_BITS)); };
+    constexpr size_t MIN_MATCH = 32;                       // shorter repeats (the zero bytes of CIGAR words) are left to the entropy code
+    size_t matched = 0;                                    // bytes covered by matches so far
     size_t next_insert = 0;                                // every eighth position enters the table: a repeat of MIN_MATCH bytes holds two of them
     while (i <= last) {
-        while (next_insert <= i) { if (next_insert <= last) table[hash8(next_insert)] = (uint16_t)(next_insert + 1); next_insert += 8; }
-        size_t const cand1 = (i & 7u) == 0 ? 0 : table[hash8(i)];      // (position i itself has just entered: nothing to find there)
+        while (next_insert < i) { if (next_insert <= last) table[hash8(next_insert)] = (uint16_t)(next_insert + 1); next_insert += 8; }
+        // (looked up before it enters the table itself: records whose size is a multiple of eight repeat at exactly the table's positions)
+        uint32_t const h = hash8(i);
+        size_t const cand1 = table[h];
+        if (next_insert == i) { table[h] = (uint16_t)(i + 1); next_insert += 8; }
         size_t c = cand1 ? cand1 - 1 : 0;
-        if (cand1 && c < i && i - c <= 32768 && read64(c) == read64(i)) {
-            size_t len = 8;
-            while (i + len <= last && read64(c + len) == read64(i + len)) len += 8;
+        // (four words of a CIGAR array do repeat here and there: a candidate has to hold for 32 bytes before it is looked at any closer)
+        if (cand1 && c < i && i - c <= 32768 && i + 32 <= n && read64(c) == read64(i) && read64(c + 8) == read64(i + 8) && read64(c + 16) == read64(i + 16) &&
+            read64(c + 24) == read64(i + 24)) {
+            size_t len = 32;
+            while (i + len + 8 <= n && read64(c + len) == read64(i + len)) len += 8;
             while (i + len < n && data[c + len] == data[i + len]) ++len;
             size_t at = i;
             while (at > lit_start && c > 0 && data[c - 1] == data[at - 1]) { --c; --at; ++len; }      // the match began before the table's position
@@ -261,13 +268,13 @@ size_t lz_deflate(const uint8_t* data, size_t n, uint8_t* out) {
                 }
                 i = at + len;
                 lit_start = i;
-                miss = 0;
+                matched += len;
                 continue;
             }
         }
-        ++miss;
-        i += 1 + (miss >> 7);                              // data without repeats: look less and less often
-        if (i >= 16384 && tokens.empty()) return literal_deflate(data, n, out);      // a quarter of the block without one: records that share nothing (-I)
+        // (every position is looked up: only every eighth is in the table, and a stride would miss the repeats whose distance it does not divide)
+        ++i;
+        if (i == 16384 && matched < 4096) return literal_deflate(data, n, out);      // a quarter of the block and little to show: records that share nothing (-I)
     }
     uint16_t const tail_run = flush_literals(n);
     // literal frequencies: everything outside the matches
@@ -551,15 +558,57 @@ extern "C" int flx_sam_write(flx_sam_writer* w, const char* const* read_ids, con
                              const char* const* quals, const flx_record* records, uint64_t n_records, const uint32_t* cigar_words) {
     if (!w || (n_records && (!records || !read_ids || !read_pool || !read_offsets))) { set_error("flx_sam_write: null argument"); return FLX_ERR_INVALID; }
     if (w->failed) { set_error("write error on the alignment output"); return FLX_ERR_IO; }
-    // records are formatted in parallel (contiguous ranges, one buffer each), then written / compressed in order
+    if (w->bam) {
+        // BAM: a worker formats a fixed number of records at a time into a small buffer and deflates every 64 KB of it into BGZF blocks as
+        // it goes (the last block of a part is short: BGZF blocks need not be full), so the uncompressed records - 280 KB per read at default
+        // flags, 18 GB for 65 536 reads - never leave the cache; the parts' blocks are written in order. Parts are cut by record count, not
+        // by thread count: the file's bytes do not depend on --threads. (Round 3 formatted a whole batch, copied it into one pending
+        // buffer and compressed that: three passes over gigabytes of freshly faulted-in memory, 12 of the CLI's 13 s at default flags.)
+        if (!w->pending.empty() && !bgzf_flush(w, true)) { w->failed = true; set_error("write error on the alignment output"); return FLX_ERR_IO; }
+        constexpr uint64_t PART_RECORDS = 256;
+        size_t const n_parts = (size_t)((n_records + PART_RECORDS - 1) / PART_RECORDS);
+        std::vector<std::vector<uint8_t>> parts(n_parts);
+        std::vector<std::string> errs(n_parts);
+        io_parallel(n_parts, w->threads, [&](size_t p) {
+            uint64_t const r0 = (uint64_t)p * PART_RECORDS, r1 = std::min<uint64_t>(n_records, r0 + PART_RECORDS);
+            thread_local std::vector<uint8_t> raw;
+            raw.clear();
+            std::vector<uint8_t>& outv = parts[p];
+            size_t done = 0;                                   // bytes of raw already compressed
+            auto deflate_full_blocks = [&](bool all) {
+                while (raw.size() - done >= BGZF_BLOCK || (all && raw.size() > done)) {
+                    size_t const len = std::min(BGZF_BLOCK, raw.size() - done);
+                    size_t const at = outv.size();
+                    outv.resize(at + BGZF_MAX_OUT);
+                    size_t const c = bgzf_compress_block(raw.data() + done, len, outv.data() + at);
+                    if (c == 0) { errs[p] = "BGZF compression failed"; outv.resize(at); return; }
+                    outv.resize(at + c);
+                    done += len;
+                }
+                if (done == raw.size()) { raw.clear(); done = 0; }
+                else if (done >= (4u << 20)) { raw.erase(raw.begin(), raw.begin() + (long)done); done = 0; }
+            };
+            for (uint64_t i = r0; i < r1 && errs[p].empty(); ++i) {
+                if (!format_record(w, records[i], read_ids, read_pool, read_offsets, quals, cigar_words, raw, errs[p])) break;
+                deflate_full_blocks(false);
+            }
+            if (errs[p].empty()) deflate_full_blocks(true);
+        });
+        for (auto const& e : errs) if (!e.empty()) { set_error(e); return FLX_ERR_INVALID; }
+        for (auto const& part : parts)
+            if (!part.empty() && fwrite(part.data(), 1, part.size(), w->f) != part.size()) { w->failed = true; break; }
+        if (w->failed) { set_error("write error on the alignment output"); return FLX_ERR_IO; }
+        return FLX_OK;
+    }
+    // SAM: records are formatted in parallel (contiguous ranges, one buffer each), then written in order
     size_t const n_parts = std::max<size_t>(1, std::min<size_t>(w->threads * 4, n_records / 64));
     std::vector<std::vector<uint8_t>> parts(n_parts);
     std::vector<std::string> errs(n_parts);
     io_parallel(n_parts, w->threads, [&](size_t p) {
         uint64_t const r0 = n_records * p / n_parts, r1 = n_records * (p + 1) / n_parts;
         {
-            // the part's size, roughly (BAM: 4 bytes per CIGAR operation, 1.5 per base of a record with SEQ / QUAL; SAM: about twice
-            // that), so that the buffer is allocated once instead of doubling its way up through copies
+            // the part's size, roughly (about 8 bytes per CIGAR operation and 2 per base of a record with SEQ / QUAL), so that the buffer is
+            // allocated once instead of doubling its way up through copies
             size_t guess = 0;
             for (uint64_t i = r0; i < r1; ++i) {
                 flx_record const& r = records[i];
@@ -567,20 +616,17 @@ extern "C" int flx_sam_write(flx_sam_writer* w, const char* const* read_ids, con
                 size_t const slen = with_seq ? (size_t)(read_offsets[r.read_index + 1] - read_offsets[r.read_index]) : 0;
                 guess += 96 + 4 * (size_t)r.cigar_length + slen + slen / 2;
             }
-            parts[p].reserve(w->bam ? guess : 2 * guess);
+            parts[p].reserve(2 * guess);
         }
         for (uint64_t i = r0; i < r1 && errs[p].empty(); ++i)
             if (!format_record(w, records[i], read_ids, read_pool, read_offsets, quals, cigar_words, parts[p], errs[p])) break;
     });
     for (auto const& e : errs) if (!e.empty()) { set_error(e); return FLX_ERR_INVALID; }
-    if (w->bam) { size_t total = w->pending.size(); for (auto const& part : parts) total += part.size(); w->pending.reserve(total); }
     for (auto const& part : parts) {
         if (part.empty()) continue;
-        if (!w->bam) { if (fwrite(part.data(), 1, part.size(), w->f) != part.size()) w->failed = true; }
-        else w->pending.insert(w->pending.end(), part.begin(), part.end());
+        if (fwrite(part.data(), 1, part.size(), w->f) != part.size()) w->failed = true;
         if (w->failed) break;
     }
-    if (w->bam && !w->failed && !bgzf_flush(w, false)) w->failed = true;
     if (w->failed) { set_error("write error on the alignment output"); return FLX_ERR_IO; }
     return FLX_OK;
 }

@@ -2177,7 +2177,10 @@ int align_slice(Lane* lane, const flx_params* P, const flx_reads* RD, u64 first_
                 if (lane_form)
                     return DeviceApi::align_exists_lanes(lane->stream, d_text, d_peq, B.jobs, max_jobs, B.scalars + VR2_N_JOBS + (round & 1u), B.scalars + VR2_QUEUE,
                                                          lane_waves, lane_cap, B.outs, lane_stats, team);
-                return DeviceApi::align_exists_counted(lane->stream, d_text, d_peq, B.jobs, max_jobs, B.scalars + VR2_N_JOBS + (round & 1u), shape, 8192u, B.outs);
+                // (a fixed grid of at most this many waves takes the round's job groups in turn; FLX_EXISTS_MAX_WAVES: how much of the chip one
+                // round's launch may hold while the other lanes' kernels want room)
+                static u32 const exists_waves = [] { const char* e = getenv("FLX_EXISTS_MAX_WAVES"); return (u32)(e ? std::max(64, atoi(e)) : 8192); }();
+                return DeviceApi::align_exists_counted(lane->stream, d_text, d_peq, B.jobs, max_jobs, B.scalars + VR2_N_JOBS + (round & 1u), shape, exists_waves, B.outs);
             });
             if (rc) return rc;
             int const e2 = DeviceApi::vr2_apply(lane->stream, B, n, lane->vr_host_scalars);

@@ -1,12 +1,12 @@
 #!/bin/bash
 # On the GPU box: one bench line per BASELINE.json configuration, without and with -I, plus the repeat-rich GRCh38-size reference.
 # usage: bash scripts/gpu_bench_configs.sh <tag>      -> gpurun_out/<tag>_bench_<config>[_I].json
-T=${1:-r03}
+T=${1:-r04}
 R=/root/repo
 mkdir -p $R/gpurun_out
 run() {
     name=$1; shift
-    timeout -k 10 420 python3 $R/bench.py --steps 12 --warmup 3 "$@" > $R/gpurun_out/${T}_bench_${name}.json 2> $R/gpurun_out/${T}_bench_${name}.err
+    timeout -k 10 420 python3 $R/bench.py --steps 12 --warmup 3 --no-host-inputs-leg --no-repeat-rich-leg "$@" > $R/gpurun_out/${T}_bench_${name}.json 2> $R/gpurun_out/${T}_bench_${name}.err
     python3 -c "
 import json
 try:
@@ -22,5 +22,5 @@ for cfg in ecoli chr1 hifi; do
     run ${cfg}_I --config $cfg --no-cpu-baseline --interval-optimization
 done
 run grch38_I --config grch38 --no-cpu-baseline --interval-optimization
-run repeat_rich --config grch38 --repeat-rich --cpu-sample 256
+run repeat_rich --config grch38 --repeat-rich --cpu-sample 128
 run repeat_rich_I --config grch38 --repeat-rich --no-cpu-baseline --interval-optimization

@@ -33,8 +33,9 @@ static std::vector<uint8_t> bam_like(std::mt19937& rng, size_t n, unsigned words
     unsigned k = 0;
     while (v.size() < n) {
         if (k++ % repeat == 0) { cig.clear(); for (unsigned w = 0; w < words; ++w) cig.push_back(w % 2 ? ((1u << 4) | (rng() % 3 == 0 ? 8 : rng() % 2 + 1)) : (((rng() % 23) + 1) << 4 | 7)); }
-        uint8_t head[36]; for (auto& b : head) b = (uint8_t)rng();
-        v.insert(v.end(), head, head + 36);
+        uint8_t head[36 + 21]; for (auto& b : head) b = (uint8_t)rng();
+        // (record sizes: a multiple of eight - a repeat sits at exactly the table's stride -, odd, and anything)
+        v.insert(v.end(), head, head + (words == 1600 ? (repeat == 40 ? 40 : 57) : 36 + words % 5));
         const uint8_t* p = (const uint8_t*)cig.data(); v.insert(v.end(), p, p + cig.size() * 4);
     }
     v.resize(n);
@@ -76,7 +77,7 @@ int main() {
         ok &= roundtrip(v);
     }
     // speed and size on BAM-like data: one record per read (-I) and forty records sharing a CIGAR (default flags), against zlib level 1
-    for (unsigned rep : {1u, 40u}) {
+    for (unsigned rep : {1u, 40u, 41u}) {
         std::vector<uint8_t> b = bam_like(rng, 65280, 1600, rep);
         std::vector<uint8_t> o(70000);
         for (int enc = 0; enc < 3; ++enc) {
