@@ -30,7 +30,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
-PROFILE_TAG = "r03"        # profiles/<tag>_pmc_traffic_<kernel>.json, profiles/<tag>_oracle_extensions.json
+PROFILE_TAG = "r04"        # profiles/<tag>_pmc_traffic_<kernel>.json, profiles/<tag>_oracle_extensions.json
 
 # BASELINE.json configs (per GPU): reference length, sequences, read length, error rate, reads per step
 CONFIGS = {
@@ -403,6 +403,15 @@ def main():
                  "avg_launch_ms": round(st["device_ms"] / st["launches"], 4),
                  "algorithmic_bytes_per_launch": int(alg / st["launches"]), "launches": st["launches"],
                  "work_units_per_launch": int(st["work_units"] / st["launches"]), "note": note}
+            if name in ("ed_align_trace", "ed_align_exists"):
+                # The DP kernels are bit-vector arithmetic: their bound is vector-instruction issue, not HBM. One word-step (64 rows of one
+                # column) is ~40 VALU instructions of one lane (flx_device.hip, ed_block_body); a wave64 instruction takes 2 cycles on a
+                # CDNA4 SIMD-32, 4 when the wave is alone on its SIMD (MI355X_MICROARCH.md): 1024 SIMDs x 2.4 GHz / 2.
+                wave_instr = st["work_units"] * 40.0 / 64.0
+                peak = 1024 * 2.4e9 / 2
+                r["valu_issue"] = {"model": "40 VALU instructions per word-step, 64 lanes per wave instruction", "wave_instructions_per_launch": int(wave_instr / st["launches"]),
+                                   "achieved_G_per_s": round(wave_instr / (st["device_ms"] / 1e3) / 1e9, 1), "peak_G_per_s": round(peak / 1e9, 1),
+                                   "frac": round(wave_instr / (st["device_ms"] / 1e3) / peak, 4)}
             if name == "fm_search" and ext_per_read is not None and reads_per_launch:
                 # SURVEY.md 8(d) prices the seeding at 2 x 64 B per cursor extension OF THE REFERENCE'S WALK on this input (counted by the
                 # restatement). This build answers the same questions with fewer rank queries (presence filter, text walk), so that

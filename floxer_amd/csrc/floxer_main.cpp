@@ -103,7 +103,8 @@ double parse_double(std::string const& name, std::string const& v) {
 void range_check(std::string const& name, double v, double lo, double hi) {
     if (v < lo || v > hi) throw CliError{"Validation failed for option --" + name + ": Value " + std::to_string(v) + " is not in range [" + std::to_string(lo) + "," + std::to_string(hi) + "]."};
 }
-bool file_readable(std::string const& p) { FILE* f = fopen(p.c_str(), "rb"); if (!f) return false; fclose(f); return true; }
+// (by permission, not by opening: opening and closing a FIFO would break the pipe under its writer before the reader gets to it)
+bool file_readable(std::string const& p) { return access(p.c_str(), R_OK) == 0; }
 
 Options parse_cli(int argc, char** argv) {
     Options o;

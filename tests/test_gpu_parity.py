@@ -1035,8 +1035,8 @@ def test_scale_250mb_repeat_rich_matches_oracle(capsys):
 
 
 def test_cli_devices_stats_fastq_forms_and_accuracy(tmp_path):
-    """The drop-in CLI beyond the reference's own test: (1) a FASTQ as plain text, gzip, with CR LF line ends and without a final
-    line end gives the same SAM; (2) two contexts (--devices 0,0: batches dealt in turn, written in input order) and several I/O
+    """The drop-in CLI beyond the reference's own test: (1) a FASTQ as plain text, gzip, with CR LF line ends, without a final
+    line end, and through a named pipe (plain and gzip) gives the same SAM; (2) two contexts (--devices 0,0: batches dealt in turn, written in input order) and several I/O
     threads give the same records as one; SAM and BAM hold the same records; (3) --stats writes the reference's TOML (query count,
     histogram totals consistent with the records); (4) --index is saved, reused, and refused for another reference;
     (5) simulated_dataset verify finds every read of the simulated set at its origin."""
@@ -1075,6 +1075,19 @@ def test_cli_devices_stats_fastq_forms_and_accuracy(tmp_path):
         r = run(path, o, "--threads", "3")
         assert r.returncode == 0, (name, r.stderr.decode())
         assert sam_records(o) == base, name
+
+    # the queries through a named pipe, plain and gzip (the reference reads a FIFO named *.fastq through its ifstream just as well)
+    import threading
+    for name in ("plain", "gz"):
+        fifo = str(tmp_path / (f"pipe_{name}.fastq" + (".gz" if name == "gz" else "")))
+        os.mkfifo(fifo)
+        feeder = threading.Thread(target=lambda src=forms[name], dst=fifo: open(dst, "wb").write(open(src, "rb").read()))
+        feeder.start()
+        o = str(tmp_path / f"pipe_{name}.sam")
+        r = run(fifo, o, "--threads", "3")
+        feeder.join()
+        assert r.returncode == 0, (name, r.stderr.decode())
+        assert sam_records(o) == base, f"fifo {name}"
 
     # two contexts on the one GPU, five I/O threads, statistics, index saved
     o2, toml, idx = str(tmp_path / "two.sam"), str(tmp_path / "stats.toml"), str(tmp_path / "g.index")
