@@ -457,6 +457,7 @@ def main():
         #      reads, same flags), made by a child process once this one has given the GPU's memory back.
         repeat_rich_line = None
         index_device_bytes = int(index.device_bytes)
+        index_derived_bytes = int(index.derived_device_bytes)
         if (world == 1 and not args.no_repeat_rich_leg and not args.repeat_rich and not args.isolated_only and args.config == "grch38"
                 and (args.genome, args.read_length, args.error_rate) == (CONFIGS["grch38"]["genome"], 10000, 0.08)):
             del image, index, genome, pool, batches
@@ -503,7 +504,7 @@ def main():
                        "parallelism": f"read-sharded x{world}, index replicated",
                        "gather": None if world == 1 else ("records + CIGAR words" if args.gather_cigars else "fixed-size records") + " to rank 0 per step, inside the timed region"},
             "gbases_per_s": round(value * mean_len / 1e9, 5), "records": n_records, "index_build_s": round(index_s, 2),
-            "index_device_bytes": index_device_bytes,
+            "index_device_bytes": index_device_bytes, "index_derived_device_bytes": index_derived_bytes,
             "gather_s": None if gather_s is None else round(gather_s, 3),      # time rank 0 spent in the per-step gathers (inside the timed region)
             "roofline": roofline, "roofline_fm_search": roofline_fm, "roofline_timed_region": roofline_timed, "cpu_baseline": cpu,
             "parity_sample": parity,

@@ -145,6 +145,11 @@ class fmindex:
     def device_bytes(self):
         return lib().flx_index_device_bytes(self.h)
 
+    @property
+    def derived_device_bytes(self):
+        """inverse suffix array + presence filter a context adds to the image when the device has room"""
+        return lib().flx_index_derived_device_bytes(self.h)
+
     def suffix_array(self):
         out = np.zeros(self.text_length, dtype=np.uint64)
         check(lib().flx_index_copy_sa(self.h, ptr(out, u64p)))

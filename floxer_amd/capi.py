@@ -84,7 +84,7 @@ class KernelStat(C.Structure):
 EXPORTED = [
     "flx_last_error", "flx_version", "flx_ceil_div", "flx_floating_point_error_aware_ceil", "flx_saturate_value_to_int32_max",
     "flx_chars_to_rank_sequence", "flx_reverse_complement_rank", "flx_pex_tree_build", "flx_index_build", "flx_index_build_on_device", "flx_index_save",
-    "flx_index_load", "flx_index_free", "flx_index_text_length", "flx_index_num_references", "flx_index_device_bytes",
+    "flx_index_load", "flx_index_free", "flx_index_text_length", "flx_index_num_references", "flx_index_device_bytes", "flx_index_derived_device_bytes",
     "flx_index_copy_sa", "flx_index_copy_sa_u32", "flx_index_copy_bwt", "flx_ctx_create", "flx_ctx_destroy", "flx_ctx_set_stream", "flx_search_seeds",
     "flx_search_groups", "flx_align_batch", "flx_params_default", "flx_align_reads", "flx_reads_upload", "flx_reads_free",
     "flx_align_reads_resident", "flx_run_num_records",
@@ -128,6 +128,8 @@ def lib():
     L.flx_index_num_references.argtypes = [C.c_void_p]
     L.flx_index_device_bytes.restype = C.c_uint64
     L.flx_index_device_bytes.argtypes = [C.c_void_p]
+    L.flx_index_derived_device_bytes.restype = C.c_uint64
+    L.flx_index_derived_device_bytes.argtypes = [C.c_void_p]
     L.flx_index_copy_sa.argtypes = [C.c_void_p, u64p]
     L.flx_index_copy_sa_u32.argtypes = [C.c_void_p, u32p]
     L.flx_index_copy_bwt.argtypes = [C.c_void_p, C.c_int, u8p]

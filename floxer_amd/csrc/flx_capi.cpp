@@ -149,7 +149,15 @@ int make_context(int hip_device, const flx_index* index, void* const image[5], b
     if (!getenv("FLX_NO_DERIVED") && H.n > 0) {
         u32 fk = 0;
         (void)DeviceApi::derived_bytes(H.n, &fk);
-        if ((rc = ctx->isa.ensure(H.n * 4 + 64, true))) return rc;
+        // (neither table is needed for correct results: a device that cannot hold one - shared with other contexts or processes - gets a
+        // context without it: no text walk without the inverse suffix array, no pruning without the filter)
+        bool have_isa = false;
+        {
+            size_t free_i = 0, total_i = 0;
+            FLX_HIP(hipMemGetInfo(&free_i, &total_i));
+            size_t const want = (size_t)H.n * 4 + 64;
+            have_isa = want < free_i / 2 && ctx->isa.ensure(want, true) == FLX_OK;
+        }
         bool have_filter = false;
         if (fk) {
             size_t free_f = 0, total_f = 0;
@@ -157,7 +165,7 @@ int make_context(int hip_device, const flx_index* index, void* const image[5], b
             size_t const want = (size_t)(((1ull << (2 * fk)) + 63) / 64) * 8;
             have_filter = want < free_f / 2 && ctx->filter.ensure(want, true) == FLX_OK;
         }
-        int const e = DeviceApi::derive_index(s0, ctx->didx, ctx->isa.as<u32>(), have_filter ? ctx->filter.as<u64>() : nullptr);
+        int const e = DeviceApi::derive_index(s0, ctx->didx, have_isa ? ctx->isa.as<u32>() : nullptr, have_filter ? ctx->filter.as<u64>() : nullptr);
         if (e) { set_error(std::string("derive_index: ") + hipGetErrorString((hipError_t)e)); return FLX_ERR_NO_DEVICE; }
         FLX_HIP(hipStreamSynchronize(s0));
     }

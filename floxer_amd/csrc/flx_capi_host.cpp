@@ -5,7 +5,7 @@
 #include <cstring>
 #include <memory>
 
-#include "flx_internal.hpp"
+#include "flx_fm_core.hpp"
 
 namespace flx {
 const char* last_error_cstr();
@@ -75,6 +75,12 @@ uint64_t flx_index_device_bytes(const flx_index* index) {
     // (from the sizes, so that an index without arrays reports what its image takes as well)
     u64 const nb = h.n / OCC_BLOCK_POS + 1;
     return 2 * nb * sizeof(OccBlock) + h.n * 4 + h.n + 2 * TEXT_PAD + (((u64)1 << (2 * KMER_Q)) * 3) * 4;
+}
+uint64_t flx_index_derived_device_bytes(const flx_index* index) {
+    if (!index || index->host->n == 0) return 0;
+    u64 const n = index->host->n;
+    u32 const k = filter_k_default(n);
+    return n * 4 + filter_words(k) * 8;
 }
 int flx_index_matches_reference(const flx_index* index, const uint8_t* concat, const uint64_t* lens, uint32_t n_refs) {
     if (!index || !concat || !lens) { set_error("flx_index_matches_reference: null argument"); return FLX_ERR_INVALID; }

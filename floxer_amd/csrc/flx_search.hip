@@ -79,7 +79,7 @@ size_t DeviceApi::derived_bytes(u64 n, u32* k_out) {
     return (size_t)n * 4 + (k ? (size_t)filter_words(k) * 8 : 0);
 }
 
-// isa and the presence filter from idx.text / idx.sa into d_isa (n words) and d_filter (filter_words(k) 64-bit words, k = filter_k_for(n);
+// isa and the presence filter from idx.text / idx.sa into d_isa (n words; may be null: no text walk) and d_filter (filter_words(k) 64-bit words, k = filter_k_for(n);
 // may be null with k == 0); sets the four derived fields of idx
 int DeviceApi::derive_index(void* stream, DevIndex& idx, u32* d_isa, u64* d_filter) {
     hipStream_t s = (hipStream_t)stream;
@@ -90,7 +90,7 @@ int DeviceApi::derive_index(void* stream, DevIndex& idx, u32* d_isa, u64* d_filt
     idx.filter_k = k;
     idx.filter_tmin = k ? filter_tmin_for(n, k) : 0u;
     if (n == 0) return 0;
-    hipLaunchKernelGGL(isa_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, idx.sa, n, d_isa);
+    if (d_isa) hipLaunchKernelGGL(isa_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, idx.sa, n, d_isa);
     if (k) {
         hipError_t e = hipMemsetAsync(d_filter, 0, (size_t)filter_words(k) * 8, s);
         if (e != hipSuccess) return (int)e;

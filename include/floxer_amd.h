@@ -72,7 +72,10 @@ int flx_index_load(const char* path, flx_index** out);
 void flx_index_free(flx_index* index);
 uint64_t flx_index_text_length(const flx_index* index);     /* concatenated text incl. sentinel padding */
 uint32_t flx_index_num_references(const flx_index* index);
-uint64_t flx_index_device_bytes(const flx_index* index);    /* HBM footprint once uploaded */
+uint64_t flx_index_device_bytes(const flx_index* index);    /* HBM footprint of the index image once uploaded */
+/* what a context adds to the image when the device has room for it: the inverse suffix array (4 B per text symbol) and the presence
+   filter of the seeding kernels (4^K / 8 bytes, K = ceil(log4 n) + 2); a context made without either gives the same results, slower */
+uint64_t flx_index_derived_device_bytes(const flx_index* index);
 /* FLX_OK iff the index was built from exactly these reference sequences (guards --index against a stale file, floxer.cpp:63-79) */
 int flx_index_matches_reference(const flx_index* index, const uint8_t* ref_ranks_concat, const uint64_t* ref_lens, uint32_t n_refs);
 /* test hooks: suffix array / BWT as built (text_length entries) */
