@@ -70,7 +70,7 @@ def parse():
     ap.add_argument("--dump-gathered", default="", help="rank 0 saves the record table of timed step 0 as it arrives from all ranks (numpy .npy; tests)")
     ap.add_argument("--no-host-inputs-leg", action="store_true", help="skip the second timed region (reads in pageable host memory: H2D and Peq build inside the clock)")
     ap.add_argument("--no-repeat-rich-leg", action="store_true", help="metric configuration only: skip the secondary line on the repeat-rich (hg38-like) reference")
-    ap.add_argument("--repeat-rich-steps", type=int, default=4)
+    ap.add_argument("--repeat-rich-steps", type=int, default=8)
     args = ap.parse_args()
     cfg = CONFIGS[args.config]
     args.genome = args.genome or cfg["genome"]
@@ -466,7 +466,7 @@ def main():
             import gc
             gc.collect()
             torch.cuda.empty_cache()
-            cmd = [sys.executable, os.path.abspath(__file__), "--repeat-rich", "--steps", str(args.repeat_rich_steps), "--warmup", "2", "--no-cpu-baseline",
+            cmd = [sys.executable, os.path.abspath(__file__), "--repeat-rich", "--steps", str(args.repeat_rich_steps), "--warmup", "3", "--no-cpu-baseline",
                    "--no-isolated-pass", "--no-host-inputs-leg", "--lanes", str(args.lanes), "--inflight", str(args.inflight)]
             if args.interval_optimization:
                 cmd.append("--interval-optimization")

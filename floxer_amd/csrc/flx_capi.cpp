@@ -145,7 +145,7 @@ int make_context(int hip_device, const flx_index* index, void* const image[5], b
     // The tables the seeding kernels use beyond the image: the inverse suffix array and the presence filter, made here from the
     // text and the suffix array in HBM (hg38 size: 12.4 GB + 8.6 GB, a fraction of a second). FLX_NO_DERIVED=1: neither (the walk
     // then uses rank queries only); a filter that does not fit is left out.
-    ctx->didx.isa = nullptr; ctx->didx.filter = nullptr; ctx->didx.filter_k = 0; ctx->didx.filter_tmin = 0;
+    ctx->didx.isa = nullptr; ctx->didx.filter = nullptr; ctx->didx.filter_m = nullptr; ctx->didx.filter_k = 0; ctx->didx.filter_tmin = 0;
     if (!getenv("FLX_NO_DERIVED") && H.n > 0) {
         u32 fk = 0;
         (void)DeviceApi::derived_bytes(H.n, &fk);
@@ -158,14 +158,20 @@ int make_context(int hip_device, const flx_index* index, void* const image[5], b
             size_t const want = (size_t)H.n * 4 + 64;
             have_isa = want < free_i / 2 && ctx->isa.ensure(want, true) == FLX_OK;
         }
-        bool have_filter = false;
+        bool have_filter = false, have_filter_m = false;
         if (fk) {
             size_t free_f = 0, total_f = 0;
             FLX_HIP(hipMemGetInfo(&free_f, &total_f));
             size_t const want = (size_t)(((1ull << (2 * fk)) + 63) / 64) * 8;
             have_filter = want < free_f / 2 && ctx->filter.ensure(want, true) == FLX_OK;
+            // the mirrored twin (the children of a leftward extension in one word; FLX_MIRRORED_FILTER=1): measured at 3.1 Gb it takes 8 % of
+            // the filter walk's lines away (91.5 -> 84.0 GB per 16384 reads) and none of its time, for another 8.6 GB: off by default
+            if (have_filter && getenv("FLX_MIRRORED_FILTER")) {
+                FLX_HIP(hipMemGetInfo(&free_f, &total_f));
+                have_filter_m = want < free_f / 2 && ctx->filter_m.ensure(want, true) == FLX_OK;
+            }
         }
-        int const e = DeviceApi::derive_index(s0, ctx->didx, have_isa ? ctx->isa.as<u32>() : nullptr, have_filter ? ctx->filter.as<u64>() : nullptr);
+        int const e = DeviceApi::derive_index(s0, ctx->didx, have_isa ? ctx->isa.as<u32>() : nullptr, have_filter ? ctx->filter.as<u64>() : nullptr, have_filter_m ? ctx->filter_m.as<u64>() : nullptr);
         if (e) { set_error(std::string("derive_index: ") + hipGetErrorString((hipError_t)e)); return FLX_ERR_NO_DEVICE; }
         FLX_HIP(hipStreamSynchronize(s0));
     }

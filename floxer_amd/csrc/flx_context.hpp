@@ -75,7 +75,7 @@ struct flx_ctx {
     const flx::HostIndex* hidx = nullptr;
     flx::DevIndex didx{};
     flx::DeviceBuffer occ0, occ1, sa, text, text_rev, kmer, seq_start;
-    flx::DeviceBuffer isa, filter;   // derived from text and suffix array when the context is made (flx_search.hip)
+    flx::DeviceBuffer isa, filter, filter_m;   // derived from text and suffix array when the context is made (flx_search.hip)
     bool text_rev_ready = false;
     std::mutex mu;                   // guards text_rev upload and the statistics
     std::vector<std::unique_ptr<flx::Lane>> lanes;

@@ -133,17 +133,21 @@ inline u32 filter_tmin_for(u64 n, u32 k) {
 
 // The builder's unit of work: the windows that end at text positions [q0, q1). run = length of the run of A/C/G/T that ends at the
 // current position (capped at K), code = the last K symbols. set(word, mask) ors into the table.
-template <class SET>
-FLX_HD inline void filter_add_range(const u8* __restrict__ text, i64 n, i64 q0, i64 q1, u32 K, u32 tmin, SET&& set) {
-    u64 code = 0;
+// set_m(word, mask) ors into the mirrored table (rightmost symbol lowest: full windows only), see FmFilterKind::mirrored
+template <class SET, class SETM>
+FLX_HD inline void filter_add_range(const u8* __restrict__ text, i64 n, i64 q0, i64 q1, u32 K, u32 tmin, SET&& set, SETM&& set_m) {
+    u64 code = 0, code_m = 0;
     u32 run = 0;
     u64 const kmask = K >= 32u ? ~0ull : ((1ull << (2u * K)) - 1ull);
     for (i64 q = q0 - (i64)K + 1; q < q1; ++q) {
         u32 const c = (q >= 0 && q < n) ? text[q] : 0u;
-        if (c >= 1u && c <= 4u) { code = ((code >> 2) | ((u64)(c - 1u) << (2u * (K - 1u)))) & kmask; run = run < K ? run + 1u : K; }
-        else { run = 0; code = 0; }
+        if (c >= 1u && c <= 4u) {
+            code = ((code >> 2) | ((u64)(c - 1u) << (2u * (K - 1u)))) & kmask;
+            code_m = ((code_m << 2) | (u64)(c - 1u)) & kmask;
+            run = run < K ? run + 1u : K;
+        } else { run = 0; code = 0; code_m = 0; }
         if (q < q0) continue;
-        if (run >= K) set(code >> 6, 1ull << (code & 63ull));
+        if (run >= K) { set(code >> 6, 1ull << (code & 63ull)); set_m(code_m >> 6, 1ull << (code_m & 63ull)); }
         else if (run >= tmin && K - run <= 3u) {
             // the run's symbols are the top `run` symbols of code; every left extension of them counts as present
             u32 const u = K - run;
@@ -152,6 +156,18 @@ FLX_HD inline void filter_add_range(const u8* __restrict__ text, i64 n, i64 q0, 
             set(start >> 6, cnt >= 64u ? ~0ull : (((1ull << cnt) - 1ull) << (start & 63ull)));
         }
     }
+}
+
+template <class SET>
+FLX_HD inline void filter_add_range(const u8* __restrict__ text, i64 n, i64 q0, i64 q1, u32 K, u32 tmin, SET&& set) {
+    filter_add_range(text, n, q0, q1, K, tmin, set, [](u64, u64) {});
+}
+// the first cnt 2-bit symbols of v in reverse order
+FLX_HD inline u64 rev_syms(u64 v, u32 cnt) {
+    v = ((v >> 2) & 0x3333333333333333ull) | ((v & 0x3333333333333333ull) << 2);
+    v = ((v >> 4) & 0x0F0F0F0F0F0F0F0Full) | ((v & 0x0F0F0F0F0F0F0F0Full) << 4);
+    v = __builtin_bswap64(v);
+    return cnt >= 32u ? v : cnt == 0u ? 0ull : v >> (2u * (32u - cnt));
 }
 
 // ------------------------------------------------------------------------------------------------ state words, keys
@@ -280,11 +296,16 @@ FLX_HD inline FmFilterPre fm_filter_prefetch(FmConst const& C, FmLane const& L, 
 }
 // one kind of child (0 substitution, 1 deletion, 2 insertion): the code of its string without the junction symbol, where that symbol
 // goes, how far the code is shifted up (unknown symbols in front of a string shorter than K), and the symbols to ask for
-struct FmFilterKind { u64 base; u32 csh, ush, want; };
+// mirrored: the lookup goes to the mirrored table (rightmost symbol of the window lowest). The four substitution (or deletion) children of a
+// node differ in the junction symbol only; when that symbol sits in the code's low six bits they share one 64-bit word = one memory request.
+// In the plain code that is so for rightward extension in the narrow look (two string symbols, the junction, the forced run); for leftward
+// extension the same window has the junction near the top of the plain code (nine lines per node: two thirds of the filter walk's requests
+// in round 3's counters) and near the bottom of the mirrored one.
+struct FmFilterKind { u64 base; u32 csh, ush, want; bool mirrored; };
 // wide: the window with as many symbols of the string as fit (second look at a child that passed the first, whose window holds as
 // many forced symbols as fit: the two share about half of their symbols)
-FLX_HD inline FmFilterKind fm_filter_kind(u32 kind, u32 K, u32 tmin, u32 x, u32 right, u32 F, u32 want, u64 xs, u64 xf, bool wide) {
-    FmFilterKind Q{0ull, 0u, 0u, 0u};
+FLX_HD inline FmFilterKind fm_filter_kind(u32 kind, u32 K, u32 tmin, u32 x, u32 right, u32 F, u32 want, u64 xs, u64 xf, bool wide, bool have_mirrored) {
+    FmFilterKind Q{0ull, 0u, 0u, 0u, false};
     u32 const jn = kind == 2u ? 0u : 1u;                             // a junction symbol c (the insertion has none: the position is skipped)
     u32 h, r;
     if (!wide) {
@@ -302,10 +323,17 @@ FLX_HD inline FmFilterKind fm_filter_kind(u32 kind, u32 K, u32 tmin, u32 x, u32 
     if (right) { str = r ? xs >> (2u * (32u - r)) : 0ull; forced = low_syms(xf >> skip, h); }
     else { str = low_syms(xs, r); forced = (xf << skip) >> (2u * (32u - h)); }
     // codes: leftmost symbol lowest. right: string | c | forced; left: forced | c | string
-    Q.base = right ? str | (forced << (2u * (r + jn))) : forced | (str << (2u * (h + jn)));
-    Q.csh = 2u * (right ? r : h);
     Q.ush = 2u * (K - t);
     Q.want = want;
+    if (!right && have_mirrored && jn && t == K) {
+        // window left to right: forced (h) | c | string (r); mirrored code: the string's last symbol lowest, c at symbol r
+        Q.base = rev_syms(str, r) | (rev_syms(forced, h) << (2u * (r + 1u)));
+        Q.csh = 2u * r;
+        Q.mirrored = true;
+        return Q;
+    }
+    Q.base = right ? str | (forced << (2u * (r + jn))) : forced | (str << (2u * (h + jn)));
+    Q.csh = 2u * (right ? r : h);
     return Q;
 }
 // The presence filter at a branching node without errors so far: the node's string is seed[a, a + x). Children that have no error
@@ -322,21 +350,24 @@ FLX_HD inline u32 fm_filter_children(FmConst const& C, FmLane& L, u32 x, u64 e64
     if (sch_upper((u32)e64) == 1u) F0 = sch_run_end(e64) - x;
     if ((F1 | F0) == 0u) return mask;
     const u64* __restrict__ bits = C.idx.filter;
+    bool const have_m = C.idx.filter_m != nullptr;
     // symbols asked for per kind, bit 2(c-1): symbol c
     u32 want_s = (mask >> 2) & 0x55u, want_d = (mask >> 1) & 0x55u, want_i = (mask >> 11) & 1u;
 #pragma unroll 1
     for (u32 look = 0; look < C.use_filter; ++look) {
-        FmFilterKind const qs = fm_filter_kind(0u, K, tmin, x, right, F1, want_s, P.xs, P.xf, look != 0u);
-        FmFilterKind const qd = fm_filter_kind(1u, K, tmin, x, right, F0, want_d, P.xs, P.xf, look != 0u);
-        FmFilterKind const qi = fm_filter_kind(2u, K, tmin, x, right, F1, want_i, P.xs, P.xf, look != 0u);
+        FmFilterKind const qs = fm_filter_kind(0u, K, tmin, x, right, F1, want_s, P.xs, P.xf, look != 0u, have_m);
+        FmFilterKind const qd = fm_filter_kind(1u, K, tmin, x, right, F0, want_d, P.xs, P.xf, look != 0u, have_m);
+        FmFilterKind const qi = fm_filter_kind(2u, K, tmin, x, right, F1, want_i, P.xs, P.xf, look != 0u, false);
+        const u64* __restrict__ bits_s = qs.mirrored ? C.idx.filter_m : bits;
+        const u64* __restrict__ bits_d = qd.mirrored ? C.idx.filter_m : bits;
         if ((qs.want | qd.want | qi.want) == 0u) break;
         // a lookup is the 64-bit word that holds the string's bit, or the 4 / 16 / 64 bits of its left extensions; all of them are
         // asked for before the first is looked at
         u64 ws[4], wd[4];
 #pragma unroll
         for (u32 c = 0; c < 4u; ++c) {
-            ws[c] = ((qs.want >> (2u * c)) & 1u) ? bits[((qs.base | ((u64)c << qs.csh)) << qs.ush) >> 6] : ~0ull;
-            wd[c] = ((qd.want >> (2u * c)) & 1u) ? bits[((qd.base | ((u64)c << qd.csh)) << qd.ush) >> 6] : ~0ull;
+            ws[c] = ((qs.want >> (2u * c)) & 1u) ? bits_s[((qs.base | ((u64)c << qs.csh)) << qs.ush) >> 6] : ~0ull;
+            wd[c] = ((qd.want >> (2u * c)) & 1u) ? bits_d[((qd.base | ((u64)c << qd.csh)) << qd.ush) >> 6] : ~0ull;
         }
         u64 const wi = qi.want ? bits[(qi.base << qi.ush) >> 6] : ~0ull;
         u64 const span_s = qs.ush >= 6u ? ~0ull : (1ull << (1u << qs.ush)) - 1ull;
@@ -351,7 +382,8 @@ FLX_HD inline u32 fm_filter_children(FmConst const& C, FmLane& L, u32 x, u64 e64
             if (((wd[c] >> at_d) & span_d) == 0ull) drop_d |= 1u << (2u * c);
         }
         if (((wi >> ((u32)(qi.base << qi.ush) & 63u)) & span_i) == 0ull) drop_i = 1u;
-        L.n_lookup += fm_popc(qs.want) + fm_popc(qd.want) + qi.want;
+        // (counted in 64-bit words asked for: the children of one kind share a word when the junction symbol is within its low six bits)
+        L.n_lookup += (qs.want ? (qs.csh + qs.ush <= 4u ? 1u : fm_popc(qs.want)) : 0u) + (qd.want ? (qd.csh + qd.ush <= 4u ? 1u : fm_popc(qd.want)) : 0u) + qi.want;
         if (STATS) L.n_pruned += fm_popc(drop_s) + fm_popc(drop_d) + drop_i;
         mask &= ~((drop_s << 2) | (drop_d << 1) | (drop_i << 11));
         // the second look: only the children the first one was asked about and let pass

@@ -82,6 +82,7 @@ struct DevIndex {
     // derived from text and sa on the device when a context is made (flx_search.hip): not part of the index file or image
     const u32* isa;        // inverse suffix array: row of the suffix that starts at a text position
     const u64* filter;     // presence bits of the text's filter_k-mers (flx_fm_core.hpp); null: no filter
+    const u64* filter_m;   // the same bits under the mirrored code (rightmost symbol lowest): the children of a leftward extension share a word; may be null
     u32 filter_k, filter_tmin;   // strings of filter_tmin .. filter_k symbols can be asked for
     u32 C[7];
     u32 n;
@@ -247,7 +248,7 @@ struct DeviceApi {
     // the tables a context derives from text and suffix array: bytes of isa + filter for a text of n symbols; derive_index fills
     // d_isa (n words) and d_filter (null: no filter) and sets idx.isa / filter / filter_k / filter_tmin
     static size_t derived_bytes(u64 n, u32* filter_k_out);
-    static int derive_index(void* stream, DevIndex& idx, u32* d_isa, u64* d_filter);
+    static int derive_index(void* stream, DevIndex& idx, u32* d_isa, u64* d_filter, u64* d_filter_mirrored = nullptr);
     // reserves the hardware queue's scratch for the pipeline's kernels (see scratch_warm_kernel)
     static int warm_scratch(void* stream);
     // DevSeeds of a chunk in launch order from the chunk's description (all pointers on the device)

@@ -15,7 +15,7 @@
 
 namespace flx {
 
-struct FrameItem { u32 w[24]; };               // [0..17] the frame (word 14: the children that go), [18] seed position, [19] exo, [20] ws, [21..22] qoff
+struct FrameItem { u32 w[24]; };               // [0..17] the frame (word 14: the children that go), [18] seed position, [19] exo, [20] ws, [21..22] qoff, [23] rows of the seed so far
 // Hand-over of subtrees between the waves of one launch (see fm_search_filter_kernel). All in HBM, zeroed before the launch but `items`:
 //   ctrl: waves started (MBC_STARTED), waves waiting or gone (MBC_WAITING), tail / head of the hungry list (MBC_TAIL, MBC_HEAD), a flag set once a
 //   wave's queue has been dry for long (MBC_LONG: the launch has heavy seeds: finished waves then wait for work instead of leaving) - each in
@@ -45,12 +45,13 @@ __global__ void __launch_bounds__(256) isa_kernel(const u32* __restrict__ sa, u6
 }
 
 constexpr u32 FILTER_SPAN = 64;             // window ends per thread
-__global__ void __launch_bounds__(256) filter_build_kernel(const u8* __restrict__ text, u64 n, u32 K, u32 tmin, u64* __restrict__ bits) {
+__global__ void __launch_bounds__(256) filter_build_kernel(const u8* __restrict__ text, u64 n, u32 K, u32 tmin, u64* __restrict__ bits, u64* __restrict__ bits_m) {
     u64 const t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     i64 const q0 = (i64)(t * FILTER_SPAN);
     if (q0 >= (i64)n) return;
     i64 const q1 = q0 + (i64)FILTER_SPAN < (i64)n ? q0 + (i64)FILTER_SPAN : (i64)n;
-    filter_add_range(text, (i64)n, q0, q1, K, tmin, [&](u64 word, u64 mask) { atomicOr((unsigned long long*)&bits[word], (unsigned long long)mask); });
+    filter_add_range(text, (i64)n, q0, q1, K, tmin, [&](u64 word, u64 mask) { atomicOr((unsigned long long*)&bits[word], (unsigned long long)mask); },
+                     [&](u64 word, u64 mask) { if (bits_m) atomicOr((unsigned long long*)&bits_m[word], (unsigned long long)mask); });
 }
 
 // 16 symbols per thread -> one word
@@ -76,17 +77,18 @@ size_t DeviceApi::mailbox_bytes(u32 waves) { return ((size_t)MB_CTRL_WORDS + (si
 size_t DeviceApi::derived_bytes(u64 n, u32* k_out) {
     u32 const k = filter_k_for(n);
     if (k_out) *k_out = k;
-    return (size_t)n * 4 + (k ? (size_t)filter_words(k) * 8 : 0);
+    return (size_t)n * 4 + (k ? (size_t)filter_words(k) * 8 : 0);          // the inverse suffix array and the filter
 }
 
 // isa and the presence filter from idx.text / idx.sa into d_isa (n words; may be null: no text walk) and d_filter (filter_words(k) 64-bit words, k = filter_k_for(n);
 // may be null with k == 0); sets the four derived fields of idx
-int DeviceApi::derive_index(void* stream, DevIndex& idx, u32* d_isa, u64* d_filter) {
+int DeviceApi::derive_index(void* stream, DevIndex& idx, u32* d_isa, u64* d_filter, u64* d_filter_mirrored) {
     hipStream_t s = (hipStream_t)stream;
     u64 const n = idx.n;
     u32 const k = d_filter ? filter_k_for(n) : 0u;
     idx.isa = d_isa;
     idx.filter = k ? d_filter : nullptr;
+    idx.filter_m = k ? d_filter_mirrored : nullptr;
     idx.filter_k = k;
     idx.filter_tmin = k ? filter_tmin_for(n, k) : 0u;
     if (n == 0) return 0;
@@ -94,8 +96,9 @@ int DeviceApi::derive_index(void* stream, DevIndex& idx, u32* d_isa, u64* d_filt
     if (k) {
         hipError_t e = hipMemsetAsync(d_filter, 0, (size_t)filter_words(k) * 8, s);
         if (e != hipSuccess) return (int)e;
+        if (d_filter_mirrored && (e = hipMemsetAsync(d_filter_mirrored, 0, (size_t)filter_words(k) * 8, s)) != hipSuccess) return (int)e;
         u64 const threads = (n + FILTER_SPAN - 1) / FILTER_SPAN;
-        hipLaunchKernelGGL(filter_build_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, idx.text, n, k, idx.filter_tmin, d_filter);
+        hipLaunchKernelGGL(filter_build_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, idx.text, n, k, idx.filter_tmin, d_filter, d_filter_mirrored);
     }
     return (int)hipGetLastError();
 }
@@ -355,7 +358,7 @@ __global__ void __launch_bounds__(64, 4) fm_search_filter_kernel(FmConst C, u32 
                     // the donor's seed and search
                     u32 const d_pos = (u32)__shfl((int)L.pos, (int)from), d_exo = (u32)__shfl((int)L.exo, (int)from), d_ws = (u32)__shfl((int)L.ws, (int)from);
                     u32 const d_qlo = (u32)__shfl((int)(u32)L.qoff, (int)from), d_qhi = (u32)__shfl((int)(u32)(L.qoff >> 32), (int)from);
-                    u32 const d_give = (u32)__shfl((int)give, (int)from);
+                    u32 const d_give = (u32)__shfl((int)give, (int)from), d_ct = (u32)__shfl((int)L.ct, (int)from);
                     u32 w[FM_FRAME_WORDS];
 #pragma unroll
                     for (u32 i = 0; i < FM_FRAME_WORDS; ++i) w[i] = lds[i * 64u + from];          // frame 0 of lane `from`
@@ -366,7 +369,7 @@ __global__ void __launch_bounds__(64, 4) fm_search_filter_kernel(FmConst C, u32 
                         for (u32 i = 0; i < FM_FRAME_WORDS; ++i) if (i != 14u) fr(0, i) = w[i];
                         fr(0, 14) = d_give;
                         L.pos = d_pos; L.exo = d_exo; L.ws = d_ws | (1u << 28); L.qoff = (u64)d_qlo | ((u64)d_qhi << 32);
-                        L.ct = 0;
+                        L.ct = d_ct;                                // (the seed's rows as the donor has counted them: both stop at the cap from there)
                         L.wn = WN_BUSY | WN_IN_SEARCH | WN_NEED_CHILD | WN_DEPTH1;
                     }
                     n_steals += n_pairs;
@@ -394,7 +397,7 @@ __global__ void __launch_bounds__(64, 4) fm_search_filter_kernel(FmConst C, u32 
                             dst[2] = uint4{fr(0, 8), fr(0, 9), fr(0, 10), fr(0, 11)};
                             dst[3] = uint4{fr(0, 12), fr(0, 13), give, fr(0, 15)};
                             dst[4] = uint4{fr(0, 16), fr(0, 17), L.pos, L.exo};
-                            dst[5] = uint4{L.ws, (u32)L.qoff, (u32)(L.qoff >> 32), 0u};
+                            dst[5] = uint4{L.ws, (u32)L.qoff, (u32)(L.qoff >> 32), L.ct};
                             fr(0, 14) = fmask & ~give;
                         }
                         if (lane == 0) MB.count[to] = (u32)__popcll(sending);
@@ -449,7 +452,7 @@ __global__ void __launch_bounds__(64, 4) fm_search_filter_kernel(FmConst C, u32 
                 fr(0, 8) = q2.x; fr(0, 9) = q2.y; fr(0, 10) = q2.z; fr(0, 11) = q2.w; fr(0, 12) = q3.x; fr(0, 13) = q3.y; fr(0, 14) = q3.z; fr(0, 15) = q3.w;
                 fr(0, 16) = q4.x; fr(0, 17) = q4.y;
                 L.pos = q4.z; L.exo = q4.w; L.ws = q5.x | (1u << 28); L.qoff = (u64)q5.y | ((u64)q5.z << 32);
-                L.ct = 0;
+                L.ct = q5.w;
                 L.wn = WN_BUSY | WN_IN_SEARCH | WN_NEED_CHILD | WN_DEPTH1;
             }
             if (lane == 0) mb_store(&MB.state[me], (u32)MB_INACTIVE);

@@ -22,13 +22,13 @@ namespace {
 
 struct Hit { u32 lb, len, e; u64 key; };
 
-struct Mode { const char* name; bool filter, text; u32 k_override; };
+struct Mode { const char* name; bool filter, text; u32 k_override; bool mirrored = true; };
 
 struct Harness {
     HostIndex* H = nullptr;
     std::vector<u8> padded;            // TEXT_PAD zeros, the text, TEXT_PAD zeros
     std::vector<u32> isa;
-    std::vector<u64> filter;
+    std::vector<u64> filter, filter_m;
     DevIndex didx{};
     u64 lookups = 0, pruned = 0, ext = 0, items = 0, tx_nodes = 0, kills = 0;
 
@@ -53,16 +53,20 @@ struct Harness {
         didx.n = (u32)n;
         set_filter(k_override);
     }
+    bool mirrored = true;              // the mirrored table is there (leftward lookups go to it)
     void set_filter(u32 k_override) {
         u64 const n = H->n;
         u32 const K = k_override ? k_override : filter_k_default(n);
         didx.filter_k = K;
         didx.filter_tmin = filter_tmin_for(n, K);
         filter.assign(filter_words(K), 0);
+        filter_m.assign(filter_words(K), 0);
         // (in pieces, like the kernel's threads)
         for (i64 q0 = 0; q0 < (i64)n; q0 += 64)
-            filter_add_range(didx.text, (i64)n, q0, std::min<i64>((i64)n, q0 + 64), K, didx.filter_tmin, [&](u64 w, u64 m) { filter[w] |= m; });
+            filter_add_range(didx.text, (i64)n, q0, std::min<i64>((i64)n, q0 + 64), K, didx.filter_tmin, [&](u64 w, u64 m) { filter[w] |= m; },
+                             [&](u64 w, u64 m) { filter_m[w] |= m; });
         didx.filter = filter.data();
+        didx.filter_m = mirrored ? filter_m.data() : nullptr;
     }
 
     // hits of one seed in emission order
@@ -212,9 +216,11 @@ int run(u32 n_seeds, u64 rng_seed, bool read_like) {
 
     u32 const kd = filter_k_default(hs.H->n);
     Mode const modes[] = {{"rank queries only", false, false, 0}, {"filter", true, false, 0}, {"text", false, true, 0}, {"filter + text", true, true, 0},
-                          {"filter + text, K - 1", true, true, kd - 1}, {"filter + text, K + 2", true, true, kd + 2}, {"filter + text, K = 8", true, true, 8}};
+                          {"filter + text, K - 1", true, true, kd - 1}, {"filter + text, K + 2", true, true, kd + 2}, {"filter + text, K = 8", true, true, 8},
+                          {"filter + text, plain table only", true, true, 0, false}, {"filter, plain table only", true, false, 0, false}};
     int failures = 0;
     for (Mode const& mode : modes) {
+        hs.mirrored = mode.mirrored;
         hs.set_filter(mode.k_override);
         hs.lookups = hs.pruned = hs.ext = hs.items = hs.tx_nodes = hs.kills = 0;
         u64 n_hits = 0, oracle_ext = 0;
@@ -248,7 +254,7 @@ int run(u32 n_seeds, u64 rng_seed, bool read_like) {
                 }
             }
         }
-        printf("mode %-24s K %2u tmin %2u: hits %llu, rank pairs %llu (oracle extensions %llu), filter lookups %llu dropped %llu prefix kills %llu, "
+        printf("mode %-24s K %2u tmin %2u: hits %llu, rank pairs %llu (oracle extensions %llu), filter words asked %llu, children dropped %llu, prefix kills %llu, "
                "subtrees %llu text steps %llu\n", mode.name, hs.didx.filter_k, hs.didx.filter_tmin, (unsigned long long)n_hits, (unsigned long long)hs.ext,
                (unsigned long long)oracle_ext, (unsigned long long)hs.lookups, (unsigned long long)hs.pruned, (unsigned long long)hs.kills,
                (unsigned long long)hs.items, (unsigned long long)hs.tx_nodes);
