@@ -32,6 +32,7 @@ struct DeviceBuffer {
     ~DeviceBuffer() { release(); }   // (error paths drop half-made owners: nothing stays allocated)
     int ensure(size_t bytes, bool exact = false);      // grow-only; contents are NOT preserved; exact: no growth slack
     void release();
+    void take(DeviceBuffer& other) { release(); ptr = other.ptr; cap = other.cap; other.ptr = nullptr; other.cap = 0; }      // this one owns other's memory now
     template <class T> T* as() const { return reinterpret_cast<T*>(ptr); }
 };
 
@@ -80,6 +81,11 @@ struct flx_ctx {
     std::mutex mu;                   // guards text_rev upload and the statistics
     std::vector<std::unique_ptr<flx::Lane>> lanes;
     hipStream_t upload_stream = nullptr;   // flx_reads_upload copies here, so that it can run while the lanes are busy
+    // Device buffers of read batches that have been freed (flx_reads_free), by role (pool, 2-bit form, Peq planes, reversed pool, its Peq
+    // planes): the next batch takes them instead of allocating. hipFree waits for the whole device, so a caller that hands batches over in
+    // host memory (flx_align_reads: three buffers made and freed per batch) used to stall every lane three times per batch.
+    std::mutex spare_mu;
+    std::vector<std::unique_ptr<flx::DeviceBuffer>> spare_read_buffers[5];
     bool external_stream = false;    // a caller-owned stream is installed on lane 0: run on that lane only
     // accounting
     bool timing = false;

@@ -1713,6 +1713,33 @@ struct flx_reads {
     mutable hipEvent_t rev_event = nullptr;
 };
 
+namespace {
+// a freed batch's buffer of this role, if the context keeps one (the largest): buf owns it afterwards
+void take_spare_read_buffer(flx_ctx* ctx, int role, DeviceBuffer& buf) {
+    if (buf.ptr) return;
+    std::lock_guard<std::mutex> g(ctx->spare_mu);
+    auto& v = ctx->spare_read_buffers[role];
+    if (v.empty()) return;
+    size_t best = 0;
+    for (size_t i = 1; i < v.size(); ++i) if (v[i]->cap > v[best]->cap) best = i;
+    buf.take(*v[best]);
+    v.erase(v.begin() + (long)best);
+}
+void keep_spare_read_buffer(flx_ctx* ctx, int role, DeviceBuffer& buf) {
+    if (!buf.ptr) return;
+    {
+        std::lock_guard<std::mutex> g(ctx->spare_mu);
+        auto& v = ctx->spare_read_buffers[role];
+        if (v.size() < 6) {                               // (as many batches as a caller keeps in flight, and a few)
+            v.emplace_back(new DeviceBuffer());
+            v.back()->take(buf);
+            return;
+        }
+    }
+    buf.release();
+}
+}  // namespace
+
 extern "C" int flx_reads_upload(flx_ctx* ctx, const uint8_t* read_pool, const uint64_t* read_offsets, uint64_t n_reads, flx_reads** out) {
     if (!ctx || !out || (n_reads && (!read_pool || !read_offsets))) { set_error("flx_reads_upload: null argument"); return FLX_ERR_INVALID; }
     FLX_HIP(hipSetDevice(ctx->device));
@@ -1756,6 +1783,7 @@ extern "C" int flx_reads_upload(flx_ctx* ctx, const uint8_t* read_pool, const ui
         for (auto& th : pool) th.join();
     }
     if (bad_rank) { set_error("read rank > 5"); return FLX_ERR_INVALID; }
+    take_spare_read_buffer(ctx, 0, rd->d_pool);
     int rc = rd->d_pool.ensure(total + 256);
     if (rc) return rc;
     hipStream_t const s0 = ctx->external_stream ? ctx->lane0()->stream : ctx->upload_stream;
@@ -1769,6 +1797,13 @@ extern "C" int flx_reads_upload(flx_ctx* ctx, const uint8_t* read_pool, const ui
 extern "C" void flx_reads_free(flx_reads* reads) {
     if (!reads) return;
     if (reads->ctx) (void)hipSetDevice(reads->ctx->device);
+    if (reads->ctx) {
+        keep_spare_read_buffer(reads->ctx, 0, reads->d_pool);
+        keep_spare_read_buffer(reads->ctx, 1, reads->d_pack);
+        keep_spare_read_buffer(reads->ctx, 2, reads->d_peq);
+        keep_spare_read_buffer(reads->ctx, 3, reads->d_pool_rev);
+        keep_spare_read_buffer(reads->ctx, 4, reads->d_peq_rev);
+    }
     reads->d_pool.release();
     reads->d_pack.release();
     reads->d_peq.release();
@@ -2340,6 +2375,8 @@ int align_slice(Lane* lane, const flx_params* P, const flx_reads* RD, u64 first_
             std::lock_guard<std::mutex> g(RD->peq_mu);
             if (!RD->rev_built) {
                 hvec<u8> qrev(pool.rbegin(), pool.rend());
+                take_spare_read_buffer(ctx, 3, RD->d_pool_rev);
+                take_spare_read_buffer(ctx, 4, RD->d_peq_rev);
                 if ((rc = RD->d_pool_rev.ensure(qrev.size() + 256))) return rc;
                 FLX_HIP(hipMemcpyAsync(RD->d_pool_rev.ptr, qrev.data(), qrev.size(), hipMemcpyHostToDevice, lane->stream));
                 FLX_HIP(hipMemsetAsync((char*)RD->d_pool_rev.ptr + qrev.size(), 0, 192, lane->stream));
@@ -2461,6 +2498,8 @@ extern "C" int flx_align_reads_resident(flx_ctx* ctx, const flx_params* P, const
         std::lock_guard<std::mutex> g(RD->peq_mu);
         if (!RD->peq_built && n_reads) {
             LaneLease lease(ctx, ctx->external_stream ? 0 : -1);
+            take_spare_read_buffer(ctx, 2, RD->d_peq);
+            take_spare_read_buffer(ctx, 1, RD->d_pack);
             int const rc = build_peq(lease.lane, RD->d_pool.as<u8>(), RD->pool.size(), RD->d_peq);
             if (rc) return rc;
             if (ctx->didx.filter) {
