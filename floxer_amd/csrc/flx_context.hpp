@@ -53,7 +53,7 @@ struct Lane {
     hipStream_t own_stream = nullptr, stream = nullptr;
     DeviceBuffer seq, seq_rev, peq, peq_rev, scheme, seeds, stack, hits, counters, rows, rows_out, qpack, items;
     DeviceBuffer jobs, job_out, trace, tjobs, tjob_out, cigar, user_text, user_text_rev, lastrow, row_windows, row_out,
-        seed_cnt, hit_off, grouped, sel_stat, sel_n, sel_off, sel_out, sel_tmp, sel_rows, sel_row_off, sel_sparse, sel_lists, vr, lane_rows, seed_gen, frame_q;
+        seed_cnt, hit_off, grouped, sel_stat, sel_n, sel_off, sel_out, sel_tmp, sel_rows, sel_row_off, sel_sparse, sel_lists, vr, lane_rows, seed_gen, mailboxes;
     size_t trace_budget_bytes = 0;
     std::vector<PendingTiming> pending;
     std::vector<hipEvent_t> event_pool;

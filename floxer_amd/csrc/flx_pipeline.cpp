@@ -95,13 +95,13 @@ hvec<DeviceBuffer*> lane_workspaces(Lane& l) {
     return {&l.seq, &l.seq_rev, &l.peq, &l.peq_rev, &l.scheme, &l.seeds, &l.stack, &l.hits, &l.counters, &l.rows, &l.rows_out, &l.jobs,
             &l.job_out, &l.trace, &l.tjobs, &l.tjob_out, &l.cigar, &l.user_text, &l.user_text_rev, &l.lastrow, &l.row_windows, &l.row_out,
             &l.seed_cnt, &l.hit_off, &l.grouped, &l.sel_stat, &l.sel_n, &l.sel_off, &l.sel_out, &l.sel_tmp, &l.sel_rows, &l.sel_row_off, &l.sel_sparse, &l.sel_lists, &l.vr, &l.lane_rows,
-            &l.qpack, &l.items, &l.seed_gen, &l.frame_q};
+            &l.qpack, &l.items, &l.seed_gen, &l.mailboxes};
 }
 // FLX_ALLOC_DEBUG: the address ranges of a lane's workspaces (a GPU memory fault reports an address)
 static void dump_lane_buffers(Lane& l, const char* when) {
     static const char* const names[] = {"seq", "seq_rev", "peq", "peq_rev", "scheme", "seeds", "stack", "hits", "counters", "rows", "rows_out", "jobs", "job_out",
         "trace", "tjobs", "tjob_out", "cigar", "user_text", "user_text_rev", "lastrow", "row_windows", "row_out", "seed_cnt", "hit_off", "grouped", "sel_stat",
-        "sel_n", "sel_off", "sel_out", "sel_tmp", "sel_rows", "sel_row_off", "sel_sparse", "sel_lists", "vr", "lane_rows", "qpack", "items", "seed_gen", "frame_q"};
+        "sel_n", "sel_off", "sel_out", "sel_tmp", "sel_rows", "sel_row_off", "sel_sparse", "sel_lists", "vr", "lane_rows", "qpack", "items", "seed_gen", "mailboxes"};
     auto const ws = lane_workspaces(l);
     for (size_t i = 0; i < ws.size(); ++i)
         if (ws[i]->ptr) fprintf(stderr, "[flx alloc] lane %d %s %s %p .. %p\n", l.id, when, names[i], ws[i]->ptr, (void*)((char*)ws[i]->ptr + ws[i]->cap));
@@ -441,7 +441,7 @@ int search_seeds_device(Lane* ctx, const u8* d_seq_pool_or_null, const u8* h_seq
     }
     // the mailboxes through which the waves of a search launch hand subtrees to each other (at most 4096 waves per launch, 6 KB each)
     u32 const mailbox_waves = device_select ? 4096u : 0u;
-    if (mailbox_waves && (rc = ctx->frame_q.ensure(DeviceApi::mailbox_bytes(mailbox_waves)))) return rc;
+    if (mailbox_waves && (rc = ctx->mailboxes.ensure(DeviceApi::mailbox_bytes(mailbox_waves)))) return rc;
     u32 counters[32];
     u64 sel_cap = (u64)(ctx->sel_rows_per_seed * 1.25 * (double)n_seeds);      // entries of the selected-anchor list (at least hit_cap, below)
     struct K1Token { flx_ctx* c; explicit K1Token(flx_ctx* c_) : c(c_) { c->k1_acquire(); } ~K1Token() { c->k1_release(); } };
@@ -471,7 +471,7 @@ int search_seeds_device(Lane* ctx, const u8* d_seq_pool_or_null, const u8* h_seq
                                                   max_hits, max_errors, ctx->hits.as<DevHit>(), (u32)std::min<u64>(hit_cap, 0xFFFFFFFFu),
                                                   item_cap ? ctx->items.as<DevHit>() : nullptr, (u32)std::min<u64>(item_cap, 0xFFFFFFFFu),
                                                   ctx->counters.as<u32>(), device_select ? ctx->seed_cnt.as<u32>() : nullptr,
-                                                  device_select ? ctx->sel_rows.as<u32>() : nullptr, device_select ? ctx->frame_q.ptr : nullptr, mailbox_waves, concurrent);
+                                                  device_select ? ctx->sel_rows.as<u32>() : nullptr, device_select ? ctx->mailboxes.ptr : nullptr, mailbox_waves, concurrent);
             return DeviceApi::search(ctx->stream, ctx->ctx->didx, d_seq, ctx->scheme.as<u64>(), ctx->seeds.as<DevSeed>(), (u32)n_seeds,
                                      max_hits, ctx->stack.as<DevFrame>(), ctx->hits.as<DevHit>(), (u32)std::min<u64>(hit_cap, 0xFFFFFFFFu),
                                      ctx->counters.as<u32>(), device_select ? ctx->seed_cnt.as<u32>() : nullptr);
