@@ -496,7 +496,7 @@ int search_seeds_device(Lane* ctx, const u8* d_seq_pool_or_null, const u8* h_seq
             if ((rc = d2h(ctx, sel_stat.data(), ctx->sel_stat.ptr, n_seeds * sizeof(DevSelStat)))) return rc;
         }
         if ((rc = ctx->sync())) return rc;
-        if (getenv("FLX_SEARCH_DEBUG")) fprintf(stderr, "[fm_search] seeds %llu ext %u (of single-row intervals %u) wave-iterations %u (max per wave %u) busy pair-iterations %u, after the queue ran dry %u (max %u), subtrees handed over %u, from wave to wave %u\n", (unsigned long long)n_seeds, counters[2], counters[3], counters[4], counters[5], counters[6], counters[8], counters[9], counters[14], counters[15]);
+        if (getenv("FLX_SEARCH_DEBUG")) fprintf(stderr, "[fm_search] seeds %llu ext %u (of single-row intervals %u) wave-iterations %u (max per wave %u) busy pair-iterations %u, after the queue ran dry %u (max %u), subtrees handed over %u, from wave to wave %u, walks abandoned over the cap %u\n", (unsigned long long)n_seeds, counters[2], counters[3], counters[4], counters[5], counters[6], counters[8], counters[9], counters[14], counters[15], counters[20]);
         if (getenv("FLX_SEARCH_DEBUG") && filtered) fprintf(stderr, "[fm_search filtered] subtrees queued %u (slots %u of %llu), filter words asked %u, children dropped %u, searches ended by the prefix lookup %u; text walk: lane-steps %u, wave-iterations %u\n", counters[3], counters[16], (unsigned long long)item_cap, counters[10], counters[11], counters[12], counters[18], counters[19]);
         if (counters[1]) { set_error(counters[1] & 2u ? "fm_search: a subtree handed between waves was not taken" : "fm_search: DFS stack reservation exceeded"); return FLX_ERR_INTERNAL; }
         bool const items_fit = !item_cap || counters[16] <= item_cap;

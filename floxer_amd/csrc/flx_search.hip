@@ -154,6 +154,7 @@ int DeviceApi::pack_pool(void* stream, const u8* d_seq, u64 len, u32* d_qpack) {
 // ================================================================================================ the search kernels
 // counters (32 words): [0] hit slots reserved, [1] frame overflow flag, [2] cursor extensions (rank pairs), [3] subtrees queued (records
 //   written, without the unused ends of the slot ranges), [13] hits written (both kernels), [14] subtrees handed from lane to lane, [15] subtrees handed from wave to wave,
+//   [20] walks abandoned because their seed had passed the hard cap elsewhere,
 //   [4] wave-iterations, [5] their maximum over the waves, [6] busy lane-iterations, [7] seed queue head, [8] wave-iterations after the
 //   seed queue ran dry, [9] their maximum, [10] filter lookups, [11] children dropped by the filter, [12] searches ended by the prefix
 //   lookup, [16] item slots reserved, [17] item queue head, [18] text-mode lane-steps, [19] text-mode wave-iterations
@@ -262,7 +263,8 @@ __global__ void __launch_bounds__(64, 4) fm_search_filter_kernel(FmConst C, u32 
     WaveSlots HS, IS;
     FmLane L;
     bool exhausted = false;
-    u32 n_iter = 0, n_busy_iter = 0, n_tail_iter = 0, n_hits = 0, n_items = 0, n_steals = 0, n_given = 0;      // (wave-uniform but n_busy_iter)
+    u32 n_iter = 0, n_busy_iter = 0, n_tail_iter = 0, n_hits = 0, n_items = 0, n_steals = 0, n_given = 0;      // (wave-uniform but n_busy_iter, n_capped)
+    u32 n_capped = 0;
     bool counted_waiting = false, flagged_long = false;                                                         // (wave-uniform)
     u32* const pair = lds + C.levels * FM_FRAME_WORDS * 64u;
     u32 const me = blockIdx.x;
@@ -460,13 +462,20 @@ __global__ void __launch_bounds__(64, 4) fm_search_filter_kernel(FmConst C, u32 
         ++n_iter;
         if (tail) ++n_tail_iter;
         if (!L.busy() || (!go && !L.in_search())) continue;
+        // In a long tail a lane looks now and then whether its seed has passed the hard cap meanwhile (the other lanes and waves that walk the
+        // seed's subtrees count into the same word): such a seed is excluded downstream whatever else it has, and the lane is better used on
+        // work another lane can spare. (A lane on its own seed notices at its next hit anyway; this is for the long stretches without one.)
+        if (seed_rows && n_tail_iter >= steal_after && (n_iter & 63u) == 0u && L.in_search()) {
+            if (seed_rows[seeds[L.pos].id] >= C.max_hits) { L.wn = 0; ++n_capped; continue; }
+        }
         ++n_busy_iter;
         fm_step<STATS>(C, L, fr);
     }
     wave_slots_close(HS, hits, hit_cap, lane);
     wave_slots_close(IS, items, item_cap, lane);
-    u32 const s_ext = s_wave_sum(L.n_ext), s_busy = s_wave_sum(n_busy_iter), s_look = s_wave_sum(L.n_lookup);
+    u32 const s_ext = s_wave_sum(L.n_ext), s_busy = s_wave_sum(n_busy_iter), s_look = s_wave_sum(L.n_lookup), s_capped = s_wave_sum(n_capped);
     if (lane == 0) {
+        atomicAdd(&counters[20], s_capped);
         if (MB.ctrl && !counted_waiting) atomicAdd(&MB.ctrl[MBC_WAITING], 1u);       // gone: nothing more to give
         atomicAdd(&counters[2], s_ext); atomicAdd(&counters[6], s_busy);
         atomicAdd(&counters[4], n_iter); atomicMax(&counters[5], n_iter); atomicAdd(&counters[8], n_tail_iter); atomicMax(&counters[9], n_tail_iter);
