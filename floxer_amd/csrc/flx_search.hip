@@ -250,7 +250,7 @@ __device__ __forceinline__ void mb_release() { __builtin_amdgcn_fence(__ATOMIC_R
 template <bool STATS>
 __global__ void __launch_bounds__(64, 4) fm_search_filter_kernel(FmConst C, u32 n_seeds, DevHit* __restrict__ hits,
                                                               u32 hit_cap, DevHit* __restrict__ items, u32 item_cap, u32* __restrict__ counters,
-                                                              u32* __restrict__ seed_cnt, u32* __restrict__ seed_rows, Mailboxes MB, u32 refill, u32 prio, u32 steal_min, u32 steal_after) {
+                                                              u32* __restrict__ seed_cnt, u32* __restrict__ seed_rows, Mailboxes MB, u32 refill, u32 prio, u32 steal_min, u32 steal_after, u32 cap_look) {
     extern __shared__ u32 lds[];                // frames: [level][FM_FRAME_WORDS][64 lanes], then 64 words for the pairing of lanes
     if (prio == 3u) __builtin_amdgcn_s_setprio(3);
     else if (prio == 2u) __builtin_amdgcn_s_setprio(2);
@@ -465,7 +465,7 @@ __global__ void __launch_bounds__(64, 4) fm_search_filter_kernel(FmConst C, u32 
         // In a long tail a lane looks now and then whether its seed has passed the hard cap meanwhile (the other lanes and waves that walk the
         // seed's subtrees count into the same word): such a seed is excluded downstream whatever else it has, and the lane is better used on
         // work another lane can spare. (A lane on its own seed notices at its next hit anyway; this is for the long stretches without one.)
-        if (seed_rows && n_tail_iter >= steal_after && (n_iter & 63u) == 0u && L.in_search()) {
+        if (seed_rows && n_tail_iter >= steal_after && (n_iter & cap_look) == 0u && L.in_search()) {
             if (seed_rows[seeds[L.pos].id] >= C.max_hits) { L.wn = 0; ++n_capped; continue; }
         }
         ++n_busy_iter;
@@ -623,6 +623,7 @@ int DeviceApi::search_filtered(void* stream, const DevIndex& idx, const u8* d_se
     size_t const lds_bytes = (size_t)C.levels * FM_FRAME_WORDS * 64 * sizeof(u32) + 64 * sizeof(u32) + extra_lds;
     u32 const steal_min = env_u32("FLX_FM_STEAL_MIN", 1);              // idle lanes a wave waits for before it shares work (0: never)
     u32* const seed_rows = steal_min ? d_seed_rows : nullptr;
+    u32 const cap_look = env_u32("FLX_FM_CAP_LOOK", 64) - 1u;         // a lane in a long tail looks at its seed's row count every so many iterations (a power of two)
     u32 const steal_after = env_u32("FLX_FM_STEAL_AFTER", 64);         // iterations a wave's queue has been dry before its lanes share work
     static u32 const stats = env_u32("FLX_SEARCH_DEBUG", 0);           // the diagnostic counters [11], [12] cost two registers per lane
     // the mailboxes of this launch's waves: control words, states, counts and the hungry list zeroed, then the subtree slots
@@ -637,7 +638,7 @@ int DeviceApi::search_filtered(void* stream, const DevIndex& idx, const u8* d_se
         MB.items = reinterpret_cast<FrameItem*>((char*)d_mailboxes + (zeroed + 255) / 256 * 256);
     }
     auto const kernel = stats ? fm_search_filter_kernel<true> : fm_search_filter_kernel<false>;
-    hipLaunchKernelGGL(kernel, grid, dim3(64), lds_bytes, s, C, n_seeds, d_hits, hit_cap, d_items, item_cap, d_counters, d_seed_cnt, seed_rows, MB, refill_a, fm_prio, std::max(1u, steal_min), steal_after);
+    hipLaunchKernelGGL(kernel, grid, dim3(64), lds_bytes, s, C, n_seeds, d_hits, hit_cap, d_items, item_cap, d_counters, d_seed_cnt, seed_rows, MB, refill_a, fm_prio, std::max(1u, steal_min), steal_after, cap_look);
     if (C.text_min_remain) {
         // (the number of queued subtrees is only known on the device: a fixed grid, waves without work leave at once; the walk is a
         // chain of dependent loads from the L2, so it wants every wave slot: 8 per SIMD)
