@@ -2,7 +2,9 @@
 this module only marshals numpy arrays. There is no CPU fallback: without the built library or without a GPU every
 device entry point raises FloxerError."""
 import ctypes as C
+import importlib.util
 import os
+import sys
 
 import numpy as np
 
@@ -98,6 +100,32 @@ EXPORTED = [
 _lib = None
 
 
+def _share_torchs_hip_runtime():
+    """One HIP runtime per process. A ROCm build of PyTorch brings its own libamdhip64.so (soname libamdhip64.so.7, like the system's)
+    and looks it up by path, so a process that loads this library first and torch later ends up with two runtimes, and the second
+    one cannot attach to the GPU (KFD gives a process one VM: AMDKFD_IOC_ACQUIRE_VM fails, torch reports "No HIP GPUs are
+    available"). Loading torch's copy first makes the dynamic loader hand the same copy to this library (it asks for the soname)
+    and to torch whenever it comes. Nothing is imported; FLX_SYSTEM_HIP=1 keeps the system's runtime (then import torch never, or
+    before floxer_amd's first call)."""
+    if os.environ.get("FLX_SYSTEM_HIP") == "1" or "torch" in sys.modules:
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.origin:
+        return
+    path = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+    if os.path.exists(path):
+        C.CDLL(path, mode=C.RTLD_GLOBAL)
+
+
+def hip_runtime_paths():
+    """the libamdhip64 copies mapped into this process (one, unless something went wrong)"""
+    with open("/proc/self/maps") as f:
+        return sorted({line.split()[-1] for line in f if "libamdhip64" in line})
+
+
 def lib():
     global _lib
     if _lib is not None:
@@ -105,6 +133,7 @@ def lib():
     if not os.path.exists(LIB_PATH):
         raise FloxerError(f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                           "(floxer_amd has no CPU fallback)")
+    _share_torchs_hip_runtime()
     L = C.CDLL(LIB_PATH)
     L.flx_last_error.restype = C.c_char_p
     L.flx_version.restype = C.c_char_p

@@ -56,7 +56,7 @@ struct alignas(32) OccBlock {
     u32 w[8];
 };
 constexpr u32 OCC_BLOCK_POS = 32;
-constexpr u32 TEXT_PAD = 128;     // bytes of padding in front of and behind the device copy of a reference text
+constexpr u32 TEXT_PAD = 256;     // bytes of padding in front of and behind the device copy of a reference text (the text walk copies up to 176 symbols around a position)
 
 struct HostIndex {
     u64 n = 0;                            // padded text length
@@ -242,7 +242,9 @@ struct DeviceApi {
     // (see fm_search_filter_kernel)
     static int search_filtered(void* stream, const DevIndex& idx, const u8* d_seq, const u32* d_qpack, const u64* d_scheme, const DevSeed* d_seeds,
                                u32 n_seeds, u32 max_hits_per_seed, u32 frame_levels, DevHit* d_hits, u32 hit_cap, DevHit* d_items, u32 item_cap,
-                               u32* d_counters, u32* d_seed_cnt, u32* d_seed_rows, void* d_mailboxes, u32 mailbox_waves, u32 concurrent_launches);
+                               u32* d_counters, u32* d_seed_cnt, u32* d_seed_rows, void* d_mailboxes, u32 mailbox_waves, u32 concurrent_launches,
+                               bool long_seeds = false);
+    // long_seeds: most seeds of the launch have more than 64 symbols (the text walk then takes its larger LDS windows: up to 160 symbols)
     // the mailboxes through which the waves of one launch of the filter walk hand subtrees to each other (room for `waves` waves; may be null)
     static size_t mailbox_bytes(u32 waves);
     // the tables a context derives from text and suffix array: bytes of isa + filter for a text of n symbols; derive_index fills

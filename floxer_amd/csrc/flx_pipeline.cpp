@@ -369,6 +369,14 @@ int search_seeds_device(Lane* ctx, const u8* d_seq_pool_or_null, const u8* h_seq
         }
     }
     if (scheme_table.empty()) scheme_table.push_back(0);
+    // most seeds longer than 64 symbols (20-kb reads at 2 %: leaves of 98 .. 147)? The text walk then takes its larger LDS windows.
+    bool long_seeds = false;
+    {
+        u64 n_long = 0, n_all = 0;
+        if (gen) { for (auto const& lf : gen->leaves) { n_long += lf.length > 64u; ++n_all; } }
+        else for (u64 i = 0; i < n_seeds; ++i) { n_long += seeds[i].length > 64u; ++n_all; }
+        long_seeds = 2 * n_long > n_all;
+    }
 
     sprof.mark("prep");
     int rc;
@@ -471,7 +479,7 @@ int search_seeds_device(Lane* ctx, const u8* d_seq_pool_or_null, const u8* h_seq
                                                   max_hits, max_errors, ctx->hits.as<DevHit>(), (u32)std::min<u64>(hit_cap, 0xFFFFFFFFu),
                                                   item_cap ? ctx->items.as<DevHit>() : nullptr, (u32)std::min<u64>(item_cap, 0xFFFFFFFFu),
                                                   ctx->counters.as<u32>(), device_select ? ctx->seed_cnt.as<u32>() : nullptr,
-                                                  device_select ? ctx->sel_rows.as<u32>() : nullptr, device_select ? ctx->mailboxes.ptr : nullptr, mailbox_waves, concurrent);
+                                                  device_select ? ctx->sel_rows.as<u32>() : nullptr, device_select ? ctx->mailboxes.ptr : nullptr, mailbox_waves, concurrent, long_seeds);
             return DeviceApi::search(ctx->stream, ctx->ctx->didx, d_seq, ctx->scheme.as<u64>(), ctx->seeds.as<DevSeed>(), (u32)n_seeds,
                                      max_hits, ctx->stack.as<DevFrame>(), ctx->hits.as<DevHit>(), (u32)std::min<u64>(hit_cap, 0xFFFFFFFFu),
                                      ctx->counters.as<u32>(), device_select ? ctx->seed_cnt.as<u32>() : nullptr);

@@ -493,7 +493,9 @@ __global__ void __launch_bounds__(64, 4) fm_search_filter_kernel(FmConst C, u32 
 // seed (up to TX_WIN_MAXLEN symbols) and the text from 4 symbols left of the leftmost position the subtree can reach to 4 right of the
 // rightmost (string + remaining seed symbols + one per error either side), four bits per symbol, into LDS; the walk then reads LDS.
 // Longer seeds (the one leaf of a PEX tree that takes the remainder, 20-kb reads at 2 %) keep reading memory.
-constexpr u32 TX_WIN_MAXLEN = 64, TX_WIN_T = 10, TX_WIN_Q = 9;      // seed symbols; 8-symbol words of the text window (64 + 3 + 8 + 3 <= 80) and of the seed (64 + 3 <= 72)
+// Two sizes: seeds of up to 64 symbols (10-kb reads at 8 %: leaves of 24 and 36) or of up to 160 (20-kb reads at 2 %: leaves of 98 .. 147;
+// 11 KB of windows per wave). MAXLEN seed symbols need (MAXLEN + 3 + 8 + 3) / 8 words of text window and (MAXLEN + 3) / 8 of seed.
+template <u32 MAXLEN> struct TxWin { static constexpr u32 T = (MAXLEN + 14u + 7u) / 8u, Q = (MAXLEN + 3u + 7u) / 8u; };
 __device__ __forceinline__ u32 nibbles_of(u32 lo, u32 hi) {          // eight bytes (values 0..15) -> eight nibbles, first byte lowest
     u32 a = (lo | (lo >> 4)) & 0x00FF00FFu, b = (hi | (hi >> 4)) & 0x00FF00FFu;
     a = (a | (a >> 8)) & 0xFFFFu; b = (b | (b >> 8)) & 0xFFFFu;
@@ -515,10 +517,12 @@ struct TxWinAccess {
     }
 };
 
+template <u32 TX_WIN_MAXLEN>
 __global__ void __launch_bounds__(64) fm_search_text_kernel(FmConst C, const DevSeed* __restrict__ seeds, const DevHit* __restrict__ items, u32 item_cap,
                                                             DevHit* __restrict__ hits, u32 hit_cap, u32* __restrict__ counters, u32* __restrict__ seed_cnt,
                                                             u32 refill, u32 prio, u32 windows) {
     extern __shared__ u32 lds[];                // frames: [level][TX_FRAME_WORDS][64 lanes]; then the text windows and the seed windows, [word][lane]
+    constexpr u32 TX_WIN_T = TxWin<TX_WIN_MAXLEN>::T, TX_WIN_Q = TxWin<TX_WIN_MAXLEN>::Q;
     if (prio == 3u) __builtin_amdgcn_s_setprio(3);
     else if (prio == 2u) __builtin_amdgcn_s_setprio(2);
     else if (prio == 1u) __builtin_amdgcn_s_setprio(1);
@@ -597,7 +601,7 @@ static u32 env_u32(const char* name, u32 dflt) {
 // queued). frame_levels = largest error count of a seed. d_counters: 32 words, zeroed by the caller.
 int DeviceApi::search_filtered(void* stream, const DevIndex& idx, const u8* d_seq, const u32* d_qpack, const u64* d_scheme, const DevSeed* d_seeds,
                                u32 n_seeds, u32 max_hits_per_seed, u32 frame_levels, DevHit* d_hits, u32 hit_cap, DevHit* d_items, u32 item_cap,
-                               u32* d_counters, u32* d_seed_cnt, u32* d_seed_rows, void* d_mailboxes, u32 mailbox_waves, u32 concurrent_launches) {
+                               u32* d_counters, u32* d_seed_cnt, u32* d_seed_rows, void* d_mailboxes, u32 mailbox_waves, u32 concurrent_launches, bool long_seeds) {
     if (n_seeds == 0) return 0;
     static u32 const spw = env_u32("FLX_FM_SEEDS_PER_WAVE", 256);
     static u32 const forced_waves = env_u32("FLX_FM_MAX_WAVES", 0);
@@ -646,9 +650,13 @@ int DeviceApi::search_filtered(void* stream, const DevIndex& idx, const u8* d_se
         u32 const tw = std::max(1u, text_waves / std::max(1u, std::min(concurrent_launches, 8u)));
         // (the windows need 4-byte aligned bases: the text is, a sequence pool handed in at an odd address is read byte by byte as before)
         u32 const windows = env_u32("FLX_FM_NO_WINDOWS", 0) == 0 && ((uintptr_t)d_seq & 3u) == 0 && ((uintptr_t)idx.text & 3u) == 0;
-        hipLaunchKernelGGL(fm_search_text_kernel, dim3(std::min<u32>(std::max<u32>(grid.x * 4u, 64u), tw)), dim3(64),
-                           ((size_t)C.levels * TX_FRAME_WORDS + TX_WIN_T + TX_WIN_Q) * 64 * sizeof(u32), s, C,
-                           d_seeds, d_items, item_cap, d_hits, hit_cap, d_counters, d_seed_cnt, refill_t, fm_prio, windows);
+        dim3 const tgrid(std::min<u32>(std::max<u32>(grid.x * 4u, 64u), tw));
+        if (long_seeds)
+            hipLaunchKernelGGL(fm_search_text_kernel<160>, tgrid, dim3(64), ((size_t)C.levels * TX_FRAME_WORDS + TxWin<160>::T + TxWin<160>::Q) * 64 * sizeof(u32), s, C,
+                               d_seeds, d_items, item_cap, d_hits, hit_cap, d_counters, d_seed_cnt, refill_t, fm_prio, windows);
+        else
+            hipLaunchKernelGGL(fm_search_text_kernel<64>, tgrid, dim3(64), ((size_t)C.levels * TX_FRAME_WORDS + TxWin<64>::T + TxWin<64>::Q) * 64 * sizeof(u32), s, C,
+                               d_seeds, d_items, item_cap, d_hits, hit_cap, d_counters, d_seed_cnt, refill_t, fm_prio, windows);
     }
     return (int)hipGetLastError();
 }

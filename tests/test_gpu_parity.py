@@ -1172,6 +1172,17 @@ def test_context_on_an_index_image_and_two_contexts():
         c.close()
 
 
+def test_torch_started_after_the_library_has_worked_finds_the_gpu():
+    """the order a test run of this file alone has (the library works, torch comes later): one HIP runtime in the process, so
+    torch's initialisation finds the GPU (scripts/torch_after_lib.py; a child process, so that the order is this test's)"""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "scripts", "torch_after_lib.py"), "G"], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert "torch after the library: ok" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
+
+
 def test_device_rounds_equal_host_rounds():
     """The inner PEX levels with the anchors' state on the device (requests, de-duplication, clusters, moves up the trees as kernels)
     against the host form of the same rounds (taken when a statistics object is attached: it wants every request's window), on a

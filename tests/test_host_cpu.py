@@ -25,6 +25,21 @@ def test_library_exports_every_declared_symbol():
     assert b"floxer_amd" in capi.lib().flx_version()
 
 
+def test_one_hip_runtime_per_process_whichever_is_loaded_first():
+    """capi._share_torchs_hip_runtime: the library loaded before torch must leave one libamdhip64 in the process (two cannot both
+    attach to the GPU). A fresh interpreter, so that the order is this test's."""
+    import subprocess
+    import sys
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "from floxer_amd import capi\n"
+            "capi.lib(); first = capi.hip_runtime_paths()\n"
+            "import torch\n"
+            "both = capi.hip_runtime_paths(); print(len(first), len(both), first == both)\n") % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert out.stdout.split() == ["1", "1", "True"], out.stdout
+
+
 def test_math_and_input_pins(pins):
     for a, b, e in pins["math"]["ceil_div"]:
         assert F.ceil_div(a, b) == e
