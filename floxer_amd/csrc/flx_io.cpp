@@ -3,9 +3,13 @@
 //   the primary record carries the forward read + qualities, secondary records have empty SEQ/QUAL;
 //   unmapped records: flag 4, RNAME *, no tags. Format chosen by extension (output.hpp:33-38). BGZF via zlib.
 #include <zlib.h>
+#if defined(__x86_64__)
+#include <immintrin.h>
+#endif
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -29,6 +33,12 @@ struct flx_sam_writer {
 };
 
 namespace {
+
+// FLX_WRITER_PROFILE=1: seconds the writer's threads spent formatting records, deflating and on checksums (summed over the threads), on
+// stderr when the file is closed
+std::atomic<uint64_t> g_ns_format{0}, g_ns_deflate{0}, g_ns_crc{0};
+bool writer_profile() { static bool const v = getenv("FLX_WRITER_PROFILE") != nullptr; return v; }
+inline uint64_t prof_ns() { return writer_profile() ? (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count() : 0; }
 
 constexpr size_t BGZF_BLOCK = 0xff00;
 constexpr size_t BGZF_MAX_OUT = 0x10000 + 64;
@@ -208,8 +218,14 @@ void canonical_codes(const uint8_t* len, unsigned n, uint32_t* code) {
     for (unsigned b = 0; b < n; ++b) code[b] = len[b] ? bit_reverse(next[len[b]]++, len[b]) : 0;
 }
 
+// What the caller knows about a stretch of the block. dist > 0, a repeat: data[pos, pos + len) == data[pos - dist, pos - dist + len) (the
+// CIGAR array of a record that shares it with the record before); checked before it is used, a wrong one is ignored. dist == 0, nothing to
+// find: the stretch repeats nothing in front of it and nothing behind it will want it (a CIGAR array seen for the first time in this block: the
+// records that share it are hinted themselves): it is coded as literals without a look at the table. Sorted by pos, no overlaps.
+struct LzHint { uint32_t pos, len, dist; };
+
 // raw deflate stream for data[0, n), n <= BGZF_BLOCK, into out (capacity >= n + 1200); returns its length
-size_t lz_deflate(const uint8_t* data, size_t n, uint8_t* out) {
+size_t lz_deflate(const uint8_t* data, size_t n, uint8_t* out, const LzHint* hints = nullptr, size_t n_hints = 0) {
     if (n < 64) return literal_deflate(data, n, out);
     // ---- parse
     constexpr unsigned HASH_BITS = 13;
@@ -234,7 +250,52 @@ size_t lz_deflate(const uint8_t* data, size_t n, uint8_t* out) {
     constexpr size_t MIN_MATCH = 32;                       // shorter repeats (the zero bytes of CIGAR words) are left to the entropy code
     size_t matched = 0;                                    // bytes covered by matches so far
     size_t next_insert = 0;                                // every eighth position enters the table: a repeat of MIN_MATCH bytes holds two of them
+    auto emit_match = [&](size_t at, size_t len, unsigned dist) {
+        uint16_t const run = flush_literals(at);
+        // a long match goes out as pieces of at most 258 bytes (never leaving a piece shorter than 3)
+        unsigned dcode, deb, dev;
+        distance_code(dist, dcode, deb, dev);
+        size_t left = len;
+        bool first = true;
+        while (left) {
+            size_t const piece = left > 258 ? (left - 258 < 3 ? 255 : 258) : left;
+            tokens.push_back(LzToken{first ? run : (uint16_t)0, (uint16_t)piece, (uint16_t)dist});
+            unsigned code, eb, ev;
+            length_code((unsigned)piece, code, eb, ev);
+            ++lfreq[code];
+            ++dfreq[dcode];
+            left -= piece;
+            first = false;
+        }
+        lit_start = at + len;
+        matched += len;
+    };
+    size_t hint_at = 0;
     while (i <= last) {
+        // a hinted repeat that starts here (or that the scan has walked into): taken whole, and nothing of it enters the table - the record
+        // after it is hinted too, or finds the literal copy at the start of the block
+        while (hint_at < n_hints && (size_t)hints[hint_at].pos + hints[hint_at].len <= i) ++hint_at;
+        if (hint_at < n_hints && hints[hint_at].pos <= i) {
+            LzHint const& h = hints[hint_at];
+            size_t const end = std::min<size_t>((size_t)h.pos + h.len, n);
+            if (h.dist == 0) {
+                i = end;
+                next_insert = (i + 7) & ~(size_t)7;
+                ++hint_at;
+                continue;
+            }
+            if (h.dist >= 1 && h.dist <= 32768 && h.dist <= i && end - i >= MIN_MATCH && memcmp(data + i, data + i - h.dist, end - i) == 0) {
+                emit_match(i, end - i, h.dist);
+                // (a position in 64 still enters the table: a repeat nobody announced - the same array again after another one - finds this copy,
+                // and is extended back to its start from wherever it is hit)
+                for (size_t k = (i + 63) & ~(size_t)63; k < end && k <= last; k += 64) table[hash8(k)] = (uint16_t)(k + 1);
+                i = end;
+                next_insert = (i + 7) & ~(size_t)7;
+                ++hint_at;
+                continue;
+            }
+            ++hint_at;
+        }
         while (next_insert < i) { if (next_insert <= last) table[hash8(next_insert)] = (uint16_t)(next_insert + 1); next_insert += 8; }
         // (looked up before it enters the table itself: records whose size is a multiple of eight repeat at exactly the table's positions)
         uint32_t const h = hash8(i);
@@ -250,25 +311,8 @@ size_t lz_deflate(const uint8_t* data, size_t n, uint8_t* out) {
             size_t at = i;
             while (at > lit_start && c > 0 && data[c - 1] == data[at - 1]) { --c; --at; ++len; }      // the match began before the table's position
             if (len >= MIN_MATCH) {
-                unsigned const dist = (unsigned)(at - c);
-                uint16_t const run = flush_literals(at);
-                // a long match goes out as pieces of at most 258 bytes (never leaving a piece shorter than 3)
-                size_t left = len;
-                bool first = true;
-                while (left) {
-                    size_t const piece = left > 258 ? (left - 258 < 3 ? 255 : 258) : left;
-                    tokens.push_back(LzToken{first ? run : (uint16_t)0, (uint16_t)piece, (uint16_t)dist});
-                    unsigned code, eb, ev;
-                    length_code((unsigned)piece, code, eb, ev);
-                    ++lfreq[code];
-                    distance_code(dist, code, eb, ev);
-                    ++dfreq[code];
-                    left -= piece;
-                    first = false;
-                }
+                emit_match(at, len, (unsigned)(at - c));
                 i = at + len;
-                lit_start = i;
-                matched += len;
                 continue;
             }
         }
@@ -279,12 +323,21 @@ size_t lz_deflate(const uint8_t* data, size_t n, uint8_t* out) {
     uint16_t const tail_run = flush_literals(n);
     // literal frequencies: everything outside the matches
     {
+        // (four tables: three of four CIGAR bytes are zero, and one counter incremented byte after byte is a chain of store-to-load forwards)
+        uint32_t h4[4][256];
+        memset(h4, 0, sizeof(h4));
+        auto count = [&](const uint8_t* p, size_t len) {
+            size_t k = 0;
+            for (; k + 4 <= len; k += 4) { ++h4[0][p[k]]; ++h4[1][p[k + 1]]; ++h4[2][p[k + 2]]; ++h4[3][p[k + 3]]; }
+            for (; k < len; ++k) ++h4[0][p[k]];
+        };
         size_t pos = 0;
         for (auto const& t : tokens) {
-            for (size_t k = 0; k < t.lit_run; ++k) ++lfreq[data[pos + k]];
+            count(data + pos, t.lit_run);
             pos += (size_t)t.lit_run + t.len;
         }
-        for (size_t k = 0; k < tail_run; ++k) ++lfreq[data[pos + k]];
+        count(data + pos, tail_run);
+        for (unsigned b = 0; b < 256; ++b) lfreq[b] += h4[0][b] + h4[1][b] + h4[2][b] + h4[3][b];
     }
     lfreq[256] = 1;
     bool any_dist = false;
@@ -335,11 +388,67 @@ size_t lz_deflate(const uint8_t* data, size_t n, uint8_t* out) {
     return (size_t)(bs.finish() - out);
 }
 
-// one BGZF block (a gzip member with the BC extra field) for `len` <= BGZF_BLOCK bytes; returns its size, 0 on failure
-size_t bgzf_compress_block(const uint8_t* data, size_t len, uint8_t* out) {
+// ---- CRC-32 of a block by carry-less multiplication (Gopal et al., "Fast CRC Computation for Generic Polynomials Using PCLMULQDQ
+// Instruction", Intel 2009; bit-reflected form for the gzip polynomial): four 128-bit lanes are folded 64 bytes ahead per step
+// (x^(512+64) and x^512 mod P), the lanes folded into one (x^(128+64), x^128), then 128 -> 64 -> 32 bits (x^96, x^64; Barrett with
+// floor(x^64 / P) and P). zlib 1.2.11's table code runs at 0.9 GB/s and was a third of a writer thread's time at default flags.
+#if defined(__x86_64__)
+#define FLX_CLMUL __attribute__((target("pclmul,sse4.1")))
+FLX_CLMUL inline __m128i clmul_load(const uint8_t* p) { return _mm_loadu_si128(reinterpret_cast<const __m128i*>(p)); }
+FLX_CLMUL inline __m128i clmul_fold(__m128i x, __m128i k, __m128i next) {
+    return _mm_xor_si128(_mm_xor_si128(_mm_clmulepi64_si128(x, k, 0x00), _mm_clmulepi64_si128(x, k, 0x11)), next);
+}
+FLX_CLMUL uint32_t crc32_clmul(const uint8_t* buf, size_t len, uint32_t state) {      // len >= 64, a multiple of 16; state: the inverted CRC
+    __m128i const k_512 = _mm_set_epi64x(0x01c6e41596, 0x0154442bd4);        // low: x^(512+64) mod P, high: x^512 mod P
+    __m128i const k_128 = _mm_set_epi64x(0x00ccaa009e, 0x01751997d0);        // low: x^(128+64) mod P, high: x^128 mod P
+    __m128i const k_64 = _mm_set_epi64x(0, 0x0163cd6124);                    // x^64 mod P
+    __m128i const k_poly = _mm_set_epi64x(0x01f7011641, 0x01db710641);       // low: P, high: floor(x^64 / P)
+#define load clmul_load
+#define fold clmul_fold
+    __m128i x1 = _mm_xor_si128(load(buf), _mm_cvtsi32_si128((int)state)), x2 = load(buf + 16), x3 = load(buf + 32), x4 = load(buf + 48);
+    buf += 64; len -= 64;
+    while (len >= 64) {
+        x1 = fold(x1, k_512, load(buf));
+        x2 = fold(x2, k_512, load(buf + 16));
+        x3 = fold(x3, k_512, load(buf + 32));
+        x4 = fold(x4, k_512, load(buf + 48));
+        buf += 64; len -= 64;
+    }
+    x1 = fold(x1, k_128, x2);
+    x1 = fold(x1, k_128, x3);
+    x1 = fold(x1, k_128, x4);
+    while (len >= 16) { x1 = fold(x1, k_128, load(buf)); buf += 16; len -= 16; }
+    __m128i const mask32 = _mm_setr_epi32(~0, 0, ~0, 0);
+    __m128i t = _mm_clmulepi64_si128(x1, k_128, 0x10);                       // 128 -> 96 bits
+    x1 = _mm_xor_si128(_mm_srli_si128(x1, 8), t);
+    t = _mm_srli_si128(x1, 4);                                               // 96 -> 64
+    x1 = _mm_xor_si128(_mm_clmulepi64_si128(_mm_and_si128(x1, mask32), k_64, 0x00), t);
+    t = _mm_and_si128(_mm_clmulepi64_si128(_mm_and_si128(x1, mask32), k_poly, 0x10), mask32);      // Barrett
+    t = _mm_clmulepi64_si128(t, k_poly, 0x00);
+    return (uint32_t)_mm_extract_epi32(_mm_xor_si128(x1, t), 1);
+#undef load
+#undef fold
+}
+#endif
+uint32_t block_crc32(const uint8_t* data, size_t len) {
+#if defined(__x86_64__)
+    static bool const have = __builtin_cpu_supports("pclmul") && __builtin_cpu_supports("sse4.1") && !getenv("FLX_CRC_ZLIB");
+    if (have && len >= 64) {
+        size_t const head = len & ~(size_t)15;
+        uint32_t const c = ~crc32_clmul(data, head, 0xFFFFFFFFu);
+        return head == len ? c : (uint32_t)crc32(c, data + head, (uInt)(len - head));
+    }
+#endif
+    return (uint32_t)crc32(crc32(0L, Z_NULL, 0), data, (uInt)len);
+}
+
+// one BGZF block (a gzip member with the BC extra field) for `len` <= BGZF_BLOCK bytes; returns its size, 0 on failure.
+// hints: repeats the caller knows of (lz_deflate)
+size_t bgzf_compress_block(const uint8_t* data, size_t len, uint8_t* out, const LzHint* hints = nullptr, size_t n_hints = 0) {
     size_t clen;
     BgzfEncoder const enc = bgzf_encoder();
-    if (enc == ENC_LZ) clen = lz_deflate(data, len, out + 18);
+    uint64_t const t_deflate = prof_ns();
+    if (enc == ENC_LZ) clen = lz_deflate(data, len, out + 18, hints, n_hints);
     else if (enc == ENC_LITERAL) clen = literal_deflate(data, len, out + 18);
     else {
         thread_local BlockDeflater deflater;
@@ -359,7 +468,9 @@ size_t bgzf_compress_block(const uint8_t* data, size_t len, uint8_t* out) {
     memcpy(out, hdr, 16);
     out[16] = (uint8_t)((bsize - 1) & 0xff);
     out[17] = (uint8_t)((bsize - 1) >> 8);
-    uint32_t const crc = (uint32_t)crc32(crc32(0L, Z_NULL, 0), data, (uInt)len);
+    uint64_t const t_crc = prof_ns();
+    uint32_t const crc = block_crc32(data, len);
+    if (writer_profile()) { g_ns_deflate += t_crc - t_deflate; g_ns_crc += prof_ns() - t_crc; }
     uint32_t const isize = (uint32_t)len;
     memcpy(out + 18 + clen, &crc, 4);
     memcpy(out + 18 + clen + 4, &isize, 4);
@@ -458,8 +569,10 @@ extern "C" int flx_sam_open(const char* path, const char* const* ref_ids, const 
 
 namespace {
 // one record as SAM text or as a BAM record, appended to `out`; false: the record cannot be represented (error set)
+// cigar_at (BAM): where in `out` the record's CIGAR array starts (SIZE_MAX: it has none of its own)
 bool format_record(flx_sam_writer const* w, flx_record const& r, const char* const* read_ids, const uint8_t* read_pool,
-                   const uint64_t* read_offsets, const char* const* quals, const uint32_t* cigar_words, std::vector<uint8_t>& out, std::string& err) {
+                   const uint64_t* read_offsets, const char* const* quals, const uint32_t* cigar_words, std::vector<uint8_t>& out, std::string& err,
+                   size_t* cigar_at = nullptr) {
     static const char ops[] = "MIDNSHP=X";
     const char* id = read_ids[r.read_index];
     bool const unmapped = (r.flag & 4u) != 0;
@@ -497,11 +610,19 @@ bool format_record(flx_sam_writer const* w, flx_record const& r, const char* con
     }
     size_t const l_name = strlen(id) + 1;
     if (l_name > 255) { err = std::string("read name longer than 254 characters cannot be written to BAM: ") + id; return false; }
-    int64_t ref_span = 0;
-    for (uint32_t c = 0; c < r.cigar_length; ++c) {
-        uint32_t const op = cig[c] & 15, len = cig[c] >> 4;
-        if (op == 0 || op == 2 || op == 3 || op == 7 || op == 8) ref_span += len;
+    // (the forty records of a read at one locus share one CIGAR array: its span is summed once)
+    thread_local const uint32_t* span_of = nullptr;
+    thread_local uint32_t span_len = 0;
+    thread_local int64_t span = 0;
+    if (span_of != cig || span_len != r.cigar_length || !cig) {
+        span = 0;
+        for (uint32_t c = 0; c < r.cigar_length; ++c) {
+            uint32_t const op = cig[c] & 15, len = cig[c] >> 4;
+            if (op == 0 || op == 2 || op == 3 || op == 7 || op == 8) span += len;
+        }
+        span_of = cig; span_len = r.cigar_length;
     }
+    int64_t const ref_span = span;
     // more than 65535 operations do not fit n_cigar_op: the record carries kSmN and the real CIGAR in the CG:B,I tag (SAM spec 4.2.2)
     bool const long_cigar = r.cigar_length > 65535u;
     size_t const start = out.size();
@@ -523,14 +644,24 @@ bool format_record(flx_sam_writer const* w, flx_record const& r, const char* con
     out.insert(out.end(), id, id + l_name);
     // (the placeholder's S length is the stored SEQ length, 0 for a secondary record written without SEQ: that is what htslib's
     // bam_tag2cigar and seqan3 compare it with)
+    if (cigar_at) *cigar_at = SIZE_MAX;
     if (long_cigar) { put32((int32_t)(((uint32_t)slen << 4) | 4u)); put32((int32_t)(((uint32_t)ref_span << 4) | 3u)); }
-    else { size_t const at = out.size(); out.resize(at + 4 * (size_t)r.cigar_length); memcpy(out.data() + at, cig, 4 * (size_t)r.cigar_length); }
-    static const uint8_t nib[6] = {15, 1, 2, 4, 8, 15};       // =ACMGRSVTWYHKDBN codes for $ACGTN
-    for (uint64_t b = 0; b < slen; b += 2) {
-        uint8_t const hi = nib[seq[b] < 6 ? seq[b] : 5], lo = b + 1 < slen ? nib[seq[b + 1] < 6 ? seq[b + 1] : 5] : 0;
-        out.push_back((uint8_t)(hi << 4 | lo));
+    else {
+        size_t const at = out.size();
+        if (r.cigar_length) out.insert(out.end(), reinterpret_cast<const uint8_t*>(cig), reinterpret_cast<const uint8_t*>(cig + r.cigar_length));
+        if (cigar_at && r.cigar_length) *cigar_at = at;
     }
-    { size_t const at = out.size(); out.resize(at + slen); for (uint64_t b = 0; b < slen; ++b) out[at + b] = qual && *qual ? (uint8_t)(qual[b] - 33) : 0xff; }
+    if (slen) {
+        static const uint8_t nib[6] = {15, 1, 2, 4, 8, 15};   // =ACMGRSVTWYHKDBN codes for $ACGTN
+        size_t const at = out.size(), packed = (size_t)((slen + 1) / 2);
+        out.resize(at + packed + slen);
+        uint8_t* const sp = out.data() + at;
+        for (uint64_t b = 0; b + 1 < slen; b += 2) sp[b >> 1] = (uint8_t)(nib[seq[b] < 6 ? seq[b] : 5] << 4 | nib[seq[b + 1] < 6 ? seq[b + 1] : 5]);
+        if (slen & 1) sp[slen >> 1] = (uint8_t)(nib[seq[slen - 1] < 6 ? seq[slen - 1] : 5] << 4);
+        uint8_t* const qp = sp + packed;
+        if (qual && *qual) for (uint64_t b = 0; b < slen; ++b) qp[b] = (uint8_t)(qual[b] - 33);
+        else memset(qp, 0xff, slen);
+    }
     if (!unmapped) {
         out.push_back('N'); out.push_back('M');
         if (r.num_errors < 256) { out.push_back('C'); out.push_back((uint8_t)r.num_errors); }
@@ -575,21 +706,50 @@ extern "C" int flx_sam_write(flx_sam_writer* w, const char* const* read_ids, con
             raw.clear();
             std::vector<uint8_t>& outv = parts[p];
             size_t done = 0;                                   // bytes of raw already compressed
+            size_t base = 0;                                   // bytes of the part's stream that have left raw: stream position = base + index
+            // what the deflate encoder is told: a record whose CIGAR array is the one of the record before it (same offset and length in the
+            // run's pool) repeats it at the distance of the two arrays; stream positions
+            struct StreamHint { size_t pos, len, dist; };
+            thread_local std::vector<StreamHint> hints;
+            thread_local std::vector<LzHint> block_hints;
+            hints.clear();
+            size_t hint_first = 0;                             // hints before this one lie wholly in front of `done`
             auto deflate_full_blocks = [&](bool all) {
                 while (raw.size() - done >= BGZF_BLOCK || (all && raw.size() > done)) {
                     size_t const len = std::min(BGZF_BLOCK, raw.size() - done);
+                    size_t const b0 = base + done, b1 = b0 + len;
+                    block_hints.clear();
+                    while (hint_first < hints.size() && hints[hint_first].pos + hints[hint_first].len <= b0) ++hint_first;
+                    for (size_t h = hint_first; h < hints.size() && hints[h].pos < b1; ++h) {
+                        size_t const lo = std::max(hints[h].pos, b0), to = std::min(hints[h].pos + hints[h].len, b1);
+                        if (hints[h].dist == 0 || hints[h].dist > 32768) { block_hints.push_back(LzHint{(uint32_t)(lo - b0), (uint32_t)(to - lo), 0u}); continue; }
+                        // the part of the repeat whose source lies in this block too; what is in front of it has nothing to repeat here
+                        size_t const from = std::min(std::max(lo, b0 + hints[h].dist), to);
+                        if (lo < from) block_hints.push_back(LzHint{(uint32_t)(lo - b0), (uint32_t)(from - lo), 0u});
+                        if (from < to) block_hints.push_back(LzHint{(uint32_t)(from - b0), (uint32_t)(to - from), (uint32_t)hints[h].dist});
+                    }
                     size_t const at = outv.size();
                     outv.resize(at + BGZF_MAX_OUT);
-                    size_t const c = bgzf_compress_block(raw.data() + done, len, outv.data() + at);
+                    size_t const c = bgzf_compress_block(raw.data() + done, len, outv.data() + at, block_hints.data(), block_hints.size());
                     if (c == 0) { errs[p] = "BGZF compression failed"; outv.resize(at); return; }
                     outv.resize(at + c);
                     done += len;
                 }
-                if (done == raw.size()) { raw.clear(); done = 0; }
-                else if (done >= (4u << 20)) { raw.erase(raw.begin(), raw.begin() + (long)done); done = 0; }
+                if (done == raw.size()) { base += raw.size(); raw.clear(); done = 0; }
+                else if (done >= (4u << 20)) { base += done; raw.erase(raw.begin(), raw.begin() + (long)done); done = 0; }
             };
+            size_t prev_cigar_at = SIZE_MAX;                   // stream position of the previous record's CIGAR array
             for (uint64_t i = r0; i < r1 && errs[p].empty(); ++i) {
-                if (!format_record(w, records[i], read_ids, read_pool, read_offsets, quals, cigar_words, raw, errs[p])) break;
+                size_t cigar_at = SIZE_MAX;
+                uint64_t const t_format = prof_ns();
+                if (!format_record(w, records[i], read_ids, read_pool, read_offsets, quals, cigar_words, raw, errs[p], &cigar_at)) break;
+                if (writer_profile()) g_ns_format += prof_ns() - t_format;
+                if (cigar_at != SIZE_MAX) {
+                    cigar_at += base;
+                    bool const same = prev_cigar_at != SIZE_MAX && i > r0 && records[i].cigar_offset == records[i - 1].cigar_offset && records[i].cigar_length == records[i - 1].cigar_length;
+                    hints.push_back(StreamHint{cigar_at, 4 * (size_t)records[i].cigar_length, same ? cigar_at - prev_cigar_at : 0});
+                }
+                prev_cigar_at = cigar_at;
                 deflate_full_blocks(false);
             }
             if (errs[p].empty()) deflate_full_blocks(true);
@@ -633,6 +793,8 @@ extern "C" int flx_sam_write(flx_sam_writer* w, const char* const* read_ids, con
 
 extern "C" int flx_sam_close(flx_sam_writer* w) {
     if (!w) return FLX_OK;
+    if (writer_profile() && w->bam)
+        fprintf(stderr, "[flx writer profile] summed over the I/O threads: formatting %.2f s, deflate %.2f s, checksums %.2f s\n", g_ns_format.load() / 1e9, g_ns_deflate.load() / 1e9, g_ns_crc.load() / 1e9);
     bool ok = !w->failed;
     if (w->bam) {
         ok = bgzf_flush(w, true) && ok;

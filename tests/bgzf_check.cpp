@@ -25,6 +25,21 @@ static bool roundtrip_with(const std::vector<uint8_t>& in, bool lz) {
     if (!ok) printf("FAIL (%s) n=%zu rc=%d out=%lu c=%zu\n", lz ? "lz" : "literal", in.size(), rc, zs.total_out, c);
     return ok;
 }
+// lz_deflate with hints: the stream must come back whatever the hints say (true repeats, stretches declared free of repeats, wrong ones)
+static bool roundtrip_hinted(const std::vector<uint8_t>& in, const std::vector<LzHint>& hints, size_t* clen = nullptr) {
+    std::vector<uint8_t> out(in.size() + 2048);
+    size_t const c = lz_deflate(in.data(), in.size(), out.data(), hints.data(), hints.size());
+    if (clen) *clen = c;
+    std::vector<uint8_t> back(in.size() + 16);
+    z_stream zs; memset(&zs, 0, sizeof(zs));
+    inflateInit2(&zs, -15);
+    zs.next_in = out.data(); zs.avail_in = (uInt)c; zs.next_out = back.data(); zs.avail_out = (uInt)back.size();
+    int rc = inflate(&zs, Z_FINISH);
+    bool ok = rc == Z_STREAM_END && zs.total_out == in.size() && memcmp(back.data(), in.data(), in.size()) == 0 && zs.avail_in == 0;
+    inflateEnd(&zs);
+    if (!ok) printf("FAIL (hinted, %zu hints) n=%zu rc=%d out=%lu c=%zu\n", hints.size(), in.size(), rc, zs.total_out, c);
+    return ok;
+}
 static bool roundtrip(const std::vector<uint8_t>& in) { return roundtrip_with(in, false) & roundtrip_with(in, true); }
 // BAM-like payload: records of a fixed head + a CIGAR array of `words` words; `repeat` consecutive records share the array
 static std::vector<uint8_t> bam_like(std::mt19937& rng, size_t n, unsigned words, unsigned repeat) {
@@ -75,6 +90,41 @@ int main() {
             else { size_t const l = 1 + rng() % 300; for (size_t k = 0; k < l && v.size() < n; ++k) v.push_back((uint8_t)(rng() % (1 + rng() % 255))); }
         }
         ok &= roundtrip(v);
+    }
+    // hints (flx_sam_write tells the encoder which CIGAR arrays repeat the one before and which are new): records of 40 + 6400 bytes that share
+    // their array; all hints true, no hints, literal hints over true repeats (larger, still valid), wrong distances and ranges past the end
+    {
+        std::vector<uint8_t> b = bam_like(rng, 65280, 1600, 40);
+        size_t const rec = 40 + 6400;
+        std::vector<LzHint> good, lits, wrong;
+        for (size_t r = 0; r * rec + rec <= b.size(); ++r) {
+            uint32_t const at = (uint32_t)(r * rec + 40);
+            good.push_back(LzHint{at, 6400u, r ? (uint32_t)rec : 0u});
+            lits.push_back(LzHint{at, 6400u, 0u});
+            wrong.push_back(LzHint{at + 3, 6400u, r ? (uint32_t)(rec - 4 * (r % 3)) : 0u});
+        }
+        wrong.push_back(LzHint{65000u, 5000u, 100u});          // runs past the end of the block
+        size_t c_plain = 0, c_good = 0, c_lits = 0, c_wrong = 0;
+        ok &= roundtrip_hinted(b, {}, &c_plain) & roundtrip_hinted(b, good, &c_good) & roundtrip_hinted(b, lits, &c_lits) & roundtrip_hinted(b, wrong, &c_wrong);
+        if (c_good > c_plain + 96 || c_lits < 4 * c_good) { printf("FAIL hinted sizes: plain %zu, true hints %zu, literal hints %zu, wrong hints %zu\n", c_plain, c_good, c_lits, c_wrong); ok = false; }
+        for (int r = 0; r < 100; ++r) {                        // random hints over random mixtures
+            std::vector<uint8_t> v = bam_like(rng, 2000 + rng() % 63000, 1 + rng() % 2000, 1 + rng() % 5);
+            std::vector<LzHint> h;
+            for (uint32_t at = rng() % 500; at + 64 < v.size();) { uint32_t const l = 1 + rng() % 9000; h.push_back(LzHint{at, l, rng() % 3 ? (uint32_t)(rng() % 40000) : 0u}); at += l + rng() % 3000; }
+            ok &= roundtrip_hinted(v, h);
+        }
+        auto t0h = std::chrono::steady_clock::now();
+        for (int r = 0; r < 2000; ++r) lz_deflate(b.data(), b.size(), std::vector<uint8_t>(70000).data(), good.data(), good.size());
+        double const sh = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0h).count();
+        printf("records sharing a CIGAR: 40  lz+hints %6.0f MB/s  ratio %6.2f (no hints: %.2f)\n", 2000 * 65280 / 1e6 / sh, 65280.0 / c_good, 65280.0 / c_plain);
+    }
+    // the block checksum by carry-less multiplication against zlib's, all lengths around the 16- and 64-byte steps, odd starts
+    {
+        std::vector<uint8_t> v(70000); for (auto& x : v) x = (uint8_t)rng();
+        bool crc_ok = true;
+        for (size_t len = 0; len < 700; ++len) for (size_t off : {0ul, 1ul, 5ul}) crc_ok &= block_crc32(v.data() + off, len) == (uint32_t)crc32(0, v.data() + off, (uInt)len);
+        for (size_t len : {4096ul, 65279ul, 65280ul, 65536ul, 69990ul}) crc_ok &= block_crc32(v.data() + 3, len) == (uint32_t)crc32(0, v.data() + 3, (uInt)len);
+        if (!crc_ok) { printf("FAIL block_crc32\n"); ok = false; }
     }
     // speed and size on BAM-like data: one record per read (-I) and forty records sharing a CIGAR (default flags), against zlib level 1
     for (unsigned rep : {1u, 40u, 41u}) {

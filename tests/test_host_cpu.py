@@ -375,7 +375,7 @@ def test_index_meta_roundtrip_and_image_layout():
     assert light.meta() == meta
     sizes = idx.image_layout()
     n = idx.text_length
-    assert sizes == light.image_layout() == [(n // 32 + 1) * 32, (n // 32 + 1) * 32, 4 * n, n + 2 * 128 + 16, 4 ** 8 * 3 * 4]
+    assert sizes == light.image_layout() == [(n // 32 + 1) * 32, (n // 32 + 1) * 32, 4 * n, n + 2 * 256 + 16, 4 ** 8 * 3 * 4]      # (text: TEXT_PAD guard bytes each side)
     assert sum(sizes) == idx.device_bytes + 16
     with pytest.raises(F.FloxerError):
         F.fmindex.from_meta(b"\0" * 96)
