@@ -535,10 +535,6 @@ int main(int argc, char** argv) {
     flx_sam_set_threads(out, n_io);
     size_t batch_reads = 16384;      // 1024 reads per lane and chunk (see flx_align_reads_resident)
     if (const char* env = getenv("FLX_BATCH_READS")) { size_t const v = strtoull(env, nullptr, 10); if (v) batch_reads = v; }
-    // The first batches are short (2048, 4096, 8192 reads): the GPU starts after an eighth of a batch's parsing time and the writer after an
-    // eighth of its aligning time, instead of each stage sitting out the full first batch of the one before it (65 536 reads are four
-    // batches: a third of that run was the pipeline filling). Records do not depend on where batches are cut. FLX_BATCH_RAMP=0: off.
-    bool const ramp = !getenv("FLX_BATCH_RAMP") || atoi(getenv("FLX_BATCH_RAMP")) != 0;
     // Batches are independent: up to three are in a context at a time (their chunks share its lanes), the next one is parsed
     // while they run, and results are written in input order.
     struct Finished { std::unique_ptr<ReadBatch> batch; std::vector<flx_record> recs; std::vector<uint32_t> cig; std::vector<uint8_t> skipped; int rc = FLX_OK; std::string err; };
@@ -620,8 +616,7 @@ int main(int argc, char** argv) {
         }
         if (!batch) batch = std::make_unique<ReadBatch>();
         uint64_t const t_parse = now_us();
-        size_t const this_batch = ramp && n_batches < 3 ? std::min<size_t>(batch_reads, (size_t)2048 << n_batches) : batch_reads;
-        bool const got = qin.next(*batch, this_batch, err);
+        bool const got = qin.next(*batch, batch_reads, err);
         us_parse += now_us() - t_parse;
         if (!got) {
             eof = true;
