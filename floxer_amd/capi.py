@@ -9,7 +9,7 @@ import sys
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libfloxer_amd.so")
+LIB_PATH = os.environ.get("FLX_LIBRARY") or os.path.join(_HERE, "libfloxer_amd.so")      # (FLX_LIBRARY: another build of the library, for A/B runs on one box)
 
 u8p = C.POINTER(C.c_uint8)
 u32p = C.POINTER(C.c_uint32)

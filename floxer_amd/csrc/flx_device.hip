@@ -1414,10 +1414,12 @@ __global__ void __launch_bounds__(64) ed_band_kernel(const u8* __restrict__ text
 // TRACE (K4): per block-step T = b + g, ring lane and word the block's 16 pairs of carry bits that enter the word from above (one
 // u32) and the word's {vp, vn} before the block (one 16-byte slot) are written out (TraceLayout; ed_traceback_wave_kernel recomputes
 // any word's trace bits over any block from those), and the last group stores D[m][c] of its columns.
+// queue: hand-over slots per job behind the equality masks in LDS (a power of two, or 0: no job of the launch has a ring that waits, ring_delay);
+// err: set when a job's delay does not fit the queue (null: the host chose the shape per job and knows it fits)
 template <int W, bool TRACE>
 __device__ __forceinline__ void ed_block_body(const u8* __restrict__ text, const u64* __restrict__ peq, const DevAlignJob* __restrict__ jobs, u32 n_jobs,
                                               u32 log2_r, DevAlignOut* __restrict__ out, u32 blk, u64* __restrict__ lds_eq,
-                                              u64* __restrict__ trace, u16* __restrict__ lastrow) {
+                                              u64* __restrict__ trace, u16* __restrict__ lastrow, u32 queue, u32* __restrict__ err) {
     u32 const lane = lane_id();
     u32 const R = 1u << log2_r;
     u32 const p = lane & (R - 1u);
@@ -1437,6 +1439,18 @@ __device__ __forceinline__ void ed_block_body(const u8* __restrict__ text, const
     int const Lg = (nw + W - 1) / W;
     int const band_hi = n - m + k;
     u32 const src_lane = (lane & ~(R - 1u)) | ((lane - 1u) & (R - 1u));
+    // the ring's schedule (flx_internal.hpp): group g takes block b at block-step b + g + (g / R) delay
+    int delay = valid ? (int)ring_delay((u32)n, (u32)m, (u32)k, (u32)W, R) : 0;
+    if (delay > 0 && (u32)delay + 1u > queue) {          // (a shape that does not hold the job: reported, never computed wrongly)
+        if (err && p == 0u) atomicOr(err, 1u);
+        if (p == 0u) { DevAlignOut o; o.score = 0xFFFFFFFFu; o.end_col = 0u; out[job.out_index] = o; }
+        valid = false;
+        delay = 0;
+    }
+    bool const any_delay = __any(delay > 0);
+    uint2* __restrict__ const hand = reinterpret_cast<uint2*>(lds_eq + 7u * 64u * W) + (size_t)(lane >> log2_r) * queue;      // this job's hand-over slots
+    u32 const qmask = queue - 1u;
+    auto offset_of = [&](int gg) { return gg + (gg >> log2_r) * delay; };
 #pragma unroll
     for (int w = 0; w < W; ++w) lds_eq[(6u * 64u + lane) * W + w] = 0ull;
 
@@ -1446,7 +1460,8 @@ __device__ __forceinline__ void ed_block_body(const u8* __restrict__ text, const
     int const pad = Lg * 64 * W - m;                      // 0 <= pad < 64 W: only group 0 holds padding
     int g = (int)p;
     int b_lo = 0, b_hi = -1, rows_g = 0;
-    int t_above_end = 0;                                  // last block-step of the group above (its lane may run a later group after that)
+    int above_b_hi = 0;                                   // last block of the group above (its lane may run a later group after that)
+    int off_g = 0;                                        // offset_of(g)
     u64 vp[W], vn[W];
     auto enter_group = [&]() {
         int const r0 = max(0, 64 * W * g - pad);
@@ -1455,7 +1470,8 @@ __device__ __forceinline__ void ed_block_body(const u8* __restrict__ text, const
         b_lo = max(0, r0 - k) >> 4;
         b_hi = min(n - 1, r1 - 1 + band_hi) >> 4;
         if (g + 1 < Lg) b_hi = max(b_hi, max(0, r1 - k) >> 4);
-        t_above_end = max(min(n - 1, r0 - 1 + band_hi) >> 4, b_lo) + g - 1;      // (group g - 1: rows up to r0, kept going for this group's first block)
+        above_b_hi = max(min(n - 1, r0 - 1 + band_hi) >> 4, b_lo);      // (group g - 1: rows up to r0, kept going for this group's first block)
+        off_g = offset_of(g);
 #pragma unroll
         for (int w = 0; w < W; ++w) {
             int const rs = 64 * (g * W + w) - pad;        // real row of the word's bit 0 (negative: that many padding rows first)
@@ -1486,13 +1502,13 @@ __device__ __forceinline__ void ed_block_body(const u8* __restrict__ text, const
 #pragma unroll
         for (int w = 0; w < W; ++w) { vp[w] = ~0ull; vn[w] = 0ull; }
     }
-    u32 const my_steps = valid ? (u32)(((n - 1) >> 4) + Lg) : 0u;
+    u32 const my_steps = valid ? (u32)(((n - 1) >> 4) + offset_of(Lg - 1) + 1) : 0u;
     u32 const t_max = wave_max_u32(my_steps);
     const u8* __restrict__ ref = text + job.ref_off;
     u32* __restrict__ carry_out = nullptr;
     ulonglong2* __restrict__ ckpt_out = nullptr;
     if (TRACE) {
-        TraceLayout const tl = ckpt_trace_layout(job.n, job.m, (u32)W, R);
+        TraceLayout const tl = ckpt_trace_layout(job.n, job.m, job.k, (u32)W, R);
         carry_out = reinterpret_cast<u32*>(reinterpret_cast<ulonglong2*>(trace) + job.trace_off);
         ckpt_out = reinterpret_cast<ulonglong2*>(trace) + job.trace_off + tl.carry_slots;
     }
@@ -1524,18 +1540,24 @@ __device__ __forceinline__ void ed_block_body(const u8* __restrict__ text, const
         }
     };
     for (u32 T = 0; T < t_max; ++T) {
-        int b = (int)T - g;
-        if (has_group && b > b_hi && g + (int)R < Lg) {   // this lane's group is finished: group g + R starts strictly later
+        int b = (int)T - off_g;
+        if (has_group && b > b_hi && g + (int)R < Lg) {   // this lane's group is finished: group g + R starts no earlier than now (ring_delay)
             g += (int)R;
             enter_group();
-            b = (int)T - g;
+            b = (int)T - off_g;
         }
         u32 cw_in = (u32)__shfl((int)cw_out, (int)src_lane);
         int botv_in = __shfl(botv_out, (int)src_lane);
+        if (any_delay) {
+            // the last lane of a ring leaves what it handed down at step T - 1 in the job's queue; the first lane, in a later revolution than
+            // the group above it, takes what that group handed down `delay` steps before that: the same block of the group above
+            if (delay > 0 && p == R - 1u) hand[(T - 1u) & qmask] = make_uint2(cw_out, (u32)botv_out);
+            if (delay > 0 && p == 0u && g >= (int)R) { uint2 const h = hand[(T - 1u - (u32)delay) & qmask]; cw_in = h.x; botv_in = (int)h.y; }
+        }
         bool const active = has_group && b >= b_lo && b <= b_hi;
         if (active) {
             if (g == 0) { cw_in = 0u; botv_in = 0; }      // the row above the matrix: D = 0 in every column
-            else if ((int)T > t_above_end + 1) cw_in = 0x55555555u;      // the group above has ended (what its lane hands down now belongs to a later group): +1 per column
+            else if (b > above_b_hi) cw_in = 0x55555555u;      // the group above has ended (what its lane hands down now belongs to a later group): +1 per column
             if (b == b_lo) bot = botv_in + rows_g;        // column left of the window: all vertical deltas +1 below the group above
             int const bot_start = bot;
             bool const last = g == Lg - 1;
@@ -1616,34 +1638,73 @@ __device__ __forceinline__ void ed_block_body(const u8* __restrict__ text, const
 template <int W>
 __global__ void __launch_bounds__(64) ed_exists_block_kernel(const u8* __restrict__ text, const u64* __restrict__ peq,
                                                              const DevAlignJob* __restrict__ jobs, u32 n_jobs, u32 log2_r,
-                                                             DevAlignOut* __restrict__ out, const u32* __restrict__ n_jobs_dev) {
-    // LDS: [7 symbols][64 lanes][W words] equality masks; symbol 6 (columns past the end of the window) matches nothing
+                                                             DevAlignOut* __restrict__ out, const u32* __restrict__ n_jobs_dev, u32 queue, u32* __restrict__ err) {
+    // LDS: [7 symbols][64 lanes][W words] equality masks; symbol 6 (columns past the end of the window) matches nothing; then `queue`
+    // hand-over slots per job of the wave
     extern __shared__ __attribute__((aligned(16))) u64 lds_eq[];
     if (n_jobs_dev) n_jobs = min(n_jobs, *n_jobs_dev);
     u32 const jobs_per_wave = 64u >> log2_r;
     for (u32 blk = blockIdx.x; blk * jobs_per_wave < n_jobs; blk += gridDim.x)
-        ed_block_body<W, false>(text, peq, jobs, n_jobs, log2_r, out, blk, lds_eq, nullptr, nullptr);
+        ed_block_body<W, false>(text, peq, jobs, n_jobs, log2_r, out, blk, lds_eq, nullptr, nullptr, queue, err);
 }
 
 // K4: the same body with the checkpointed trace and the last rows written out, one wave per group of jobs
 template <int W>
 __global__ void __launch_bounds__(64) ed_trace_block_kernel(const u8* __restrict__ text, const u64* __restrict__ peq,
                                                             const DevAlignJob* __restrict__ jobs, u32 n_jobs, u32 log2_r,
-                                                            u64* __restrict__ trace, DevAlignOut* __restrict__ out, u16* __restrict__ lastrow) {
+                                                            u64* __restrict__ trace, DevAlignOut* __restrict__ out, u16* __restrict__ lastrow, u32 queue) {
     extern __shared__ __attribute__((aligned(16))) u64 lds_eq[];
     __builtin_amdgcn_s_setprio(2);                   // (few waves, long chains, 18 KB of LDS each: they go first on a shared SIMD)
-    ed_block_body<W, true>(text, peq, jobs, n_jobs, log2_r, out, blockIdx.x, lds_eq, trace, lastrow);
+    ed_block_body<W, true>(text, peq, jobs, n_jobs, log2_r, out, blockIdx.x, lds_eq, trace, lastrow, queue, nullptr);
 }
 
-static AlignShape choose_align_shape_uncached(u32 nw, i64 width, bool band, bool parallel) {
+static bool exists_block_form() {            // FLX_EXISTS_STEPWISE=1: existence tests through ed_band_kernel (one column per step)
+    static int const v = getenv("FLX_EXISTS_STEPWISE") ? 0 : 1;
+    return v != 0;
+}
+// hand-over slots a job with this delay needs (a power of two; 0: none)
+static u32 ring_queue_for(u32 delay) {
+    if (delay == 0) return 0;
+    u32 q = 32;
+    while (q < delay + 1u) q *= 2;
+    return q;
+}
+// the widest band (diagonals - 1 = n - m + 2k) a shape holds: any when every group has a lane; else the one whose ring_delay still fits
+// `queue` hand-over slots (three blocks of slack for the roundings of ring_group_blocks; a job beyond it is reported by the kernel)
+static u64 shape_width_cap(u32 nw, AlignShape sh) {
+    u32 const w = sh.words_per_lane, r = sh.lanes_per_job;
+    if ((nw + w - 1) / w <= r) return 0xFFFFFFFFull;
+    u64 const no_wait = (u64)64 * w * (r - 1) + r;
+    if (sh.queue < 8) return no_wait;
+    return no_wait + 16ull * (sh.queue - 5u);
+}
+u64 DeviceApi::shape_width_cap(u32 nw, AlignShape sh) { return flx::shape_width_cap(nw, sh); }
+
+// n, m, k: the job the shape is for (shape_holding: a job as wide as its class allows)
+static AlignShape choose_align_shape_uncached(u32 n, u32 m, u32 k, bool band, bool parallel) {
+    u32 const nw = (m + 63) / 64;
+    i64 const width = (i64)n - (i64)m + 2 * (i64)k;
+    // rings that wait (ring_delay): block kernels only, throughput form only; FLX_RING_STRETCH = how much longer than the shortest schedule a
+    // job's block-steps may get, in percent (default 135; 100 = round 3's shapes)
+    static int const stretch = [] { const char* e = getenv("FLX_RING_STRETCH"); int const v = e ? atoi(e) : 135; return v < 100 ? 100 : v; }();
+    bool const may_wait = band && !parallel && exists_block_form() && stretch > 100;
     AlignShape best{0, 0, 0};
     u64 best_cost = ~0ull;
+    u64 shortest = ~0ull, shortest_key = ~0ull;           // block-steps of the shape round 3 chose (fewest lanes x words among the rings that never wait)
+    for (int pass = 0; pass < (may_wait ? 2 : 1); ++pass)
     for (u32 w : kWordsPerLane)
         for (u32 r = 1; r <= 64; r *= 2) {
             u32 const groups = (nw + w - 1) / w;
             bool ok = groups <= r;                        // every group has its own lane
             if (!ok && band) ok = (i64)64 * w * (r - 1) + r + 1 > width;   // group g + r starts after group g has ended
+            u32 delay = 0;
+            if (!ok && may_wait && pass == 1) {
+                delay = ring_delay(n, m, k, w, r);
+                ok = delay + 1u <= RING_QUEUE_MAX;
+            }
             if (!ok) continue;
+            u64 const steps = band ? ring_steps(n, m, k, w, r) : (u64)n + groups;
+            if (pass == 0 && may_wait) { u64 const key = (u64)w * r * 1000 + w; if (key < shortest_key) { shortest_key = key; shortest = steps; } continue; }
             // throughput form: cost ~ wave slots consumed (words per lane times lanes reserved), fewer words per lane on ties;
             // parallel form: fewest words per lane first (shortest dependent chain per step, most waves), then fewest lanes.
             // (A cost by instructions issued, r * (35 + 25 w), which prefers four words per lane over one at the same w * r, made
@@ -1651,10 +1712,16 @@ static AlignShape choose_align_shape_uncached(u32 nw, i64 width, bool band, bool
             // with the larger LDS tables; measured in round 2, gpurun_out r02u.)
             // (FLX_SHAPE_MODEL=a,b: throughput form by instructions issued instead, r * (a + b * w): per column a lane pays `a` whatever its
             // words and `b` per word)
+            // Round 4, rings that wait: cost = the block-steps the job's lanes sit through, lanes x steps x words - what the launch issues for
+            // the job whether a lane has a block to compute or not - among the shapes whose schedule is at most `stretch` percent of the one round 3 chose
             static int const model_a = [] { const char* e = getenv("FLX_SHAPE_MODEL"); int a = 0, b = 0; return e && sscanf(e, "%d,%d", &a, &b) == 2 ? a : 0; }();
             static int const model_b = [] { const char* e = getenv("FLX_SHAPE_MODEL"); int a = 0, b = 0; return e && sscanf(e, "%d,%d", &a, &b) == 2 ? b : 0; }();
-            u64 const cost = parallel ? (u64)w * 1000 + r : model_b ? (u64)r * (u64)(model_a + model_b * (int)w) * 16 + w : (u64)w * r * 1000 + w;
-            if (cost < best_cost) { best_cost = cost; best = AlignShape{w, r, band ? 1u : 0u}; }
+            u64 cost;
+            if (may_wait) {
+                if (steps * 100 > shortest * (u64)stretch) continue;
+                cost = steps * r * (8 * w + 1);
+            } else cost = parallel ? (u64)w * 1000 + r : model_b ? (u64)r * (u64)(model_a + model_b * (int)w) * 16 + w : (u64)w * r * 1000 + w;
+            if (cost < best_cost) { best_cost = cost; best = AlignShape{w, r, band ? 1u : 0u, ring_queue_for(delay)}; }
         }
     return best;
 }
@@ -1665,22 +1732,25 @@ AlignShape choose_align_shape(u32 n, u32 m, u32 k, bool parallel) {
     i64 const width = (i64)n - (i64)m + 2 * (i64)k;       // diagonals that matter, minus one
     if (const char* forced = getenv("FLX_FORCE_SHAPE")) {   // "W,R": measurements of one launch shape (scripts/shape_cost.py)
         u32 w = 0, r = 0;
-        if (sscanf(forced, "%u,%u", &w, &r) == 2 && w && r && ((nw + w - 1) / w <= r || (band && (i64)64 * w * (r - 1) + r + 1 > width)))
-            return AlignShape{w, r, band ? 1u : 0u};
+        if (sscanf(forced, "%u,%u", &w, &r) == 2 && w && r) {
+            if ((nw + w - 1) / w <= r || (band && (i64)64 * w * (r - 1) + r + 1 > width)) return AlignShape{w, r, band ? 1u : 0u};
+            u32 const delay = band && exists_block_form() ? ring_delay(n, m, k, w, r) : RING_QUEUE_MAX;
+            if (delay + 1u <= RING_QUEUE_MAX) return AlignShape{w, r, 1u, ring_queue_for(delay)};
+        }
     }
-    // the jobs of one verification level repeat a handful of (words, band width) pairs: small direct-mapped memo per thread
-    struct Entry { u32 nw; i64 width; AlignShape shape; bool valid; };
+    // the jobs of one verification level repeat a handful of (rows, columns, errors) triples: small direct-mapped memo per thread
+    struct Entry { u32 n, m, k; AlignShape shape; bool valid; };
     thread_local Entry memo[2][256] = {};
-    Entry& e = memo[parallel ? 1 : 0][(nw * 31u + (u32)width) & 255u];
-    if (e.valid && e.nw == nw && e.width == width) return e.shape;
-    e = Entry{nw, width, choose_align_shape_uncached(nw, width, band, parallel), true};
+    Entry& e = memo[parallel ? 1 : 0][(m * 31u + n * 7u + k) & 255u];
+    if (e.valid && e.n == n && e.m == m && e.k == k) return e.shape;
+    e = Entry{n, m, k, choose_align_shape_uncached(n, m, k, band, parallel), true};
     return e.shape;
 }
 u32 align_supported_max_query() { return 25u * 64u * 64u; }
 
-u64 align_trace_slots(u32 n, u32 m, AlignShape sh) {
+u64 align_trace_slots(u32 n, u32 m, u32 k, AlignShape sh) {
     if (sh.banded) {
-        TraceLayout const tl = ckpt_trace_layout(n, m, sh.words_per_lane, sh.lanes_per_job);
+        TraceLayout const tl = ckpt_trace_layout(n, m, k, sh.words_per_lane, sh.lanes_per_job);
         return tl.carry_slots + tl.ckpt_slots;
     }
     // full trace, step-major: (n + groups - 1) steps x groups lanes x W words of {hp, vp}
@@ -1689,13 +1759,9 @@ u64 align_trace_slots(u32 n, u32 m, AlignShape sh) {
     return ((u64)n + groups - 1) * groups * sh.words_per_lane;
 }
 
-static bool exists_block_form() {            // FLX_EXISTS_STEPWISE=1: existence tests through ed_band_kernel (one column per step)
-    static int const v = getenv("FLX_EXISTS_STEPWISE") ? 0 : 1;
-    return v != 0;
-}
 template <int W>
 static int launch_align(hipStream_t s, const u8* d_text, const u64* d_peq, const DevAlignJob* d_jobs, u32 n_jobs, u32 log2_g, bool trace,
-                        bool banded, u64* d_trace, DevAlignOut* d_out, u16* d_lastrow) {
+                        bool banded, u64* d_trace, DevAlignOut* d_out, u16* d_lastrow, u32 queue) {
     u32 const jobs_per_wave = 64u >> log2_g;
     u32 const blocks = (n_jobs + jobs_per_wave - 1) / jobs_per_wave;
     size_t const lds = (size_t)6 * 64 * W * sizeof(u64) + (banded ? (size_t)jobs_per_wave * (log2_g <= 2u ? 128 : 256) : 0);
@@ -1705,15 +1771,15 @@ static int launch_align(hipStream_t s, const u8* d_text, const u64* d_peq, const
         hipLaunchKernelGGL((KERNEL), dim3(blocks), dim3(64), lds, s, d_text, d_peq, d_jobs, n_jobs, log2_g, d_trace, d_out, d_lastrow); \
     } while (0)
     if (banded && !trace && !d_lastrow && exists_block_form()) {
-        size_t const lds_b = (size_t)7 * 64 * W * sizeof(u64);
+        size_t const lds_b = (size_t)7 * 64 * W * sizeof(u64) + (size_t)jobs_per_wave * queue * sizeof(uint2);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ed_exists_block_kernel<W>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_b);
-        hipLaunchKernelGGL((ed_exists_block_kernel<W>), dim3(blocks), dim3(64), lds_b, s, d_text, d_peq, d_jobs, n_jobs, log2_g, d_out, (const u32*)nullptr);
+        hipLaunchKernelGGL((ed_exists_block_kernel<W>), dim3(blocks), dim3(64), lds_b, s, d_text, d_peq, d_jobs, n_jobs, log2_g, d_out, (const u32*)nullptr, queue, (u32*)nullptr);
         return (int)hipGetLastError();
     }
     if (banded && trace) {
-        size_t const lds_b = (size_t)7 * 64 * W * sizeof(u64);
+        size_t const lds_b = (size_t)7 * 64 * W * sizeof(u64) + (size_t)jobs_per_wave * queue * sizeof(uint2);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ed_trace_block_kernel<W>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_b);
-        hipLaunchKernelGGL((ed_trace_block_kernel<W>), dim3(blocks), dim3(64), lds_b, s, d_text, d_peq, d_jobs, n_jobs, log2_g, d_trace, d_out, d_lastrow);
+        hipLaunchKernelGGL((ed_trace_block_kernel<W>), dim3(blocks), dim3(64), lds_b, s, d_text, d_peq, d_jobs, n_jobs, log2_g, d_trace, d_out, d_lastrow, queue);
         return (int)hipGetLastError();
     }
     if (banded) FLX_LAUNCH((ed_band_kernel<W>));
@@ -1726,35 +1792,42 @@ static int launch_align(hipStream_t s, const u8* d_text, const u64* d_peq, const
 // groups of jobs in turn
 template <int W>
 static int launch_exists_counted(hipStream_t s, const u8* d_text, const u64* d_peq, const DevAlignJob* d_jobs, u32 max_jobs, u32 log2_g, DevAlignOut* d_out,
-                                 const u32* d_n_jobs, u32 max_waves) {
+                                 const u32* d_n_jobs, u32 max_waves, u32 queue, u32* d_err) {
     u32 const jobs_per_wave = 64u >> log2_g;
     u32 const blocks = std::max(1u, std::min((max_jobs + jobs_per_wave - 1) / jobs_per_wave, max_waves));
-    size_t const lds_b = (size_t)7 * 64 * W * sizeof(u64);
+    size_t const lds_b = (size_t)7 * 64 * W * sizeof(u64) + (size_t)jobs_per_wave * queue * sizeof(uint2);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ed_exists_block_kernel<W>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_b);
-    hipLaunchKernelGGL((ed_exists_block_kernel<W>), dim3(blocks), dim3(64), lds_b, s, d_text, d_peq, d_jobs, max_jobs, log2_g, d_out, d_n_jobs);
+    hipLaunchKernelGGL((ed_exists_block_kernel<W>), dim3(blocks), dim3(64), lds_b, s, d_text, d_peq, d_jobs, max_jobs, log2_g, d_out, d_n_jobs, queue, d_err);
     return (int)hipGetLastError();
 }
 int DeviceApi::align_exists_counted(void* stream, const u8* d_text, const u64* d_peq, const DevAlignJob* d_jobs, u32 max_jobs, const u32* d_n_jobs,
-                                    AlignShape shape, u32 max_waves, DevAlignOut* d_out) {
+                                    AlignShape shape, u32 max_waves, DevAlignOut* d_out, u32* d_err) {
     if (max_jobs == 0) return 0;
     u32 log2_g = 0;
     while ((1u << log2_g) < shape.lanes_per_job) ++log2_g;
     hipStream_t s = (hipStream_t)stream;
     switch (shape.words_per_lane) {
-        case 1: return launch_exists_counted<1>(s, d_text, d_peq, d_jobs, max_jobs, log2_g, d_out, d_n_jobs, max_waves);
-        case 2: return launch_exists_counted<2>(s, d_text, d_peq, d_jobs, max_jobs, log2_g, d_out, d_n_jobs, max_waves);
-        case 3: return launch_exists_counted<3>(s, d_text, d_peq, d_jobs, max_jobs, log2_g, d_out, d_n_jobs, max_waves);
-        case 4: return launch_exists_counted<4>(s, d_text, d_peq, d_jobs, max_jobs, log2_g, d_out, d_n_jobs, max_waves);
-        case 5: return launch_exists_counted<5>(s, d_text, d_peq, d_jobs, max_jobs, log2_g, d_out, d_n_jobs, max_waves);
-        case 6: return launch_exists_counted<6>(s, d_text, d_peq, d_jobs, max_jobs, log2_g, d_out, d_n_jobs, max_waves);
-        case 8: return launch_exists_counted<8>(s, d_text, d_peq, d_jobs, max_jobs, log2_g, d_out, d_n_jobs, max_waves);
-        case 13: return launch_exists_counted<13>(s, d_text, d_peq, d_jobs, max_jobs, log2_g, d_out, d_n_jobs, max_waves);
-        case 25: return launch_exists_counted<25>(s, d_text, d_peq, d_jobs, max_jobs, log2_g, d_out, d_n_jobs, max_waves);
+        case 1: return launch_exists_counted<1>(s, d_text, d_peq, d_jobs, max_jobs, log2_g, d_out, d_n_jobs, max_waves, shape.queue, d_err);
+        case 2: return launch_exists_counted<2>(s, d_text, d_peq, d_jobs, max_jobs, log2_g, d_out, d_n_jobs, max_waves, shape.queue, d_err);
+        case 3: return launch_exists_counted<3>(s, d_text, d_peq, d_jobs, max_jobs, log2_g, d_out, d_n_jobs, max_waves, shape.queue, d_err);
+        case 4: return launch_exists_counted<4>(s, d_text, d_peq, d_jobs, max_jobs, log2_g, d_out, d_n_jobs, max_waves, shape.queue, d_err);
+        case 5: return launch_exists_counted<5>(s, d_text, d_peq, d_jobs, max_jobs, log2_g, d_out, d_n_jobs, max_waves, shape.queue, d_err);
+        case 6: return launch_exists_counted<6>(s, d_text, d_peq, d_jobs, max_jobs, log2_g, d_out, d_n_jobs, max_waves, shape.queue, d_err);
+        case 8: return launch_exists_counted<8>(s, d_text, d_peq, d_jobs, max_jobs, log2_g, d_out, d_n_jobs, max_waves, shape.queue, d_err);
+        case 13: return launch_exists_counted<13>(s, d_text, d_peq, d_jobs, max_jobs, log2_g, d_out, d_n_jobs, max_waves, shape.queue, d_err);
+        case 25: return launch_exists_counted<25>(s, d_text, d_peq, d_jobs, max_jobs, log2_g, d_out, d_n_jobs, max_waves, shape.queue, d_err);
         default: return (int)hipErrorInvalidValue;
     }
 }
 // the cheapest shape (parallel: the one with the fewest words per lane) that holds every job of at most nw query words and `width` diagonals
-AlignShape DeviceApi::shape_holding(u32 nw, i64 width, bool parallel) { return choose_align_shape_uncached(nw, width, use_band(), parallel); }
+// the shape for a round's size class: a job of nw words whose band is `width` diagonals wide (a window of its own: n - m + 2k = 4k + 1)
+AlignShape DeviceApi::shape_holding(u32 nw, i64 width, bool parallel) {
+    u32 const m = 64u * nw, k = (u32)(std::max<i64>(width, 1) / 4), n = (u32)((i64)m + std::max<i64>(width, 1) - 2 * (i64)k);
+    AlignShape sh = choose_align_shape_uncached(n, m, k, use_band(), parallel);
+    // room for the unions of a cluster's windows: slots for a band a quarter wider than the class's own, when that costs no more than the next size
+    if (sh.queue) { u32 const wider = ring_queue_for(ring_delay(n + (u32)(width / 4), m, k, sh.words_per_lane, sh.lanes_per_job) + 3u); if (wider <= RING_QUEUE_MAX) sh.queue = std::max(sh.queue, wider); }
+    return sh;
+}
 
 int DeviceApi::align(void* stream, const u8* d_text, const u64* d_peq, const DevAlignJob* d_jobs, u32 n_jobs, AlignShape shape, bool trace,
                      u64* d_trace, DevAlignOut* d_out, u16* d_lastrow) {
@@ -1763,16 +1836,18 @@ int DeviceApi::align(void* stream, const u8* d_text, const u64* d_peq, const Dev
     while ((1u << log2_g) < shape.lanes_per_job) ++log2_g;
     hipStream_t s = (hipStream_t)stream;
     bool const b = shape.banded != 0;
+    // (jobs of one launch share its words and lanes, not their delays: the most slots a shape may ask for, for any ring that may wait)
+    u32 const queue = b && shape.lanes_per_job < 64 ? RING_QUEUE_MAX : 0u;
     switch (shape.words_per_lane) {
-        case 1: return launch_align<1>(s, d_text, d_peq, d_jobs, n_jobs, log2_g, trace, b, d_trace, d_out, d_lastrow);
-        case 2: return launch_align<2>(s, d_text, d_peq, d_jobs, n_jobs, log2_g, trace, b, d_trace, d_out, d_lastrow);
-        case 3: return launch_align<3>(s, d_text, d_peq, d_jobs, n_jobs, log2_g, trace, b, d_trace, d_out, d_lastrow);
-        case 4: return launch_align<4>(s, d_text, d_peq, d_jobs, n_jobs, log2_g, trace, b, d_trace, d_out, d_lastrow);
-        case 5: return launch_align<5>(s, d_text, d_peq, d_jobs, n_jobs, log2_g, trace, b, d_trace, d_out, d_lastrow);
-        case 6: return launch_align<6>(s, d_text, d_peq, d_jobs, n_jobs, log2_g, trace, b, d_trace, d_out, d_lastrow);
-        case 8: return launch_align<8>(s, d_text, d_peq, d_jobs, n_jobs, log2_g, trace, b, d_trace, d_out, d_lastrow);
-        case 13: return launch_align<13>(s, d_text, d_peq, d_jobs, n_jobs, log2_g, trace, b, d_trace, d_out, d_lastrow);
-        case 25: return launch_align<25>(s, d_text, d_peq, d_jobs, n_jobs, log2_g, trace, b, d_trace, d_out, d_lastrow);
+        case 1: return launch_align<1>(s, d_text, d_peq, d_jobs, n_jobs, log2_g, trace, b, d_trace, d_out, d_lastrow, queue);
+        case 2: return launch_align<2>(s, d_text, d_peq, d_jobs, n_jobs, log2_g, trace, b, d_trace, d_out, d_lastrow, queue);
+        case 3: return launch_align<3>(s, d_text, d_peq, d_jobs, n_jobs, log2_g, trace, b, d_trace, d_out, d_lastrow, queue);
+        case 4: return launch_align<4>(s, d_text, d_peq, d_jobs, n_jobs, log2_g, trace, b, d_trace, d_out, d_lastrow, queue);
+        case 5: return launch_align<5>(s, d_text, d_peq, d_jobs, n_jobs, log2_g, trace, b, d_trace, d_out, d_lastrow, queue);
+        case 6: return launch_align<6>(s, d_text, d_peq, d_jobs, n_jobs, log2_g, trace, b, d_trace, d_out, d_lastrow, queue);
+        case 8: return launch_align<8>(s, d_text, d_peq, d_jobs, n_jobs, log2_g, trace, b, d_trace, d_out, d_lastrow, queue);
+        case 13: return launch_align<13>(s, d_text, d_peq, d_jobs, n_jobs, log2_g, trace, b, d_trace, d_out, d_lastrow, queue);
+        case 25: return launch_align<25>(s, d_text, d_peq, d_jobs, n_jobs, log2_g, trace, b, d_trace, d_out, d_lastrow, queue);
         default: return (int)hipErrorInvalidValue;
     }
 }
@@ -1932,7 +2007,8 @@ __global__ void __launch_bounds__(64) ed_traceback_wave_kernel(const u8* __restr
     int const nw = (max(m, 1) + 63) >> 6;
     int const Lg = (nw + W - 1) / W;
     int const pad = Lg * 64 * W - max(m, 1);
-    TraceLayout const tl = ckpt_trace_layout(job.n, job.m ? job.m : 1u, (u32)W, (u32)R);
+    TraceLayout const tl = ckpt_trace_layout(job.n, job.m ? job.m : 1u, job.k, (u32)W, (u32)R);
+    int const ring_wait = (int)ring_delay(job.n, job.m ? job.m : 1u, job.k, (u32)W, (u32)R);      // (K4's schedule: block b of group g at block-step b + g + (g / R) wait)
     const u32* __restrict__ carry = reinterpret_cast<const u32*>(reinterpret_cast<const ulonglong2*>(trace) + job.trace_off);
     const ulonglong2* __restrict__ ckpt = reinterpret_cast<const ulonglong2*>(trace) + job.trace_off + tl.carry_slots;
 
@@ -2005,7 +2081,7 @@ __global__ void __launch_bounds__(64) ed_traceback_wave_kernel(const u8* __restr
                 }
                 // all 16 columns of the block must be in the symbol cache
                 if (b >= b_lo && b <= b_hi && 16 * b >= ref_base && 16 * b + 16 <= ref_base + (int)TBW_REF) {
-                    u64 const slot = ((u64)(b + g) * R + p) * W + ww;
+                    u64 const slot = ((u64)(b + g + (g / R) * ring_wait) * R + p) * W + ww;
                     ulonglong2 const v = ckpt[slot];
                     u64 pv = v.x, mv = v.y;
                     u32 const cw = carry[slot];

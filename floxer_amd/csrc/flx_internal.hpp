@@ -189,8 +189,8 @@ struct Vr2Buffers {
     u32* scalars;
 };
 
-// launch geometry for one alignment job shape
-struct AlignShape { u32 words_per_lane; u32 lanes_per_job; u32 banded; };
+// launch geometry for one alignment job shape. queue: hand-over slots per job in LDS (a power of two; 0: the ring never waits, see ring_delay)
+struct AlignShape { u32 words_per_lane; u32 lanes_per_job; u32 banded; u32 queue = 0; };
 
 // Banded TRACE launches (K4) do not store the trace itself. A lane computes its word group 16 columns (one block) per step, group g
 // takes block b at block-step T = b + g; per (block-step, ring lane, word) the launch keeps the 16 pairs of horizontal-delta bits
@@ -202,10 +202,45 @@ struct TraceLayout { u64 steps, carry_words, carry_slots, ckpt_slots; };   // st
 #else
 #define FLX_HD
 #endif
-FLX_HD inline TraceLayout ckpt_trace_layout(u32 n, u32 m, u32 W, u32 R) {
+
+// The ring schedule of the banded block kernels (ed_block_body). A job's word groups (64 W rows each) go round its R lanes: lane p takes
+// the groups p, p + R, ...; group g computes the blocks (16 columns) b_lo(g) .. b_hi(g) of its band, block b at block-step
+// T = b + ring_offset(g), one step behind the group above it, whose bottom row it needs. With R so large that group g + R starts only after
+// group g has ended (64 W (R - 1) + R + 1 > diagonals: what round 3 asked of a shape) a lane idles from the end of one group to the start of
+// its next: 40 % of the block-steps of a 10-kb root alignment on 16 lanes. With fewer lanes a lane is still at work when its next group
+// could start: every revolution of the ring then begins `delay` block-steps later than the one above it would allow, offset(g) =
+// g + (g / R) delay, the lanes work back to back, and what lane R - 1 hands down to lane 0 waits those steps in a queue in LDS.
+constexpr u32 RING_QUEUE_MAX = 128;          // most hand-over slots per job: delay + 1 of them are in use
+FLX_HD inline void ring_group_blocks(int n, int m, int k, int W, int Lg, int pad, int g, int& b_lo, int& b_hi) {
+    int const band_hi = n - m + k;
+    int const r0 = 64 * W * g - pad > 0 ? 64 * W * g - pad : 0, r1 = 64 * W * (g + 1) - pad;
+    b_lo = (r0 - k > 0 ? r0 - k : 0) >> 4;
+    int const hi = r1 - 1 + band_hi < n - 1 ? r1 - 1 + band_hi : n - 1;
+    b_hi = hi >> 4;
+    if (g + 1 < Lg) { int const next_lo = (r1 - k > 0 ? r1 - k : 0) >> 4; if (next_lo > b_hi) b_hi = next_lo; }      // (kept going for the block in which the group below starts)
+}
+FLX_HD inline u32 ring_delay(u32 n, u32 m, u32 k, u32 W, u32 R) {
+    if (n == 0 || m == 0 || (u64)n + k < m) return 0;
+    int const nw = (int)((m + 63u) / 64u), Lg = (nw + (int)W - 1) / (int)W, pad = Lg * 64 * (int)W - (int)m;
+    int delay = 0;
+    for (int g = 0; g + (int)R < Lg; ++g) {
+        int lo0, hi0, lo1, hi1;
+        ring_group_blocks((int)n, (int)m, (int)k, (int)W, Lg, pad, g, lo0, hi0);
+        ring_group_blocks((int)n, (int)m, (int)k, (int)W, Lg, pad, g + (int)R, lo1, hi1);
+        int const d = hi0 - lo1 + 1 - (int)R;             // the lane is free at block-step hi0 + offset(g) + 1; its next group wants lo1 + offset(g) + R + delay
+        if (d > delay) delay = d;
+    }
+    return (u32)delay;
+}
+FLX_HD inline u64 ring_offset(u32 g, u32 R, u32 delay) { return (u64)g + (u64)(g / R) * delay; }
+// block-steps of a job: the last group's last block is the window's last
+FLX_HD inline u64 ring_steps(u32 n, u32 m, u32 k, u32 W, u32 R) {
     u64 const nw = (m + 63u) / 64u, groups = (nw + W - 1) / W;
+    return (n ? (u64)(n - 1) / 16 : 0) + ring_offset((u32)groups - 1u, R, ring_delay(n, m, k, W, R)) + 1;
+}
+FLX_HD inline TraceLayout ckpt_trace_layout(u32 n, u32 m, u32 k, u32 W, u32 R) {
     TraceLayout l;
-    l.steps = (n ? (u64)(n - 1) / 16 : 0) + groups;
+    l.steps = ring_steps(n, m, k, W, R);
     l.carry_words = l.steps * R * W;
     l.carry_slots = (l.carry_words + 3) / 4;
     l.ckpt_slots = l.steps * R * W;
@@ -214,7 +249,7 @@ FLX_HD inline TraceLayout ckpt_trace_layout(u32 n, u32 m, u32 W, u32 R) {
 // parallel = false: the shape that occupies the fewest wave slots (launches with many jobs); true: the shape with the shortest
 // per-step chain and the most waves (launches whose jobs would not fill the GPU otherwise)
 AlignShape choose_align_shape(u32 n, u32 m, u32 k, bool parallel = false);
-u64 align_trace_slots(u32 n, u32 m, AlignShape sh);     // 16-byte trace slots a TRACE launch of this shape needs for one job
+u64 align_trace_slots(u32 n, u32 m, u32 k, AlignShape sh);     // 16-byte trace slots a TRACE launch of this shape needs for one job
 u32 align_supported_max_query();
 u32 fm_search_max_keyed_length();
 
@@ -284,8 +319,9 @@ struct DeviceApi {
     static int align_exists_lanes(void* stream, const u8* d_text, const u64* d_peq, const DevAlignJob* d_jobs, u32 max_jobs, const u32* d_n_jobs,
                                   u32* d_queue, u32 waves, u32 cap_blocks, DevAlignOut* d_out, unsigned long long* d_stats, u32 lanes_per_job = 1);
     static int align_exists_counted(void* stream, const u8* d_text, const u64* d_peq, const DevAlignJob* d_jobs, u32 max_jobs, const u32* d_n_jobs,
-                                    AlignShape shape, u32 max_waves, DevAlignOut* d_out);
+                                    AlignShape shape, u32 max_waves, DevAlignOut* d_out, u32* d_err = nullptr);
     static AlignShape shape_holding(u32 nw, i64 width, bool parallel);
+    static u64 shape_width_cap(u32 nw, AlignShape sh);       // the widest band (n - m + 2k) the shape holds for jobs of nw words
     static int lastrow_min(void* stream, const u16* d_lastrow, const DevRowWindow* d_windows, u32 n_windows, DevAlignOut* d_out);
     static int traceback(void* stream, const u8* d_text, const u8* d_query, const u64* d_peq, const u64* d_trace,
                          const DevTraceJob* d_jobs, u32 n_jobs, bool checkpointed, u32* d_cigar, DevTraceOut* d_out);

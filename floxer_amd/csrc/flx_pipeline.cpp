@@ -505,7 +505,7 @@ int search_seeds_device(Lane* ctx, const u8* d_seq_pool_or_null, const u8* h_seq
         }
         if ((rc = ctx->sync())) return rc;
         if (getenv("FLX_SEARCH_DEBUG")) fprintf(stderr, "[fm_search] seeds %llu ext %u (of single-row intervals %u) wave-iterations %u (max per wave %u) busy pair-iterations %u, after the queue ran dry %u (max %u), subtrees handed over %u, from wave to wave %u, walks abandoned over the cap %u\n", (unsigned long long)n_seeds, counters[2], counters[3], counters[4], counters[5], counters[6], counters[8], counters[9], counters[14], counters[15], counters[20]);
-        if (getenv("FLX_SEARCH_DEBUG") && filtered) fprintf(stderr, "[fm_search filtered] subtrees queued %u (slots %u of %llu), filter words asked %u, children dropped %u, searches ended by the prefix lookup %u; text walk: lane-steps %u, wave-iterations %u\n", counters[3], counters[16], (unsigned long long)item_cap, counters[10], counters[11], counters[12], counters[18], counters[19]);
+        if (getenv("FLX_SEARCH_DEBUG") && filtered) fprintf(stderr, "[fm_search filtered] subtrees queued %u (slots %u of %llu), filter words asked %u, children dropped %u, searches ended by the prefix lookup %u; text walk: lane-steps %u, wave-iterations %u in %u waves (longest %u)\n", counters[3], counters[16], (unsigned long long)item_cap, counters[10], counters[11], counters[12], counters[18], counters[19], counters[22], counters[21]);
         if (counters[1]) { set_error(counters[1] & 2u ? "fm_search: a subtree handed between waves was not taken" : "fm_search: DFS stack reservation exceeded"); return FLX_ERR_INTERNAL; }
         bool const items_fit = !item_cap || counters[16] <= item_cap;
         if (items_fit && counters[0] <= hit_cap && (!device_select || sel_rows_total <= sel_cap)) break;      // (selected anchors <= rows)
@@ -1207,7 +1207,7 @@ int run_trace_jobs_union(Lane* ctx, const u8* d_text, const u8* d_query, const u
     hvec<u64> slots(ureqs.size());
     u64 const budget_slots = std::max<u64>(ctx->trace_budget_bytes / 16, 1);
     for (size_t i = 0; i < ureqs.size(); ++i) {
-        slots[i] = align_trace_slots(ureqs[i].n, ureqs[i].m, shapes[i]);
+        slots[i] = align_trace_slots(ureqs[i].n, ureqs[i].m, ureqs[i].k, shapes[i]);
         if (slots[i] > budget_slots) { set_error("one alignment needs more trace memory than the configured budget (FLX_TRACE_ARENA_MB)"); return FLX_ERR_CAPACITY; }
     }
     hvec<AlignRequest> fallback;
@@ -1241,7 +1241,7 @@ int run_trace_jobs_union(Lane* ctx, const u8* d_text, const u8* d_query, const u
                 off += slots[id];
                 rows += ((u64)r.n + 15) / 16 * 16;   // K4 stores a block's 16 last-row values as two 16-byte words
                 l.word_steps += job_word_steps(r.n, r.m, r.k, shapes[id]);
-                TraceLayout const tl = ckpt_trace_layout(r.n, r.m, shapes[id].words_per_lane, shapes[id].lanes_per_job);
+                TraceLayout const tl = ckpt_trace_layout(r.n, r.m, r.k, shapes[id].words_per_lane, shapes[id].lanes_per_job);
                 l.bytes += (u64)r.n + r.m + (tl.carry_slots + tl.ckpt_slots) * 16 + 2ull * r.n;
             }
             launches.push_back(l);
@@ -1363,7 +1363,7 @@ int run_trace_jobs_unique(Lane* ctx, const u8* d_text, const u8* d_query, const 
     hvec<u64> slots(reqs.size());
     u64 const budget_slots = std::max<u64>(ctx->trace_budget_bytes / 16, 1);
     for (size_t i = 0; i < reqs.size(); ++i) {
-        slots[i] = align_trace_slots(reqs[i].n, reqs[i].m, shapes[i]);
+        slots[i] = align_trace_slots(reqs[i].n, reqs[i].m, reqs[i].k, shapes[i]);
         if (slots[i] > budget_slots) { set_error("one alignment needs more trace memory than the configured budget (FLX_TRACE_ARENA_MB)"); return FLX_ERR_CAPACITY; }
     }
     int rc;
@@ -1398,7 +1398,7 @@ int run_trace_jobs_unique(Lane* ctx, const u8* d_text, const u8* d_query, const 
                 // reference + query symbols read; trace written: full form 16 B per word-step, checkpointed form its carry and
                 // checkpoint regions
                 if (shapes[id].banded) {
-                    TraceLayout const tl = ckpt_trace_layout(r.n, r.m, shapes[id].words_per_lane, shapes[id].lanes_per_job);
+                    TraceLayout const tl = ckpt_trace_layout(r.n, r.m, r.k, shapes[id].words_per_lane, shapes[id].lanes_per_job);
                     l.bytes += (u64)r.n + r.m + (tl.carry_slots + tl.ckpt_slots) * 16;
                 } else l.bytes += (u64)r.n + r.m + ws * 16;
             }
@@ -2159,8 +2159,7 @@ int align_slice(Lane* lane, const flx_params* P, const flx_reads* RD, u64 first_
                 RoundClass const& c = plan[r];
                 AlignShape const shape = DeviceApi::shape_holding(c.nw_max, c.width_max, false);
                 u32 lane_waves = 0, lane_cap = 0;
-                u64 const cap = shape.words_per_lane == 0 ? 0 : (c.nw_max + shape.words_per_lane - 1) / shape.words_per_lane <= shape.lanes_per_job
-                                    ? 0xFFFFFFFFull : 64ull * shape.words_per_lane * (shape.lanes_per_job - 1) + shape.lanes_per_job;
+                u64 const cap = shape.words_per_lane == 0 ? 0 : DeviceApi::shape_width_cap(c.nw_max, shape);
                 u64 const width_cap = std::min<u64>(cap, std::max<u64>(8 * (u64)c.width_max, 1024));
                 if (shape.words_per_lane == 0 || !shape.banded || !exists_lane_setup(max_jobs, (i64)std::max<u64>(width_cap, (u64)c.width_max), lane_waves, lane_cap)) {
                     queued = false;                                    // (a class the lane form does not take: the loop below from here on)
@@ -2217,9 +2216,9 @@ int align_slice(Lane* lane, const flx_params* P, const flx_reads* RD, u64 first_
             if (shape_t.words_per_lane == 0 || shape_p.words_per_lane == 0) { set_error("query longer than the supported maximum"); return FLX_ERR_UNSUPPORTED; }
             AlignShape const shape = prev_jobs * shape_t.lanes_per_job / 64 >= few_waves ? shape_t : shape_p;
             // what the shape holds beyond that goes to the clusters' union windows (a shape holds a job when every word group has a lane of
-            // its own, or when the ring's lanes are free again before their next group starts: 64 W (R - 1) + R + 1 > diagonals)
-            u64 const cap = (nw_max + shape.words_per_lane - 1) / shape.words_per_lane <= shape.lanes_per_job
-                                ? 0xFFFFFFFFull : 64ull * shape.words_per_lane * (shape.lanes_per_job - 1) + shape.lanes_per_job;
+            // its own, when the ring's lanes are free again before their next group starts: 64 W (R - 1) + R + 1 > diagonals, or when the
+            // steps a revolution of the ring has to wait fit the launch's hand-over slots: flx_internal.hpp, ring_delay)
+            u64 const cap = DeviceApi::shape_width_cap(nw_max, shape);
             // (the lane-per-job kernel holds any window its row buffers hold: unions up to the ring shape's cap, or eight windows' width)
             u32 lane_waves = 0, lane_cap = 0;
             u32 const max_jobs = (u32)std::min<u64>(2ull * n_climbing, 2ull * n);
@@ -2237,7 +2236,7 @@ int align_slice(Lane* lane, const flx_params* P, const flx_reads* RD, u64 first_
                 // (a fixed grid of at most this many waves takes the round's job groups in turn; FLX_EXISTS_MAX_WAVES: how much of the chip one
                 // round's launch may hold while the other lanes' kernels want room)
                 static u32 const exists_waves = [] { const char* e = getenv("FLX_EXISTS_MAX_WAVES"); return (u32)(e ? std::max(64, atoi(e)) : 8192); }();
-                return DeviceApi::align_exists_counted(lane->stream, d_text, d_peq, B.jobs, max_jobs, B.scalars + VR2_N_JOBS + (round & 1u), shape, exists_waves, B.outs);
+                return DeviceApi::align_exists_counted(lane->stream, d_text, d_peq, B.jobs, max_jobs, B.scalars + VR2_N_JOBS + (round & 1u), shape, exists_waves, B.outs, B.scalars + VR2_QUEUE_ERR);
             });
             if (rc) return rc;
             int const e2 = DeviceApi::vr2_apply(lane->stream, B, n, lane->vr_host_scalars);

@@ -589,7 +589,7 @@ __global__ void __launch_bounds__(64) fm_search_text_kernel(FmConst C, const Dev
     wave_slots_close(HS, hits, hit_cap, lane);
     if (__any(L.overflow) && lane == 0) atomicOr(&counters[1], 1u);
     u32 const s_nodes = s_wave_sum(L.n_nodes);
-    if (lane == 0) { atomicAdd(&counters[18], s_nodes); atomicAdd(&counters[19], n_iter); atomicAdd(&counters[13], n_hits); }
+    if (lane == 0) { atomicAdd(&counters[18], s_nodes); atomicAdd(&counters[19], n_iter); atomicAdd(&counters[13], n_hits); atomicMax(&counters[21], n_iter); atomicAdd(&counters[22], n_iter ? 1u : 0u); }
 }
 
 static u32 env_u32(const char* name, u32 dflt) {

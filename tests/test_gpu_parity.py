@@ -201,6 +201,38 @@ def test_align_batch_random_all_shapes(small_genome):
         assert g == exp, (ql, rl, k, mode)
 
 
+@pytest.mark.parametrize("shape", ["1,2", "1,8", "2,4", "3,4", "5,2", "5,8", "8,2"])
+def test_align_batch_on_rings_that_wait(small_genome, monkeypatch, shape):
+    """launch shapes with fewer lanes than a job's band asks for: every revolution of the ring waits (flx_internal.hpp: ring_delay), what the
+    last lane hands to the first goes through the queue in LDS; existence, score / end and traced alignments (K4's slots, K5's reading of
+    them) against the oracle, sizes from one word group to 26 000 rows"""
+    _, _, ctx, _ = small_genome
+    monkeypatch.setenv("FLX_FORCE_SHAPE", shape)
+    rng = np.random.default_rng(33)
+    refs, queries, jobs = [], [], []
+    ro = qo = 0
+    for m in [130, 257, 700, 1025, 1500, 2049, 3000, 4097, 5000, 6200, 8200, 10000, 12500, 16500, 26000]:
+        for rep in range(2):
+            err = 0.08 if rep == 0 else 0.25
+            ref, q = _rand_align_case(rng, m, err, int(rng.integers(0, m // 4 + 10)))
+            k = int(m * (0.1 if rep == 0 else 0.2)) + int(rng.integers(0, 3))
+            for mode in (0, 1, 2):
+                jobs.append((ro, len(ref), qo, len(q), k, mode))
+            refs.append(ref)
+            queries.append(q)
+            ro += len(ref)
+            qo += len(q)
+    rpool, qpool = np.concatenate(refs), np.concatenate(queries)
+    got = F.align_batch(ctx, qpool, jobs, reference_pool=rpool)
+    for (ro_, rl, qo_, ql, k, mode), g in zip(jobs, got):
+        exp = O.align(rpool[ro_:ro_ + rl], qpool[qo_:qo_ + ql], k, mode=mode, algo=1)
+        if mode == 0 and exp is not None:
+            exp = (exp[0], 0, "")
+        if mode == 1 and exp is not None:
+            exp = (exp[0], exp[1], "")
+        assert g == exp, (shape, ql, rl, k, mode)
+
+
 def test_align_against_context_text(small_genome):
     refs, idx, ctx, _ = small_genome
     rng = np.random.default_rng(32)
@@ -685,7 +717,8 @@ def test_existence_with_cutoff_matches_oracle(small_genome, monkeypatch, team):
 def test_caller_owned_stream():
     """flx_ctx_set_stream: every launch goes to the caller's HIP stream (one lane); results do not change"""
     import ctypes
-    hip = ctypes.CDLL("libamdhip64.so")
+    capi.lib()
+    hip = ctypes.CDLL(capi.hip_runtime_paths()[0])          # the HIP runtime this process already has (capi._share_torchs_hip_runtime), not a second one
     genome = S.make_genome(200000, 1, seed=71)
     reads, _, _ = S.make_reads(genome, 60, 1500, 0.06, seed=72)
     ctx = F.context(F.fmindex(genome))

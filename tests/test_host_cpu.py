@@ -196,6 +196,17 @@ def test_std_sort_emulation_matches_std_sort(tmp_path):
     assert out.returncode == 0 and out.stdout.startswith("ok "), out.stdout + out.stderr
 
 
+def test_ring_schedule_of_the_block_kernels(tmp_path):
+    """the block-step schedule K3 / K4 / K5 share (flx_internal.hpp: ring_delay and friends): no lane asked for two blocks at once, every
+    hand-over in place before it is read, round 3's shapes unchanged; tests/ring_check.cpp on 60 000 random job shapes"""
+    import subprocess
+    exe = str(tmp_path / "ring_check")
+    src = os.path.join(os.path.dirname(os.path.abspath(__file__)), "ring_check.cpp")
+    subprocess.run(["g++", "-O2", "-std=c++17", "-I", os.path.join(ROOT, "include"), "-o", exe, src], check=True)
+    out = subprocess.run([exe], capture_output=True, text=True)
+    assert out.returncode == 0 and out.stdout.startswith("ok "), out.stdout + out.stderr
+
+
 def test_fm_core_matches_oracle(tmp_path):
     """K1's lane logic (flx_fm_core.hpp: the walk with LDS frames and keys, the presence filter, the text walk of one-row subtrees) is
     plain code the HIP kernels and this check share: compiled for the host it is run seed by seed over the product's host-built index
