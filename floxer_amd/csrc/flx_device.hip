@@ -1837,7 +1837,7 @@ int DeviceApi::align(void* stream, const u8* d_text, const u64* d_peq, const Dev
     hipStream_t s = (hipStream_t)stream;
     bool const b = shape.banded != 0;
     // (jobs of one launch share its words and lanes, not their delays: the most slots a shape may ask for, for any ring that may wait)
-    u32 const queue = b && shape.lanes_per_job < 64 ? RING_QUEUE_MAX : 0u;
+    u32 const queue = b ? RING_QUEUE_MAX : 0u;
     switch (shape.words_per_lane) {
         case 1: return launch_align<1>(s, d_text, d_peq, d_jobs, n_jobs, log2_g, trace, b, d_trace, d_out, d_lastrow, queue);
         case 2: return launch_align<2>(s, d_text, d_peq, d_jobs, n_jobs, log2_g, trace, b, d_trace, d_out, d_lastrow, queue);
