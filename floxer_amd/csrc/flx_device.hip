@@ -7,6 +7,8 @@
 //   K3/K4 ed_align    seqan3 edit-distance semi-global DP (alignment.cpp:89-125, 160): score + end column, optional trace
 //   K5 ed_traceback   trace walk + CIGAR (alignment.cpp:166-180)
 #include <hip/hip_runtime.h>
+
+#include <type_traits>
 #include <hipcub/hipcub.hpp>
 #include <rocprim/rocprim.hpp>
 
@@ -1580,41 +1582,66 @@ __device__ __forceinline__ void ed_block_body(const u8* __restrict__ text, const
                 for (int q = 0; q < 8; ++q) rowv[q] = 0xFFFFFFFFu;
             }
             if (b < b_hi) { __builtin_memcpy(&tq_pre, ref + 16 * (b + 1), 16); pre_b = b + 1; }
+            // The block's 16 columns, in two forms. Only a job's last group looks at its bottom row column by column (the score and its
+            // rightmost column; K4: the last row itself): a wave none of whose lanes is in a last group - most block-steps of a launch, the
+            // jobs of a wave start together and are of one size class - runs the form without that, takes the group's bottom value across
+            // the block from the carries' bit counts, and shifts the outgoing carries into their word instead of placing each pair.
+            auto block16 = [&](auto track_tag) {
+                constexpr bool TRACK = decltype(track_tag)::value;
+                // (the block's inputs through an empty asm: values of this form alone. Otherwise the compiler computes what the two forms have in
+                // common - sixteen columns' symbols, addresses, carry bits, end-of-window tests - once, in front of the branch, and keeps it all
+                // in registers through the block: 186 of them for one word per lane instead of 79)
+                u32 qv[4] = {quad[0], quad[1], quad[2], quad[3]};
+                u32 cwi = cw_in;
+                int bb = b;
+                asm volatile("" : "+v"(qv[0]), "+v"(qv[1]), "+v"(qv[2]), "+v"(qv[3]), "+v"(cwi), "+v"(bb));
+                u32 acc = 0;
 #pragma unroll
-            for (int qd = 0; qd < 4; ++qd) {
+                for (int qd = 0; qd < 4; ++qd) {
+                    __builtin_amdgcn_sched_barrier(0);    // (nothing moves across four columns: the form without comparisons would have all sixteen columns' loads in flight)
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    int const j = 4 * qd + i;
-                    int const c = 16 * b + j;
-                    u32 sym = (quad[qd] >> (8 * i)) & 0xFFu;
-                    sym = c < n ? sym : 6u;
-                    u64 c_hp = (cw_in >> (2 * j)) & 1u, c_hn = (cw_in >> (2 * j + 1)) & 1u;
-                    const u64* __restrict__ eqp = &lds_eq[(sym * 64u + lane) * W];
+                    for (int i = 0; i < 4; ++i) {
+                        int const j = 4 * qd + i;
+                        int const c = 16 * bb + j;
+                        u32 sym = (qv[qd] >> (8 * i)) & 0xFFu;
+                        sym = c < n ? sym : 6u;
+                        u64 c_hp = (cwi >> (2 * j)) & 1u, c_hn = (cwi >> (2 * j + 1)) & 1u;
+                        const u64* __restrict__ eqp = &lds_eq[(sym * 64u + lane) * W];
+                        u64 hp_last = 0, hn_last = 0;
 #pragma unroll
-                    for (int w = 0; w < W; ++w) {
-                        if (TRACE) cbits[w] |= ((u32)c_hp | ((u32)c_hn << 1)) << (2 * j);
-                        u64 const eq = eqp[w];
-                        u64 const pv = vp[w], mv = vn[w];
-                        u64 const x = eq | mv;
-                        u64 const tt = pv + (x & pv) + c_hn;
-                        u64 const d0 = (tt ^ pv) | x;
-                        u64 const hn = pv & d0;
-                        u64 const hp = mv | ~(pv | d0);
-                        u64 const xh = (hp << 1) | c_hp;
-                        vn[w] = xh & d0;
-                        vp[w] = (hn << 1) | ~(xh | d0) | c_hn;
-                        c_hp = hp >> 63;
-                        c_hn = hn >> 63;
-                    }
-                    cw |= ((u32)c_hp | ((u32)c_hn << 1)) << (2 * j);
-                    bot += (int)(u32)c_hp - (int)(u32)c_hn;       // the group's last row is its last word's bit 63
-                    if (last && c < n && bot <= best) { best = bot; best_col = c + 1; }
-                    if (TRACE && c < n) {
-                        u32 const v16 = (u32)min(bot, 0xFFFF);
-                        rowv[j >> 1] = (j & 1) ? (rowv[j >> 1] & 0xFFFFu) | (v16 << 16) : (rowv[j >> 1] & 0xFFFF0000u) | v16;
+                        for (int w = 0; w < W; ++w) {
+                            if (TRACE) cbits[w] |= ((u32)c_hp | ((u32)c_hn << 1)) << (2 * j);
+                            u64 const eq = eqp[w];
+                            u64 const pv = vp[w], mv = vn[w];
+                            u64 const x = eq | mv;
+                            u64 const tt = pv + (x & pv) + c_hn;
+                            u64 const d0 = (tt ^ pv) | x;
+                            u64 const hn = pv & d0;
+                            u64 const hp = mv | ~(pv | d0);
+                            u64 const xh = (hp << 1) | c_hp;
+                            vn[w] = xh & d0;
+                            vp[w] = (hn << 1) | ~(xh | d0) | c_hn;
+                            if (w + 1 < W || TRACK) { c_hp = hp >> 63; c_hn = hn >> 63; }
+                            if (w + 1 == W) { hp_last = hp; hn_last = hn; }
+                        }
+                        if (TRACK) {
+                            acc |= ((u32)c_hp | ((u32)c_hn << 1)) << (2 * j);
+                            bot += (int)(u32)c_hp - (int)(u32)c_hn;       // the group's last row is its last word's bit 63
+                            if (last && c < n && bot <= best) { best = bot; best_col = c + 1; }
+                            if (TRACE && c < n) {
+                                u32 const v16 = (u32)min(bot, 0xFFFF);
+                                rowv[j >> 1] = (j & 1) ? (rowv[j >> 1] & 0xFFFFu) | (v16 << 16) : (rowv[j >> 1] & 0xFFFF0000u) | v16;
+                            }
+                        } else {
+                            // (column j's pair ends at bits 2j, 2j + 1 once the fifteen columns after it have pushed it down)
+                            acc = (acc >> 2) | (((u32)(hp_last >> 32) >> 1) & 0x40000000u) | ((u32)(hn_last >> 32) & 0x80000000u);
+                        }
                     }
                 }
-            }
+                if (!TRACK) bot += (int)__popc(acc & 0x55555555u) - (int)__popc(acc & 0xAAAAAAAAu);
+                return acc;
+            };
+            cw = __any(last) ? block16(std::true_type{}) : block16(std::false_type{});
             if (TRACE) { pend = true; pend_last = last; pend_slot = slot; pend_b = b; }
             cw_out = cw;
             botv_out = bot_start;
@@ -1635,8 +1662,10 @@ __device__ __forceinline__ void ed_block_body(const u8* __restrict__ text, const
 
 // A launch is a grid over the groups of jobs, or (n_jobs_dev: the job count is on the device, verification rounds of flx_rounds.hip)
 // a fixed grid whose waves take the groups in turn until the count is reached.
+// (waves per SIMD the register allocation is held to: what round 3's single-form block had - the two forms of the block made the
+// scheduler keep every equality mask of a block in flight, 186 registers for one word per lane)
 template <int W>
-__global__ void __launch_bounds__(64) ed_exists_block_kernel(const u8* __restrict__ text, const u64* __restrict__ peq,
+__global__ void __launch_bounds__(64, (W <= 2 ? 4 : W <= 5 ? 3 : W <= 8 ? 2 : 1)) ed_exists_block_kernel(const u8* __restrict__ text, const u64* __restrict__ peq,
                                                              const DevAlignJob* __restrict__ jobs, u32 n_jobs, u32 log2_r,
                                                              DevAlignOut* __restrict__ out, const u32* __restrict__ n_jobs_dev, u32 queue, u32* __restrict__ err) {
     // LDS: [7 symbols][64 lanes][W words] equality masks; symbol 6 (columns past the end of the window) matches nothing; then `queue`
@@ -1650,7 +1679,7 @@ __global__ void __launch_bounds__(64) ed_exists_block_kernel(const u8* __restric
 
 // K4: the same body with the checkpointed trace and the last rows written out, one wave per group of jobs
 template <int W>
-__global__ void __launch_bounds__(64) ed_trace_block_kernel(const u8* __restrict__ text, const u64* __restrict__ peq,
+__global__ void __launch_bounds__(64, (W <= 4 ? 3 : W <= 6 ? 2 : 1)) ed_trace_block_kernel(const u8* __restrict__ text, const u64* __restrict__ peq,
                                                             const DevAlignJob* __restrict__ jobs, u32 n_jobs, u32 log2_r,
                                                             u64* __restrict__ trace, DevAlignOut* __restrict__ out, u16* __restrict__ lastrow, u32 queue) {
     extern __shared__ __attribute__((aligned(16))) u64 lds_eq[];

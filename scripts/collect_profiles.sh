@@ -14,6 +14,9 @@ stats_csv() { find $1 -name "*kernel_stats.csv" | head -1; }
 pmc_csv() { find $1 -name "*counter_collection.csv" | head -1; }
 fail() { echo "FAILED: $1"; tail -5 "$2"; exit 1; }
 
+# FLX_PROFILE_PHASE=a: the two bench lines only; b: the rocprofv3 passes only (a gpurun call is at most 20 minutes); unset: both
+PHASE=${FLX_PROFILE_PHASE:-ab}
+if [[ $PHASE == *a* ]]; then
 # the driver's command: the metric's configuration with the oracle leg (cpu_baseline + parity_sample), the host-inputs leg and the repeat-rich leg
 timeout -k 10 900 python3 $ROOT/bench.py --steps 20 --warmup 5 "$@" > $OUT/${P}_bench_default.json 2> $OUT/${P}_bench_default.err || fail "default bench" $OUT/${P}_bench_default.err
 python3 - <<PY
@@ -25,6 +28,8 @@ print("  cpu_baseline", d.get("cpu_baseline", {}).get("value"), "repeat_rich", (
 PY
 timeout -k 10 400 python3 $ROOT/bench.py --steps 20 --warmup 5 --interval-optimization --no-cpu-baseline --no-isolated-pass --no-repeat-rich-leg --no-host-inputs-leg "$@" > $OUT/${P}_bench_interval_optimization.json 2> $OUT/${P}_bench_interval_optimization.err || fail "-I bench" $OUT/${P}_bench_interval_optimization.err
 echo "-I done"
+fi
+[[ $PHASE == *b* ]] || { ls -la $OUT; exit 0; }
 rm -rf /tmp/k2 && timeout -k 10 400 rocprofv3 --kernel-trace --stats -d /tmp/k2 -o k2 --output-format csv -- python3 $ROOT/bench.py --isolated-only --no-cpu-baseline "$@" > $OUT/${P}_bench_isolated.json 2> $OUT/${P}_bench_isolated.err || fail "isolated pass under rocprofv3" $OUT/${P}_bench_isolated.err
 F=$(stats_csv /tmp/k2); [ -n "$F" ] && cp "$F" $OUT/${P}_bench_isolated_kernel_stats.csv || fail "no kernel stats csv" $OUT/${P}_bench_isolated.err
 echo "rocprof isolated done"
