@@ -612,9 +612,21 @@ struct TxPlainAccess {
     const u8* text; const u8* q;
     FLX_HD u32 text_at(i64 pos) const { return text[pos]; }
     FLX_HD u32 q_at(u32 qp) const { return q[qp]; }
+    // seed symbols qp, qp + 1, ... against text symbols tpos, tpos + 1, ...: how many of the first `run` agree (an A, C, G, T or N on both sides)
+    FLX_HD u32 run_right(u32 qp, i64 tpos, u32 run) const {
+        u32 i = 0;
+        for (; i < run; ++i) { u32 const c = q[qp + i]; if (c != text[tpos + (i64)i] || c - 1u >= 5u) break; }
+        return i;
+    }
+    // the same leftwards: seed symbols qp, qp - 1, ... against text symbols tpos, tpos - 1, ...
+    FLX_HD u32 run_left(u32 qp, i64 tpos, u32 run) const {
+        u32 i = 0;
+        for (; i < run; ++i) { u32 const c = q[qp - i]; if (c != text[tpos - (i64)i] || c - 1u >= 5u) break; }
+        return i;
+    }
 };
 
-// AC: text_at(absolute text position), q_at(seed position)
+// AC: text_at(absolute text position), q_at(seed position), run_right / run_left (a forced run compared in one call)
 template <class FR, class AC>
 FLX_HD inline void tx_step(FmConst const& C, TxLane& L, FR&& fr, AC const& ac) {
     ++L.n_nodes;
@@ -671,9 +683,7 @@ FLX_HD inline void tx_step(FmConst const& C, TxLane& L, FR&& fr, AC const& ac) {
         // a run of forced positions: seed and text symbol by symbol up to the end of the run (entries of one direction and one
         // upper bound = ne; their lower bounds cannot exceed it)
         u32 const run = sch_run_end(e64) - L.nx;
-        u32 i = 0;
-        if (right) { for (; i < run; ++i) { u32 const c = ac.q_at(qp + i); if (c != ac.text_at((i64)L.pR + 1 + (i64)i) || c - 1u >= 5u) break; } }
-        else { for (; i < run; ++i) { u32 const c = ac.q_at(qp - i); if (c != ac.text_at((i64)L.pL - 1 - (i64)i) || c - 1u >= 5u) break; } }
+        u32 const i = right ? ac.run_right(qp, (i64)L.pR + 1, run) : ac.run_left(qp, (i64)L.pL - 1, run);
         if (i < run) { L.need_child = true; return; }
         if (right) { L.pR += run; L.nri = FM_INFO_M; } else { L.pL -= run; L.nli = FM_INFO_M; }
         L.nx += run;
