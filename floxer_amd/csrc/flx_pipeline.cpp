@@ -837,22 +837,37 @@ int choose_shapes(hvec<AlignRequest> const& reqs, hvec<AlignShape>& shapes) {
     auto fits = [](AlignRequest const& r, AlignShape const& sh) {
         u32 const nw = (r.m + 63) / 64, W = sh.words_per_lane, R = sh.lanes_per_job;
         i64 const width = (i64)r.n - (i64)r.m + 2 * (i64)r.k;
-        return (nw + W - 1) / W <= R || (sh.banded && (i64)64 * W * (R - 1) + R + 1 > width);
+        if ((nw + W - 1) / W <= R || (sh.banded && (i64)64 * W * (R - 1) + R + 1 > width)) return true;
+        return sh.banded && sh.queue != 0 && ring_delay(r.n, r.m, r.k, W, R) + 1u <= RING_QUEUE_MAX;      // (a ring that waits: DeviceApi::align gives it the largest queue)
     };
     if (!reqs.empty() && lanes / 64 >= align_few_waves()) {
-        // a launch lasts at least as long as its longest job: a handful of jobs with a shape of their own join the most common
-        // shape that can hold them instead of getting a launch
-        std::map<ShapeKey, u32> count;
-        for (auto const& sh : shapes) count[ShapeKey{sh.words_per_lane, sh.lanes_per_job, sh.banded}]++;
+        // A launch lasts at least as long as its longest job, and the jobs of a batch differ by a few columns (unions of a locus' windows): the
+        // shape is chosen per class of query words, for the class's widest band - a ring's delay is the job's own (ring_delay), so the narrower
+        // jobs of the class lose nothing on it. (Per job, 10-kb root alignments over a repeat-rich reference fell into a dozen launches of two
+        // shapes and took 171 ms per 16384 reads instead of 46.)
+        std::map<u32, size_t> widest;                        // query words -> request with the widest band
+        auto width_of = [](AlignRequest const& r) { return (i64)r.n - (i64)r.m + 2 * (i64)r.k; };
+        for (size_t i = 0; i < reqs.size(); ++i) {
+            u32 const nw = (reqs[i].m + 63) / 64;
+            auto it = widest.find(nw);
+            if (it == widest.end() || width_of(reqs[i]) > width_of(reqs[it->second])) widest[nw] = i;
+        }
+        for (size_t i = 0; i < reqs.size(); ++i) {
+            AlignShape const cand = shapes[widest[(reqs[i].m + 63) / 64]];
+            if (fits(reqs[i], cand)) shapes[i] = cand;
+        }
+        // a handful of jobs with a shape of their own join the most common shape that can hold them instead of getting a launch
+        std::map<ShapeKey, std::pair<u32, u32>> count;       // jobs, queue
+        for (auto const& sh : shapes) { auto& c = count[ShapeKey{sh.words_per_lane, sh.lanes_per_job, sh.banded}]; c.first++; c.second = std::max(c.second, sh.queue); }
         if (count.size() > 1) {
             for (size_t i = 0; i < reqs.size(); ++i) {
                 ShapeKey const mine{shapes[i].words_per_lane, shapes[i].lanes_per_job, shapes[i].banded};
-                if (count[mine] >= 64) continue;
+                if (count[mine].first >= 64) continue;
                 u32 best_n = 0;
                 AlignShape best = shapes[i];
                 for (auto const& kv : count) {
-                    AlignShape const cand{kv.first.w, kv.first.g, kv.first.banded};
-                    if (kv.second >= 64 && kv.second > best_n && fits(reqs[i], cand)) { best_n = kv.second; best = cand; }
+                    AlignShape const cand{kv.first.w, kv.first.g, kv.first.banded, kv.second.second};
+                    if (kv.second.first >= 64 && kv.second.first > best_n && fits(reqs[i], cand)) { best_n = kv.second.first; best = cand; }
                 }
                 shapes[i] = best;
             }
