@@ -260,6 +260,8 @@ struct DefaultInit : std::allocator<T> {
 
 struct ReadBatch {
     std::vector<char, DefaultInit<char>> raw;   // the batch's FASTQ text; ids / quals point into it
+    std::vector<size_t> nl;                     // line ends of the text (FastqReader::next_text), four per record
+    size_t n_rec = 0;                           // records the text holds
     std::vector<const char*> ids, quals;
     std::vector<uint8_t> pool;
     std::vector<uint64_t> offsets{0};
@@ -273,6 +275,8 @@ struct FastqReader {
     bool eof = false;
     unsigned threads;
     size_t file_pos = 0, last_batch_bytes = 0;  // plain input: where the next read starts; the text the last batch took
+    double s_read = 0, s_scan = 0, s_records = 0; // seconds spent reading, finding line ends, and on the records (FLX_CLI_PROFILE)
+    static double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
     FastqReader(const char* path, unsigned threads_) : threads(threads_) {
         int const probe = open(path, O_RDONLY);
         if (probe < 0) return;
@@ -297,6 +301,16 @@ struct FastqReader {
 
     // the next batch of up to max_reads records; false at the end of the file or on a malformed record (err set)
     bool next(ReadBatch& b, size_t max_reads, std::string& err) {
+        if (!next_text(b, max_reads, err)) return false;
+        double const t_records = now_s();
+        bool const ok = parse_records(b, threads, err);
+        s_records += now_s() - t_records;
+        return ok;
+    }
+    // Stage one, the reader's own thread: the text of the next batch (whole records) and its line ends. Stage two (parse_records) needs
+    // nothing but the batch: the CLI runs it in the batch's task, next to the other batches' alignment, so that the one thread that has to
+    // read the file in order does nothing else (it was the bound of the CLI with -I: 2.9 of 3.4 s).
+    bool next_text(ReadBatch& b, size_t max_reads, std::string& err) {
         // (a recycled batch keeps its buffers: 330 MB of text and 165 MB of ranks per 16384 reads of 10 kb are not faulted in again)
         b.ids.clear(); b.quals.clear(); b.pool.clear(); b.offsets.assign(1, 0);
         auto& raw = b.raw;
@@ -305,8 +319,11 @@ struct FastqReader {
         carry.clear();
         // ---- read until the text holds max_reads records (4 lines each) or the file ends
         size_t lines = 0, scanned = 0;
-        std::vector<size_t> nl;                 // positions of the line ends
+        std::vector<size_t>& nl = b.nl;         // positions of the line ends
+        nl.clear();
+        b.n_rec = 0;
         auto scan = [&]() {                     // line ends of raw[scanned, size): pieces of at least 8 MB, one thread each
+            double const t_scan = now_s();
             size_t const lo = scanned, hi = raw.size();
             unsigned const t = (unsigned)std::min<size_t>(std::max(1u, threads), std::max<size_t>(1, (hi - lo) >> 23));
             std::vector<std::vector<size_t>> found(t);
@@ -326,12 +343,14 @@ struct FastqReader {
             for (auto& th : pool) th.join();
             for (auto const& v : found) { nl.insert(nl.end(), v.begin(), v.end()); lines += v.size(); }
             scanned = hi;
+            s_scan += now_s() - t_scan;
         };
         scan();
         while (!eof && lines < 4 * max_reads) {
             // plain input: as much as the last batch took (and a little more) in one go, the pieces read by several threads (pread);
             // gzip input: 16 MB at a time through zlib
             size_t const at = raw.size(), want = f ? (size_t)16 << 20 : std::max<size_t>((size_t)16 << 20, last_batch_bytes > at ? last_batch_bytes - at + (1u << 20) : (size_t)16 << 20);
+            double const t_read = now_s();
             raw.resize(at + want);
             long got;
             if (f) got = gzread(f, raw.data() + at, (unsigned)want);
@@ -362,6 +381,7 @@ struct FastqReader {
             }
             if (got < 0) { err = "read error on the query file"; return false; }
             raw.resize(at + (size_t)got);
+            s_read += now_s() - t_read;
             if (f && (size_t)got < want) {
                 // a short read is the end of the data only when zlib agrees (a truncated .gz ends with Z_BUF_ERROR / Z_DATA_ERROR)
                 int zerr = Z_OK;
@@ -382,6 +402,14 @@ struct FastqReader {
         raw.resize(used);
         last_batch_bytes = used;
         if (n_rec == 0) return false;
+        b.n_rec = n_rec;
+        return true;
+    }
+    // Stage two: ids, sequences (rank-encoded into the batch's pool) and qualities of the batch's records; false on a malformed record
+    static bool parse_records(ReadBatch& b, unsigned threads, std::string& err) {
+        auto& raw = b.raw;
+        std::vector<size_t> const& nl = b.nl;
+        size_t const n_rec = b.n_rec;
         // ---- records: id (up to the first blank, input.cpp:161-163), sequence, quality; terminated in place
         struct Rec { size_t id, seq, seq_len, qual; bool keep; };
         std::vector<Rec> recs(n_rec);
@@ -458,6 +486,20 @@ int main(int argc, char** argv) {
     g_debug = o.console_debug_logs;
     if (!o.logfile.empty()) g_logfile = fopen(o.logfile.c_str(), "a");
     log_line("info", "successfully parsed CLI input ... starting");
+    if (getenv("FLX_CLI_PARSE_ONLY")) {          // diagnostic: the FASTQ reader alone (no GPU): batches, records, seconds per stage
+        FastqReader qin(o.queries.c_str(), io_threads(o.threads));
+        if (!qin.is_open()) { log_line("error", "cannot open %s", o.queries.c_str()); return -1; }
+        ReadBatch batch;
+        std::string perr;
+        uint64_t n = 0, batches = 0;
+        double const t0 = FastqReader::now_s();
+        while (qin.next(batch, 16384, perr)) { n += batch.ids.size(); ++batches; }
+        double const secs = FastqReader::now_s() - t0;
+        if (!perr.empty()) { log_line("error", "%s", perr.c_str()); return -1; }
+        fprintf(stderr, "[flx cli parse only] %llu records in %llu batches, %.2f s (%.0f reads/s): reading %.2f s, line ends %.2f s, records %.2f s\n",
+                (unsigned long long)n, (unsigned long long)batches, secs, n / secs, qin.s_read, qin.s_scan, qin.s_records);
+        return 0;
+    }
 
     Reference ref;
     std::string err;
@@ -537,14 +579,22 @@ int main(int argc, char** argv) {
     if (const char* env = getenv("FLX_BATCH_READS")) { size_t const v = strtoull(env, nullptr, 10); if (v) batch_reads = v; }
     // Batches are independent: up to three are in a context at a time (their chunks share its lanes), the next one is parsed
     // while they run, and results are written in input order.
-    struct Finished { std::unique_ptr<ReadBatch> batch; std::vector<flx_record> recs; std::vector<uint32_t> cig; std::vector<uint8_t> skipped; int rc = FLX_OK; std::string err; };
+    struct Finished { std::unique_ptr<ReadBatch> batch; std::vector<flx_record> recs; std::vector<uint32_t> cig; std::vector<uint8_t> skipped; int rc = FLX_OK; std::string err; bool reader_error = false; };
     // FLX_CLI_PROFILE=1: seconds this run spent parsing (this thread), aligning (sum over the batches' tasks) and writing (the writer
     // thread) on stderr at the end: which of the three stages bounds the end-to-end rate
-    std::atomic<uint64_t> us_parse{0}, us_align{0}, us_copy{0}, us_write{0};
+    std::atomic<uint64_t> us_parse{0}, us_align{0}, us_copy{0}, us_write{0}, us_records{0};
     auto const now_us = [] { return (uint64_t)std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     auto align_batch = [&](std::unique_ptr<ReadBatch> b, flx_ctx* ctx) {
         Finished f;
         flx_run* run = nullptr;
+        {
+            // the second stage of the reader, in this batch's own task
+            uint64_t const tr = now_us();
+            std::string perr;
+            bool const ok = FastqReader::parse_records(*b, n_io, perr);
+            us_records += now_us() - tr;
+            if (!ok) { f.rc = FLX_ERR_INVALID; f.err = perr; f.reader_error = true; f.batch = std::move(b); return f; }
+        }
         uint64_t const t0 = now_us();
         f.rc = flx_align_reads(ctx, &p, b->pool.data(), b->offsets.data(), b->ids.size(), &run);
         us_align += now_us() - t0;
@@ -572,7 +622,8 @@ int main(int argc, char** argv) {
     auto write_one = [&](Finished& f) {
         if (failed.load()) return;
         if (f.rc != FLX_OK) {
-            log_line("error", "An error occurred while aligning a batch of queries.\nShutting down. The output file is likely incomplete. Error message:\n%s", f.err.c_str());
+            if (f.reader_error) log_line("error", "An error occured while trying to read the queries from the file %s.\n%s", o.queries.c_str(), f.err.c_str());
+            else log_line("error", "An error occurred while aligning a batch of queries.\nShutting down. The output file is likely incomplete. Error message:\n%s", f.err.c_str());
             failed.store(true);
             return;
         }
@@ -616,14 +667,13 @@ int main(int argc, char** argv) {
         }
         if (!batch) batch = std::make_unique<ReadBatch>();
         uint64_t const t_parse = now_us();
-        bool const got = qin.next(*batch, batch_reads, err);
+        bool const got = qin.next_text(*batch, batch_reads, err);
         us_parse += now_us() - t_parse;
         if (!got) {
             eof = true;
             if (!err.empty()) { log_line("error", "An error occured while trying to read the queries from the file %s.\n%s", o.queries.c_str(), err.c_str()); failed.store(true); }
             break;
         }
-        if (batch->ids.empty()) continue;           // every record of the block was filtered
         flx_ctx* const target = ctxs[n_batches++ % ctxs.size()];
         {
             std::unique_lock<std::mutex> g(q_mu);
@@ -636,14 +686,17 @@ int main(int argc, char** argv) {
     q_cv.notify_all();
     writer.join();
     if (flx_sam_close(out) != FLX_OK) { log_line("error", "%s", flx_last_error()); failed.store(true); }
+    // (the alignment phase ends with the output file: floxer.cpp:154-179 stops its watch there; giving 40 GB of HBM back is not part of it)
+    double const secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_align).count();
     for (flx_ctx* c : ctxs) flx_ctx_destroy(c);
     flx_index_free(index);
     if (failed.load() || timed_out) return -1;
-    double const secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_align).count();
     log_line("info", "finished aligning successfully in %.3f seconds (%llu queries, %llu records)", secs, (unsigned long long)total_reads, (unsigned long long)total_records);
-    if (getenv("FLX_CLI_PROFILE"))
+    if (getenv("FLX_CLI_PROFILE")) {
+        fprintf(stderr, "[flx cli profile] reader thread: reading %.2f s, line ends %.2f s; records (ids, rank encoding: in the batches' own tasks) %.2f s\n", qin.s_read, qin.s_scan, us_records.load() / 1e6);
         fprintf(stderr, "[flx cli profile] wall %.2f s: parsing %.2f s (reader thread), aligning %.2f s summed over %llu batches (up to %zu in flight), copying results %.2f s, writing %.2f s (writer thread, %u I/O threads)\n",
                 secs, us_parse.load() / 1e6, us_align.load() / 1e6, (unsigned long long)n_batches, max_in_flight, us_copy.load() / 1e6, us_write.load() / 1e6, n_io);
+    }
     if (stats) {                                                                       // floxer.cpp:182-192
         uint64_t len = 0;
         flx_stats_format(stats, o.stats != "terminal", nullptr, &len);
